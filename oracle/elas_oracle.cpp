@@ -1,0 +1,590 @@
+// oracle/elas_oracle.cpp — TEST INFRASTRUCTURE (scalar CPU restatement of libelas), not product code.
+//
+// A from-scratch, scalar, SSE-free restatement of the ELAS pipeline as the reference runs it
+// (reference: /root/reference/src/elas, call site point_cloud.cpp:416-419).  Every function cites
+// the reference lines it follows.  It exists so that (a) the HIP kernels have a checker that
+// travels to the GPU box, and (b) bench.py has a `cpu_baseline` of kind "port".
+// It is pinned, stage by stage and end to end, against the compiled reference in oracle/_ref
+// (tests/test_oracle_vs_reference.py) and against the survey's known-answer hashes.
+//
+// Build with -ffp-contract=off: the reference's results depend on the absence of FMA contraction.
+// Not supported (returns status 2): subsampling=1 (unused by the reference node).
+#include "oracle.h"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+inline int sad16(const uint8_t* a, const uint8_t* b) {
+  int s = 0;
+  for (int i = 0; i < 16; i++) s += std::abs((int)a[i] - (int)b[i]);
+  return s;
+}
+inline int texture16(const uint8_t* a) {
+  int s = 0;
+  for (int i = 0; i < 16; i++) s += std::abs((int)a[i] - 128);
+  return s;
+}
+inline uint8_t sat_u8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+struct SupportPt { int32_t u, v, d; };
+
+}  // namespace
+
+// elas.h:92-145
+extern "C" void orc_params_default(orc_params* p, int setting) {
+  p->disp_min = 0; p->disp_max = 255; p->support_texture = 10; p->candidate_stepsize = 5;
+  p->incon_window_size = 5; p->incon_threshold = 5; p->incon_min_support = 5; p->grid_size = 20;
+  p->beta = 0.02f; p->sigma = 1; p->lr_threshold = 2; p->speckle_sim_threshold = 1; p->speckle_size = 200;
+  p->subsampling = 0;
+  if (setting == 0) {
+    p->support_threshold = 0.85f; p->add_corners = 0; p->gamma = 3; p->sradius = 2; p->match_texture = 1;
+    p->ipol_gap_width = 3; p->filter_median = 0; p->filter_adaptive_mean = 1; p->postprocess_only_left = 1;
+  } else {
+    p->support_threshold = 0.95f; p->add_corners = 1; p->gamma = 5; p->sradius = 3; p->match_texture = 0;
+    p->ipol_gap_width = 5000; p->filter_median = 1; p->filter_adaptive_mean = 0; p->postprocess_only_left = 0;
+  }
+}
+
+// filter.cpp:372-416 (column pass), :227-267 (du row pass), :176-222 (dv row pass).
+// S = [1 2 1]^T, T = [1 0 -1]^T column filters in int16; then du = sat(((S[u-1]-S[u+1])>>2)+128),
+// dv = sat(((T[u-1]+2T[u]+T[u+1])>>2)+128).  Defined here for rows 1..H-2, cols 1..bpl-2; the
+// reference's first/last column values come from flattened-array wrap-around and its rows 0/H-1
+// are uninitialised — none of those are ever read by the descriptor (descriptor.cpp:84-111).
+extern "C" void orc_sobel3x3(const uint8_t* I, int32_t bpl, int32_t H, uint8_t* du, uint8_t* dv) {
+  std::vector<int16_t> S((size_t)bpl), T((size_t)bpl);
+  for (int v = 1; v < H - 1; v++) {
+    const uint8_t* r0 = I + (size_t)(v - 1) * bpl; const uint8_t* r1 = r0 + bpl; const uint8_t* r2 = r1 + bpl;
+    for (int u = 0; u < bpl; u++) {
+      S[u] = (int16_t)(r0[u] + 2 * r1[u] + r2[u]);
+      T[u] = (int16_t)(r0[u] - r2[u]);
+    }
+    uint8_t* o1 = du + (size_t)v * bpl; uint8_t* o2 = dv + (size_t)v * bpl;
+    o1[0] = o2[0] = 0; o1[bpl - 1] = o2[bpl - 1] = 0;
+    for (int u = 1; u < bpl - 1; u++) {
+      o1[u] = sat_u8(((S[u - 1] - S[u + 1]) >> 2) + 128);
+      o2[u] = sat_u8(((T[u - 1] + 2 * T[u] + T[u + 1]) >> 2) + 128);
+    }
+  }
+}
+
+// descriptor.cpp:28-36, 84-111.  16 taps: 12 from du (5-row diamond), 4 from dv.
+extern "C" void orc_descriptor(const uint8_t* I, int32_t W, int32_t H, int32_t pitch, uint8_t* desc) {
+  const int bpl = W + 15 - (W - 1) % 16;                              // elas.cpp:37
+  std::vector<uint8_t> img((size_t)bpl * H, 0), du((size_t)bpl * H, 0), dv((size_t)bpl * H, 0);
+  for (int v = 0; v < H; v++) memcpy(&img[(size_t)v * bpl], I + (size_t)v * pitch, W);   // elas.cpp:40-52
+  orc_sobel3x3(img.data(), bpl, H, du.data(), dv.data());
+  memset(desc, 0, (size_t)16 * W * H);
+  for (int v = 3; v < H - 3; v++) {
+    const uint8_t* u0 = &du[(size_t)(v - 2) * bpl]; const uint8_t* u1 = u0 + bpl; const uint8_t* u2 = u1 + bpl;
+    const uint8_t* u3 = u2 + bpl; const uint8_t* u4 = u3 + bpl;
+    const uint8_t* v1 = &dv[(size_t)(v - 1) * bpl]; const uint8_t* v2 = v1 + bpl; const uint8_t* v3 = v2 + bpl;
+    for (int u = 3; u < W - 3; u++) {
+      uint8_t* o = desc + ((size_t)v * W + u) * 16;
+      o[0] = u0[u];     o[1] = u1[u - 2]; o[2] = u1[u];      o[3] = u1[u + 2];
+      o[4] = u2[u - 1]; o[5] = u2[u];     o[6] = u2[u];      o[7] = u2[u + 1];
+      o[8] = u3[u - 2]; o[9] = u3[u];     o[10] = u3[u + 2]; o[11] = u4[u];
+      o[12] = v1[u];    o[13] = v2[u - 1]; o[14] = v2[u + 1]; o[15] = v3[u];
+    }
+  }
+}
+
+// elas.cpp:269-373
+extern "C" int32_t orc_match_candidate(const orc_params* p, const uint8_t* desc1, const uint8_t* desc2, int32_t W,
+                                       int32_t H, int32_t u, int32_t v, int right) {
+  const int ustep = 2, vstep = 2, win = 3;
+  if (!(u >= win + ustep && u <= W - win - 1 - ustep && v >= win + vstep && v <= H - win - 1 - vstep)) return -1;
+  const uint8_t* A = right ? desc2 : desc1;     // image the candidate lives in
+  const uint8_t* B = right ? desc1 : desc2;     // image searched along the scanline
+  auto at = [W](const uint8_t* d, int uu, int vv) { return d + ((size_t)vv * W + uu) * 16; };
+  if (texture16(at(A, u, v)) < p->support_texture) return -1;                 // :301-305
+  int dmin = std::max(p->disp_min, 0);
+  int dmax = right ? std::min(p->disp_max, W - u - win - ustep) : std::min(p->disp_max, u - win - ustep);
+  if (dmax - dmin < 10) return -1;                                             // :329
+  const uint8_t* a0 = at(A, u - ustep, v - vstep); const uint8_t* a1 = at(A, u + ustep, v - vstep);
+  const uint8_t* a2 = at(A, u - ustep, v + vstep); const uint8_t* a3 = at(A, u + ustep, v + vstep);
+  int16_t e1 = 32767, e2 = 32767; int d1 = -1, d2 = -1;
+  for (int d = dmin; d <= dmax; d++) {
+    int uw = right ? u + d : u - d;
+    int sum = sad16(a0, at(B, uw - ustep, v - vstep)) + sad16(a1, at(B, uw + ustep, v - vstep)) +
+              sad16(a2, at(B, uw - ustep, v + vstep)) + sad16(a3, at(B, uw + ustep, v + vstep));
+    if (sum < e1) { e2 = e1; d2 = d1; e1 = (int16_t)sum; d1 = d; }
+    else if (sum < e2) { e2 = (int16_t)sum; d2 = d; }
+  }
+  if (d1 >= 0 && d2 >= 0 && (float)e1 < p->support_threshold * (float)e2) return d1;   // :366
+  return -1;
+}
+
+// elas.cpp:379-413: candidate lattice, forward match + backward check.  D_can is [ch][cw].
+extern "C" int32_t orc_candidates(const orc_params* p, const uint8_t* desc1, const uint8_t* desc2, int32_t W,
+                                  int32_t H, int16_t* D_can, int32_t* cw_, int32_t* ch_) {
+  const int step = p->candidate_stepsize;
+  int cw = 0, ch = 0;
+  for (int u = 0; u < W; u += step) cw++;
+  for (int v = 0; v < H; v += step) ch++;
+  *cw_ = cw; *ch_ = ch;
+  if (!D_can) return cw * ch;
+  memset(D_can, 0, sizeof(int16_t) * cw * ch);                                 // calloc at :388
+  for (int uc = 1; uc < cw; uc++)
+    for (int vc = 1; vc < ch; vc++) {
+      int u = uc * step, v = vc * step;
+      int16_t out = -1;
+      int d = orc_match_candidate(p, desc1, desc2, W, H, u, v, 0);
+      if (d >= 0) {
+        int d2 = orc_match_candidate(p, desc1, desc2, W, H, u - d, v, 1);
+        if (d2 >= 0 && std::abs(d - d2) <= p->lr_threshold) out = (int16_t)d;
+      }
+      D_can[vc * cw + uc] = out;
+    }
+  return cw * ch;
+}
+
+// elas.cpp:153-179 — in place, u-outer / v-inner: later points see earlier deletions.
+extern "C" void orc_remove_inconsistent(const orc_params* p, int16_t* D, int32_t cw, int32_t ch) {
+  const int win = p->incon_window_size;
+  for (int u = 0; u < cw; u++)
+    for (int v = 0; v < ch; v++) {
+      int d = D[v * cw + u];
+      if (d < 0) continue;
+      int support = 0;
+      for (int u2 = u - win; u2 <= u + win; u2++)
+        for (int v2 = v - win; v2 <= v + win; v2++)
+          if (u2 >= 0 && v2 >= 0 && u2 < cw && v2 < ch) {
+            int e = D[v2 * cw + u2];
+            if (e >= 0 && std::abs(d - e) <= p->incon_threshold) support++;
+          }
+      if (support < p->incon_min_support) D[v * cw + u] = -1;
+    }
+}
+
+// elas.cpp:181-235 — in place; a point is dropped if BOTH directions along the axis hold a
+// similar point within max_dist steps.
+extern "C" void orc_remove_redundant(int16_t* D, int32_t cw, int32_t ch, int32_t max_dist, int32_t thresh, int vertical) {
+  const int du[2] = {vertical ? 0 : -1, vertical ? 0 : 1};
+  const int dv[2] = {vertical ? -1 : 0, vertical ? 1 : 0};
+  for (int u = 0; u < cw; u++)
+    for (int v = 0; v < ch; v++) {
+      int d = D[v * cw + u];
+      if (d < 0) continue;
+      bool redundant = true;
+      for (int i = 0; i < 2 && redundant; i++) {
+        int u2 = u, v2 = v; bool support = false;
+        for (int j = 0; j < max_dist; j++) {
+          u2 += du[i]; v2 += dv[i];
+          if (u2 < 0 || v2 < 0 || u2 >= cw || v2 >= ch) break;
+          int e = D[v2 * cw + u2];
+          if (e >= 0 && std::abs(d - e) <= thresh) { support = true; break; }
+        }
+        if (!support) redundant = false;
+      }
+      if (redundant) D[v * cw + u] = -1;
+    }
+}
+
+namespace {
+
+// elas.cpp:237-267
+void add_corner_points(std::vector<SupportPt>& s, int W, int H) {
+  SupportPt b[6] = {{0, 0, 0}, {0, H - 1, 0}, {W - 1, 0, 0}, {W - 1, H - 1, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = 0; i < 4; i++) {
+    int best = 10000000;
+    for (size_t j = 0; j < s.size(); j++) {
+      int du = b[i].u - s[j].u, dv = b[i].v - s[j].v, dist = du * du + dv * dv;
+      if (dist < best) { best = dist; b[i].d = s[j].d; }
+    }
+  }
+  b[4] = {b[2].u + b[2].d, b[2].v, b[2].d};
+  b[5] = {b[3].u + b[3].d, b[3].v, b[3].d};
+  for (int i = 0; i < 6; i++) s.push_back(b[i]);
+}
+
+std::vector<SupportPt> support_points(const orc_params* p, const uint8_t* d1, const uint8_t* d2, int W, int H) {
+  int cw, ch;
+  orc_candidates(p, d1, d2, W, H, nullptr, &cw, &ch);
+  std::vector<int16_t> D((size_t)cw * ch);
+  orc_candidates(p, d1, d2, W, H, D.data(), &cw, &ch);
+  orc_remove_inconsistent(p, D.data(), cw, ch);                               // elas.cpp:416
+  orc_remove_redundant(D.data(), cw, ch, 5, 1, 1);                            // :421
+  orc_remove_redundant(D.data(), cw, ch, 5, 1, 0);                            // :422
+  std::vector<SupportPt> s;
+  const int step = p->candidate_stepsize;
+  for (int uc = 1; uc < cw; uc++)                                             // :425-431, u-major
+    for (int vc = 1; vc < ch; vc++)
+      if (D[vc * cw + uc] >= 0) s.push_back({uc * step, vc * step, D[vc * cw + uc]});
+  if (p->add_corners) add_corner_points(s, W, H);
+  return s;
+}
+
+// matrix.cpp:414-502 specialised to a 3x3 system with one right-hand side: Gauss-Jordan with full
+// pivoting, `>=` in the pivot search (last maximum wins), double precision, eps 1e-20.
+bool gauss_jordan3(double A[3][3], double b[3]) {
+  int ipiv[3] = {0, 0, 0};
+  for (int i = 0; i < 3; i++) {
+    double big = 0.0; int irow = 0, icol = 0;
+    for (int j = 0; j < 3; j++)
+      if (ipiv[j] != 1)
+        for (int k = 0; k < 3; k++)
+          if (ipiv[k] == 0)
+            if (std::fabs(A[j][k]) >= big) { big = std::fabs(A[j][k]); irow = j; icol = k; }
+    ++ipiv[icol];
+    if (irow != icol) {
+      for (int l = 0; l < 3; l++) std::swap(A[irow][l], A[icol][l]);
+      std::swap(b[irow], b[icol]);
+    }
+    if (std::fabs(A[icol][icol]) < 1e-20) return false;
+    double pivinv = 1.0 / A[icol][icol];
+    A[icol][icol] = 1.0;
+    for (int l = 0; l < 3; l++) A[icol][l] *= pivinv;
+    b[icol] *= pivinv;
+    for (int ll = 0; ll < 3; ll++)
+      if (ll != icol) {
+        double dum = A[ll][icol];
+        A[ll][icol] = 0.0;
+        for (int l = 0; l < 3; l++) A[ll][l] -= A[icol][l] * dum;
+        b[ll] -= b[icol] * dum;
+      }
+  }
+  return true;   // column unscrambling (:488-493) only permutes A, which is discarded
+}
+
+}  // namespace
+
+extern "C" int32_t orc_support(const orc_params* p, const uint8_t* desc1, const uint8_t* desc2, int32_t W, int32_t H,
+                               int32_t* uvd, int32_t cap) {
+  std::vector<SupportPt> s = support_points(p, desc1, desc2, W, H);
+  for (size_t i = 0; i < s.size() && (int32_t)i < cap; i++) { uvd[3 * i] = s[i].u; uvd[3 * i + 1] = s[i].v; uvd[3 * i + 2] = s[i].d; }
+  return (int32_t)s.size();
+}
+
+// elas.cpp:445-505 (point list for Triangle) + :507-577 (two plane fits per triangle).
+extern "C" int32_t orc_triangles(const int32_t* uvd, int32_t n, int right, int32_t* corners, float* planes, int32_t cap) {
+  std::vector<float> xy((size_t)2 * n);
+  for (int i = 0; i < n; i++) {
+    xy[2 * i] = (float)(right ? uvd[3 * i] - uvd[3 * i + 2] : uvd[3 * i]);
+    xy[2 * i + 1] = (float)uvd[3 * i + 1];
+  }
+  int32_t nt = orc_triangulate(xy.data(), n, corners, cap);
+  if (nt < 0) return nt;
+  for (int t = 0; t < nt && t < cap; t++) {
+    const int32_t* c = corners + 3 * t;
+    for (int side = 0; side < 2; side++) {
+      double A[3][3], b[3];
+      for (int r = 0; r < 3; r++) {
+        const int32_t* s = uvd + 3 * c[r];
+        A[r][0] = side ? s[0] - s[2] : s[0]; A[r][1] = s[1]; A[r][2] = 1; b[r] = s[2];
+      }
+      float* o = planes + 6 * t + 3 * side;
+      if (gauss_jordan3(A, b)) { o[0] = (float)b[0]; o[1] = (float)b[1]; o[2] = (float)b[2]; }
+      else { o[0] = o[1] = o[2] = 0; }
+    }
+  }
+  return nt;
+}
+
+// elas.cpp:579-659.  The 3x3 dilation runs over the FLATTENED cell index, so border columns wrap
+// into neighbouring rows and the first/last cell rows stay empty — reproduced, not fixed.
+extern "C" void orc_grid(const orc_params* p, const int32_t* uvd, int32_t n, int32_t W, int32_t H, int right,
+                         int32_t* grid, int32_t* dims3) {
+  const int gs = p->grid_size, ND = p->disp_max + 1;
+  const int gw = (int)std::ceil((float)W / (float)gs), gh = (int)std::ceil((float)H / (float)gs);   // elas.cpp:90-91
+  dims3[0] = p->disp_max + 2; dims3[1] = gw; dims3[2] = gh;
+  const size_t cells = (size_t)gw * gh;
+  std::vector<int32_t> t1(cells * ND, 0), t2(cells * ND, 0);
+  for (int i = 0; i < n; i++) {
+    int xc = uvd[3 * i], yc = uvd[3 * i + 1], dc = uvd[3 * i + 2];
+    int lo = std::max(dc - 1, 0), hi = std::min(dc + 1, p->disp_max);
+    for (int d = lo; d <= hi; d++) {
+      int x = right ? (int)std::floor((float)(xc - dc) / (float)gs) : (int)std::floor((float)(xc / gs));
+      int y = (int)std::floor((float)yc / (float)gs);
+      if (x >= 0 && x < gw && y >= 0 && y < gh) t1[((size_t)y * gw + x) * ND + d] = 1;
+    }
+  }
+  const long long total = (long long)cells * ND;
+  const long long first = (long long)(gw + 1) * ND;
+  const long long count = total - (long long)(2 * gw + 2) * ND;
+  const long long off[9] = {-(long long)(gw + 1) * ND, -(long long)gw * ND, -(long long)(gw - 1) * ND, -ND, 0, ND,
+                            (long long)(gw - 1) * ND, (long long)gw * ND, (long long)(gw + 1) * ND};
+  for (long long r = first; r < first + count; r++) {
+    int32_t acc = 0;
+    for (int k = 0; k < 9; k++) acc |= t1[r + off[k]];
+    t2[r] = acc;
+  }
+  memset(grid, 0, sizeof(int32_t) * cells * (p->disp_max + 2));
+  for (int x = 0; x < gw; x++)
+    for (int y = 0; y < gh; y++) {
+      int32_t* cell = grid + ((size_t)y * gw + x) * (p->disp_max + 2);
+      int cnt = 0;
+      for (int d = 0; d <= p->disp_max; d++)
+        if (t2[((size_t)y * gw + x) * ND + d] > 0) cell[++cnt] = d;
+      cell[0] = cnt;
+    }
+}
+
+namespace {
+
+struct DenseCtx {
+  const orc_params* p; int W, H; const int32_t* grid; const int32_t* gd;
+  const uint8_t* A; const uint8_t* B;   // A: descriptors of the image being filled, B: the other one
+  const int32_t* P; int radius; bool right; float* D;
+};
+
+// elas.cpp:683-780
+inline void find_match(const DenseCtx& c, int u, int v, float pa, float pb, float pc, bool valid) {
+  const int W = c.W, H = c.H, win = 2, disp_num = c.gd[0] - 1;
+  if (u < win || u >= W - win) return;
+  const int vr = std::max(std::min(v, H - 3), 2);
+  const uint8_t* lineA = c.A + (size_t)16 * W * vr; const uint8_t* lineB = c.B + (size_t)16 * W * vr;
+  const uint8_t* a = lineA + 16 * u;
+  if (texture16(a) < c.p->match_texture) return;
+  const int d_plane = (int32_t)(pa * (float)u + pb * (float)v + pc);
+  const int lo = std::max(d_plane - c.radius, 0), hi = std::min(d_plane + c.radius, disp_num - 1);
+  const int gx = (int)std::floor((float)u / (float)c.p->grid_size), gy = (int)std::floor((float)v / (float)c.p->grid_size);
+  const int32_t* cell = c.grid + ((size_t)gy * c.gd[1] + gx) * c.gd[0];
+  const int ng = cell[0];
+  int best = 10000, best_d = -1;
+  for (int i = 0; i < ng; i++) {
+    int d = cell[1 + i];
+    if (d < lo || d > hi) {
+      int uw = c.right ? u + d : u - d;
+      if (uw < win || uw >= W - win) continue;
+      int val = sad16(a, lineB + 16 * uw);
+      if (val < best) { best = val; best_d = d; }
+    }
+  }
+  for (int d = lo; d <= hi; d++) {
+    int uw = c.right ? u + d : u - d;
+    if (uw < win || uw >= W - win) continue;
+    int val = sad16(a, lineB + 16 * uw) + (valid ? c.P[std::abs(d - d_plane)] : 0);
+    if (val < best) { best = val; best_d = d; }
+  }
+  c.D[(size_t)v * W + u] = best_d >= 0 ? (float)best_d : -1.0f;
+}
+
+}  // namespace
+
+// elas.cpp:783-907
+extern "C" void orc_dense(const orc_params* p, const int32_t* uvd, int32_t nsup, const int32_t* corners,
+                          const float* planes, int32_t ntri, const int32_t* grid, const int32_t* gd,
+                          const uint8_t* desc1, const uint8_t* desc2, int32_t W, int32_t H, int right, float* D) {
+  (void)nsup;
+  const int disp_num = gd[0] - 1;
+  for (size_t i = 0; i < (size_t)W * H; i++) D[i] = -10;
+  std::vector<int32_t> P(disp_num);
+  const float two_sigma_sq = 2 * p->sigma * p->sigma;
+  for (int dd = 0; dd < disp_num; dd++)                                        // :804-805, all in float
+    P[dd] = (int32_t)((-std::log(p->gamma + std::exp(-dd * dd / two_sigma_sq)) + std::log(p->gamma)) / p->beta);
+  DenseCtx c{p, W, H, grid, gd, right ? desc2 : desc1, right ? desc1 : desc2, P.data(),
+             (int32_t)std::max((float)std::ceil(p->sigma * p->sradius), 2.0f), right != 0, D};
+  for (int t = 0; t < ntri; t++) {
+    const float* pl = planes + 6 * t;
+    const float pa = right ? pl[3] : pl[0], pb = right ? pl[4] : pl[1], pc = right ? pl[5] : pl[2];
+    const float pd = right ? pl[0] : pl[3];
+    float tu[3], tv[3];
+    for (int k = 0; k < 3; k++) {
+      const int32_t* s = uvd + 3 * corners[3 * t + k];
+      tu[k] = (float)(right ? s[0] - s[2] : s[0]); tv[k] = (float)s[1];
+    }
+    for (int j = 0; j < 3; j++)                                               // :847-854
+      for (int k = 0; k < j; k++)
+        if (tu[k] > tu[j]) { std::swap(tu[j], tu[k]); std::swap(tv[j], tv[k]); }
+    const float Au = tu[0], Av = tv[0], Bu = tu[1], Bv = tv[1], Cu = tu[2], Cv = tv[2];
+    float ABa = 0, ACa = 0, BCa = 0;
+    if ((int32_t)Au != (int32_t)Bu) ABa = (Av - Bv) / (Au - Bu);
+    if ((int32_t)Au != (int32_t)Cu) ACa = (Av - Cv) / (Au - Cu);
+    if ((int32_t)Bu != (int32_t)Cu) BCa = (Bv - Cv) / (Bu - Cu);
+    const float ABb = Av - ABa * Au, ACb = Av - ACa * Au, BCb = Bv - BCa * Bu;
+    const bool valid = std::fabs(pa) < 0.7 && std::fabs(pd) < 0.7;             // :872 (double compare)
+    if ((int32_t)Au != (int32_t)Bu)
+      for (int u = std::max((int32_t)Au, 0); u < std::min((int32_t)Bu, W); u++) {
+        int v1 = (int32_t)(uint32_t)(ACa * (float)u + ACb), v2 = (int32_t)(uint32_t)(ABa * (float)u + ABb);
+        for (int v = std::min(v1, v2); v < std::max(v1, v2); v++) find_match(c, u, v, pa, pb, pc, valid);
+      }
+    if ((int32_t)Bu != (int32_t)Cu)
+      for (int u = std::max((int32_t)Bu, 0); u < std::min((int32_t)Cu, W); u++) {
+        int v1 = (int32_t)(uint32_t)(ACa * (float)u + ACb), v2 = (int32_t)(uint32_t)(BCa * (float)u + BCb);
+        for (int v = std::min(v1, v2); v < std::max(v1, v2); v++) find_match(c, u, v, pa, pb, pc, valid);
+      }
+  }
+}
+
+// elas.cpp:909-979
+extern "C" void orc_lr_check(const orc_params* p, float* D1, float* D2, int32_t W, int32_t H) {
+  std::vector<float> c1(D1, D1 + (size_t)W * H), c2(D2, D2 + (size_t)W * H);
+  for (int u = 0; u < W; u++)
+    for (int v = 0; v < H; v++) {
+      size_t a = (size_t)v * W + u;
+      float d1 = c1[a], d2 = c2[a];
+      float w1 = (float)u - d1, w2 = (float)u + d2;
+      if (d1 >= 0 && w1 >= 0 && w1 < W) {
+        if (std::fabs(c2[(size_t)v * W + (int32_t)w1] - d1) > p->lr_threshold) D1[a] = -10;
+      } else D1[a] = -10;
+      if (d2 >= 0 && w2 >= 0 && w2 < W) {
+        if (std::fabs(c1[(size_t)v * W + (int32_t)w2] - d2) > p->lr_threshold) D2[a] = -10;
+      } else D2[a] = -10;
+    }
+}
+
+// elas.cpp:981-1099: flood fill in u-outer/v-inner start order; segments smaller than
+// speckle_size are invalidated.
+extern "C" void orc_speckle(const orc_params* p, float* D, int32_t W, int32_t H) {
+  std::vector<uint8_t> done((size_t)W * H, 0);
+  std::vector<int32_t> list((size_t)W * H);
+  for (int u = 0; u < W; u++)
+    for (int v = 0; v < H; v++) {
+      int start = v * W + u;
+      if (done[start]) continue;
+      int count = 1, cur = 0; list[0] = start;
+      while (cur < count) {
+        int a = list[cur]; int cu = a % W, cv = a / W;
+        const int nu[4] = {cu - 1, cu + 1, cu, cu}, nv[4] = {cv, cv, cv - 1, cv + 1};
+        for (int i = 0; i < 4; i++)
+          if (nu[i] >= 0 && nv[i] >= 0 && nu[i] < W && nv[i] < H) {
+            int b = nv[i] * W + nu[i];
+            if (!done[b] && D[b] >= 0 && std::fabs(D[a] - D[b]) <= p->speckle_sim_threshold) { list[count++] = b; done[b] = 1; }
+          }
+        cur++; done[a] = 1;
+      }
+      if (count < p->speckle_size)
+        for (int i = 0; i < count; i++) D[list[i]] = -10;
+    }
+}
+
+// elas.cpp:1101-1284
+extern "C" void orc_gap(const orc_params* p, float* D, int32_t W, int32_t H) {
+  const int gap = p->ipol_gap_width; const float discon = 3.0f;
+  auto fill = [&](int n, auto at) {   // one scan line of length n through accessor at(i) -> float&
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+      if (at(i) >= 0) {
+        if (count >= 1 && count <= gap) {
+          int first = i - count, last = i - 1;
+          if (first > 0 && last < n - 1) {
+            float d1 = at(first - 1), d2 = at(last + 1);
+            float dip = std::fabs(d1 - d2) < discon ? (d1 + d2) / 2 : std::min(d1, d2);
+            for (int k = first; k <= last; k++) at(k) = dip;
+          }
+        }
+        count = 0;
+      } else count++;
+    }
+    if (p->add_corners) {            // :1169-1198 / :1253-1282 extrapolation to the borders
+      for (int i = 0; i < n; i++)
+        if (at(i) >= 0) { for (int k = std::max(i - gap, 0); k < i; k++) at(k) = at(i); break; }
+      for (int i = n - 1; i >= 0; i--)
+        if (at(i) >= 0) { for (int k = i; k <= std::min(i + gap, n - 1); k++) at(k) = at(i); break; }
+    }
+  };
+  for (int v = 0; v < H; v++) fill(W, [&](int u) -> float& { return D[(size_t)v * W + u]; });
+  for (int u = 0; u < W; u++) fill(H, [&](int v) -> float& { return D[(size_t)v * W + u]; });
+}
+
+namespace {
+// elas.cpp:1311-1320, 1411-1432.  `_mm_set1_ps(0x7FFFFFFF)` converts the INTEGER to float (2^31,
+// bit pattern 0x4F000000), so the "abs mask" keeps only a few exponent bits of the difference:
+// the weight is 4 for |delta|<2, 2 for 2<=|delta|<8, 0 otherwise.  Reproduced bit for bit.
+inline float am_weight(float x, float centre) {
+  float diff = x - centre; uint32_t b; memcpy(&b, &diff, 4); b &= 0x4F000000u;
+  float m; memcpy(&m, &b, 4);
+  return std::max(0.0f, 4.0f - m);
+}
+// 8-slot ring (slot = index mod 8); sums formed lane-wise (slot l + slot l+4) then ((l0+l1)+l2)+l3.
+inline bool am_eval(const float val[8], float centre, float& out) {
+  float w[8], f[8];
+  for (int i = 0; i < 8; i++) { w[i] = am_weight(val[i], centre); f[i] = val[i] * w[i]; }
+  float ws[4], fs[4];
+  for (int l = 0; l < 4; l++) { ws[l] = w[l] + w[l + 4]; fs[l] = f[l] + f[l + 4]; }
+  float wsum = ws[0] + ws[1] + ws[2] + ws[3], fsum = fs[0] + fs[1] + fs[2] + fs[3];
+  if (wsum > 0) { float d = fsum / wsum; if (d >= 0) { out = d; return true; } }
+  return false;
+}
+}  // namespace
+
+// elas.cpp:1287-1492 (full-resolution branch :1394-1484).  The reference's D_tmp is malloc'ed and
+// only partially written; here it starts as a copy of D_copy, which only changes values the
+// reference leaves indeterminate (never reached for ROBOTICS inputs — SURVEY.md §8a note).
+extern "C" void orc_adaptive_mean(float* D, int32_t W, int32_t H) {
+  std::vector<float> cp((size_t)W * H), tmp((size_t)W * H);
+  for (size_t i = 0; i < (size_t)W * H; i++) cp[i] = D[i] < 0 ? -10.0f : D[i];
+  tmp = cp;
+  float val[8];
+  for (int v = 3; v < H - 3; v++) {
+    const float* row = &cp[(size_t)v * W];
+    for (int u = 0; u < 7 && u < W; u++) val[u] = row[u];
+    for (int u = 7; u < W; u++) {
+      float centre = row[u - 3];
+      val[u % 8] = row[u];
+      float d; if (am_eval(val, centre, d)) tmp[(size_t)v * W + u - 3] = d;
+    }
+  }
+  for (int u = 3; u < W - 3; u++) {
+    for (int v = 0; v < 7 && v < H; v++) val[v] = tmp[(size_t)v * W + u];
+    for (int v = 7; v < H; v++) {
+      float centre = tmp[(size_t)(v - 3) * W + u];
+      val[v % 8] = tmp[(size_t)v * W + u];
+      float d; if (am_eval(val, centre, d)) D[(size_t)(v - 3) * W + u] = d;
+    }
+  }
+}
+
+// elas.cpp:1494-1560 (7-tap separable median; the vertical pass tests D, reads D_temp).
+extern "C" void orc_median(float* D, int32_t W, int32_t H) {
+  std::vector<float> tmp((size_t)W * H, 0.0f);
+  const int win = 3; float vals[7];
+  auto med = [&](auto get) {
+    int j = 0;
+    for (int k = -win; k <= win; k++) {
+      float t = get(k); int i = j - 1;
+      while (i >= 0 && vals[i] > t) { vals[i + 1] = vals[i]; i--; }
+      vals[i + 1] = t; j++;
+    }
+    return vals[win];
+  };
+  for (int u = win; u < W - win; u++)
+    for (int v = win; v < H - win; v++) {
+      size_t a = (size_t)v * W + u;
+      tmp[a] = D[a] >= 0 ? med([&](int k) { return D[a + k]; }) : D[a];
+    }
+  for (int u = win; u < W - win; u++)
+    for (int v = win; v < H - win; v++) {
+      size_t a = (size_t)v * W + u;
+      if (D[a] >= 0) D[a] = med([&](int k) { return tmp[(size_t)(v + k) * W + u]; });
+    }
+}
+
+// elas.cpp:32-151
+extern "C" int32_t orc_elas_process(const orc_params* p, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                                    int32_t W, int32_t H, int32_t pitch) {
+  if (p->subsampling) return 2;
+  std::vector<uint8_t> desc1((size_t)16 * W * H), desc2((size_t)16 * W * H);
+  orc_descriptor(I1, W, H, pitch, desc1.data());
+  orc_descriptor(I2, W, H, pitch, desc2.data());
+  std::vector<SupportPt> sup = support_points(p, desc1.data(), desc2.data(), W, H);
+  if (sup.size() < 3) return 1;                                               // :66-71, outputs untouched
+  const int32_t n = (int32_t)sup.size();
+  const int32_t* uvd = &sup[0].u;
+  const int32_t cap = 2 * n + 16;
+  std::vector<int32_t> c1((size_t)3 * cap), c2((size_t)3 * cap);
+  std::vector<float> pl1((size_t)6 * cap), pl2((size_t)6 * cap);
+  int32_t n1 = orc_triangles(uvd, n, 0, c1.data(), pl1.data(), cap);
+  int32_t n2 = orc_triangles(uvd, n, 1, c2.data(), pl2.data(), cap);
+  if (n1 < 0 || n2 < 0) return 3;
+  int32_t gd[3];
+  const int gw = (int)std::ceil((float)W / (float)p->grid_size), gh = (int)std::ceil((float)H / (float)p->grid_size);
+  std::vector<int32_t> g1((size_t)gw * gh * (p->disp_max + 2)), g2(g1.size());
+  orc_grid(p, uvd, n, W, H, 0, g1.data(), gd);
+  orc_grid(p, uvd, n, W, H, 1, g2.data(), gd);
+  orc_dense(p, uvd, n, c1.data(), pl1.data(), n1, g1.data(), gd, desc1.data(), desc2.data(), W, H, 0, D1);
+  orc_dense(p, uvd, n, c2.data(), pl2.data(), n2, g2.data(), gd, desc1.data(), desc2.data(), W, H, 1, D2);
+  orc_lr_check(p, D1, D2, W, H);
+  orc_speckle(p, D1, W, H);
+  if (!p->postprocess_only_left) orc_speckle(p, D2, W, H);
+  orc_gap(p, D1, W, H);
+  if (!p->postprocess_only_left) orc_gap(p, D2, W, H);
+  if (p->filter_adaptive_mean) { orc_adaptive_mean(D1, W, H); if (!p->postprocess_only_left) orc_adaptive_mean(D2, W, H); }
+  if (p->filter_median) { orc_median(D1, W, H); if (!p->postprocess_only_left) orc_median(D2, W, H); }
+  return 0;
+}

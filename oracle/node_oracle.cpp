@@ -1,0 +1,167 @@
+// oracle/node_oracle.cpp — TEST INFRASTRUCTURE (CPU restatement), not product code.
+//
+// Restates the per-frame arithmetic of the reference node that sits after Elas::process
+// (reference: src/obstacle_avoidance/point_cloud.cpp).  That file needs ROS + OpenCV and cannot
+// be compiled in this image, so these functions are pinned by definition, not by execution:
+//   * Mat::convertTo(CV_8U)        -> round-half-to-even + saturate (OpenCV saturate_cast/cvRound)
+//   * Mat 4x4*4x1 / 3x3*3x1 double -> plain dot products in row order
+//   * everything else              -> the literal C++ of the cited lines.
+// PARITY UNPINNED for the OpenCV boundary (no reference test or runnable build exists for it);
+// BASELINE.json asks for float reprojection within 1e-4, which this definition satisfies.
+//
+// One intentional divergence: the reference indexes scan[k] without a bounds
+// check and divides by pos.w without a zero check; here pixels with pos.w == 0 are skipped and
+// out-of-range bins are not written (their angle/range still enter the min/max, which the
+// reference computes before the undefined write).
+#include "oracle.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+namespace {
+const double INF_RANGE = 1e9;   // point_cloud.cpp:54
+
+struct P3 { double x, y, z; };
+
+// point_cloud.cpp:237-253: pos = Q*[i+ox, j+oy, d, 1]; cam = pos.xyz/pos.w; robot = XR*cam + XT
+inline bool reproject(const orc_scan_params* sp, int i, int j, int d, P3& out) {
+  const double V[4] = {(double)(i + sp->crop_offset_x), (double)(j + sp->crop_offset_y), (double)d, 1.0};
+  double pos[4];
+  for (int r = 0; r < 4; r++) {
+    double s = 0;
+    for (int k = 0; k < 4; k++) s += sp->Q[4 * r + k] * V[k];
+    pos[r] = s;
+  }
+  if (pos[3] == 0.0) return false;
+  const double c[3] = {pos[0] / pos[3], pos[1] / pos[3], pos[2] / pos[3]};
+  double o[3];
+  for (int r = 0; r < 3; r++) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += sp->XR[3 * r + k] * c[k];
+    o[r] = s + sp->XT[r];
+  }
+  out.x = o[0]; out.y = o[1]; out.z = o[2];
+  return true;
+}
+
+// point_cloud.cpp:128-137 / :166-172: true if the point is ground (to be ignored)
+inline bool is_ground(const orc_scan_params* sp, double X, double Z) {
+  if (X < sp->gp_dist_thresh) return Z < sp->gp_height_thresh;
+  return Z < sp->gp_height_thresh + std::tan(sp->gp_angle_thresh) * (X - sp->gp_dist_thresh);
+}
+
+struct ScanAcc {
+  double* bins; int nb; double amin, amax, rmin, rmax;
+  void init(double* b, int n) { bins = b; nb = n; for (int i = 0; i < n; i++) b[i] = INF_RANGE; amin = 400; amax = -400; rmin = INF_RANGE; rmax = -500; }
+  // point_cloud.cpp:253-267
+  void add(const orc_scan_params* sp, double X, double Y) {
+    double th = std::atan2(Y, X);
+    double deg = th * 180. / sp->pi_approx;
+    amin = std::min(amin, th); amax = std::max(amax, th);
+    double r = std::sqrt(Y * Y + X * X);
+    rmax = std::max(rmax, r); rmin = std::min(rmin, r);
+    double kf = std::floor((double)nb * (sp->fov_deg / 2. - deg) / sp->fov_deg);
+    if (!(kf >= 0 && kf < nb)) return;
+    int k = (int)kf;
+    if (r < bins[k]) bins[k] = r;
+  }
+  void meta(double* m) { m[0] = amin; m[1] = amax; m[2] = rmin; m[3] = rmax; }
+};
+}  // namespace
+
+// Q in the analytic zero-disparity form stereoRectify produces, f/cx/cy scaled
+// from K1 of calibration/amrl_jackal_webcam_stereo.yml (640x360) to WxH, Tx from T[0]; XR/XT
+// from the same file (:39-52).
+extern "C" void orc_scan_params_default(orc_scan_params* sp, int32_t W, int32_t H) {
+  const double sx = (double)W / 640.0, sy = (double)H / 360.0;
+  const double f = 4.6417933392659904e+02 * sx, cx = 3.2479711799310849e+02 * sx, cy = 1.8685472713963392e+02 * sy;
+  const double Tx = -9.4052586442980660e-02;
+  const double Q[16] = {1, 0, 0, -cx, 0, 1, 0, -cy, 0, 0, 0, f, 0, 0, -1.0 / Tx, 0};
+  memcpy(sp->Q, Q, sizeof(Q));
+  const double XR[9] = {-0.0007962732853436516, -0.2675000227968607, 0.9635575706420958,
+                        -0.9999984502796089, -0.001321509725770019, -0.00119326128710218,
+                        0.001592547981999815, -0.9635569909380592, -0.2674985457970802};
+  memcpy(sp->XR, XR, sizeof(XR));
+  sp->XT[0] = 0; sp->XT[1] = 0; sp->XT[2] = 0.28;
+  sp->crop_offset_x = 0; sp->crop_offset_y = 0;
+  sp->gp_height_thresh = 0.05; sp->gp_angle_thresh = 4. * 3.1415 / 180.; sp->gp_dist_thresh = 1.0;   // :66-68
+  sp->fov_deg = 90.; sp->bins = 90; sp->pi_approx = 3.1415;                                            // :217-218,254
+}
+
+// point_cloud.cpp:422
+extern "C" void orc_disparity_to_u8(const float* D, uint8_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    float r = std::nearbyintf(D[i]);              // round-half-even in the default FP environment
+    out[i] = (uint8_t)(r < 0.f ? 0 : (r > 255.f ? 255 : (int)r));
+  }
+}
+
+// point_cloud.cpp:104-147.  lut[...][0] = smallest d in [3,255] whose robot-frame point is above
+// the ground model, stored in a uchar so "none" (256) wraps to 0; lut[...][1] = 255.
+extern "C" void orc_build_valid_disp_lut(const orc_scan_params* sp, int32_t W, int32_t H, uint8_t* lut) {
+  for (int i = 0; i < W; i++)
+    for (int j = 0; j < H; j++) {
+      int d;
+      for (d = 3; d <= 255; d++) {
+        P3 p;
+        if (!reproject(sp, i, j, d, p)) continue;
+        if (p.z < 0.) continue;
+        if (is_ground(sp, p.x, p.z)) continue;
+        break;
+      }
+      lut[((size_t)j * W + i) * 2] = (uint8_t)d;
+      lut[((size_t)j * W + i) * 2 + 1] = 255;
+    }
+}
+
+// point_cloud.cpp:213-296
+extern "C" int64_t orc_obstacle_scan(const orc_scan_params* sp, const uint8_t* disp, const uint8_t* lut, int32_t W,
+                                     int32_t H, double* bins, double* meta4) {
+  ScanAcc acc; acc.init(bins, sp->bins);
+  int64_t used = 0;
+  for (int i = 0; i < W; i++)
+    for (int j = 0; j < H; j++) {
+      int d = disp[(size_t)j * W + i];
+      const uint8_t* l = lut + ((size_t)j * W + i) * 2;
+      if (d < l[0] || d > l[1]) continue;
+      P3 p;
+      if (!reproject(sp, i, j, d, p)) continue;
+      acc.add(sp, p.x, p.y); used++;
+    }
+  acc.meta(meta4);
+  return used;
+}
+
+// point_cloud.cpp:278-282
+extern "C" int32_t orc_compact_ranges(const double* bins, int32_t nb, float* ranges) {
+  int32_t n = 0;
+  for (int i = nb - 1; i >= 0; i--)
+    if (bins[i] < INF_RANGE - 1) ranges[n++] = (float)bins[i];
+  return n;
+}
+
+// point_cloud.cpp:321-352 (-g): every pixel with d >= 2, i-outer / j-inner, as float32 Point32.
+extern "C" int64_t orc_point_cloud(const orc_scan_params* sp, const uint8_t* disp, int32_t W, int32_t H, float* xyz) {
+  int64_t n = 0;
+  for (int i = 0; i < W; i++)
+    for (int j = 0; j < H; j++) {
+      int d = disp[(size_t)j * W + i];
+      if (d < 2) continue;
+      P3 p;
+      if (!reproject(sp, i, j, d, p)) continue;
+      xyz[3 * n] = (float)p.x; xyz[3 * n + 1] = (float)p.y; xyz[3 * n + 2] = (float)p.z; n++;
+    }
+  return n;
+}
+
+// point_cloud.cpp:149-211
+extern "C" int64_t orc_obstacle_scan_points(const orc_scan_params* sp, const double* xyz, int64_t n, double* bins, double* meta4) {
+  ScanAcc acc; acc.init(bins, sp->bins);
+  int64_t used = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (is_ground(sp, xyz[3 * i], xyz[3 * i + 2])) continue;
+    acc.add(sp, xyz[3 * i], xyz[3 * i + 1]); used++;
+  }
+  acc.meta(meta4);
+  return used;
+}
