@@ -1,0 +1,211 @@
+/* jn_stereo.h — C ABI of libjn_stereo.so: the MI355X (gfx950) replacement for the per-frame hot
+ * path of jackal_nav's `point_cloud` node.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * repository sourishg/jackal-navigation).  Plain pointers and sizes only; no C++/torch types.
+ * "device pointer" = memory of the GPU the handle was created on (hipMalloc or a torch tensor's
+ * data_ptr()); everything else is host memory.
+ *
+ * Seam B1  Elas::parameters / Elas::process          src/elas/elas.h:59-162, elas.cpp:32-151
+ * Seam B2  convertTo(CV_8U), cacheDisparityValues,    src/obstacle_avoidance/point_cloud.cpp:422,
+ *          publishObstacleScan(Mat&), publishPointCloud   :104-147, :213-296, :298-404
+ *
+ * There is no CPU fallback: every compute entry point returns JN_ERR_NO_DEVICE when no gfx950
+ * device is usable.
+ */
+#ifndef JN_STEREO_H
+#define JN_STEREO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum jn_status {
+  JN_OK = 0,
+  JN_ERR_FEW_SUPPORT = 1,   /* elas.cpp:66-71 "Need at least 3 support points": outputs left untouched */
+  JN_ERR_UNSUPPORTED = 2,   /* parameter combination outside the HIP path (see jn_elas_create) */
+  JN_ERR_INVALID = 3,       /* bad argument */
+  JN_ERR_NO_DEVICE = 4,     /* no usable HIP device / HIP runtime failure */
+  JN_ERR_INTERNAL = 5
+} jn_status;
+
+/* ---- Seam B1 ------------------------------------------------------------------------------ */
+
+/* Field-for-field mirror of Elas::parameters (elas.h:60-82); bools widened to int32. */
+typedef struct jn_elas_params {
+  int32_t disp_min;
+  int32_t disp_max;
+  float   support_threshold;
+  int32_t support_texture;
+  int32_t candidate_stepsize;
+  int32_t incon_window_size;
+  int32_t incon_threshold;
+  int32_t incon_min_support;
+  int32_t add_corners;
+  int32_t grid_size;
+  float   beta;
+  float   gamma;
+  float   sigma;
+  float   sradius;
+  int32_t match_texture;
+  int32_t lr_threshold;
+  float   speckle_sim_threshold;
+  int32_t speckle_size;
+  int32_t ipol_gap_width;
+  int32_t filter_median;
+  int32_t filter_adaptive_mean;
+  int32_t postprocess_only_left;
+  int32_t subsampling;
+} jn_elas_params;
+
+#define JN_SETTING_ROBOTICS   0
+#define JN_SETTING_MIDDLEBURY 1
+
+/* Elas::parameters::parameters(setting) — elas.h:85-145. */
+void jn_elas_params_default(jn_elas_params* p, int32_t setting);
+
+typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:148) */
+
+/* Replaces `Elas elas(param)` (point_cloud.cpp:416-418), but long-lived: all device and pinned
+ * buffers for up to `max_batch` WxH pairs per pipeline slot are allocated once.
+ *   device        HIP device ordinal
+ *   host_threads  worker threads for the host stage (support-point filters, Delaunay, planes,
+ *                 grid prior); 0 = one per online core
+ *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
+ * Unsupported (JN_ERR_UNSUPPORTED): subsampling, add_corners, filter_median, disp_max > 255,
+ * disp_min != 0, ipol_gap_width > 64, candidate_stepsize < 1, plane radius > 7. */
+jn_status jn_elas_create(const jn_elas_params* p, int32_t width, int32_t height, int32_t max_batch,
+                         int32_t device, int32_t host_threads, int32_t slots, jn_elas** out);
+void jn_elas_destroy(jn_elas* h);
+
+/* Drop-in for Elas::process (elas.h:154-162, elas.cpp:32).  Host pointers; synchronous.
+ * dims = {width, height, bytes per line}; D1/D2 are caller-allocated width*height floats.
+ * Valid disparities are >= 0, invalid ones are -10.  On JN_ERR_FEW_SUPPORT D1/D2 are left
+ * untouched exactly as the reference does (it prints an error and returns). */
+jn_status jn_elas_process(jn_elas* h, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
+                          const int32_t dims[3]);
+
+/* Batched form, device pointers: n rectified pairs, image b at dI + b*image_stride (bytes, rows
+ * `pitch` bytes apart); outputs dD + b*width*height floats.  status[b] (host, may be NULL)
+ * receives JN_OK or JN_ERR_FEW_SUPPORT per pair.  Synchronous on slot 0. */
+jn_status jn_elas_process_batch(jn_elas* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2,
+                                int32_t pitch, int64_t image_stride, float* dD1, float* dD2,
+                                int32_t* status);
+
+/* Pipelined form: enqueue a batch on `slot` and return; the slot's worker runs
+ * GPU stage A -> host stage -> GPU stage B.  jn_elas_wait blocks until that slot is idle and
+ * returns the batch's status (per-pair codes in the `status` array given to submit). */
+jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2,
+                         int32_t pitch, int64_t image_stride, float* dD1, float* dD2, int32_t* status);
+jn_status jn_elas_wait(jn_elas* h, int32_t slot);
+
+/* Per-stage timings of the last batch on a slot, milliseconds (reference stage names,
+ * elas.cpp:54-144 PROFILE labels + JackalTimeLog fields msg/JackalTimeLog.msg:1-4). */
+typedef struct jn_stage_times {
+  float gpu_descriptor, gpu_support, d2h, host_stage, h2d, gpu_matching, gpu_lr, gpu_speckle,
+        gpu_gap, gpu_adaptive_mean, total;
+} jn_stage_times;
+jn_status jn_elas_last_times(jn_elas* h, int32_t slot, jn_stage_times* out);
+
+/* ---- Seam B2 ------------------------------------------------------------------------------ */
+
+/* The file-scope state of point_cloud.cpp that the scan functions read (:28-69, :217-218). */
+typedef struct jn_scan_params {
+  double  Q[16];            /* 4x4 row-major, stereoRectify output (point_cloud.cpp:543-544) */
+  double  XR[9];            /* camera->robot rotation (calibration yml, point_cloud.cpp:537) */
+  double  XT[3];            /* camera->robot translation (:538) */
+  int32_t crop_offset_x;    /* :51 */
+  int32_t crop_offset_y;    /* :52 */
+  double  gp_height_thresh; /* GP_HEIGHT_THRESH :66 */
+  double  gp_angle_thresh;  /* GP_ANGLE_THRESH  :67 */
+  double  gp_dist_thresh;   /* GP_DIST_THRESH   :68 */
+  double  fov_deg;          /* :217 */
+  int32_t bins;             /* :218, <= 1024 */
+  double  pi_approx;        /* the literal 3.1415 of :254 */
+} jn_scan_params;
+
+/* Defaults: reference constants, XR/XT of calibration/amrl_jackal_webcam_stereo.yml:39-52 and the
+ * analytic zero-disparity Q for K1/T of that file scaled from 640x360 to width x height. */
+void jn_scan_params_default(jn_scan_params* sp, int32_t width, int32_t height);
+
+#define JN_SCAN_EMPTY 1e9   /* `INF` of point_cloud.cpp:54: value of a bin no pixel fell into */
+
+/* leftdpf.convertTo(show, CV_8U, 1.) (point_cloud.cpp:422): round-half-even, saturate; -10 -> 0.
+ * Device pointers, n elements. */
+jn_status jn_disparity_to_u8(int32_t device, const float* dD, uint8_t* dOut, int64_t n);
+
+/* cacheDisparityValues() (point_cloud.cpp:104-147): dLut is [height][width][2] uint8 (CV_8UC2). */
+jn_status jn_build_valid_disp_lut(int32_t device, const jn_scan_params* sp, int32_t width, int32_t height,
+                                  uint8_t* dLut);
+
+/* publishObstacleScan(Mat&) (point_cloud.cpp:213-296) for n u8 disparity maps (device,
+ * contiguous).  Outputs, device pointers: dBins [n][bins] doubles, un-compacted, JN_SCAN_EMPTY =
+ * no return; dMeta [n][4] = angle_min, angle_max, range_min, range_max (initial values 400, -400,
+ * 1e9, -500 as at :219-220 when no pixel qualifies).
+ * Divergence from the reference (which has undefined behaviour there): pixels whose homogeneous
+ * w is 0 are skipped and bins outside [0,bins) are not written. */
+jn_status jn_obstacle_scan(int32_t device, const jn_scan_params* sp, int32_t n, const uint8_t* dDisp,
+                           const uint8_t* dLut, int32_t width, int32_t height, double* dBins, double* dMeta);
+
+/* Fused tail of the node: float disparity -> u8 map (published on /webcam/left/depth_map) -> scan. */
+jn_status jn_disparity_scan(int32_t device, const jn_scan_params* sp, int32_t n, const float* dD,
+                            const uint8_t* dLut, int32_t width, int32_t height, uint8_t* dDispU8,
+                            double* dBins, double* dMeta);
+
+/* The `ranges` compaction of point_cloud.cpp:278-282 (host): bins < 1e9-1, pushed from the last
+ * bin to the first, as float32.  Returns the count. */
+int32_t jn_compact_ranges(const double* bins, int32_t nbins, float* ranges);
+
+/* publishPointCloud -g (point_cloud.cpp:321-352): every pixel with d >= 2 as a robot-frame
+ * float32 xyz triple, in the reference's i-outer / j-inner order.  dXyz must hold
+ * width*height*3 floats; *count (host) receives the number of points. */
+jn_status jn_point_cloud(int32_t device, const jn_scan_params* sp, const uint8_t* dDisp, int32_t width,
+                         int32_t height, float* dXyz, int64_t* count);
+
+/* ---- utilities ---------------------------------------------------------------------------- */
+
+/* Synthetic rectified pair of the benchmark (SURVEY.md Appendix A generator), host buffers. */
+void jn_synth_pair(int32_t width, int32_t height, int32_t scene_disp, uint32_t seed, uint8_t* L, uint8_t* R);
+
+/* Device helpers so that non-torch callers (tests, C hosts) need no HIP headers. */
+jn_status jn_device_count(int32_t* count);
+jn_status jn_device_malloc(int32_t device, int64_t bytes, void** out);
+jn_status jn_device_free(int32_t device, void* p);
+jn_status jn_memcpy_h2d(int32_t device, void* dst, const void* src, int64_t bytes);
+jn_status jn_memcpy_d2h(int32_t device, void* dst, const void* src, int64_t bytes);
+jn_status jn_device_synchronize(int32_t device);
+
+/* Timing of one kernel class with HIP events on the library's own stream, for bench.py's
+ * roofline block: average milliseconds per launch of the dense-matching kernel during the last
+ * batch of `slot` (both sides), and launches counted. */
+jn_status jn_elas_kernel_time(jn_elas* h, int32_t slot, const char* kernel, float* avg_ms, int32_t* launches);
+
+const char* jn_version(void);
+
+/* ---- host-stage hooks (CPU only; no device needed) ------------------------------------------
+ * The serial middle of ELAS runs on host threads between the two GPU stages.  These two entry
+ * points expose it so it can be verified, and reused by other hosts, without a GPU. */
+
+/* Triangle's "zQB" divide-and-conquer result (src/elas/triangle.cpp:8499 as called from
+ * elas.cpp:487-488) for n integer points: writes (org,dest,apex) per triangle into tri
+ * (capacity 6*n ints); returns the triangle count or -1. */
+int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri);
+
+/* Support filters + support list + Delaunay x2 + planes + grid prior for ONE frame
+ * (elas.cpp:416-431, :445-577, :579-659).  d_can [ch][cw] is filtered in place.  payload receives
+ * the records the GPU consumes (layout: jn_host_frame_info); returns bytes used or -1 if
+ * payload_cap is too small. */
+typedef struct jn_host_frame_info {
+  int32_t ok, nsup, ntri[2];
+  int64_t tri_offset[2];    /* 48-byte triangle records: int16 Au,Bu,Cu; uint16 flags; float ACa,ACb,ABa,ABb,BCa,BCb; float pa,pb,pc; int32 pad */
+  int64_t grid_offset[2];   /* [gh*gw][8] uint32 candidate bitsets */
+} jn_host_frame_info;
+int64_t jn_host_stage(const jn_elas_params* p, int32_t width, int32_t height, int16_t* d_can, uint8_t* payload,
+                      int64_t payload_cap, jn_host_frame_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JN_STEREO_H */

@@ -1,0 +1,10 @@
+"""jackal_navigation_amd — MI355X (gfx950) implementation of jackal_nav's `point_cloud` hot path.
+
+Rectified stereo pair -> ELAS disparity -> u8 depth map -> Q reprojection -> ground-plane filter ->
+90-bin obstacle scan, as hand-written HIP kernels behind a C ABI (include/jn_stereo.h,
+libjn_stereo.so).  This package is the thin host-side mirror of the reference interfaces; all
+compute lives in csrc/.  Importing the compute API requires the built library; there is no CPU path.
+"""
+from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # noqa: F401
+from .elas import Elas  # noqa: F401
+from . import node, device  # noqa: F401

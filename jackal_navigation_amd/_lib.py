@@ -1,0 +1,110 @@
+"""Loader for libjn_stereo.so (the C-ABI declared in include/jn_stereo.h).
+
+There is no CPU fallback: if the shared library is missing or does not load, importing the compute
+API raises.  When PyTorch is installed it is imported FIRST so that this library binds to the HIP
+runtime torch already loaded (one HIP runtime per process; see csrc/Makefile).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjn_stereo.so")
+
+JN_OK, JN_ERR_FEW_SUPPORT, JN_ERR_UNSUPPORTED, JN_ERR_INVALID, JN_ERR_NO_DEVICE, JN_ERR_INTERNAL = range(6)
+STATUS_NAMES = ["JN_OK", "JN_ERR_FEW_SUPPORT", "JN_ERR_UNSUPPORTED", "JN_ERR_INVALID", "JN_ERR_NO_DEVICE", "JN_ERR_INTERNAL"]
+
+
+class JnError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__("%s: %s" % (what, STATUS_NAMES[status] if 0 <= status < len(STATUS_NAMES) else status))
+        self.status = status
+
+
+class ElasParams(C.Structure):
+    """jn_elas_params == Elas::parameters (reference src/elas/elas.h:60-82)."""
+    _fields_ = [
+        ("disp_min", C.c_int32), ("disp_max", C.c_int32), ("support_threshold", C.c_float),
+        ("support_texture", C.c_int32), ("candidate_stepsize", C.c_int32), ("incon_window_size", C.c_int32),
+        ("incon_threshold", C.c_int32), ("incon_min_support", C.c_int32), ("add_corners", C.c_int32),
+        ("grid_size", C.c_int32), ("beta", C.c_float), ("gamma", C.c_float), ("sigma", C.c_float),
+        ("sradius", C.c_float), ("match_texture", C.c_int32), ("lr_threshold", C.c_int32),
+        ("speckle_sim_threshold", C.c_float), ("speckle_size", C.c_int32), ("ipol_gap_width", C.c_int32),
+        ("filter_median", C.c_int32), ("filter_adaptive_mean", C.c_int32), ("postprocess_only_left", C.c_int32),
+        ("subsampling", C.c_int32),
+    ]
+
+
+class ScanParams(C.Structure):
+    """jn_scan_params: file-scope state of point_cloud.cpp read by the scan functions (:28-69, :217-218)."""
+    _fields_ = [("Q", C.c_double * 16), ("XR", C.c_double * 9), ("XT", C.c_double * 3),
+                ("crop_offset_x", C.c_int32), ("crop_offset_y", C.c_int32),
+                ("gp_height_thresh", C.c_double), ("gp_angle_thresh", C.c_double), ("gp_dist_thresh", C.c_double),
+                ("fov_deg", C.c_double), ("bins", C.c_int32), ("pi_approx", C.c_double)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("gpu_descriptor", "gpu_support", "d2h", "host_stage", "h2d", "gpu_matching",
+                                         "gpu_lr", "gpu_speckle", "gpu_gap", "gpu_adaptive_mean", "total")]
+
+    def as_dict(self):
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
+
+
+# every symbol include/jn_stereo.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "jn_elas_params_default", "jn_elas_create", "jn_elas_destroy", "jn_elas_process", "jn_elas_process_batch",
+    "jn_elas_submit", "jn_elas_wait", "jn_elas_last_times", "jn_scan_params_default", "jn_disparity_to_u8",
+    "jn_build_valid_disp_lut", "jn_obstacle_scan", "jn_disparity_scan", "jn_compact_ranges", "jn_point_cloud",
+    "jn_synth_pair", "jn_device_count", "jn_device_malloc", "jn_device_free", "jn_memcpy_h2d", "jn_memcpy_d2h",
+    "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
+]
+
+_lib = None
+
+
+def load():
+    """Return the ctypes handle of libjn_stereo.so; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libjn_stereo.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C jackal_navigation_amd/csrc`); there is no CPU fallback")
+    try:  # share torch's HIP runtime when torch is present
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
+        pass
+    L = C.CDLL(LIB_PATH)
+    L.jn_version.restype = C.c_char_p
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.jn_elas_create.argtypes = [C.POINTER(ElasParams), i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
+    L.jn_elas_destroy.argtypes = [vp]
+    L.jn_elas_process.argtypes = [vp, vp, vp, vp, vp, C.POINTER(i32 * 3)]
+    L.jn_elas_process_batch.argtypes = [vp, i32, vp, vp, i32, i64, vp, vp, vp]
+    L.jn_elas_submit.argtypes = [vp, i32, i32, vp, vp, i32, i64, vp, vp, vp]
+    L.jn_elas_wait.argtypes = [vp, i32]
+    L.jn_elas_last_times.argtypes = [vp, i32, C.POINTER(StageTimes)]
+    L.jn_elas_kernel_time.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_float), C.POINTER(i32)]
+    L.jn_disparity_to_u8.argtypes = [i32, vp, vp, i64]
+    L.jn_build_valid_disp_lut.argtypes = [i32, C.POINTER(ScanParams), i32, i32, vp]
+    L.jn_obstacle_scan.argtypes = [i32, C.POINTER(ScanParams), i32, vp, vp, i32, i32, vp, vp]
+    L.jn_disparity_scan.argtypes = [i32, C.POINTER(ScanParams), i32, vp, vp, i32, i32, vp, vp, vp]
+    L.jn_compact_ranges.argtypes = [vp, i32, vp]
+    L.jn_point_cloud.argtypes = [i32, C.POINTER(ScanParams), vp, i32, i32, vp, C.POINTER(i64)]
+    L.jn_synth_pair.argtypes = [i32, i32, i32, C.c_uint32, vp, vp]
+    L.jn_device_count.argtypes = [C.POINTER(i32)]
+    L.jn_device_malloc.argtypes = [i32, i64, C.POINTER(vp)]
+    L.jn_device_free.argtypes = [i32, vp]
+    L.jn_memcpy_h2d.argtypes = [i32, vp, vp, i64]
+    L.jn_memcpy_d2h.argtypes = [i32, vp, vp, i64]
+    L.jn_device_synchronize.argtypes = [i32]
+    L.jn_host_triangulate.argtypes = [vp, vp, i32, vp]
+    L.jn_host_stage.argtypes = [C.POINTER(ElasParams), i32, i32, vp, vp, i64, vp]
+    L.jn_host_stage.restype = i64
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != JN_OK:
+        raise JnError(status, what)

@@ -1,0 +1,306 @@
+// delaunay.cpp — see delaunay.h.  Host stage of the stereo path (product code).
+//
+// Decision sequence reproduced (reference line numbers in src/elas/triangle.cpp):
+//   sort by (x,y) with LCG-pivot quicksort      :4045-4049, :5446-5500
+//   duplicates: first in sorted order survives   :6179-6194
+//   alternating-cut re-partition                 :5514-5606, :6197-6206
+//   2-/3-vertex bases, recursive hull zipping     :5638-5947, :5953-6103
+//   output = non-ghost triangles, creation order, (org,dest,apex) of edge 0   :6105-6148, :7832-7843
+// Predicates are evaluated exactly in int64 (coordinates are pixel integers), which equals the
+// sign the reference's adaptive float predicates return (:2706-2745, :3334-3379).
+#include "delaunay.h"
+
+namespace jnav {
+
+inline int Delaunay::orient(int a, int b, int c) const {
+  const int64_t acx = x_[a] - x_[c], acy = y_[a] - y_[c], bcx = x_[b] - x_[c], bcy = y_[b] - y_[c];
+  const int64_t det = acx * bcy - acy * bcx;
+  return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+
+inline int Delaunay::in_circle(int a, int b, int c, int d) const {
+  const int64_t ax = x_[a] - x_[d], ay = y_[a] - y_[d];
+  const int64_t bx = x_[b] - x_[d], by = y_[b] - y_[d];
+  const int64_t cx = x_[c] - x_[d], cy = y_[c] - y_[d];
+  const int64_t det = (ax * ax + ay * ay) * (bx * cy - by * cx) + (bx * bx + by * by) * (cx * ay - cy * ax) +
+                      (cx * cx + cy * cy) * (ax * by - ay * bx);
+  return det > 0 ? 1 : (det < 0 ? -1 : 0);
+}
+
+inline bool Delaunay::precedes(int a, int b, int axis) const {
+  const int32_t pa = axis ? y_[a] : x_[a], pb = axis ? y_[b] : x_[b];
+  if (pa != pb) return pa < pb;
+  return (axis ? x_[a] : y_[a]) < (axis ? x_[b] : y_[b]);
+}
+
+unsigned Delaunay::draw(unsigned choices) {
+  lcg_ = (lcg_ * 1366u + 150889u) % 714025u;
+  return (unsigned)(lcg_ / (714025u / choices + 1u));
+}
+
+Delaunay::H Delaunay::fresh() {
+  const int t = ntri_++;
+  link_[3 * t] = link_[3 * t + 1] = link_[3 * t + 2] = -1;
+  vert_[3 * t] = vert_[3 * t + 1] = vert_[3 * t + 2] = -1;
+  return (H)t << 2;
+}
+
+void Delaunay::partition(int32_t* a, int n, int axis, int& l, int& r) {
+  const int pv = a[draw((unsigned)n)];
+  l = -1; r = n;
+  while (l < r) {
+    do ++l; while (l <= r && precedes(a[l], pv, axis));
+    do --r; while (l <= r && precedes(pv, a[r], axis));
+    if (l < r) { const int32_t t = a[l]; a[l] = a[r]; a[r] = t; }
+  }
+}
+
+void Delaunay::quicksort(int32_t* a, int n) {
+  if (n == 2) {
+    if (precedes(a[1], a[0], 0)) { const int32_t t = a[0]; a[0] = a[1]; a[1] = t; }
+    return;
+  }
+  int l, r;
+  partition(a, n, 0, l, r);
+  if (l > 1) quicksort(a, l);
+  if (r < n - 2) quicksort(a + r + 1, n - r - 1);
+}
+
+void Delaunay::select(int32_t* a, int n, int m, int axis) {
+  if (n == 2) {
+    if (precedes(a[1], a[0], axis)) { const int32_t t = a[0]; a[0] = a[1]; a[1] = t; }
+    return;
+  }
+  int l, r;
+  partition(a, n, axis, l, r);
+  if (l > m) select(a, l, m, axis);
+  if (r < m - 1) select(a + r + 1, n - r - 1, m - r - 1, axis);
+}
+
+void Delaunay::cuts(int32_t* a, int n, int axis) {
+  const int half = n >> 1;
+  if (n <= 3) axis = 0;
+  select(a, n, half, axis);
+  if (n - half >= 2) {
+    if (half >= 2) cuts(a, half, 1 - axis);
+    cuts(a + half, n - half, 1 - axis);
+  }
+}
+
+// Merge two triangulated halves by walking up the seam between their hulls.
+void Delaunay::zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis) {
+  int il_dest = v_dest(innerleft), il_apex = v_apex(innerleft);
+  int ir_org = v_org(innerright), ir_apex = v_apex(innerright);
+
+  if (axis == 1) {   // horizontal cut: hull handles must point at the extreme-y vertices
+    int fl_pt = v_org(farleft), fl_apex = v_apex(farleft);
+    int fr_pt = v_dest(farright);
+    while (y_[fl_apex] < y_[fl_pt]) {
+      farleft = across(ccw_edge(farleft));
+      fl_pt = fl_apex; fl_apex = v_apex(farleft);
+    }
+    H probe = across(innerleft); int pv = v_apex(probe);
+    while (y_[pv] > y_[il_dest]) {
+      innerleft = ccw_edge(probe);
+      il_apex = il_dest; il_dest = pv;
+      probe = across(innerleft); pv = v_apex(probe);
+    }
+    while (y_[ir_apex] < y_[ir_org]) {
+      innerright = across(ccw_edge(innerright));
+      ir_org = ir_apex; ir_apex = v_apex(innerright);
+    }
+    probe = across(farright); pv = v_apex(probe);
+    while (y_[pv] > y_[fr_pt]) {
+      farright = ccw_edge(probe);
+      fr_pt = pv;
+      probe = across(farright); pv = v_apex(probe);
+    }
+  }
+
+  for (bool again = true; again;) {   // slide down to the lower common tangent
+    again = false;
+    if (orient(il_dest, il_apex, ir_org) > 0) {
+      innerleft = across(cw_edge(innerleft));
+      il_dest = il_apex; il_apex = v_apex(innerleft); again = true;
+    }
+    if (orient(ir_apex, ir_org, il_dest) > 0) {
+      innerright = across(ccw_edge(innerright));
+      ir_org = ir_apex; ir_apex = v_apex(innerright); again = true;
+    }
+  }
+
+  H lcand = across(innerleft), rcand = across(innerright);
+  H base = fresh();
+  glue(base, innerleft);  base = ccw_edge(base);
+  glue(base, innerright); base = ccw_edge(base);
+  v_org(base) = ir_org; v_dest(base) = il_dest;
+  if (il_dest == v_org(farleft)) farleft = ccw_edge(base);
+  if (ir_org == v_dest(farright)) farright = cw_edge(base);
+
+  int lo_l = il_dest, lo_r = ir_org;
+  int up_l = v_apex(lcand), up_r = v_apex(rcand);
+
+  for (;;) {
+    const bool l_done = orient(up_l, lo_l, lo_r) <= 0;
+    const bool r_done = orient(up_r, lo_l, lo_r) <= 0;
+    if (l_done && r_done) {
+      H cap = fresh();
+      v_org(cap) = lo_l; v_dest(cap) = lo_r;
+      glue(cap, base);  cap = ccw_edge(cap);
+      glue(cap, rcand); cap = ccw_edge(cap);
+      glue(cap, lcand);
+      if (axis == 1) {   // back to extreme-x handles
+        int fl_pt = v_org(farleft);
+        int fr_pt = v_dest(farright), fr_apex = v_apex(farright);
+        H probe = across(farleft); int pv = v_apex(probe);
+        while (x_[pv] < x_[fl_pt]) {
+          farleft = cw_edge(probe);
+          fl_pt = pv;
+          probe = across(farleft); pv = v_apex(probe);
+        }
+        while (x_[fr_apex] > x_[fr_pt]) {
+          farright = across(cw_edge(farright));
+          fr_pt = fr_apex; fr_apex = v_apex(farright);
+        }
+      }
+      return;
+    }
+    if (!l_done) {   // flip away left-hull edges that the new cross edge invalidates
+      H e = across(cw_edge(lcand));
+      int w = v_apex(e);
+      if (w >= 0) {
+        bool bad = in_circle(lo_l, lo_r, up_l, w) > 0;
+        while (bad) {
+          e = ccw_edge(e); const H top = across(e);
+          e = ccw_edge(e); const H side = across(e);
+          glue(e, top);
+          glue(lcand, side);
+          lcand = ccw_edge(lcand); const H outer = across(lcand);
+          e = cw_edge(e);
+          glue(e, outer);
+          v_org(lcand) = lo_l; v_dest(lcand) = -1; v_apex(lcand) = w;
+          v_org(e) = -1; v_dest(e) = up_l; v_apex(e) = w;
+          up_l = w;
+          e = side; w = v_apex(e);
+          bad = w >= 0 && in_circle(lo_l, lo_r, up_l, w) > 0;
+        }
+      }
+    }
+    if (!r_done) {   // same on the right hull, mirrored
+      H e = across(ccw_edge(rcand));
+      int w = v_apex(e);
+      if (w >= 0) {
+        bool bad = in_circle(lo_l, lo_r, up_r, w) > 0;
+        while (bad) {
+          e = cw_edge(e); const H top = across(e);
+          e = cw_edge(e); const H side = across(e);
+          glue(e, top);
+          glue(rcand, side);
+          rcand = cw_edge(rcand); const H outer = across(rcand);
+          e = ccw_edge(e);
+          glue(e, outer);
+          v_org(rcand) = -1; v_dest(rcand) = lo_r; v_apex(rcand) = w;
+          v_org(e) = up_r; v_dest(e) = -1; v_apex(e) = w;
+          up_r = w;
+          e = side; w = v_apex(e);
+          bad = w >= 0 && in_circle(lo_l, lo_r, up_r, w) > 0;
+        }
+      }
+    }
+    if (l_done || (!r_done && in_circle(up_l, lo_l, lo_r, up_r) > 0)) {
+      glue(base, rcand);
+      base = cw_edge(rcand);
+      v_dest(base) = lo_l;
+      lo_r = up_r;
+      rcand = across(base);
+      up_r = v_apex(rcand);
+    } else {
+      glue(base, lcand);
+      base = ccw_edge(lcand);
+      v_org(base) = lo_r;
+      lo_l = up_l;
+      lcand = across(base);
+      up_l = v_apex(lcand);
+    }
+  }
+}
+
+void Delaunay::conquer(int32_t* a, int n, int axis, H& farleft, H& farright) {
+  if (n == 2) {   // a lone edge: two ghosts glued on all three sides
+    farleft = fresh();  v_org(farleft) = a[0];  v_dest(farleft) = a[1];
+    farright = fresh(); v_org(farright) = a[1]; v_dest(farright) = a[0];
+    glue(farleft, farright);
+    farleft = cw_edge(farleft); farright = ccw_edge(farright); glue(farleft, farright);
+    farleft = cw_edge(farleft); farright = ccw_edge(farright); glue(farleft, farright);
+    farleft = cw_edge(farright);
+    return;
+  }
+  if (n == 3) {
+    H mid = fresh(), g1 = fresh(), g2 = fresh(), g3 = fresh();
+    const int turn = orient(a[0], a[1], a[2]);
+    if (turn == 0) {   // collinear triple: two edges, four ghosts
+      v_org(mid) = a[0]; v_dest(mid) = a[1];
+      v_org(g1) = a[1];  v_dest(g1) = a[0];
+      v_org(g2) = a[2];  v_dest(g2) = a[1];
+      v_org(g3) = a[1];  v_dest(g3) = a[2];
+      glue(mid, g1); glue(g2, g3);
+      mid = ccw_edge(mid); g1 = cw_edge(g1); g2 = ccw_edge(g2); g3 = cw_edge(g3);
+      glue(mid, g3); glue(g1, g2);
+      mid = ccw_edge(mid); g1 = cw_edge(g1); g2 = ccw_edge(g2); g3 = cw_edge(g3);
+      glue(mid, g1); glue(g2, g3);
+      farleft = g1; farright = g2;
+    } else {           // one real triangle ringed by three ghosts
+      const int second = turn > 0 ? a[1] : a[2], third = turn > 0 ? a[2] : a[1];
+      v_org(mid) = a[0];   v_dest(g1) = a[0];   v_org(g3) = a[0];
+      v_dest(mid) = second; v_org(g1) = second; v_dest(g2) = second;
+      v_apex(mid) = third;  v_org(g2) = third;  v_dest(g3) = third;
+      glue(mid, g1); mid = ccw_edge(mid);
+      glue(mid, g2); mid = ccw_edge(mid);
+      glue(mid, g3);
+      g1 = cw_edge(g1); g2 = ccw_edge(g2); glue(g1, g2);
+      g1 = cw_edge(g1); g3 = cw_edge(g3);  glue(g1, g3);
+      g2 = ccw_edge(g2); g3 = cw_edge(g3); glue(g2, g3);
+      farleft = g1;
+      farright = turn > 0 ? g2 : ccw_edge(farleft);
+    }
+    return;
+  }
+  const int half = n >> 1;
+  H il, ir;
+  conquer(a, half, 1 - axis, farleft, il);
+  conquer(a + half, n - half, 1 - axis, ir, farright);
+  zip(farleft, il, ir, farright, axis);
+}
+
+int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
+  if (n < 3) return -1;
+  x_ = x; y_ = y; lcg_ = 1; ntri_ = 0;
+  const size_t cap = (size_t)8 * n + 64;   // real + ghost triangles ever created (< 4n)
+  if (link_.size() < 3 * cap) { link_.resize(3 * cap); vert_.resize(3 * cap); }
+  if (order_.size() < (size_t)n) order_.resize(n);
+  int32_t* a = order_.data();
+  for (int i = 0; i < n; i++) a[i] = i;
+  quicksort(a, n);
+  int k = 0;
+  for (int j = 1; j < n; j++)
+    if (x[a[k]] != x[a[j]] || y[a[k]] != y[a[j]]) a[++k] = a[j];
+  ++k;
+  if (k < 2) return -1;
+  const int half = k >> 1;
+  if (k - half >= 2) {
+    if (half >= 2) cuts(a, half, 1);
+    cuts(a + half, k - half, 1);
+  }
+  H hl, hr;
+  conquer(a, k, 0, hl, hr);
+  int out = 0;
+  for (int t = 0; t < ntri_; t++) {
+    const int32_t* c = &vert_[3 * t];
+    if ((c[0] | c[1] | c[2]) < 0) continue;       // ghost
+    tri[3 * out] = c[1]; tri[3 * out + 1] = c[2]; tri[3 * out + 2] = c[0];
+    out++;
+  }
+  return out;
+}
+
+}  // namespace jnav

@@ -1,0 +1,57 @@
+// delaunay.h — host-side triangulation of the support points (product code).
+//
+// ELAS triangulates its support points with Shewchuk's Triangle (reference: src/elas/elas.cpp:445-505
+// calling triangulate("zQB"), src/elas/triangle.cpp:8499).  Support points sit on a 5-pixel lattice,
+// so the Delaunay triangulation is not unique and every downstream disparity depends on the exact
+// tie-breaks of Triangle's divide-and-conquer with alternating cuts.  This class is a re-entrant,
+// allocation-free (after reserve) implementation of that same decision sequence on integer
+// coordinates, so that one instance per host worker thread can run concurrently — the reference
+// keeps its RNG seed and predicate constants in globals (triangle.cpp:541-550) and cannot.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace jnav {
+
+class Delaunay {
+ public:
+  // Triangulate n points (x[i], y[i]), |coord| < 2^15.  Writes (org,dest,apex) vertex indices of
+  // every triangle, in Triangle's output order, to tri (capacity 3*2*n ints).  Returns the number
+  // of triangles, or -1 when fewer than 2 distinct points exist.
+  int run(const int32_t* x, const int32_t* y, int n, int32_t* tri);
+
+ private:
+  typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge
+  const int32_t* x_ = nullptr;
+  const int32_t* y_ = nullptr;
+  std::vector<int32_t> link_;               // 3 per triangle: handle across that edge
+  std::vector<int32_t> vert_;               // 3 per triangle: vertex or -1 (ghost corner)
+  std::vector<int32_t> order_;
+  int ntri_ = 0;
+  uint64_t lcg_ = 1;
+
+  H fresh();
+  inline H across(H h) const { return (H)link_[3 * (h >> 2) + (h & 3)]; }
+  static inline unsigned up(unsigned e) { return e == 2 ? 0u : e + 1u; }      // edge 0->1->2->0
+  static inline unsigned down(unsigned e) { return e == 0 ? 2u : e - 1u; }    // edge 0->2->1->0
+  static inline H ccw_edge(H h) { return (h & ~3u) | up(h & 3); }
+  static inline H cw_edge(H h)  { return (h & ~3u) | down(h & 3); }
+  inline int32_t& v_org(H h)  { return vert_[3 * (h >> 2) + up(h & 3)]; }
+  inline int32_t& v_dest(H h) { return vert_[3 * (h >> 2) + down(h & 3)]; }
+  inline int32_t& v_apex(H h) { return vert_[3 * (h >> 2) + (h & 3)]; }
+  inline void glue(H a, H b) { link_[3 * (a >> 2) + (a & 3)] = (int32_t)b; link_[3 * (b >> 2) + (b & 3)] = (int32_t)a; }
+
+  inline int orient(int a, int b, int c) const;
+  inline int in_circle(int a, int b, int c, int d) const;
+  inline bool precedes(int a, int b, int axis) const;
+  unsigned draw(unsigned choices);
+  void partition(int32_t* a, int n, int axis, int& l, int& r);
+  void quicksort(int32_t* a, int n);
+  void select(int32_t* a, int n, int m, int axis);
+  void cuts(int32_t* a, int n, int axis);
+  void conquer(int32_t* a, int n, int axis, H& farleft, H& farright);
+  void zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis);
+};
+
+}  // namespace jnav

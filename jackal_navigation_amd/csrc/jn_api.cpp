@@ -1,0 +1,532 @@
+// jn_api.cpp — C-ABI of libjn_stereo.so (include/jn_stereo.h).  Product code.
+//
+// Pipeline per batch (one "slot" = one HIP stream + its buffers + one worker thread):
+//   GPU stage A : sobel -> descriptor -> support matching                    (kernels.hip)
+//   D2H         : candidate lattice D_can (int16, 2 bytes per 25 pixels)
+//   host stage  : support filters, Delaunay x2, planes, grid prior          (host_stage.cpp, thread pool)
+//   H2D         : per-frame triangle records + grid bitsets
+//   GPU stage B : raster -> dense L/R -> L/R check -> speckle -> gaps -> adaptive mean
+// Several slots in flight overlap one batch's host stage with another batch's GPU stages.
+#include "../../include/jn_stereo.h"
+#include "kernels.h"
+#include "host_stage.h"
+
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace jnav;
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      fprintf(stderr, "libjn_stereo: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return JN_ERR_NO_DEVICE;                                                              \
+    }                                                                                       \
+  } while (0)
+
+namespace {
+
+// ---- a small task pool shared by all slots of a handle ------------------------------------------
+class Pool {
+ public:
+  Pool(int threads, const HostParams& hp) {
+    for (int i = 0; i < threads; i++) workers_.emplace_back(new HostWorker(hp));
+    for (int i = 0; i < threads; i++) threads_.emplace_back([this, i] { loop(i); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> l(m_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  // Runs fn(worker, i) for i in [0,n) on the pool and blocks until all are done.
+  void run(int n, const std::function<void(HostWorker&, int)>& fn) {
+    if (n <= 0) return;
+    Group g; g.fn = &fn; g.left = n;
+    {
+      std::lock_guard<std::mutex> l(m_);
+      for (int i = 0; i < n; i++) q_.push_back({&g, i});
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> l(g.m);
+    g.cv.wait(l, [&g] { return g.left == 0; });
+  }
+  int size() const { return (int)threads_.size(); }
+
+ private:
+  struct Group { const std::function<void(HostWorker&, int)>* fn; int left; std::mutex m; std::condition_variable cv; };
+  struct Item { Group* g; int i; };
+  void loop(int id) {
+    for (;;) {
+      Item it;
+      {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+        if (stop_ && q_.empty()) return;
+        it = q_.front(); q_.pop_front();
+      }
+      (*it.g->fn)(*workers_[id], it.i);
+      std::lock_guard<std::mutex> l(it.g->m);
+      if (--it.g->left == 0) it.g->cv.notify_all();
+    }
+  }
+  std::vector<std::unique_ptr<HostWorker>> workers_;
+  std::vector<std::thread> threads_;
+  std::deque<Item> q_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+};
+
+struct Job {
+  int n = 0; const uint8_t* dI1 = nullptr; const uint8_t* dI2 = nullptr; int pitch = 0; int64_t stride = 0;
+  float* dD1 = nullptr; float* dD2 = nullptr; int32_t* status = nullptr;
+};
+
+enum { EV_BEGIN, EV_DESC, EV_SUPPORT, EV_D2H, EV_H2D0, EV_H2D, EV_RASTER, EV_DENSE, EV_LR, EV_SPECKLE, EV_GAP, EV_AM, EV_COUNT };
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[EV_COUNT] = {};
+  // device
+  uint8_t* du = nullptr; uint8_t* dv = nullptr; uint4* desc = nullptr; int16_t* d_can = nullptr;
+  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* tri_map = nullptr; float* raw = nullptr;
+  float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
+  // pinned host
+  int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
+  // worker
+  std::thread th; std::mutex m; std::condition_variable cv;
+  bool has_job = false, busy = false, quit = false;
+  Job job; jn_status result = JN_OK;
+  jn_stage_times times = {};
+  float dense_ms = 0; int dense_launches = 0;
+};
+
+}  // namespace
+
+struct jn_elas {
+  jn_elas_params p;
+  DevParams dp;
+  HostParams hp;
+  int W = 0, H = 0, max_batch = 0, device = 0;
+  size_t payload_cap = 0;
+  std::unique_ptr<Pool> pool;
+  std::vector<std::unique_ptr<Slot>> slots;
+  // staging for the host-pointer drop-in call
+  uint8_t* s_img = nullptr; float* s_D = nullptr; int s_pitch = 0;
+  std::mutex api_m;
+};
+
+namespace {
+
+jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
+  const DevParams& dp = h->dp;
+  const int n = j.n;
+  hipStream_t st = s.stream;
+  HIP_TRY(hipSetDevice(h->device));
+  auto t_begin = std::chrono::steady_clock::now();
+  HIP_TRY(hipEventRecord(s.ev[EV_BEGIN], st));
+  launch_sobel(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.du, s.dv);
+  launch_descriptor(st, dp, 2 * n, s.du, s.dv, s.desc);
+  HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
+  launch_support(st, dp, n, s.desc, s.d_can);
+  HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
+  const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
+  HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(s.ev[EV_D2H], st));
+  HIP_TRY(hipStreamSynchronize(st));
+
+  auto t_host0 = std::chrono::steady_clock::now();
+  const size_t cap = h->payload_cap;
+  h->pool->run(n, [&](HostWorker& w, int i) {
+    w.run(s.h_can + (size_t)i * dp.cw * dp.ch, s.h_payload + (size_t)i * cap, &s.h_info[i]);
+  });
+  auto t_host1 = std::chrono::steady_clock::now();
+
+  HIP_TRY(hipEventRecord(s.ev[EV_H2D0], st));
+  HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
+  int max_tri = 0, any_ok = 0;
+  for (int i = 0; i < n; i++) {
+    const FrameInfo& fi = s.h_info[i];
+    if (j.status) j.status[i] = fi.ok ? JN_OK : JN_ERR_FEW_SUPPORT;
+    if (!fi.ok) continue;
+    any_ok = 1;
+    const size_t used = (size_t)fi.tri_offset[1] + (size_t)fi.ntri[1] * sizeof(TriRec);
+    HIP_TRY(hipMemcpyAsync(s.payload + (size_t)i * cap, s.h_payload + (size_t)i * cap, used, hipMemcpyHostToDevice, st));
+    max_tri = std::max(max_tri, std::max(fi.ntri[0], fi.ntri[1]));
+  }
+  HIP_TRY(hipEventRecord(s.ev[EV_H2D], st));
+  if (any_ok) {
+    launch_raster(st, dp, n, s.info, s.payload, (int64_t)cap, max_tri, s.tri_map);
+    HIP_TRY(hipEventRecord(s.ev[EV_RASTER], st));
+    launch_dense(st, dp, n, s.info, s.payload, (int64_t)cap, s.desc, s.tri_map, s.raw);
+    HIP_TRY(hipEventRecord(s.ev[EV_DENSE], st));
+    launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
+    HIP_TRY(hipEventRecord(s.ev[EV_LR], st));
+    launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size);
+    if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size);
+    HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
+    launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
+    if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);
+    HIP_TRY(hipEventRecord(s.ev[EV_GAP], st));
+    if (h->p.filter_adaptive_mean) {
+      launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
+      if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
+    }
+    HIP_TRY(hipEventRecord(s.ev[EV_AM], st));
+  } else {
+    for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(hipEventRecord(s.ev[e], st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  auto t_end = std::chrono::steady_clock::now();
+
+  auto ms = [&](int a, int b) { float v = 0; hipEventElapsedTime(&v, s.ev[a], s.ev[b]); return v; };
+  jn_stage_times& t = s.times;
+  t.gpu_descriptor = ms(EV_BEGIN, EV_DESC); t.gpu_support = ms(EV_DESC, EV_SUPPORT); t.d2h = ms(EV_SUPPORT, EV_D2H);
+  t.host_stage = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();
+  t.h2d = ms(EV_H2D0, EV_H2D);
+  t.gpu_matching = ms(EV_H2D, EV_DENSE); t.gpu_lr = ms(EV_DENSE, EV_LR); t.gpu_speckle = ms(EV_LR, EV_SPECKLE);
+  t.gpu_gap = ms(EV_SPECKLE, EV_GAP); t.gpu_adaptive_mean = ms(EV_GAP, EV_AM);
+  t.total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
+  s.dense_ms = ms(EV_RASTER, EV_DENSE); s.dense_launches = any_ok ? 1 : 0;
+  return JN_OK;
+}
+
+void slot_loop(jn_elas* h, Slot* s) {
+  hipSetDevice(h->device);
+  for (;;) {
+    Job j;
+    {
+      std::unique_lock<std::mutex> l(s->m);
+      s->cv.wait(l, [s] { return s->quit || s->has_job; });
+      if (s->quit) return;
+      j = s->job; s->has_job = false;
+    }
+    const jn_status r = run_batch(h, *s, j);
+    {
+      std::lock_guard<std::mutex> l(s->m);
+      s->result = r; s->busy = false;
+    }
+    s->cv.notify_all();
+  }
+}
+
+template <typename T>
+hipError_t dmalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+}  // namespace
+
+extern "C" {
+
+const char* jn_version(void) { return "jn_stereo 0.1 (gfx950)"; }
+
+void jn_elas_params_default(jn_elas_params* p, int32_t setting) {
+  // elas.h:92-145
+  p->disp_min = 0; p->disp_max = 255; p->support_texture = 10; p->candidate_stepsize = 5;
+  p->incon_window_size = 5; p->incon_threshold = 5; p->incon_min_support = 5; p->grid_size = 20;
+  p->beta = 0.02f; p->sigma = 1; p->lr_threshold = 2; p->speckle_sim_threshold = 1; p->speckle_size = 200;
+  p->subsampling = 0;
+  if (setting == JN_SETTING_ROBOTICS) {
+    p->support_threshold = 0.85f; p->add_corners = 0; p->gamma = 3; p->sradius = 2; p->match_texture = 1;
+    p->ipol_gap_width = 3; p->filter_median = 0; p->filter_adaptive_mean = 1; p->postprocess_only_left = 1;
+  } else {
+    p->support_threshold = 0.95f; p->add_corners = 1; p->gamma = 5; p->sradius = 3; p->match_texture = 0;
+    p->ipol_gap_width = 5000; p->filter_median = 1; p->filter_adaptive_mean = 0; p->postprocess_only_left = 0;
+  }
+}
+
+jn_status jn_device_count(int32_t* count) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) { *count = 0; return JN_ERR_NO_DEVICE; }
+  *count = c;
+  return c > 0 ? JN_OK : JN_ERR_NO_DEVICE;
+}
+
+jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t max_batch, int32_t device,
+                         int32_t host_threads, int32_t slots, jn_elas** out) {
+  if (!p || !out || W < 32 || H < 32 || W > 8192 || H > 8192 || max_batch < 1 || slots < 1) return JN_ERR_INVALID;
+  *out = nullptr;
+  const int radius = (int)std::max((float)std::ceil(p->sigma * p->sradius), 2.0f);        // elas.cpp:806
+  if (p->subsampling || p->add_corners || p->filter_median || p->disp_max > 255 || p->disp_max < 10 ||
+      p->disp_min != 0 || p->ipol_gap_width > 64 || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
+      p->grid_size < 1 || radius > 7 || p->incon_window_size < 0)
+    return JN_ERR_UNSUPPORTED;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+
+  std::unique_ptr<jn_elas> h(new jn_elas());
+  h->p = *p; h->W = W; h->H = H; h->max_batch = max_batch; h->device = device;
+  DevParams& dp = h->dp;
+  memset(&dp, 0, sizeof(dp));
+  dp.W = W; dp.H = H; dp.pitch = (W + 63) / 64 * 64;
+  dp.disp_max = p->disp_max; dp.support_texture = p->support_texture; dp.step = p->candidate_stepsize;
+  dp.lr_threshold = p->lr_threshold; dp.support_threshold = p->support_threshold;
+  dp.cw = (W + dp.step - 1) / dp.step; dp.ch = (H + dp.step - 1) / dp.step;            // elas.cpp:384-387
+  dp.grid_size = p->grid_size;
+  dp.gw = (int)std::ceil((float)W / (float)p->grid_size); dp.gh = (int)std::ceil((float)H / (float)p->grid_size);   // elas.cpp:90-91
+  dp.match_texture = p->match_texture; dp.radius = radius;
+  const float two_sigma_sq = 2 * p->sigma * p->sigma;
+  for (int dd = 0; dd <= radius; dd++)                                                    // elas.cpp:802-805 (float math)
+    dp.P[dd] = (int32_t)((-std::log(p->gamma + std::exp(-dd * dd / two_sigma_sq)) + std::log(p->gamma)) / p->beta);
+  dp.speckle_sim = p->speckle_sim_threshold; dp.speckle_size = p->speckle_size; dp.gap_width = p->ipol_gap_width;
+
+  HostParams& hp = h->hp;
+  hp.W = W; hp.H = H; hp.disp_max = p->disp_max; hp.step = dp.step; hp.incon_window_size = p->incon_window_size;
+  hp.incon_threshold = p->incon_threshold; hp.incon_min_support = p->incon_min_support;
+  hp.grid_size = p->grid_size; hp.gw = dp.gw; hp.gh = dp.gh; hp.cw = dp.cw; hp.ch = dp.ch;
+  h->payload_cap = (HostWorker::payload_capacity(hp) + 255) / 256 * 256;
+
+  int nthreads = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+  if (nthreads < 1) nthreads = 1;
+  nthreads = std::min(nthreads, std::max(1, max_batch * slots));
+  h->pool.reset(new Pool(nthreads, hp));
+
+  const size_t px = (size_t)W * H, B = (size_t)max_batch;
+  for (int i = 0; i < slots; i++) {
+    std::unique_ptr<Slot> s(new Slot());
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    for (int e = 0; e < EV_COUNT; e++) HIP_TRY(hipEventCreate(&s->ev[e]));
+    HIP_TRY(dmalloc(&s->du, 2 * B * H * dp.pitch)); HIP_TRY(dmalloc(&s->dv, 2 * B * H * dp.pitch));
+    HIP_TRY(dmalloc(&s->desc, 2 * B * px));
+    HIP_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
+    HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
+    HIP_TRY(dmalloc(&s->tri_map, 2 * B * px)); HIP_TRY(dmalloc(&s->raw, 2 * B * px));
+    HIP_TRY(dmalloc(&s->tmp, B * px)); HIP_TRY(dmalloc(&s->label, B * px)); HIP_TRY(dmalloc(&s->size, B * px));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_can), B * dp.cw * dp.ch * sizeof(int16_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), B * sizeof(FrameInfo), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
+    h->slots.push_back(std::move(s));
+  }
+  h->s_pitch = dp.pitch;
+  HIP_TRY(dmalloc(&h->s_img, 2 * (size_t)H * dp.pitch));
+  HIP_TRY(dmalloc(&h->s_D, 2 * px));
+  for (auto& s : h->slots) s->th = std::thread(slot_loop, h.get(), s.get());
+  *out = h.release();
+  return JN_OK;
+}
+
+void jn_elas_destroy(jn_elas* h) {
+  if (!h) return;
+  for (auto& s : h->slots) {
+    { std::unique_lock<std::mutex> l(s->m); s->cv.wait(l, [&] { return !s->busy; }); s->quit = true; }
+    s->cv.notify_all();
+    if (s->th.joinable()) s->th.join();
+  }
+  hipSetDevice(h->device);
+  for (auto& s : h->slots) {
+    hipFree(s->du); hipFree(s->dv); hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
+    hipFree(s->tri_map); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
+    hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload);
+    for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
+    if (s->stream) hipStreamDestroy(s->stream);
+  }
+  hipFree(h->s_img); hipFree(h->s_D);
+  h->pool.reset();
+  delete h;
+}
+
+jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch,
+                         int64_t image_stride, float* dD1, float* dD2, int32_t* status) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dD1 || !dD2 ||
+      pitch < h->W)
+    return JN_ERR_INVALID;
+  Slot& s = *h->slots[slot];
+  {
+    std::unique_lock<std::mutex> l(s.m);
+    s.cv.wait(l, [&] { return !s.busy; });
+    s.job = Job{n, dI1, dI2, pitch, image_stride, dD1, dD2, status};
+    s.has_job = true; s.busy = true;
+  }
+  s.cv.notify_all();
+  return JN_OK;
+}
+
+jn_status jn_elas_wait(jn_elas* h, int32_t slot) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
+  Slot& s = *h->slots[slot];
+  std::unique_lock<std::mutex> l(s.m);
+  s.cv.wait(l, [&] { return !s.busy; });
+  return s.result;
+}
+
+jn_status jn_elas_process_batch(jn_elas* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch,
+                                int64_t image_stride, float* dD1, float* dD2, int32_t* status) {
+  const jn_status r = jn_elas_submit(h, 0, n, dI1, dI2, pitch, image_stride, dD1, dD2, status);
+  if (r != JN_OK) return r;
+  return jn_elas_wait(h, 0);
+}
+
+jn_status jn_elas_process(jn_elas* h, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2, const int32_t dims[3]) {
+  if (!h || !I1 || !I2 || !D1 || !D2 || !dims) return JN_ERR_INVALID;
+  if (dims[0] != h->W || dims[1] != h->H || dims[2] < dims[0]) return JN_ERR_INVALID;
+  std::lock_guard<std::mutex> guard(h->api_m);
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t img = (size_t)h->H * h->s_pitch, px = (size_t)h->W * h->H;
+  HIP_TRY(hipMemcpy2D(h->s_img, h->s_pitch, I1, dims[2], h->W, h->H, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy2D(h->s_img + img, h->s_pitch, I2, dims[2], h->W, h->H, hipMemcpyHostToDevice));
+  int32_t st = JN_OK;
+  const jn_status r = jn_elas_process_batch(h, 1, h->s_img, h->s_img + img, h->s_pitch, 0, h->s_D, h->s_D + px, &st);
+  if (r != JN_OK) return r;
+  if (st != JN_OK) {                        // elas.cpp:66-71: message, outputs untouched
+    printf("ERROR: Need at least 3 support points!\n");
+    return (jn_status)st;
+  }
+  HIP_TRY(hipMemcpy(D1, h->s_D, px * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(D2, h->s_D + px, px * sizeof(float), hipMemcpyDeviceToHost));
+  return JN_OK;
+}
+
+jn_status jn_elas_last_times(jn_elas* h, int32_t slot, jn_stage_times* out) {
+  if (!h || !out || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
+  *out = h->slots[slot]->times;
+  return JN_OK;
+}
+
+jn_status jn_elas_kernel_time(jn_elas* h, int32_t slot, const char* kernel, float* avg_ms, int32_t* launches) {
+  if (!h || !kernel || !avg_ms || !launches || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
+  if (std::string(kernel) != "k_dense") return JN_ERR_INVALID;
+  *avg_ms = h->slots[slot]->dense_ms; *launches = h->slots[slot]->dense_launches;
+  return JN_OK;
+}
+
+// ---- seam B2 ------------------------------------------------------------------------------------
+
+void jn_scan_params_default(jn_scan_params* sp, int32_t W, int32_t H) {
+  // K1 / T of calibration/amrl_jackal_webcam_stereo.yml (calibrated at 640x360, point_cloud.cpp:38),
+  // scaled to the working size; Q in the zero-disparity form stereoRectify emits.
+  const double sx = (double)W / 640.0, sy = (double)H / 360.0;
+  const double f = 4.6417933392659904e+02 * sx, cx = 3.2479711799310849e+02 * sx, cy = 1.8685472713963392e+02 * sy;
+  const double Tx = -9.4052586442980660e-02;
+  const double Q[16] = {1, 0, 0, -cx, 0, 1, 0, -cy, 0, 0, 0, f, 0, 0, -1.0 / Tx, 0};
+  memcpy(sp->Q, Q, sizeof(Q));
+  const double XR[9] = {-0.0007962732853436516, -0.2675000227968607, 0.9635575706420958,
+                        -0.9999984502796089, -0.001321509725770019, -0.00119326128710218,
+                        0.001592547981999815, -0.9635569909380592, -0.2674985457970802};
+  memcpy(sp->XR, XR, sizeof(XR));
+  sp->XT[0] = 0; sp->XT[1] = 0; sp->XT[2] = 0.28;
+  sp->crop_offset_x = 0; sp->crop_offset_y = 0;
+  sp->gp_height_thresh = 0.05; sp->gp_angle_thresh = 4. * 3.1415 / 180.; sp->gp_dist_thresh = 1.0;
+  sp->fov_deg = 90.; sp->bins = 90; sp->pi_approx = 3.1415;
+}
+
+jn_status jn_disparity_to_u8(int32_t device, const float* dD, uint8_t* dOut, int64_t n) {
+  if (!dD || !dOut || n < 0) return JN_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  if (n) launch_to_u8(nullptr, dD, dOut, n);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipGetLastError());
+  return JN_OK;
+}
+
+jn_status jn_build_valid_disp_lut(int32_t device, const jn_scan_params* sp, int32_t W, int32_t H, uint8_t* dLut) {
+  if (!sp || !dLut || W < 1 || H < 1) return JN_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  launch_valid_lut(nullptr, *sp, W, H, dLut);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipGetLastError());
+  return JN_OK;
+}
+
+static jn_status scan_common(int32_t device, const jn_scan_params* sp, int32_t n, const float* dD, uint8_t* dDisp,
+                             const uint8_t* dLut, int32_t W, int32_t H, double* dBins, double* dMeta) {
+  if (!sp || !dDisp || !dLut || !dBins || !dMeta || n < 1 || sp->bins < 1 || sp->bins > 1024) return JN_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  unsigned long long* scratch = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(unsigned long long) * 4 * n));
+  launch_scan(nullptr, *sp, n, dD, dDisp, dLut, W, H, dBins, dMeta, scratch);
+  hipError_t e = hipStreamSynchronize(nullptr);
+  hipFree(scratch);
+  HIP_TRY(e);
+  HIP_TRY(hipGetLastError());
+  return JN_OK;
+}
+
+jn_status jn_obstacle_scan(int32_t device, const jn_scan_params* sp, int32_t n, const uint8_t* dDisp, const uint8_t* dLut,
+                           int32_t W, int32_t H, double* dBins, double* dMeta) {
+  return scan_common(device, sp, n, nullptr, const_cast<uint8_t*>(dDisp), dLut, W, H, dBins, dMeta);
+}
+
+jn_status jn_disparity_scan(int32_t device, const jn_scan_params* sp, int32_t n, const float* dD, const uint8_t* dLut,
+                            int32_t W, int32_t H, uint8_t* dDispU8, double* dBins, double* dMeta) {
+  if (!dD) return JN_ERR_INVALID;
+  return scan_common(device, sp, n, dD, dDispU8, dLut, W, H, dBins, dMeta);
+}
+
+int32_t jn_compact_ranges(const double* bins, int32_t nbins, float* ranges) {
+  int32_t k = 0;
+  for (int i = nbins - 1; i >= 0; i--)                      // point_cloud.cpp:278-282
+    if (bins[i] < JN_SCAN_EMPTY - 1) ranges[k++] = (float)bins[i];
+  return k;
+}
+
+jn_status jn_point_cloud(int32_t device, const jn_scan_params* sp, const uint8_t* dDisp, int32_t W, int32_t H, float* dXyz,
+                         int64_t* count) {
+  if (!sp || !dDisp || !dXyz || !count || W < 1 || H < 1) return JN_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  long long* cols = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&cols), sizeof(long long) * (W + 1)));
+  launch_point_cloud(nullptr, *sp, dDisp, W, H, dXyz, cols);
+  long long total = 0;
+  hipError_t e = hipMemcpy(&total, cols + W, sizeof(long long), hipMemcpyDeviceToHost);
+  hipFree(cols);
+  HIP_TRY(e);
+  HIP_TRY(hipGetLastError());
+  *count = total;
+  return JN_OK;
+}
+
+// ---- host-stage hooks -----------------------------------------------------------------------------
+int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri) {
+  if (!x || !y || !tri || n < 0) return -1;
+  Delaunay dt;
+  return dt.run(x, y, n, tri);
+}
+
+static_assert(sizeof(jn_host_frame_info) == sizeof(FrameInfo), "jn_host_frame_info mirrors FrameInfo");
+
+int64_t jn_host_stage(const jn_elas_params* p, int32_t W, int32_t H, int16_t* d_can, uint8_t* payload, int64_t payload_cap,
+                      jn_host_frame_info* info) {
+  if (!p || !d_can || !payload || !info || p->candidate_stepsize < 1 || p->grid_size < 1) return -1;
+  HostParams hp;
+  hp.W = W; hp.H = H; hp.disp_max = p->disp_max; hp.step = p->candidate_stepsize;
+  hp.incon_window_size = p->incon_window_size; hp.incon_threshold = p->incon_threshold;
+  hp.incon_min_support = p->incon_min_support; hp.grid_size = p->grid_size;
+  hp.gw = (int)std::ceil((float)W / (float)p->grid_size); hp.gh = (int)std::ceil((float)H / (float)p->grid_size);
+  hp.cw = (W + hp.step - 1) / hp.step; hp.ch = (H + hp.step - 1) / hp.step;
+  if ((int64_t)HostWorker::payload_capacity(hp) > payload_cap) return -1;
+  HostWorker w(hp);
+  FrameInfo fi;
+  w.run(d_can, payload, &fi);
+  memcpy(info, &fi, sizeof(fi));
+  return fi.ok ? fi.tri_offset[1] + (int64_t)fi.ntri[1] * (int64_t)sizeof(TriRec) : 0;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------
+jn_status jn_device_malloc(int32_t device, int64_t bytes, void** out) {
+  if (!out || bytes < 0) return JN_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMalloc(out, (size_t)bytes));
+  return JN_OK;
+}
+jn_status jn_device_free(int32_t device, void* p) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipFree(p)); return JN_OK; }
+jn_status jn_memcpy_h2d(int32_t device, void* dst, const void* src, int64_t bytes) {
+  HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice)); return JN_OK;
+}
+jn_status jn_memcpy_d2h(int32_t device, void* dst, const void* src, int64_t bytes) {
+  HIP_TRY(hipSetDevice(device)); HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); return JN_OK;
+}
+jn_status jn_device_synchronize(int32_t device) { HIP_TRY(hipSetDevice(device)); HIP_TRY(hipDeviceSynchronize()); return JN_OK; }
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// jn_types.h — plain structs shared by the host stage (C++) and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+namespace jnav {
+
+// One Delaunay triangle, ready for the rasteriser/dense-matching kernels.  The host stage does the
+// corner sort and the slope/intercept divisions of reference elas.cpp:847-868 in IEEE float, the
+// GPU only evaluates a*u+b (elas.cpp:878-879, :893-894) and the plane (elas.cpp:722).
+struct TriRec {
+  int16_t Au, Bu, Cu;        // corner columns after the ascending-u sort (elas.cpp:847-859)
+  uint16_t flags;            // bit0: plane prior valid (elas.cpp:872)
+  float ACa, ACb, ABa, ABb, BCa, BCb;   // edge lines v = a*u + b (elas.cpp:862-868)
+  float pa, pb, pc;          // disparity plane of this side (elas.cpp:817-827)
+  int32_t pad;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec layout");
+
+enum { kGridWords = 8 };     // 256-bit candidate set per grid cell (disp_max <= 255)
+
+// Per-frame bookkeeping uploaded before GPU stage B.
+struct FrameInfo {
+  int32_t ok;                // 0: fewer than 3 support points -> outputs stay untouched (elas.cpp:66-71)
+  int32_t nsup;
+  int32_t ntri[2];           // left, right
+  int64_t tri_offset[2];     // byte offset of each side's TriRec array inside the frame payload
+  int64_t grid_offset[2];    // byte offset of each side's grid bitsets inside the frame payload
+};
+
+// Kernel-side view of the tunables (Elas::parameters subset + derived constants).
+struct DevParams {
+  int32_t W, H, pitch;       // image width/height, bytes per internal image row
+  int32_t disp_max;
+  int32_t support_texture, step, lr_threshold;
+  float   support_threshold;
+  int32_t cw, ch;            // candidate lattice size (elas.cpp:384-387)
+  int32_t grid_size, gw, gh;
+  int32_t match_texture;
+  int32_t radius;            // plane_radius (elas.cpp:806)
+  int32_t P[8];              // prior table P[|d-d_plane|] (elas.cpp:802-805), entries 0..radius
+  float   speckle_sim;
+  int32_t speckle_size;
+  int32_t gap_width;
+};
+
+}  // namespace jnav

@@ -1,0 +1,49 @@
+// kernels.h — launchers of the gfx950 kernels (defined in kernels.hip).  Product code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "jn_types.h"
+#include "../../include/jn_stereo.h"
+
+namespace jnav {
+
+// All launchers are asynchronous on `st`.  `n` = frames in the batch; per-frame arrays are laid out
+// frame-major with the strides given.
+
+// GPU stage A -------------------------------------------------------------------------------
+// Sobel responses (filter.cpp:372-416) of 2n images -> du/dv [H][pitch] each.
+// Image order in du/dv/desc: L0..L(n-1), R0..R(n-1).
+void launch_sobel(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
+                  int64_t in_stride, int n, uint8_t* du, uint8_t* dv);
+// 16-byte descriptors (descriptor.cpp:84-111): desc [2n][H][W] uint4; image order L0..L(n-1), R0..R(n-1).
+void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint8_t* du, const uint8_t* dv, uint4* desc);
+// Support matching with back-check (elas.cpp:269-413): D_can [n][ch][cw] int16.
+void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can);
+
+// GPU stage B -------------------------------------------------------------------------------
+// Triangle id per pixel (elas.cpp:874-901 loop structure): tri_map [n][2][H][W] int32, -1 = uncovered.
+void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                   int64_t payload_stride, int max_tri, int32_t* tri_map);
+// Dense MAP matching (elas.cpp:683-780): raw [n][2][H][W] float.
+void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                  int64_t payload_stride, const uint4* desc, const int32_t* tri_map, float* raw);
+// Left/right consistency (elas.cpp:909-979): raw -> D1, D2 (user buffers).
+void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2);
+// Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.
+void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size);
+// Gap interpolation (elas.cpp:1101-1284): rows D->tmp, columns tmp->D.
+void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
+// Adaptive mean (elas.cpp:1287-1492): horizontal D->tmp, vertical tmp->D.
+void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
+
+// Node side (point_cloud.cpp) -------------------------------------------------------------------
+void launch_to_u8(hipStream_t st, const float* D, uint8_t* out, int64_t count);
+void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, uint8_t* lut);
+// scratch: [n][4] uint64.  If dD != nullptr the u8 map is produced from it first (fused), else dDisp is read.
+void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
+                 int W, int H, double* bins, double* meta, unsigned long long* scratch);
+// Point cloud (-g): counts per column, exclusive scan, scatter.  col_count: [W+1] int64 scratch.
+void launch_point_cloud(hipStream_t st, const jn_scan_params& sp, const uint8_t* disp, int W, int H, float* xyz,
+                        long long* col_count);
+
+}  // namespace jnav

@@ -1,0 +1,634 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the stereo hot path.  Product code.
+//
+// Every kernel states the reference lines it reproduces.  Integer results are bit-exact with the
+// reference CPU path; float results are bit-exact too because the same IEEE operations are issued
+// in the same order (built with -ffp-contract=off; products/sums that must not fuse use
+// __fmul_rn/__fadd_rn explicitly).
+#include "kernels.h"
+
+namespace jnav {
+
+#define DEV static __device__ __forceinline__
+
+DEV int sad16(const uint4& a, const uint4& b) {
+  // v_sad_u8: 4 byte-wise absolute differences + accumulate, per instruction
+  unsigned s = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
+  s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
+  s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
+  s = __builtin_amdgcn_sad_u8(a.w, b.w, s);
+  return (int)s;
+}
+DEV int texture16(const uint4& a) {   // sum |byte - 128| (elas.cpp:301-305, :715-719)
+  const unsigned k = 0x80808080u;
+  unsigned s = __builtin_amdgcn_sad_u8(a.x, k, 0u);
+  s = __builtin_amdgcn_sad_u8(a.y, k, s);
+  s = __builtin_amdgcn_sad_u8(a.z, k, s);
+  s = __builtin_amdgcn_sad_u8(a.w, k, s);
+  return (int)s;
+}
+DEV int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+// ------------------------------------------------------------------------------------------------
+// Sobel (filter.cpp:372-416, :227-267, :176-222).  One thread per output byte.
+//   S = I[v-1]+2I[v]+I[v+1], T = I[v-1]-I[v+1]            (int16 column pass)
+//   du = sat(((S[u-1]-S[u+1])>>2)+128), dv = sat(((T[u-1]+2T[u]+T[u+1])>>2)+128)
+// Defined for rows 1..H-2, columns 1..W-2 (all the descriptor ever reads); 0 elsewhere.
+__global__ void __launch_bounds__(256) k_sobel(DevParams dp, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2,
+                                               int in_pitch, long long in_stride, int n, uint8_t* __restrict__ du,
+                                               uint8_t* __restrict__ dv) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, img = blockIdx.z;
+  if (u >= dp.pitch) return;
+  const uint8_t* I = (img < n ? I1 + (long long)img * in_stride : I2 + (long long)(img - n) * in_stride);
+  const size_t o = ((size_t)img * dp.H + v) * dp.pitch + u;
+  if (v < 1 || v > dp.H - 2 || u < 1 || u > dp.W - 2) { du[o] = 0; dv[o] = 0; return; }
+  const uint8_t* r0 = I + (size_t)(v - 1) * in_pitch + u;
+  const uint8_t* r1 = r0 + in_pitch;
+  const uint8_t* r2 = r1 + in_pitch;
+  const int a0 = r0[-1], a1 = r0[0], a2 = r0[1];
+  const int b0 = r1[-1], b2 = r1[1];
+  const int c0 = r2[-1], c1 = r2[0], c2 = r2[1];
+  const int Sl = a0 + 2 * b0 + c0, Sr = a2 + 2 * b2 + c2;
+  const int Tl = a0 - c0, Tm = a1 - c1, Tr = a2 - c2;
+  du[o] = (uint8_t)sat_u8(((Sl - Sr) >> 2) + 128);
+  dv[o] = (uint8_t)sat_u8(((Tl + 2 * Tm + Tr) >> 2) + 128);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Descriptor (descriptor.cpp:84-111): 12 du taps on a 5-row diamond + 4 dv taps, packed as uint4.
+// Pixels outside u in [3,W-4], v in [3,H-4] get zeros (uninitialised in the reference).
+__global__ void __launch_bounds__(256) k_descriptor(DevParams dp, const uint8_t* __restrict__ du, const uint8_t* __restrict__ dv,
+                                                    uint4* __restrict__ desc) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, img = blockIdx.z;
+  if (u >= dp.W) return;
+  uint4 d = make_uint4(0, 0, 0, 0);
+  if (u >= 3 && u <= dp.W - 4 && v >= 3 && v <= dp.H - 4) {
+    const int P = dp.pitch;
+    const uint8_t* x = du + ((size_t)img * dp.H + v) * P + u;
+    const uint8_t* y = dv + ((size_t)img * dp.H + v) * P + u;
+    d.x = x[-2 * P] | (x[-P - 2] << 8) | (x[-P] << 16) | ((unsigned)x[-P + 2] << 24);
+    d.y = x[-1] | (x[0] << 8) | (x[0] << 16) | ((unsigned)x[1] << 24);
+    d.z = x[P - 2] | (x[P] << 8) | (x[P + 2] << 16) | ((unsigned)x[2 * P] << 24);
+    d.w = y[-P] | (y[-1] << 8) | (y[1] << 16) | ((unsigned)y[P] << 24);
+  }
+  desc[((size_t)img * dp.H + v) * dp.W + u] = d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Support matching (elas.cpp:269-373 per candidate, :395-413 forward + backward check).
+// One wave64 per lattice candidate; lanes stride the disparity range, keep (best, first d of best,
+// second best) privately, then a 6-step butterfly merges them.  The reference's sequential
+// "best / second best with strict <" equals: E1 = min, d1 = smallest d attaining it, E2 = second
+// smallest of the multiset — which is what the merge computes.
+struct Best { int e1, d1, e2; };
+DEV Best merge(Best a, int e1, int d1, int e2) {
+  Best r;
+  const bool take_b = (e1 < a.e1) || (e1 == a.e1 && d1 >= 0 && (a.d1 < 0 || d1 < a.d1));
+  r.e1 = take_b ? e1 : a.e1;
+  r.d1 = take_b ? d1 : a.d1;
+  const int hi = a.e1 > e1 ? a.e1 : e1;          // larger of the two minima
+  const int lo2 = a.e2 < e2 ? a.e2 : e2;         // smaller of the two runners-up
+  r.e2 = hi < lo2 ? hi : lo2;
+  return r;
+}
+
+DEV int match_candidate(const DevParams& dp, const uint4* __restrict__ A, const uint4* __restrict__ B, int u, int v,
+                        bool right, int lane) {
+  const int W = dp.W, H = dp.H;
+  if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;            // :283
+  if (texture16(A[(size_t)v * W + u]) < dp.support_texture) return -1;       // :301-305
+  const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326 (disp_min = 0)
+  if (dmax < 10) return -1;                                                  // :329
+  const size_t top = (size_t)(v - 2) * W, bot = (size_t)(v + 2) * W;
+  const uint4 a0 = A[top + u - 2], a1 = A[top + u + 2], a2 = A[bot + u - 2], a3 = A[bot + u + 2];
+  Best b{32767, -1, 32767};
+  for (int d = lane; d <= dmax; d += 64) {
+    const int uw = right ? u + d : u - d;
+    const int s = sad16(a0, B[top + uw - 2]) + sad16(a1, B[top + uw + 2]) + sad16(a2, B[bot + uw - 2]) + sad16(a3, B[bot + uw + 2]);
+    if (s < b.e1) { b.e2 = b.e1; b.e1 = s; b.d1 = d; }
+    else if (s < b.e2) b.e2 = s;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int e1 = __shfl_xor(b.e1, off), d1 = __shfl_xor(b.d1, off), e2 = __shfl_xor(b.e2, off);
+    b = merge(b, e1, d1, e2);
+  }
+  // :366 — dmax >= 10 guarantees a second-best exists
+  if (b.d1 >= 0 && (float)b.e1 < dp.support_threshold * (float)b.e2) return b.d1;
+  return -1;
+}
+
+__global__ void __launch_bounds__(256) k_support(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can) {
+  const int lane = threadIdx.x & 63;
+  const int cand = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int frame = blockIdx.y;
+  if (cand >= dp.cw * dp.ch) return;
+  const int uc = cand % dp.cw, vc = cand / dp.cw;
+  int16_t out = 0;                                                         // row/column 0 keep calloc's 0 (:388,:395-397)
+  if (uc >= 1 && vc >= 1) {
+    const uint4* L = desc + (size_t)frame * dp.H * dp.W;
+    const uint4* R = desc + (size_t)(n + frame) * dp.H * dp.W;
+    const int u = uc * dp.step, v = vc * dp.step;
+    out = -1;
+    const int d = match_candidate(dp, L, R, u, v, false, lane);
+    if (d >= 0) {
+      const int d2 = match_candidate(dp, R, L, u - d, v, true, lane);
+      if (d2 >= 0 && abs(d - d2) <= dp.lr_threshold) out = (int16_t)d;
+    }
+  }
+  if (lane == 0) d_can[(size_t)frame * dp.cw * dp.ch + cand] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Rasteriser: which triangle owns each pixel (loop structure of elas.cpp:874-901).  Eight lanes
+// share a triangle and take every 8th column.  Triangles tile the hull without overlap (shared
+// edges evaluate the identical float line, spans are half-open), so plain stores suffice.
+__global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
+                                                long long payload_stride, int32_t* __restrict__ tri_map) {
+  const int frame = blockIdx.y, side = blockIdx.z;
+  const FrameInfo fi = info[frame];
+  if (!fi.ok) return;
+  const int t = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+  if (t >= fi.ntri[side]) return;
+  const TriRec r = reinterpret_cast<const TriRec*>(payload + (long long)frame * payload_stride + fi.tri_offset[side])[t];
+  int32_t* map = tri_map + ((size_t)(frame * 2 + side) * dp.H) * dp.W;
+  const int W = dp.W, H = dp.H;
+  for (int part = 0; part < 2; part++) {
+    const int ua = part ? r.Bu : r.Au, ub = part ? r.Cu : r.Bu;
+    if (ua == ub) continue;                                               // :875 / :890
+    const float ea = part ? r.BCa : r.ABa, eb = part ? r.BCb : r.ABb;
+    for (int u = max(ua, 0) + sub; u < min(ub, W); u += 8) {
+      const float fu = (float)u;
+      const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(r.ACa, fu), r.ACb);   // :878 / :893
+      const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);         // :879 / :894
+      const int lo = max(min(v1, v2), 0), hi = min(max(v1, v2), H);
+      for (int v = lo; v < hi; v++) map[(size_t)v * W + u] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense MAP matching (findMatch, elas.cpp:683-780).  One thread per pixel of one side.
+__global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
+                                               const uint8_t* __restrict__ payload, long long payload_stride,
+                                               const uint4* __restrict__ desc, const int32_t* __restrict__ tri_map,
+                                               float* __restrict__ raw) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  const int frame = blockIdx.z >> 1, side = blockIdx.z & 1;
+  if (u >= dp.W) return;
+  const FrameInfo fi = info[frame];
+  if (!fi.ok) return;
+  const int W = dp.W, H = dp.H;
+  const size_t pix = (size_t)v * W + u;
+  float* out = raw + ((size_t)(frame * 2 + side) * H) * W;
+  const int t = tri_map[((size_t)(frame * 2 + side) * H) * W + pix];
+  float result = -10.0f;                                                   // :797-798
+  if (t >= 0 && u >= 2 && u < W - 2) {                                     // :697
+    const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
+    const uint4* B = desc + (size_t)((side ? 0 : n) + frame) * H * W;      // image searched
+    const int vr = max(min(v, H - 3), 2);                                  // :701
+    const uint4 a = A[(size_t)vr * W + u];
+    if (texture16(a) >= dp.match_texture) {                                // :715-719
+      const uint8_t* fp = payload + (long long)frame * payload_stride;
+      const TriRec* tr = reinterpret_cast<const TriRec*>(fp + fi.tri_offset[side]) + t;
+      const float pa = tr->pa, pb = tr->pb, pc = tr->pc;
+      const bool valid = tr->flags & 1;
+      const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
+      const int lo = max(d_plane - dp.radius, 0), hi = min(d_plane + dp.radius, dp.disp_max);                // :723-724
+      const uint32_t* cell = reinterpret_cast<const uint32_t*>(fp + fi.grid_offset[side]) +
+                             ((size_t)(v / dp.grid_size) * dp.gw + (u / dp.grid_size)) * kGridWords;          // :727-731
+      const uint4* Brow = B + (size_t)vr * W;
+      int best = 10000, best_d = -1;                                       // :735-736
+      const int nwords = (dp.disp_max >> 5) + 1;
+      for (int w = 0; w < nwords; w++) {                                   // grid candidates outside the plane range (:742-750)
+        uint32_t bits = cell[w];
+        while (bits) {
+          const int d = (w << 5) + __builtin_ctz(bits);
+          bits &= bits - 1;
+          if (d >= lo && d <= hi) continue;
+          const int uw = side ? u + d : u - d;
+          if (uw < 2 || uw >= W - 2) continue;
+          const int val = sad16(a, Brow[uw]);
+          if (val < best) { best = val; best_d = d; }
+        }
+      }
+      for (int d = lo; d <= hi; d++) {                                     // plane neighbourhood with prior (:751-756)
+        const int uw = side ? u + d : u - d;
+        if (uw < 2 || uw >= W - 2) continue;
+        const int val = sad16(a, Brow[uw]) + (valid ? dp.P[abs(d - d_plane)] : 0);
+        if (val < best) { best = val; best_d = d; }
+      }
+      result = best_d >= 0 ? (float)best_d : -1.0f;                        // :778-779
+    }
+  }
+  out[pix] = result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Left/right consistency (elas.cpp:909-979), out of place: raw -> D1/D2.
+__global__ void __launch_bounds__(256) k_lr(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ raw,
+                                            float* __restrict__ D1, float* __restrict__ D2) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W;
+  const size_t plane = (size_t)dp.H * W;
+  const float* r1 = raw + (size_t)(frame * 2) * plane + (size_t)v * W;
+  const float* r2 = r1 + plane;
+  const float d1 = r1[u], d2 = r2[u];
+  const float thr = (float)dp.lr_threshold;
+  float o1 = d1, o2 = d2;
+  const float w1 = (float)u - d1, w2 = (float)u + d2;
+  if (d1 >= 0 && w1 >= 0 && w1 < (float)W) { if (fabsf(r2[(int)w1] - d1) > thr) o1 = -10.0f; } else o1 = -10.0f;
+  if (d2 >= 0 && w2 >= 0 && w2 < (float)W) { if (fabsf(r1[(int)w2] - d2) > thr) o2 = -10.0f; } else o2 = -10.0f;
+  D1[(size_t)frame * plane + (size_t)v * W + u] = o1;
+  D2[(size_t)frame * plane + (size_t)v * W + u] = o2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Speckle removal (elas.cpp:981-1099) as union-find connected components: 4-connected valid
+// pixels whose disparities differ by <= speckle_sim_threshold; components smaller than
+// speckle_size (and every invalid pixel, a "segment" of one) are set to -10.  The reference's
+// flood fill visits the same components, so the result is order-free.
+DEV int uf_find(int32_t* __restrict__ lab, int x) {
+  int p = lab[x];
+  while (p != x) { x = p; p = lab[x]; }
+  return x;
+}
+DEV void uf_union(int32_t* __restrict__ lab, int a, int b) {
+  for (;;) {
+    a = uf_find(lab, a); b = uf_find(lab, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }        // a = larger root, hang it under b
+    const int old = atomicMin(&lab[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+__global__ void __launch_bounds__(256) k_ccl_init(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
+                                                  int32_t* __restrict__ lab, int32_t* __restrict__ sz) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const size_t plane = (size_t)dp.H * dp.W;
+  const int p = v * dp.W + u;
+  lab[frame * plane + p] = D[frame * plane + p] >= 0 ? p : -1;
+  sz[frame * plane + p] = 0;
+}
+__global__ void __launch_bounds__(256) k_ccl_merge(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
+                                                   int32_t* __restrict__ lab) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const size_t plane = (size_t)dp.H * dp.W;
+  const float* Df = D + frame * plane;
+  int32_t* L = lab + frame * plane;
+  const int p = v * dp.W + u;
+  const float d = Df[p];
+  if (!(d >= 0)) return;
+  if (u + 1 < dp.W) { const float e = Df[p + 1]; if (e >= 0 && fabsf(d - e) <= dp.speckle_sim) uf_union(L, p, p + 1); }
+  if (v + 1 < dp.H) { const float e = Df[p + dp.W]; if (e >= 0 && fabsf(d - e) <= dp.speckle_sim) uf_union(L, p, p + dp.W); }
+}
+__global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo* __restrict__ info, int32_t* __restrict__ lab,
+                                                   int32_t* __restrict__ sz) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (!info[frame].ok) return;
+  const size_t plane = (size_t)dp.H * dp.W;
+  int32_t* L = lab + frame * plane;
+  const bool in = u < dp.W;
+  const int p = v * dp.W + u;
+  int root = -1;
+  if (in && L[p] >= 0) { root = uf_find(L, p); L[p] = root; }
+  // one atomic per run of equal roots inside the wave instead of one per pixel
+  const int lane = threadIdx.x & 63;
+  const int prev = __shfl_up(root, 1);
+  const bool head = root >= 0 && (lane == 0 || prev != root);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long same = __ballot(root >= 0);
+  if (head) {
+    // run ends at the next head or at the first lane without this root
+    unsigned long long after = lane == 63 ? 0ull : (~0ull << (lane + 1));
+    unsigned long long stop = (heads | ~same) & after;
+    const int end = stop ? __builtin_ctzll(stop) : 64;
+    atomicAdd(&sz[frame * plane + root], end - lane);
+  }
+}
+__global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo* __restrict__ info, float* __restrict__ D,
+                                                   const int32_t* __restrict__ lab, const int32_t* __restrict__ sz) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const size_t plane = (size_t)dp.H * dp.W;
+  const size_t p = frame * plane + (size_t)v * dp.W + u;
+  const int root = lab[p];
+  const int count = root >= 0 ? sz[frame * plane + root] : 1;
+  if (count < dp.speckle_size) D[p] = -10.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gap interpolation (elas.cpp:1101-1284) as a gather: an invalid pixel whose nearest valid
+// neighbours along the line are `a` steps before and `b` steps after, with run length a+b-1 <=
+// ipol_gap_width, takes (d1+d2)/2 if |d1-d2| < 3 else min(d1,d2).  Equivalent to the sequential
+// run scan because fills never become bounds of other runs.
+template <bool kRows>
+__global__ void __launch_bounds__(256) k_gap(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
+                                             float* __restrict__ out) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const size_t plane = (size_t)dp.H * dp.W;
+  const float* I = in + frame * plane;
+  const int W = dp.W, stride = kRows ? 1 : W, pos = kRows ? u : v, len = kRows ? W : dp.H;
+  const size_t p = (size_t)v * W + u;
+  float val = I[p];
+  if (!(val >= 0)) {
+    int a = 0, b = 0;
+    for (int k = 1; k <= dp.gap_width && pos - k >= 0; k++) if (I[p - (size_t)k * stride] >= 0) { a = k; break; }
+    if (a) {
+      for (int k = 1; k <= dp.gap_width - a + 1 && pos + k < len; k++) if (I[p + (size_t)k * stride] >= 0) { b = k; break; }
+      if (b) {
+        const float d1 = I[p - (size_t)a * stride], d2 = I[p + (size_t)b * stride];
+        val = fabsf(d1 - d2) < 3.0f ? __fadd_rn(d1, d2) / 2 : fminf(d1, d2);   // :1149-1150
+      }
+    }
+  }
+  out[frame * plane + p] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adaptive mean (elas.cpp:1287-1492, full-resolution branch).  The reference's "abs mask" is
+// _mm_set1_ps(0x7FFFFFFF) = 2^31 as a float (0x4F000000), so the weight keeps a few exponent
+// bits of the difference; reproduced bit for bit, as is the summation order of its 8-slot ring
+// (slot = position mod 8; lane l = slot l + slot l+4; total = ((l0+l1)+l2)+l3).
+DEV float am_weight(float x, float c) {
+  const float m = __uint_as_float(__float_as_uint(__fsub_rn(x, c)) & 0x4F000000u);
+  return fmaxf(0.0f, __fsub_rn(4.0f, m));
+}
+template <bool kHorizontal>
+__global__ void __launch_bounds__(256) k_adaptive_mean(DevParams dp, const FrameInfo* __restrict__ info,
+                                                       const float* __restrict__ in, const float* __restrict__ keep,
+                                                       float* __restrict__ out) {
+  // horizontal: in = D (negatives read as -10), out = tmp, default = clamped centre
+  // vertical:   in = tmp, keep = D, out = D, default = keep
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W, H = dp.H;
+  const size_t plane = (size_t)H * W;
+  const float* I = in + frame * plane;
+  const size_t p = (size_t)v * W + u;
+  float res;
+  if (kHorizontal) { res = I[p]; if (res < 0) res = -10.0f; } else res = keep[frame * plane + p];
+  const int pos = kHorizontal ? u : v, len = kHorizontal ? W : H;
+  const bool line_ok = kHorizontal ? (v >= 3 && v < H - 3) : (u >= 3 && u < W - 3);
+  if (line_ok && pos >= 4 && pos <= len - 4) {
+    const int stride = kHorizontal ? 1 : W;
+    float val[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int q = pos - 4 + k;                       // window [c-4, c+3]
+      float x = I[p + (long long)(k - 4) * stride];
+      if (kHorizontal && x < 0) x = -10.0f;            // elas.cpp:1304-1309
+      // place into ring slot q mod 8 (static indexing via the select chain below)
+      const int slot = q & 7;
+#pragma unroll
+      for (int s = 0; s < 8; s++) if (s == slot) val[s] = x;
+    }
+    float c = I[p]; if (kHorizontal && c < 0) c = -10.0f;
+    float w[8], f[8];
+#pragma unroll
+    for (int s = 0; s < 8; s++) { w[s] = am_weight(val[s], c); f[s] = __fmul_rn(val[s], w[s]); }
+    const float ws = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(w[0], w[4]), __fadd_rn(w[1], w[5])), __fadd_rn(w[2], w[6])), __fadd_rn(w[3], w[7]));
+    const float fs = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(f[0], f[4]), __fadd_rn(f[1], f[5])), __fadd_rn(f[2], f[6])), __fadd_rn(f[3], f[7]));
+    if (ws > 0) { const float d = fs / ws; if (d >= 0) res = d; }
+  }
+  out[frame * plane + p] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Node side.  convertTo(CV_8U) (point_cloud.cpp:422) = round-half-even + saturate.
+DEV uint8_t f32_to_u8(float x) {
+  const float r = rintf(x);
+  return (uint8_t)(r < 0.f ? 0 : (r > 255.f ? 255 : (int)r));
+}
+__global__ void __launch_bounds__(256) k_to_u8(const float* __restrict__ D, uint8_t* __restrict__ out, long long count) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < count) out[i] = f32_to_u8(D[i]);
+}
+
+struct ScanDev {
+  double Q[16], XR[9], XT[3];
+  int ox, oy;
+  double gp_h, gp_tan, gp_dist, fov, pi;
+  int bins;
+};
+// pos = Q*[i+ox, j+oy, d, 1]; cam = pos.xyz/pos.w; robot = XR*cam + XT (point_cloud.cpp:237-253)
+DEV bool reproject(const ScanDev& s, int i, int j, int d, double& X, double& Y, double& Z) {
+  const double V0 = (double)(i + s.ox), V1 = (double)(j + s.oy), V2 = (double)d;
+  double pos[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    double a = __dmul_rn(s.Q[4 * r], V0);
+    a = __dadd_rn(a, __dmul_rn(s.Q[4 * r + 1], V1));
+    a = __dadd_rn(a, __dmul_rn(s.Q[4 * r + 2], V2));
+    a = __dadd_rn(a, s.Q[4 * r + 3]);
+    pos[r] = a;
+  }
+  if (pos[3] == 0.0) return false;
+  const double cx = pos[0] / pos[3], cy = pos[1] / pos[3], cz = pos[2] / pos[3];
+  double o[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    double a = __dmul_rn(s.XR[3 * r], cx);
+    a = __dadd_rn(a, __dmul_rn(s.XR[3 * r + 1], cy));
+    a = __dadd_rn(a, __dmul_rn(s.XR[3 * r + 2], cz));
+    o[r] = __dadd_rn(a, s.XT[r]);
+  }
+  X = o[0]; Y = o[1]; Z = o[2];
+  return true;
+}
+DEV bool is_ground(const ScanDev& s, double X, double Z) {      // point_cloud.cpp:128-137
+  if (X < s.gp_dist) return Z < s.gp_h;
+  return Z < __dadd_rn(s.gp_h, __dmul_rn(s.gp_tan, X - s.gp_dist));
+}
+
+// cacheDisparityValues (point_cloud.cpp:104-147)
+__global__ void __launch_bounds__(256) k_valid_lut(ScanDev s, int W, int H, uint8_t* __restrict__ lut) {
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  if (i >= W) return;
+  int d;
+  for (d = 3; d <= 255; d++) {
+    double X, Y, Z;
+    if (!reproject(s, i, j, d, X, Y, Z)) continue;
+    if (Z < 0.) continue;
+    if (is_ground(s, X, Z)) continue;
+    break;
+  }
+  lut[((size_t)j * W + i) * 2] = (uint8_t)d;       // 256 wraps to 0 like the reference's uchar store (:142)
+  lut[((size_t)j * W + i) * 2 + 1] = 255;
+}
+
+// order-preserving map double -> uint64 so integer atomics implement float min/max
+DEV unsigned long long enc(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __host__ inline double dec(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  union { unsigned long long u; double d; } c; c.u = b; return c.d;
+}
+
+// publishObstacleScan(Mat&) (point_cloud.cpp:213-296).  Per block: bins and the four extrema are
+// reduced in LDS (64-bit integer atomics on order-encoded doubles), then merged into global memory.
+__global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict__ dD, uint8_t* __restrict__ dDisp,
+                                              const uint8_t* __restrict__ lut, int W, int H, unsigned long long* __restrict__ gbins,
+                                              unsigned long long* __restrict__ gmeta) {
+  extern __shared__ unsigned long long lds[];      // [bins] + 4
+  unsigned long long* lbins = lds;
+  unsigned long long* lmeta = lds + s.bins;
+  const int frame = blockIdx.z;
+  for (int k = threadIdx.x; k < s.bins; k += 256) lbins[k] = ~0ull;
+  if (threadIdx.x < 4) lmeta[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;   // min slots start high, max slots low
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  if (i < W) {
+    const size_t p = ((size_t)frame * H + j) * W + i;
+    int d;
+    if (dD) { const uint8_t q = f32_to_u8(dD[p]); dDisp[p] = q; d = q; } else d = dDisp[p];
+    const uint8_t l0 = lut[((size_t)j * W + i) * 2], l1 = lut[((size_t)j * W + i) * 2 + 1];
+    double X, Y, Z;
+    if (d >= l0 && d <= l1 && reproject(s, i, j, d, X, Y, Z)) {
+      const double th = atan2(Y, X);
+      const double deg = __dmul_rn(th, 180.) / s.pi;
+      const double r = sqrt(__dadd_rn(__dmul_rn(Y, Y), __dmul_rn(X, X)));
+      atomicMin(&lmeta[0], enc(th)); atomicMax(&lmeta[1], enc(th));
+      atomicMin(&lmeta[2], enc(r));  atomicMax(&lmeta[3], enc(r));
+      const double kf = floor(__dmul_rn((double)s.bins, __dadd_rn(s.fov / 2., -deg)) / s.fov);   // :263
+      if (kf >= 0 && kf < (double)s.bins) atomicMin(&lbins[(int)kf], enc(r));
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < s.bins; k += 256)
+    if (lbins[k] != ~0ull) atomicMin(&gbins[(size_t)frame * s.bins + k], lbins[k]);
+  if (threadIdx.x < 4) {
+    const unsigned long long x = lmeta[threadIdx.x];
+    if (threadIdx.x & 1) { if (x != 0ull) atomicMax(&gmeta[frame * 4 + threadIdx.x], x); }
+    else { if (x != ~0ull) atomicMin(&gmeta[frame * 4 + threadIdx.x], x); }
+  }
+}
+__global__ void k_scan_init(int total_bins, int n, unsigned long long* gbins, unsigned long long* gmeta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < total_bins) gbins[i] = ~0ull;
+  if (i < n * 4) gmeta[i] = (i & 1) ? 0ull : ~0ull;
+}
+__global__ void k_scan_finish(int total_bins, int n, unsigned long long* gbins, const unsigned long long* gmeta, double* meta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < total_bins) {
+    const unsigned long long k = gbins[i];
+    reinterpret_cast<double*>(gbins)[i] = (k == ~0ull) ? 1e9 : dec(k);        // INF of point_cloud.cpp:54
+  }
+  if (i < n * 4) {
+    const unsigned long long k = gmeta[i];
+    const double init[4] = {400., -400., 1e9, -500.};                          // point_cloud.cpp:219-220
+    const bool untouched = (i & 1) ? (k == 0ull) : (k == ~0ull);
+    meta[i] = untouched ? init[i & 3] : dec(k);
+  }
+}
+
+// Point cloud (-g, point_cloud.cpp:321-352): column-major order (i outer, j inner) with d >= 2.
+__global__ void __launch_bounds__(256) k_pc_count(const uint8_t* __restrict__ disp, int W, int H, long long* __restrict__ col_count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W) return;
+  int c = 0;
+  for (int j = 0; j < H; j++) c += disp[(size_t)j * W + i] >= 2;
+  col_count[i + 1] = c;
+  if (i == 0) col_count[0] = 0;
+}
+__global__ void k_pc_scan(int W, long long* col_count) {   // tiny: one thread, W <= a few thousand
+  if (threadIdx.x == 0 && blockIdx.x == 0) for (int i = 1; i <= W; i++) col_count[i] += col_count[i - 1];
+}
+__global__ void __launch_bounds__(256) k_pc_scatter(ScanDev s, const uint8_t* __restrict__ disp, int W, int H,
+                                                    const long long* __restrict__ col_count, float* __restrict__ xyz) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= W) return;
+  long long o = col_count[i];
+  for (int j = 0; j < H; j++) {
+    const int d = disp[(size_t)j * W + i];
+    if (d < 2) continue;
+    double X, Y, Z;
+    if (!reproject(s, i, j, d, X, Y, Z)) { X = Y = Z = 0; }
+    xyz[3 * o] = (float)X; xyz[3 * o + 1] = (float)Y; xyz[3 * o + 2] = (float)Z; o++;
+  }
+}
+
+// ================================================================================================
+// launchers
+static inline dim3 grid2d(int W, int H, int z) { return dim3((W + 255) / 256, H, z); }
+
+static ScanDev to_dev(const jn_scan_params& sp) {
+  ScanDev s;
+  for (int i = 0; i < 16; i++) s.Q[i] = sp.Q[i];
+  for (int i = 0; i < 9; i++) s.XR[i] = sp.XR[i];
+  for (int i = 0; i < 3; i++) s.XT[i] = sp.XT[i];
+  s.ox = sp.crop_offset_x; s.oy = sp.crop_offset_y;
+  s.gp_h = sp.gp_height_thresh; s.gp_tan = tan(sp.gp_angle_thresh); s.gp_dist = sp.gp_dist_thresh;
+  s.fov = sp.fov_deg; s.pi = sp.pi_approx; s.bins = sp.bins;
+  return s;
+}
+
+void launch_sobel(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
+                  int64_t in_stride, int n, uint8_t* du, uint8_t* dv) {
+  hipLaunchKernelGGL(k_sobel, grid2d(dp.pitch, dp.H, 2 * n), dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, du, dv);
+}
+void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint8_t* du, const uint8_t* dv, uint4* desc) {
+  hipLaunchKernelGGL(k_descriptor, grid2d(dp.W, dp.H, nimg), dim3(256), 0, st, dp, du, dv, desc);
+}
+void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
+  hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
+}
+void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                   int64_t payload_stride, int max_tri, int32_t* tri_map) {
+  hipMemsetAsync(tri_map, 0xFF, (size_t)n * 2 * dp.H * dp.W * sizeof(int32_t), st);
+  if (max_tri <= 0) return;
+  hipLaunchKernelGGL(k_raster, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, tri_map);
+}
+void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                  int64_t payload_stride, const uint4* desc, const int32_t* tri_map, float* raw) {
+  hipLaunchKernelGGL(k_dense, grid2d(dp.W, dp.H, 2 * n), dim3(256), 0, st, dp, n, info, payload, (long long)payload_stride, desc, tri_map, raw);
+}
+void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
+  hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
+}
+void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size) {
+  const dim3 g = grid2d(dp.W, dp.H, n);
+  hipLaunchKernelGGL(k_ccl_init, g, dim3(256), 0, st, dp, info, D, label, size);
+  hipLaunchKernelGGL(k_ccl_merge, g, dim3(256), 0, st, dp, info, D, label);
+  hipLaunchKernelGGL(k_ccl_count, g, dim3(256), 0, st, dp, info, label, size);
+  hipLaunchKernelGGL(k_ccl_apply, g, dim3(256), 0, st, dp, info, D, label, size);
+}
+void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
+  const dim3 g = grid2d(dp.W, dp.H, n);
+  hipLaunchKernelGGL(k_gap<true>, g, dim3(256), 0, st, dp, info, D, tmp);
+  hipLaunchKernelGGL(k_gap<false>, g, dim3(256), 0, st, dp, info, tmp, D);
+}
+void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
+  const dim3 g = grid2d(dp.W, dp.H, n);
+  hipLaunchKernelGGL(k_adaptive_mean<true>, g, dim3(256), 0, st, dp, info, D, D, tmp);
+  hipLaunchKernelGGL(k_adaptive_mean<false>, g, dim3(256), 0, st, dp, info, tmp, D, D);
+}
+void launch_to_u8(hipStream_t st, const float* D, uint8_t* out, int64_t count) {
+  hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, D, out, (long long)count);
+}
+void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, uint8_t* lut) {
+  hipLaunchKernelGGL(k_valid_lut, grid2d(W, H, 1), dim3(256), 0, st, to_dev(sp), W, H, lut);
+}
+void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
+                 int W, int H, double* bins, double* meta, unsigned long long* scratch) {
+  const ScanDev s = to_dev(sp);
+  unsigned long long* gb = reinterpret_cast<unsigned long long*>(bins);
+  const int total = n * s.bins, m = total > n * 4 ? total : n * 4;
+  hipLaunchKernelGGL(k_scan_init, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch);
+  hipLaunchKernelGGL(k_scan, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
+  hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta);
+}
+void launch_point_cloud(hipStream_t st, const jn_scan_params& sp, const uint8_t* disp, int W, int H, float* xyz, long long* col_count) {
+  const ScanDev s = to_dev(sp);
+  hipLaunchKernelGGL(k_pc_count, dim3((W + 255) / 256), dim3(256), 0, st, disp, W, H, col_count);
+  hipLaunchKernelGGL(k_pc_scan, dim3(1), dim3(64), 0, st, W, col_count);
+  hipLaunchKernelGGL(k_pc_scatter, dim3((W + 255) / 256), dim3(256), 0, st, s, disp, W, H, col_count, xyz);
+}
+
+}  // namespace jnav

@@ -1,0 +1,94 @@
+"""Host-side mirror of the reference's `Elas` interface (src/elas/elas.h:52-162) over libjn_stereo.so.
+
+    param = Elas.parameters(Elas.ROBOTICS); param.postprocess_only_left = True    # point_cloud.cpp:416-417
+    elas = Elas(param, width, height)
+    elas.process(I1, I2, D1, D2, dims)                                            # point_cloud.cpp:419
+
+`process` keeps the reference's contract: caller-allocated float32 D1/D2 of width*height, dims =
+(width, height, bytes-per-line), outputs untouched when fewer than 3 support points are found (the
+reference prints an error and returns; this mirror additionally returns the status code).
+Batched/pipelined entry points take device pointers (DeviceArray.ptr or torch tensor .data_ptr()).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ElasParams, StageTimes
+
+
+class Elas:
+    ROBOTICS = 0      # elas.h:57
+    MIDDLEBURY = 1
+
+    @staticmethod
+    def parameters(setting=0, **overrides):
+        """Elas::parameters(setting) — elas.h:85-145."""
+        p = ElasParams()
+        _lib.load().jn_elas_params_default(C.byref(p), setting)
+        for k, v in overrides.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        return p
+
+    def __init__(self, param, width, height, max_batch=1, device=0, host_threads=0, slots=1):
+        self._L = _lib.load()
+        self.param, self.width, self.height = param, int(width), int(height)
+        self.max_batch, self.device, self.slots = int(max_batch), int(device), int(slots)
+        h = C.c_void_p()
+        _lib.check(self._L.jn_elas_create(C.byref(param), width, height, max_batch, device, host_threads, slots, C.byref(h)),
+                   "jn_elas_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jn_elas_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- Elas::process(I1, I2, D1, D2, dims) ---------------------------------------------------
+    def process(self, I1, I2, D1, D2, dims=None):
+        if dims is None:
+            dims = (self.width, self.height, I1.strides[0] if I1.ndim == 2 else self.width)
+        for a, t in ((I1, np.uint8), (I2, np.uint8), (D1, np.float32), (D2, np.float32)):
+            if a.dtype != t or not a.flags["C_CONTIGUOUS"]:
+                raise TypeError("expected C-contiguous %s array" % np.dtype(t).name)
+        cdims = (C.c_int32 * 3)(*[int(x) for x in dims])
+        st = self._L.jn_elas_process(self._h, I1.ctypes.data, I2.ctypes.data, D1.ctypes.data, D2.ctypes.data, C.byref(cdims))
+        if st not in (_lib.JN_OK, _lib.JN_ERR_FEW_SUPPORT):
+            raise _lib.JnError(st, "jn_elas_process")
+        return st
+
+    # -- batched, device pointers -----------------------------------------------------------------
+    def process_batch(self, n, dI1, dI2, pitch, image_stride, dD1, dD2):
+        status = (C.c_int32 * n)()
+        _lib.check(self._L.jn_elas_process_batch(self._h, n, dI1, dI2, pitch, image_stride, dD1, dD2, status), "jn_elas_process_batch")
+        return list(status)
+
+    def submit(self, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, status=None):
+        _lib.check(self._L.jn_elas_submit(self._h, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, status), "jn_elas_submit")
+
+    def wait(self, slot):
+        _lib.check(self._L.jn_elas_wait(self._h, slot), "jn_elas_wait")
+
+    def last_times(self, slot=0):
+        t = StageTimes()
+        _lib.check(self._L.jn_elas_last_times(self._h, slot, C.byref(t)), "jn_elas_last_times")
+        return t.as_dict()
+
+    def kernel_time(self, slot=0, kernel=b"k_dense"):
+        ms, cnt = C.c_float(), C.c_int32()
+        _lib.check(self._L.jn_elas_kernel_time(self._h, slot, kernel, C.byref(ms), C.byref(cnt)), "jn_elas_kernel_time")
+        return ms.value, cnt.value

@@ -1,0 +1,75 @@
+"""Host-side mirror of the `point_cloud` node functions that follow Elas::process
+(reference src/obstacle_avoidance/point_cloud.cpp), over libjn_stereo.so.
+
+    generateDisparityMap  (:406-429)  -> disparity_to_u8
+    cacheDisparityValues  (:104-147)  -> build_valid_disp_lut
+    publishObstacleScan   (:213-296)  -> obstacle_scan / disparity_scan (+ laser_scan_message)
+    publishPointCloud -g  (:298-404)  -> point_cloud
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ScanParams
+from .device import DeviceArray
+
+INF = 1e9   # point_cloud.cpp:54
+
+
+def scan_params(width, height):
+    sp = ScanParams()
+    _lib.load().jn_scan_params_default(C.byref(sp), width, height)
+    return sp
+
+
+def disparity_to_u8(dD, dOut, n, device=0):
+    _lib.check(_lib.load().jn_disparity_to_u8(device, dD, dOut, n), "jn_disparity_to_u8")
+
+
+def build_valid_disp_lut(sp, width, height, device=0):
+    lut = DeviceArray((height, width, 2), np.uint8, device)
+    _lib.check(_lib.load().jn_build_valid_disp_lut(device, C.byref(sp), width, height, lut.ptr), "jn_build_valid_disp_lut")
+    return lut
+
+
+def obstacle_scan(sp, n, dDisp, dLut, width, height, dBins, dMeta, device=0):
+    _lib.check(_lib.load().jn_obstacle_scan(device, C.byref(sp), n, dDisp, dLut, width, height, dBins, dMeta), "jn_obstacle_scan")
+
+
+def disparity_scan(sp, n, dD, dLut, width, height, dDispU8, dBins, dMeta, device=0):
+    _lib.check(_lib.load().jn_disparity_scan(device, C.byref(sp), n, dD, dLut, width, height, dDispU8, dBins, dMeta), "jn_disparity_scan")
+
+
+def compact_ranges(bins):
+    bins = np.ascontiguousarray(bins, np.float64)
+    out = np.zeros(bins.shape[0], np.float32)
+    k = _lib.load().jn_compact_ranges(bins.ctypes.data, bins.shape[0], out.ctypes.data)
+    return out[:k].copy()
+
+
+def laser_scan_message(bins, meta, seq=0):
+    """The sensor_msgs/LaserScan fields exactly as point_cloud.cpp:271-283 fills them."""
+    return {
+        "header": {"seq": int(seq), "frame_id": "jackal"},
+        "angle_min": np.float32(meta[0]), "angle_max": np.float32(meta[1]),
+        "range_min": np.float32(meta[2]), "range_max": np.float32(meta[3]),
+        "angle_increment": np.float32(3.1415 / 180.), "scan_time": np.float32(0.001), "time_increment": np.float32(0.1),
+        "ranges": compact_ranges(bins),
+    }
+
+
+def point_cloud(sp, dDisp, width, height, device=0):
+    xyz = DeviceArray((height * width, 3), np.float32, device)
+    cnt = C.c_int64(0)
+    _lib.check(_lib.load().jn_point_cloud(device, C.byref(sp), dDisp, width, height, xyz.ptr, C.byref(cnt)), "jn_point_cloud")
+    out = xyz.numpy()[:cnt.value].copy()
+    xyz.free()
+    return out
+
+
+def synth_pair(width, height, scene_disp, seed=12345):
+    L = np.zeros((height, width), np.uint8)
+    R = np.zeros((height, width), np.uint8)
+    _lib.load().jn_synth_pair(width, height, scene_disp, seed, L.ctypes.data, R.ctypes.data)
+    return L, R
