@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — stereo-pairs/s of the MI355X hot path (rectified pair -> ELAS disparity -> u8 map ->
+reprojection -> 90-bin obstacle scan), 1280x720, disp range 128, batch 32 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one batch of `--batch` synthetic pairs (SURVEY.md Appendix A generator, seed 12345+b)
+through the whole path with inputs already resident in HBM.  Steps are pipelined over `--slots`
+library slots (GPU stage A / host stage / GPU stage B of different batches overlap).  For N>1 the
+driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); every rank processes its
+own rigs (weak scaling) and the per-step exchange is the element-wise MIN all-reduce of the scan
+bins, the only cross-rig step the path has.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# algorithmic bytes per pixel per pair of each GPU stage of the ELAS path
+STAGE_BYTES_PER_PX = {
+    "gpu_descriptor": 6.0,      # sobel 2r+4w (descriptors not counted: an implementation choice)
+    "gpu_support": 4.0,         # support match 4r
+    "gpu_matching": 16.0,       # dense L+R 8r+8w
+    "gpu_lr": 16.0,             # 8r+8w
+    "gpu_speckle": 16.0,        # 8r+8w labels included
+    "gpu_gap": 16.0,            # rows+cols 8r+8w
+    "gpu_adaptive_mean": 16.0,  # H+V 8r+8w
+}
+
+
+def cpu_baseline_worker(args):
+    """Times the CPU path on `count` pairs in this process (reference build if present, else the port)."""
+    W, H, scene, disp, seed0, count = args
+    from oracle.binding import Oracle, Reference
+    o = Oracle()
+    ref = Reference() if Reference.available() else None
+    p = o.params(disp_max=disp - 1)
+    sp = o.scan_params(W, H)
+    lut = o.valid_lut(sp, W, H)
+    pairs = [o.synth_pair(W, H, scene, seed0 + i) for i in range(count)]
+    t0 = time.perf_counter()
+    for L, R in pairs:
+        if ref is not None:
+            D1, _ = ref.process(p, L, R)
+        else:
+            _, D1, _ = o.process(p, L, R)
+        o.scan(sp, o.to_u8(D1), lut)
+    return time.perf_counter() - t0, ("reference" if ref is not None else "port")
+
+
+def cpu_baseline(W, H, scene, disp, budget_s=20.0):
+    """Reference CPU path on a bounded sample, one process per core (Triangle is not thread-safe)."""
+    import multiprocessing as mp
+    ncpu = os.cpu_count() or 1
+    procs = max(1, min(ncpu // 2, 64))
+    # single-core probe first (also the figure quoted per core)
+    t1, kind = cpu_baseline_worker((W, H, scene, disp, 12345, 2))
+    per_pair = t1 / 2
+    per_proc = max(1, min(8, int(budget_s / 2 / max(per_pair, 1e-3))))
+    ctx = mp.get_context("fork")
+    with ctx.Pool(procs) as pool:
+        t0 = time.perf_counter()
+        pool.map(cpu_baseline_worker, [(W, H, scene, disp, 12345 + 1000 * i, per_proc) for i in range(procs)])
+        wall = time.perf_counter() - t0
+    # wall includes per-process input generation and LUT build; use it as is (conservative for the CPU)
+    total = procs * per_proc
+    return {
+        "value": round(total / wall, 2), "unit": "pairs/s", "cores": procs, "kind": kind,
+        "sample": "%d pairs %dx%d disp_max=%d in %d processes (%.1f s wall); single core: %.2f pairs/s" %
+                  (total, W, H, disp - 1, procs, wall, 1.0 / per_pair),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--disp", type=int, default=128, help="disparity range D (disp_max = D-1)")
+    ap.add_argument("--slots", type=int, default=3)
+    ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    W, H, B, S = a.width, a.height, a.batch, a.slots
+
+    # CPU baseline first: it forks worker processes, which must happen before this process touches the GPU.
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(W, H, a.disp, a.disp)
+
+    import torch
+    import jackal_navigation_amd as jn
+    from jackal_navigation_amd import node
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    ncpu = os.cpu_count() or 1
+    host_threads = a.host_threads or max(4, min(ncpu // max(world, 1) - 2, B * S))
+
+    # synthetic batch of this rank, resident in HBM
+    Ls = np.empty((B, H, W), np.uint8); Rs = np.empty((B, H, W), np.uint8)
+    for b in range(B):
+        Ls[b], Rs[b] = node.synth_pair(W, H, a.disp, 12345 + b + 1000 * rank)
+    dL = torch.from_numpy(Ls).to(dev); dR = torch.from_numpy(Rs).to(dev)
+    D1 = [torch.zeros((B, H, W), dtype=torch.float32, device=dev) for _ in range(S)]
+    D2 = [torch.zeros((B, H, W), dtype=torch.float32, device=dev) for _ in range(S)]
+    U8 = [torch.zeros((B, H, W), dtype=torch.uint8, device=dev) for _ in range(S)]
+    bins = [torch.zeros((B, 90), dtype=torch.float64, device=dev) for _ in range(S)]
+    meta = [torch.zeros((B, 4), dtype=torch.float64, device=dev) for _ in range(S)]
+    status = [(C.c_int32 * B)() for _ in range(S)]
+
+    p = jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=a.disp - 1)          # point_cloud.cpp:416-417 + D
+    elas = jn.Elas(p, W, H, max_batch=B, device=local_rank, host_threads=host_threads, slots=S)
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H, device=local_rank)
+    torch.cuda.synchronize()
+
+    stage_acc = {}
+
+    def finish(slot):
+        """Tail of a batch: wait for ELAS, then u8 map + scan, then the cross-rig MIN reduce."""
+        elas.wait(slot)
+        for k, v in elas.last_times(slot).items():
+            stage_acc.setdefault(k, []).append(v)
+        node.disparity_scan(sp, B, D1[slot].data_ptr(), lut.ptr, W, H, U8[slot].data_ptr(), bins[slot].data_ptr(),
+                            meta[slot].data_ptr(), device=local_rank)
+        if dist is not None:
+            dist.all_reduce(bins[slot], op=dist.ReduceOp.MIN)
+
+    def run(steps):
+        inflight = []
+        for i in range(steps):
+            slot = i % S
+            if len(inflight) == S:
+                finish(inflight.pop(0))
+            elas.submit(slot, B, dL.data_ptr(), dR.data_ptr(), W, H * W, D1[slot].data_ptr(), D2[slot].data_ptr(), status[slot])
+            inflight.append(slot)
+        while inflight:
+            finish(inflight.pop(0))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(a.warmup)
+    sync()
+    stage_acc.clear()
+    t0 = time.perf_counter()
+    run(a.steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    failed = sum(1 for s in status for x in s if x != 0)
+    pairs = world * B * a.steps
+    value = pairs / elapsed
+
+    # roofline of the dominant GPU stage: algorithmic bytes / measured stage time (HIP events
+    # recorded by the library on the stream the kernels run on)
+    stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
+    gpu_stages = {k: stage_ms[k] for k in STAGE_BYTES_PER_PX if k in stage_ms}
+    dom = max(gpu_stages, key=gpu_stages.get)
+    alg_bytes = STAGE_BYTES_PER_PX[dom] * W * H * B
+    achieved = alg_bytes / (gpu_stages[dom] * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "ms_per_launch": round(gpu_stages[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4)}
+
+    if rank == 0:
+        out = {
+            "metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "ms_per_frame": round(elapsed / (B * a.steps) * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32",
+            "data": "synthetic",
+            "config": {"workload": "%dx%d rectified pairs, ELAS disp_max=%d (D=%d), batch=%d per GPU -> u8 map -> 90-bin scan" %
+                                   (W, H, a.disp - 1, a.disp, B),
+                       "batch_per_gpu": B, "slots": S, "host_threads": host_threads, "pairs_failed": failed,
+                       "parallelism": "rigs sharded 1 batch/GPU, MIN all-reduce of scan bins" if world > 1 else "single GPU"},
+            "stage_ms_per_batch": {k: round(v, 3) for k, v in stage_ms.items()},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    elas.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -193,14 +193,16 @@ const char* jn_version(void);
  * (capacity 6*n ints); returns the triangle count or -1. */
 int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri);
 
-/* Support filters + support list + Delaunay x2 + planes + grid prior for ONE frame
- * (elas.cpp:416-431, :445-577, :579-659).  d_can [ch][cw] is filtered in place.  payload receives
- * the records the GPU consumes (layout: jn_host_frame_info); returns bytes used or -1 if
- * payload_cap is too small. */
+/* Support filters + support list + Delaunay x2 for ONE frame (elas.cpp:416-431, :445-505).
+ * d_can [ch][cw] is filtered in place.  payload receives what the GPU stage consumes:
+ *   [nsup x (u,v,d) int32 at sup_offset][ntri[s] x 3 int32 corner indices at corner_offset[s]]
+ * (plane fits and the grid prior, elas.cpp:507-659, are computed on the GPU from these).
+ * Returns bytes used or -1 if payload_cap is too small. */
 typedef struct jn_host_frame_info {
   int32_t ok, nsup, ntri[2];
-  int64_t tri_offset[2];    /* 48-byte triangle records: int16 Au,Bu,Cu; uint16 flags; float ACa,ACb,ABa,ABb,BCa,BCb; float pa,pb,pc; int32 pad */
-  int64_t grid_offset[2];   /* [gh*gw][8] uint32 candidate bitsets */
+  int64_t sup_offset;
+  int64_t corner_offset[2];
+  int64_t reserved;
 } jn_host_frame_info;
 int64_t jn_host_stage(const jn_elas_params* p, int32_t width, int32_t height, int16_t* d_can, uint8_t* payload,
                       int64_t payload_cap, jn_host_frame_info* info);

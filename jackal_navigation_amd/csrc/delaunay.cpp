@@ -3,12 +3,13 @@
 // Decision sequence reproduced (reference line numbers in src/elas/triangle.cpp):
 //   sort by (x,y) with LCG-pivot quicksort      :4045-4049, :5446-5500
 //   duplicates: first in sorted order survives   :6179-6194
-//   alternating-cut re-partition                 :5514-5606, :6197-6206
+//   alternating-cut re-partition                 :5514-5606, :6197-6206 (same result, computed kd-style)
 //   2-/3-vertex bases, recursive hull zipping     :5638-5947, :5953-6103
 //   output = non-ghost triangles, creation order, (org,dest,apex) of edge 0   :6105-6148, :7832-7843
 // Predicates are evaluated exactly in int64 (coordinates are pixel integers), which equals the
 // sign the reference's adaptive float predicates return (:2706-2745, :3334-3379).
 #include "delaunay.h"
+#include <algorithm>
 
 namespace jnav {
 
@@ -66,25 +67,42 @@ void Delaunay::quicksort(int32_t* a, int n) {
   if (r < n - 2) quicksort(a + r + 1, n - r - 1);
 }
 
-void Delaunay::select(int32_t* a, int n, int m, int axis) {
-  if (n == 2) {
-    if (precedes(a[1], a[0], axis)) { const int32_t t = a[0]; a[0] = a[1]; a[1] = t; }
-    return;
+// Alternating-cut arrangement (the effect of triangle.cpp:5514-5606, :6197-6206).  Triangle reaches it
+// with randomised quick-select; because duplicates are gone the keys are distinct, every median
+// split is a unique set partition and the leaves (<= 3 vertices) are x-sorted, so the final array is
+// unique.  We build the same array deterministically, kd-tree style: keep the vertices once in
+// (x,y) order (array a) and once in (y,x) order; a cut along one order is a prefix, the other
+// order is stably partitioned to follow.  The x-ordered array, partitioned in place, IS the result.
+void Delaunay::split(int lo, int hi, int axis) {
+  const int n = hi - lo;
+  if (n <= 3) return;
+  const int half = n >> 1;
+  int32_t* def = (axis ? by_y_.data() : order_.data()) + lo;     // order that defines the cut
+  int32_t* oth = (axis ? order_.data() : by_y_.data()) + lo;     // order that must follow it
+  for (int i = 0; i < half; i++) left_[def[i]] = 1;
+  for (int i = half; i < n; i++) left_[def[i]] = 0;
+  int32_t* spill = tmp_.data();
+  int nl = 0, nr = 0;
+  for (int i = 0; i < n; i++) {
+    const int32_t v = oth[i];
+    if (left_[v]) oth[nl++] = v; else spill[nr++] = v;
   }
-  int l, r;
-  partition(a, n, axis, l, r);
-  if (l > m) select(a, l, m, axis);
-  if (r < m - 1) select(a + r + 1, n - r - 1, m - r - 1, axis);
+  for (int i = 0; i < nr; i++) oth[nl + i] = spill[i];
+  split(lo, lo + half, 1 - axis);
+  split(lo + half, hi, 1 - axis);
 }
 
-void Delaunay::cuts(int32_t* a, int n, int axis) {
-  const int half = n >> 1;
-  if (n <= 3) axis = 0;
-  select(a, n, half, axis);
-  if (n - half >= 2) {
-    if (half >= 2) cuts(a, half, 1 - axis);
-    cuts(a + half, n - half, 1 - axis);
-  }
+void Delaunay::arrange(int32_t* a, int n) {
+  // a == order_.data(), sorted by (x,y).  Stable counting sort by y gives the (y,x) order.
+  int32_t ymin = y_[a[0]], ymax = ymin;
+  for (int i = 1; i < n; i++) { const int32_t y = y_[a[i]]; ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax; }
+  const int range = ymax - ymin + 1;
+  if (bucket_.size() < (size_t)range + 1) bucket_.resize(range + 1);
+  std::fill(bucket_.begin(), bucket_.begin() + range + 1, 0);
+  for (int i = 0; i < n; i++) bucket_[y_[a[i]] - ymin + 1]++;
+  for (int i = 0; i < range; i++) bucket_[i + 1] += bucket_[i];
+  for (int i = 0; i < n; i++) by_y_[bucket_[y_[a[i]] - ymin]++] = a[i];
+  split(0, n, 0);
 }
 
 // Merge two triangulated halves by walking up the seam between their hulls.
@@ -277,7 +295,7 @@ int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
   x_ = x; y_ = y; lcg_ = 1; ntri_ = 0;
   const size_t cap = (size_t)8 * n + 64;   // real + ghost triangles ever created (< 4n)
   if (link_.size() < 3 * cap) { link_.resize(3 * cap); vert_.resize(3 * cap); }
-  if (order_.size() < (size_t)n) order_.resize(n);
+  if (order_.size() < (size_t)n) { order_.resize(n); by_y_.resize(n); tmp_.resize(n); left_.resize(n); }
   int32_t* a = order_.data();
   for (int i = 0; i < n; i++) a[i] = i;
   quicksort(a, n);
@@ -286,11 +304,7 @@ int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
     if (x[a[k]] != x[a[j]] || y[a[k]] != y[a[j]]) a[++k] = a[j];
   ++k;
   if (k < 2) return -1;
-  const int half = k >> 1;
-  if (k - half >= 2) {
-    if (half >= 2) cuts(a, half, 1);
-    cuts(a + half, k - half, 1);
-  }
+  arrange(a, k);
   H hl, hr;
   conquer(a, k, 0, hl, hr);
   int out = 0;

@@ -27,7 +27,8 @@ class Delaunay {
   const int32_t* y_ = nullptr;
   std::vector<int32_t> link_;               // 3 per triangle: handle across that edge
   std::vector<int32_t> vert_;               // 3 per triangle: vertex or -1 (ghost corner)
-  std::vector<int32_t> order_;
+  std::vector<int32_t> order_, by_y_, tmp_, bucket_;
+  std::vector<uint8_t> left_;
   int ntri_ = 0;
   uint64_t lcg_ = 1;
 
@@ -48,8 +49,8 @@ class Delaunay {
   unsigned draw(unsigned choices);
   void partition(int32_t* a, int n, int axis, int& l, int& r);
   void quicksort(int32_t* a, int n);
-  void select(int32_t* a, int n, int m, int axis);
-  void cuts(int32_t* a, int n, int axis);
+  void arrange(int32_t* a, int n);
+  void split(int lo, int hi, int axis);
   void conquer(int32_t* a, int n, int axis, H& farleft, H& farright);
   void zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis);
 };

@@ -4,9 +4,9 @@
 // post-processing) the reference runs four short, branchy, order-dependent steps per frame:
 //   removeInconsistentSupportPoints / removeRedundantSupportPoints   elas.cpp:153-235 (in-place, scan-order dependent)
 //   computeDelaunayTriangulation x2                                   elas.cpp:445-505 (Triangle D&C)
-//   computeDisparityPlanes x2                                         elas.cpp:507-577 (Gauss-Jordan, double)
-//   createGrid x2                                                     elas.cpp:579-659
-// One HostWorker per thread; frames of a batch are farmed out over a pool.
+// (computeDisparityPlanes and createGrid, elas.cpp:507-659, run on the GPU from the support points
+// and corner indices this stage emits.)
+// One HostWorker per thread; frames (phase 1) and frame sides (phase 2) are farmed out over a pool.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -23,28 +23,27 @@ struct HostParams {
   int32_t grid_size, gw, gh, cw, ch;
 };
 
+// Support points of one frame, shared between the two phases of the host stage.
+struct FrameScratch {
+  std::vector<int32_t> u, v, d, x;               // x = u - d (right-image column)
+};
+
 class HostWorker {
  public:
   explicit HostWorker(const HostParams& hp);
-  // d_can: this frame's candidate lattice [ch][cw] as produced by the GPU (modified in place).
-  // payload: pinned staging for this frame (capacity payload_capacity(hp)); info: filled in.
-  void run(int16_t* d_can, uint8_t* payload, FrameInfo* info);
+  // Phase 1 (one task per frame): filter this frame's candidate lattice d_can [ch][cw] in place
+  // (elas.cpp:416-422), list the support points (elas.cpp:425-431) into the payload and `fs`.
+  void filter_and_list(int16_t* d_can, uint8_t* payload, FrameInfo* info, FrameScratch* fs) const;
+  // Phase 2 (one task per frame and side): Delaunay triangulation (elas.cpp:445-505) of the points
+  // (u,v) for side 0 or (u-d,v) for side 1; corner indices go to the payload.
+  void triangulate_side(int side, const FrameScratch& fs, uint8_t* payload, FrameInfo* info);
   static size_t payload_capacity(const HostParams& hp);
 
  private:
   HostParams hp_;
   Delaunay dt_;
-  std::vector<int32_t> su_, sv_, sd_, sx_;       // support points (u, v, d) and u-d
-  std::vector<int32_t> tri_;
-  std::vector<uint32_t> mark_;
   void filter_inconsistent(int16_t* D) const;
   void filter_redundant(int16_t* D, int max_dist, int thresh, bool vertical) const;
-  int  make_side(int side, TriRec* out);
-  void make_grid(int side, uint32_t* bits);
 };
-
-// Plane through three support points (Gauss-Jordan with full pivoting in double, matrix.cpp:414-502
-// semantics).  Exposed for tests.
-bool solve_plane(const double rows[3][3], const double rhs[3], float out[3]);
 
 }  // namespace jnav

@@ -49,7 +49,8 @@ class Pool {
     cv_.notify_all();
     for (auto& t : threads_) t.join();
   }
-  // Runs fn(worker, i) for i in [0,n) on the pool and blocks until all are done.
+  // Runs fn(worker, i) for i in [0,n) on the pool and blocks until all are done.  Several callers
+  // (slot workers) may use the pool at the same time.
   void run(int n, const std::function<void(HostWorker&, int)>& fn) {
     if (n <= 0) return;
     Group g; g.fn = &fn; g.left = n;
@@ -102,6 +103,8 @@ struct Slot {
   uint8_t* du = nullptr; uint8_t* dv = nullptr; uint4* desc = nullptr; int16_t* d_can = nullptr;
   FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* tri_map = nullptr; float* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
+  uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
+  std::vector<FrameScratch> scratch;
   // pinned host
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
   // worker
@@ -120,6 +123,7 @@ struct jn_elas {
   HostParams hp;
   int W = 0, H = 0, max_batch = 0, device = 0;
   size_t payload_cap = 0;
+  int tri_cap = 0;
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
   // staging for the host-pointer drop-in call
@@ -148,28 +152,35 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
 
   auto t_host0 = std::chrono::steady_clock::now();
   const size_t cap = h->payload_cap;
-  h->pool->run(n, [&](HostWorker& w, int i) {
-    w.run(s.h_can + (size_t)i * dp.cw * dp.ch, s.h_payload + (size_t)i * cap, &s.h_info[i]);
+  h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: filters + support list, per frame
+    w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, s.h_payload + (size_t)i * cap, &s.h_info[i], &s.scratch[i]);
+  });
+  h->pool->run(2 * n, [&](HostWorker& w, int k) {        // phase 2: one triangulation per frame and side
+    const int i = k >> 1;
+    w.triangulate_side(k & 1, s.scratch[i], s.h_payload + (size_t)i * cap, &s.h_info[i]);
   });
   auto t_host1 = std::chrono::steady_clock::now();
 
   HIP_TRY(hipEventRecord(s.ev[EV_H2D0], st));
   HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
-  int max_tri = 0, any_ok = 0;
+  int max_tri = 0, max_sup = 0, any_ok = 0;
   for (int i = 0; i < n; i++) {
     const FrameInfo& fi = s.h_info[i];
     if (j.status) j.status[i] = fi.ok ? JN_OK : JN_ERR_FEW_SUPPORT;
     if (!fi.ok) continue;
     any_ok = 1;
-    const size_t used = (size_t)fi.tri_offset[1] + (size_t)fi.ntri[1] * sizeof(TriRec);
+    const size_t used = (size_t)fi.corner_offset[1] + (size_t)fi.ntri[1] * 3 * sizeof(int32_t);
     HIP_TRY(hipMemcpyAsync(s.payload + (size_t)i * cap, s.h_payload + (size_t)i * cap, used, hipMemcpyHostToDevice, st));
     max_tri = std::max(max_tri, std::max(fi.ntri[0], fi.ntri[1]));
+    max_sup = std::max(max_sup, fi.nsup);
   }
   HIP_TRY(hipEventRecord(s.ev[EV_H2D], st));
   if (any_ok) {
-    launch_raster(st, dp, n, s.info, s.payload, (int64_t)cap, max_tri, s.tri_map);
+    launch_grid(st, dp, n, s.info, s.payload, (int64_t)cap, max_sup, s.mark, s.gridbits);
+    launch_tri_setup(st, dp, n, s.info, s.payload, (int64_t)cap, max_tri, h->tri_cap, s.recs);
+    launch_raster(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.tri_map);
     HIP_TRY(hipEventRecord(s.ev[EV_RASTER], st));
-    launch_dense(st, dp, n, s.info, s.payload, (int64_t)cap, s.desc, s.tri_map, s.raw);
+    launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.gridbits, s.desc, s.tri_map, s.raw);
     HIP_TRY(hipEventRecord(s.ev[EV_DENSE], st));
     launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
     HIP_TRY(hipEventRecord(s.ev[EV_LR], st));
@@ -287,6 +298,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   hp.incon_threshold = p->incon_threshold; hp.incon_min_support = p->incon_min_support;
   hp.grid_size = p->grid_size; hp.gw = dp.gw; hp.gh = dp.gh; hp.cw = dp.cw; hp.ch = dp.ch;
   h->payload_cap = (HostWorker::payload_capacity(hp) + 255) / 256 * 256;
+  h->tri_cap = 2 * dp.cw * dp.ch + 8;
 
   int nthreads = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
@@ -304,6 +316,10 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
     HIP_TRY(dmalloc(&s->tri_map, 2 * B * px)); HIP_TRY(dmalloc(&s->raw, 2 * B * px));
     HIP_TRY(dmalloc(&s->tmp, B * px)); HIP_TRY(dmalloc(&s->label, B * px)); HIP_TRY(dmalloc(&s->size, B * px));
+    const size_t grid_words = 2 * B * dp.gw * dp.gh * kGridWords;
+    HIP_TRY(dmalloc(&s->mark, grid_words)); HIP_TRY(dmalloc(&s->gridbits, grid_words));
+    HIP_TRY(dmalloc(&s->recs, 2 * B * (size_t)h->tri_cap));
+    s->scratch.resize(B);
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_can), B * dp.cw * dp.ch * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), B * sizeof(FrameInfo), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
@@ -328,6 +344,7 @@ void jn_elas_destroy(jn_elas* h) {
   for (auto& s : h->slots) {
     hipFree(s->du); hipFree(s->dv); hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
     hipFree(s->tri_map); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
+    hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -508,9 +525,12 @@ int64_t jn_host_stage(const jn_elas_params* p, int32_t W, int32_t H, int16_t* d_
   if ((int64_t)HostWorker::payload_capacity(hp) > payload_cap) return -1;
   HostWorker w(hp);
   FrameInfo fi;
-  w.run(d_can, payload, &fi);
+  FrameScratch fs;
+  w.filter_and_list(d_can, payload, &fi, &fs);
+  w.triangulate_side(0, fs, payload, &fi);
+  w.triangulate_side(1, fs, payload, &fi);
   memcpy(info, &fi, sizeof(fi));
-  return fi.ok ? fi.tri_offset[1] + (int64_t)fi.ntri[1] * (int64_t)sizeof(TriRec) : 0;
+  return fi.ok ? fi.corner_offset[1] + (int64_t)fi.ntri[1] * 3 * (int64_t)sizeof(int32_t) : 0;
 }
 
 // ---- device helpers -------------------------------------------------------------------------------

@@ -18,13 +18,15 @@ static_assert(sizeof(TriRec) == 48, "TriRec layout");
 
 enum { kGridWords = 8 };     // 256-bit candidate set per grid cell (disp_max <= 255)
 
-// Per-frame bookkeeping uploaded before GPU stage B.
+// Per-frame bookkeeping uploaded before GPU stage B.  The frame payload the host stage produces is
+//   [support points: nsup x (u,v,d) int32][left corners: ntri[0] x 3 int32][right corners: ntri[1] x 3 int32]
 struct FrameInfo {
   int32_t ok;                // 0: fewer than 3 support points -> outputs stay untouched (elas.cpp:66-71)
   int32_t nsup;
   int32_t ntri[2];           // left, right
-  int64_t tri_offset[2];     // byte offset of each side's TriRec array inside the frame payload
-  int64_t grid_offset[2];    // byte offset of each side's grid bitsets inside the frame payload
+  int64_t sup_offset;        // byte offset of the support points inside the frame payload
+  int64_t corner_offset[2];  // byte offset of each side's triangle corner indices
+  int64_t reserved;
 };
 
 // Kernel-side view of the tunables (Elas::parameters subset + derived constants).

@@ -21,12 +21,18 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can);
 
 // GPU stage B -------------------------------------------------------------------------------
+// Grid prior (elas.cpp:579-659) from the support points: mark/gridbits [n][2][gh*gw][8] uint32.
+void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                 int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits);
+// Plane fits + edge lines per triangle (elas.cpp:507-577, :847-872): recs [n][2][tri_cap].
+void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                      int64_t payload_stride, int max_tri, int tri_cap, TriRec* recs);
 // Triangle id per pixel (elas.cpp:874-901 loop structure): tri_map [n][2][H][W] int32, -1 = uncovered.
-void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
-                   int64_t payload_stride, int max_tri, int32_t* tri_map);
+void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                   int max_tri, int32_t* tri_map);
 // Dense MAP matching (elas.cpp:683-780): raw [n][2][H][W] float.
-void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
-                  int64_t payload_stride, const uint4* desc, const int32_t* tri_map, float* raw);
+void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                  const uint32_t* gridbits, const uint4* desc, const int32_t* tri_map, float* raw);
 // Left/right consistency (elas.cpp:909-979): raw -> D1, D2 (user buffers).
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2);
 // Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.

@@ -139,17 +139,162 @@ __global__ void __launch_bounds__(256) k_support(DevParams dp, int n, const uint
 }
 
 // ------------------------------------------------------------------------------------------------
+// Grid prior (createGrid, elas.cpp:579-659) as 256-bit candidate sets per 20x20 cell.
+// mark: every support point sets d-1..d+1 in its cell (left: column u, right: column u-d).
+__global__ void __launch_bounds__(256) k_grid_mark(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
+                                                   long long payload_stride, uint32_t* __restrict__ mark) {
+  const int i = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+  const FrameInfo fi = info[frame];
+  if (!fi.ok || i >= fi.nsup) return;
+  const int32_t* s = reinterpret_cast<const int32_t*>(payload + (long long)frame * payload_stride + fi.sup_offset) + 3 * i;
+  const int u = s[0], v = s[1], d = s[2];
+  const size_t cells = (size_t)dp.gw * dp.gh;
+  const int y = (int)floorf(__fdiv_rn((float)v, (float)dp.grid_size));                         // :606
+  const int lo = max(d - 1, 0), hi = min(d + 1, dp.disp_max);                                  // :596-597
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int x = side ? (int)floorf(__fdiv_rn((float)(u - d), (float)dp.grid_size))          // :605
+                       : (int)floorf((float)(u / dp.grid_size));                               // :603 (integer division)
+    if (x < 0 || x >= dp.gw || y < 0 || y >= dp.gh) continue;
+    uint32_t* cell = mark + ((size_t)(frame * 2 + side) * cells + (size_t)y * dp.gw + x) * kGridWords;
+    for (int dd = lo; dd <= hi; dd++) atomicOr(&cell[dd >> 5], 1u << (dd & 31));
+  }
+}
+// dilate: 3x3 OR over the FLATTENED cell index, exactly the reference's pointer walk (:617-632):
+// border columns wrap into the neighbouring rows, the first and last gw+1 cells stay empty.
+__global__ void __launch_bounds__(256) k_grid_dilate(DevParams dp, const FrameInfo* __restrict__ info, const uint32_t* __restrict__ mark,
+                                                     uint32_t* __restrict__ bits) {
+  const int cells = dp.gw * dp.gh;
+  const int i = blockIdx.x * 256 + threadIdx.x, fs = blockIdx.y;     // fs = frame*2 + side
+  if (i >= cells * kGridWords || !info[fs >> 1].ok) return;
+  const int c = i / kGridWords, w = i % kGridWords;
+  uint32_t acc = 0;
+  if (c >= dp.gw + 1 && c < cells - dp.gw - 1) {
+    const uint32_t* m = mark + (size_t)fs * cells * kGridWords;
+    const int off[9] = {-dp.gw - 1, -dp.gw, -dp.gw + 1, -1, 0, 1, dp.gw - 1, dp.gw, dp.gw + 1};
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc |= m[(size_t)(c + off[k]) * kGridWords + w];
+  }
+  bits[(size_t)fs * cells * kGridWords + i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangle set-up: both plane fits (computeDisparityPlanes, elas.cpp:507-577, Gauss-Jordan with
+// full pivoting in double, matrix.cpp:414-502), the validity flag (elas.cpp:872), the ascending-u
+// corner sort and the three edge lines (elas.cpp:847-868).  One thread per triangle and side.
+// Every operation is an explicitly rounded IEEE op in the reference's order, so the floats match.
+DEV bool gauss_jordan3(double A[3][3], double b[3]) {
+  int used[3] = {0, 0, 0};
+#pragma unroll
+  for (int step = 0; step < 3; step++) {
+    double best = 0.0; int pr = 0, pc = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (used[r] == 1) continue;
+#pragma unroll
+      for (int c = 0; c < 3; c++)
+        if (used[c] == 0 && fabs(A[r][c]) >= best) { best = fabs(A[r][c]); pr = r; pc = c; }    // `>=`: last maximum wins
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) if (c == pc) ++used[c];
+    if (pr != pc) {
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double x = 0, y = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { if (r == pr) x = A[r][c]; if (r == pc) y = A[r][c]; }
+#pragma unroll
+        for (int r = 0; r < 3; r++) { if (r == pr) A[r][c] = y; if (r == pc) A[r][c] = x; }
+      }
+      double x = 0, y = 0;
+#pragma unroll
+      for (int r = 0; r < 3; r++) { if (r == pr) x = b[r]; if (r == pc) y = b[r]; }
+#pragma unroll
+      for (int r = 0; r < 3; r++) { if (r == pr) b[r] = y; if (r == pc) b[r] = x; }
+    }
+    double piv = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) if (r == pc) piv = A[r][r];
+    if (fabs(piv) < 1e-20) return false;
+    const double inv = __ddiv_rn(1.0, piv);
+    double prow[3] = {0, 0, 0}, pb = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      if (r == pc) {
+        A[r][r] = 1.0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { A[r][c] = __dmul_rn(A[r][c], inv); prow[c] = A[r][c]; }
+        b[r] = __dmul_rn(b[r], inv); pb = b[r];
+      }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if (r == pc) continue;
+      double f = 0;
+#pragma unroll
+      for (int c = 0; c < 3; c++) if (c == pc) { f = A[r][c]; A[r][c] = 0.0; }
+#pragma unroll
+      for (int c = 0; c < 3; c++) A[r][c] = __dsub_rn(A[r][c], __dmul_rn(prow[c], f));
+      b[r] = __dsub_rn(b[r], __dmul_rn(pb, f));
+    }
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
+                                                   long long payload_stride, int tri_cap, TriRec* __restrict__ recs) {
+  const int t = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y, side = blockIdx.z;
+  const FrameInfo fi = info[frame];
+  if (!fi.ok || t >= fi.ntri[side]) return;
+  const uint8_t* fp = payload + (long long)frame * payload_stride;
+  const int32_t* sup = reinterpret_cast<const int32_t*>(fp + fi.sup_offset);
+  const int32_t* c = reinterpret_cast<const int32_t*>(fp + fi.corner_offset[side]) + 3 * t;
+  int su[3], sv[3], sd[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const int32_t* s = sup + 3 * c[k]; su[k] = s[0]; sv[k] = s[1]; sd[k] = s[2]; }
+  float pl[2][3];
+#pragma unroll
+  for (int s = 0; s < 2; s++) {                               // s = 0: left-image coordinates, 1: right-image
+    double A[3][3], b[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { A[r][0] = (double)(s ? su[r] - sd[r] : su[r]); A[r][1] = (double)sv[r]; A[r][2] = 1.0; b[r] = (double)sd[r]; }
+    if (gauss_jordan3(A, b)) { pl[s][0] = (float)b[0]; pl[s][1] = (float)b[1]; pl[s][2] = (float)b[2]; }
+    else { pl[s][0] = pl[s][1] = pl[s][2] = 0.0f; }
+  }
+  TriRec o;
+  o.pa = pl[side][0]; o.pb = pl[side][1]; o.pc = pl[side][2];
+  o.flags = ((double)fabsf(pl[side][0]) < 0.7 && (double)fabsf(pl[1 - side][0]) < 0.7) ? 1 : 0;
+  float tu[3], tv[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { tu[k] = (float)(side ? su[k] - sd[k] : su[k]); tv[k] = (float)sv[k]; }
+  // bubble sort of elas.cpp:847-854, unrolled: (j,k) = (1,0), (2,0), (2,1)
+  if (tu[0] > tu[1]) { float x = tu[1]; tu[1] = tu[0]; tu[0] = x; x = tv[1]; tv[1] = tv[0]; tv[0] = x; }
+  if (tu[0] > tu[2]) { float x = tu[2]; tu[2] = tu[0]; tu[0] = x; x = tv[2]; tv[2] = tv[0]; tv[0] = x; }
+  if (tu[1] > tu[2]) { float x = tu[2]; tu[2] = tu[1]; tu[1] = x; x = tv[2]; tv[2] = tv[1]; tv[1] = x; }
+  float ABa = 0, ACa = 0, BCa = 0;
+  if ((int)tu[0] != (int)tu[1]) ABa = __fdiv_rn(__fsub_rn(tv[0], tv[1]), __fsub_rn(tu[0], tu[1]));
+  if ((int)tu[0] != (int)tu[2]) ACa = __fdiv_rn(__fsub_rn(tv[0], tv[2]), __fsub_rn(tu[0], tu[2]));
+  if ((int)tu[1] != (int)tu[2]) BCa = __fdiv_rn(__fsub_rn(tv[1], tv[2]), __fsub_rn(tu[1], tu[2]));
+  o.ABa = ABa; o.ACa = ACa; o.BCa = BCa;
+  o.ABb = __fsub_rn(tv[0], __fmul_rn(ABa, tu[0]));
+  o.ACb = __fsub_rn(tv[0], __fmul_rn(ACa, tu[0]));
+  o.BCb = __fsub_rn(tv[1], __fmul_rn(BCa, tu[1]));
+  o.Au = (int16_t)tu[0]; o.Bu = (int16_t)tu[1]; o.Cu = (int16_t)tu[2];
+  o.pad = 0;
+  recs[(size_t)(frame * 2 + side) * tri_cap + t] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Rasteriser: which triangle owns each pixel (loop structure of elas.cpp:874-901).  Eight lanes
 // share a triangle and take every 8th column.  Triangles tile the hull without overlap (shared
 // edges evaluate the identical float line, spans are half-open), so plain stores suffice.
-__global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
-                                                long long payload_stride, int32_t* __restrict__ tri_map) {
+__global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
+                                                int tri_cap, int32_t* __restrict__ tri_map) {
   const int frame = blockIdx.y, side = blockIdx.z;
   const FrameInfo fi = info[frame];
   if (!fi.ok) return;
   const int t = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   if (t >= fi.ntri[side]) return;
-  const TriRec r = reinterpret_cast<const TriRec*>(payload + (long long)frame * payload_stride + fi.tri_offset[side])[t];
+  const TriRec r = recs[(size_t)(frame * 2 + side) * tri_cap + t];
   int32_t* map = tri_map + ((size_t)(frame * 2 + side) * dp.H) * dp.W;
   const int W = dp.W, H = dp.H;
   for (int part = 0; part < 2; part++) {
@@ -169,7 +314,7 @@ __global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* _
 // ------------------------------------------------------------------------------------------------
 // Dense MAP matching (findMatch, elas.cpp:683-780).  One thread per pixel of one side.
 __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
-                                               const uint8_t* __restrict__ payload, long long payload_stride,
+                                               const TriRec* __restrict__ recs, int tri_cap, const uint32_t* __restrict__ gridbits,
                                                const uint4* __restrict__ desc, const int32_t* __restrict__ tri_map,
                                                float* __restrict__ raw) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
@@ -188,14 +333,13 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
     const int vr = max(min(v, H - 3), 2);                                  // :701
     const uint4 a = A[(size_t)vr * W + u];
     if (texture16(a) >= dp.match_texture) {                                // :715-719
-      const uint8_t* fp = payload + (long long)frame * payload_stride;
-      const TriRec* tr = reinterpret_cast<const TriRec*>(fp + fi.tri_offset[side]) + t;
+      const TriRec* tr = recs + (size_t)(frame * 2 + side) * tri_cap + t;
       const float pa = tr->pa, pb = tr->pb, pc = tr->pc;
       const bool valid = tr->flags & 1;
       const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
       const int lo = max(d_plane - dp.radius, 0), hi = min(d_plane + dp.radius, dp.disp_max);                // :723-724
-      const uint32_t* cell = reinterpret_cast<const uint32_t*>(fp + fi.grid_offset[side]) +
-                             ((size_t)(v / dp.grid_size) * dp.gw + (u / dp.grid_size)) * kGridWords;          // :727-731
+      const uint32_t* cell = gridbits + ((size_t)(frame * 2 + side) * dp.gw * dp.gh +
+                                         (size_t)(v / dp.grid_size) * dp.gw + (u / dp.grid_size)) * kGridWords;   // :727-731
       const uint4* Brow = B + (size_t)vr * W;
       int best = 10000, best_d = -1;                                       // :735-736
       const int nwords = (dp.disp_max >> 5) + 1;
@@ -263,61 +407,93 @@ DEV void uf_union(int32_t* __restrict__ lab, int a, int b) {
     a = old;
   }
 }
-__global__ void __launch_bounds__(256) k_ccl_init(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
+// Row pass: every maximal horizontal run of connected pixels gets the flat index of its first pixel
+// as label (no atomics: a block-wide max-scan of "run starts here" positions per image row).
+__global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
                                                   int32_t* __restrict__ lab, int32_t* __restrict__ sz) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (u >= dp.W || !info[frame].ok) return;
-  const size_t plane = (size_t)dp.H * dp.W;
-  const int p = v * dp.W + u;
-  lab[frame * plane + p] = D[frame * plane + p] >= 0 ? p : -1;
-  sz[frame * plane + p] = 0;
+  __shared__ int wave_max[4];
+  const int v = blockIdx.x, frame = blockIdx.y;
+  if (!info[frame].ok) return;
+  const int W = dp.W;
+  const size_t base = (size_t)frame * dp.H * W + (size_t)v * W;
+  const float* row = D + base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int carry = -1;                                           // last run start seen in earlier chunks
+  for (int u0 = 0; u0 < W; u0 += 256) {
+    const int u = u0 + threadIdx.x;
+    const float d = u < W ? row[u] : -10.0f;
+    const bool valid = d >= 0;
+    bool conn = false;
+    if (valid && u > 0) { const float e = row[u - 1]; conn = e >= 0 && fabsf(d - e) <= dp.speckle_sim; }
+    int s = (valid && !conn) ? u : -1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(s, off); if (lane >= off) s = max(s, o); }
+    if (lane == 63) wave_max[wave] = s;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < wave; w++) pre = max(pre, wave_max[w]);
+    s = max(s, pre);
+    const int chunk_last = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (u < W) { lab[base + u] = valid ? v * W + s : -1; sz[base + u] = 0; }
+    carry = max(carry, chunk_last);
+    __syncthreads();
+  }
 }
+// Column pass: unite vertically adjacent runs.  A pixel issues the union only if it is the first
+// column of the contact between its run and the run below (the pixel to its left belongs to the
+// same two runs otherwise), which removes almost all redundant atomics.
 __global__ void __launch_bounds__(256) k_ccl_merge(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
                                                    int32_t* __restrict__ lab) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (u >= dp.W || !info[frame].ok) return;
-  const size_t plane = (size_t)dp.H * dp.W;
-  const float* Df = D + frame * plane;
-  int32_t* L = lab + frame * plane;
-  const int p = v * dp.W + u;
-  const float d = Df[p];
-  if (!(d >= 0)) return;
-  if (u + 1 < dp.W) { const float e = Df[p + 1]; if (e >= 0 && fabsf(d - e) <= dp.speckle_sim) uf_union(L, p, p + 1); }
-  if (v + 1 < dp.H) { const float e = Df[p + dp.W]; if (e >= 0 && fabsf(d - e) <= dp.speckle_sim) uf_union(L, p, p + dp.W); }
-}
-__global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo* __restrict__ info, int32_t* __restrict__ lab,
-                                                   int32_t* __restrict__ sz) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (!info[frame].ok) return;
-  const size_t plane = (size_t)dp.H * dp.W;
-  int32_t* L = lab + frame * plane;
-  const bool in = u < dp.W;
-  const int p = v * dp.W + u;
-  int root = -1;
-  if (in && L[p] >= 0) { root = uf_find(L, p); L[p] = root; }
-  // one atomic per run of equal roots inside the wave instead of one per pixel
-  const int lane = threadIdx.x & 63;
-  const int prev = __shfl_up(root, 1);
-  const bool head = root >= 0 && (lane == 0 || prev != root);
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long same = __ballot(root >= 0);
-  if (head) {
-    // run ends at the next head or at the first lane without this root
-    unsigned long long after = lane == 63 ? 0ull : (~0ull << (lane + 1));
-    unsigned long long stop = (heads | ~same) & after;
-    const int end = stop ? __builtin_ctzll(stop) : 64;
-    atomicAdd(&sz[frame * plane + root], end - lane);
+  if (u >= dp.W || v + 1 >= dp.H || !info[frame].ok) return;
+  const int W = dp.W;
+  const size_t plane = (size_t)dp.H * W;
+  const float* r0 = D + frame * plane + (size_t)v * W;
+  const float* r1 = r0 + W;
+  const float sim = dp.speckle_sim;
+  const float a = r0[u], b = r1[u];
+  if (!(a >= 0 && b >= 0 && fabsf(a - b) <= sim)) return;
+  if (u > 0) {
+    const float a0 = r0[u - 1], b0 = r1[u - 1];
+    const bool same_pair = a0 >= 0 && b0 >= 0 && fabsf(a0 - b0) <= sim && fabsf(a - a0) <= sim && fabsf(b - b0) <= sim;
+    if (same_pair) return;
   }
+  int32_t* L = lab + frame * plane;
+  uf_union(L, L[v * W + u] , L[(v + 1) * W + u]);
+}
+// One atomic per run: its last pixel adds the run length to the component root.
+__global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
+                                                   int32_t* __restrict__ lab, int32_t* __restrict__ sz) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W;
+  const size_t plane = (size_t)dp.H * W;
+  const float* row = D + frame * plane + (size_t)v * W;
+  const float d = row[u];
+  if (!(d >= 0)) return;
+  if (u + 1 < W) { const float e = row[u + 1]; if (e >= 0 && fabsf(e - d) <= dp.speckle_sim) return; }   // not the run's last pixel
+  int32_t* L = lab + frame * plane;
+  const int p = v * W + u;
+  bool conn = false;
+  if (u > 0) { const float e = row[u - 1]; conn = e >= 0 && fabsf(d - e) <= dp.speckle_sim; }
+  const int start = conn ? L[p] : p;                        // a non-start pixel's label is never rewritten
+  const int root = uf_find(L, start);
+  atomicAdd(&sz[frame * plane + root], p - start + 1);
 }
 __global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo* __restrict__ info, float* __restrict__ D,
                                                    const int32_t* __restrict__ lab, const int32_t* __restrict__ sz) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
   if (u >= dp.W || !info[frame].ok) return;
   const size_t plane = (size_t)dp.H * dp.W;
-  const size_t p = frame * plane + (size_t)v * dp.W + u;
-  const int root = lab[p];
-  const int count = root >= 0 ? sz[frame * plane + root] : 1;
-  if (count < dp.speckle_size) D[p] = -10.0f;
+  const int32_t* L = lab + frame * plane;
+  const int p = v * dp.W + u;
+  int count = 1;                                            // an invalid pixel is a segment of one
+  if (L[p] >= 0) {
+    int x = p, q = L[x];
+    while (q != x) { x = q; q = L[x]; }
+    count = sz[frame * plane + x];
+  }
+  if (count < dp.speckle_size) D[frame * plane + p] = -10.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -579,24 +755,37 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
   hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
-void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
-                   int64_t payload_stride, int max_tri, int32_t* tri_map) {
+void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                 int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits) {
+  const size_t words = (size_t)n * 2 * dp.gw * dp.gh * kGridWords;
+  hipMemsetAsync(mark, 0, words * sizeof(uint32_t), st);
+  if (max_sup > 0)
+    hipLaunchKernelGGL(k_grid_mark, dim3((max_sup + 255) / 256, n), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, mark);
+  hipLaunchKernelGGL(k_grid_dilate, dim3((dp.gw * dp.gh * kGridWords + 255) / 256, 2 * n), dim3(256), 0, st, dp, info, mark, gridbits);
+}
+void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
+                      int64_t payload_stride, int max_tri, int tri_cap, TriRec* recs) {
+  if (max_tri <= 0) return;
+  hipLaunchKernelGGL(k_tri_setup, dim3((max_tri + 255) / 256, n, 2), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, tri_cap, recs);
+}
+void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                   int max_tri, int32_t* tri_map) {
   hipMemsetAsync(tri_map, 0xFF, (size_t)n * 2 * dp.H * dp.W * sizeof(int32_t), st);
   if (max_tri <= 0) return;
-  hipLaunchKernelGGL(k_raster, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, tri_map);
+  hipLaunchKernelGGL(k_raster, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, tri_map);
 }
-void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
-                  int64_t payload_stride, const uint4* desc, const int32_t* tri_map, float* raw) {
-  hipLaunchKernelGGL(k_dense, grid2d(dp.W, dp.H, 2 * n), dim3(256), 0, st, dp, n, info, payload, (long long)payload_stride, desc, tri_map, raw);
+void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                  const uint32_t* gridbits, const uint4* desc, const int32_t* tri_map, float* raw) {
+  hipLaunchKernelGGL(k_dense, grid2d(dp.W, dp.H, 2 * n), dim3(256), 0, st, dp, n, info, recs, tri_cap, gridbits, desc, tri_map, raw);
 }
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
   hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
 }
 void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size) {
   const dim3 g = grid2d(dp.W, dp.H, n);
-  hipLaunchKernelGGL(k_ccl_init, g, dim3(256), 0, st, dp, info, D, label, size);
+  hipLaunchKernelGGL(k_ccl_rows, dim3(dp.H, n), dim3(256), 0, st, dp, info, D, label, size);
   hipLaunchKernelGGL(k_ccl_merge, g, dim3(256), 0, st, dp, info, D, label);
-  hipLaunchKernelGGL(k_ccl_count, g, dim3(256), 0, st, dp, info, label, size);
+  hipLaunchKernelGGL(k_ccl_count, g, dim3(256), 0, st, dp, info, D, label, size);
   hipLaunchKernelGGL(k_ccl_apply, g, dim3(256), 0, st, dp, info, D, label, size);
 }
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
