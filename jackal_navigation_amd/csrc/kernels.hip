@@ -285,8 +285,11 @@ __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo
 
 // ------------------------------------------------------------------------------------------------
 // Rasteriser: which triangle owns each pixel (loop structure of elas.cpp:874-901).  Eight lanes
-// share a triangle and take every 8th column.  Triangles tile the hull without overlap (shared
-// edges evaluate the identical float line, spans are half-open), so plain stores suffice.
+// share a triangle and take every 8th column.  Shared edges evaluate the identical float line and
+// spans are half-open, so triangles ALMOST tile the hull — but at a vertex column the two lines
+// of one triangle can round to different rows (a*u + (v - a*u) != v in float), so a few pixels
+// are claimed twice.  The reference visits triangles in list order and the last visitor's result
+// stays (findMatch's early-outs depend on the pixel only), hence atomicMax on the triangle index.
 __global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
                                                 int tri_cap, int32_t* __restrict__ tri_map) {
   const int frame = blockIdx.y, side = blockIdx.z;
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* _
       const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(r.ACa, fu), r.ACb);   // :878 / :893
       const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);         // :879 / :894
       const int lo = max(min(v1, v2), 0), hi = min(max(v1, v2), H);
-      for (int v = lo; v < hi; v++) map[(size_t)v * W + u] = t;
+      for (int v = lo; v < hi; v++) atomicMax(&map[(size_t)v * W + u], t);
     }
   }
 }

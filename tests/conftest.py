@@ -1,0 +1,59 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU restatement under oracle/ (checker only)."""
+    from oracle.binding import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The compiled reference (oracle/_ref); tests that need it are skipped where it was not built."""
+    from oracle.binding import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref/libelas_ref.so not built (needs /root/reference)")
+    return Reference()
+
+
+@pytest.fixture(scope="session")
+def jn():
+    """The product package; fails loudly (no skip) if libjn_stereo.so is missing."""
+    import jackal_navigation_amd as jn
+    jn.load()
+    return jn
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + ".npz"))
+    return load
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    return np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+@pytest.fixture(scope="session")
+def same():
+    return bits_equal

@@ -1,0 +1,87 @@
+"""The C-ABI library loads and exports every symbol include/jn_stereo.h declares; argument
+checking that needs no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "jn_stereo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(jn_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported(jn):
+    lib = jn.load()
+    declared = _declared_functions()
+    assert len(declared) >= 24
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    assert sorted(jn.EXPORTS) == declared, "python EXPORTS list out of sync with the header"
+
+
+def test_params_default_mirror_reference_presets(jn, oracle):
+    for setting in (0, 1):
+        a = jn.Elas.parameters(setting)
+        b = oracle.params(setting)
+        for name, _ in a._fields_:
+            assert getattr(a, name) == getattr(b, name), (setting, name)
+    p = jn.Elas.parameters(0)
+    assert (p.disp_max, p.candidate_stepsize, p.grid_size, p.speckle_size, p.ipol_gap_width) == (255, 5, 20, 200, 3)   # elas.h:92-115
+
+
+def test_struct_sizes(jn):
+    assert C.sizeof(jn.ElasParams) == 23 * 4
+    from jackal_navigation_amd._lib import StageTimes
+    assert C.sizeof(StageTimes) == 11 * 4
+
+
+def test_unsupported_parameter_combinations_are_refused(jn):
+    from jackal_navigation_amd import _lib
+    L = jn.load()
+    for kw in ({"subsampling": 1}, {"add_corners": 1}, {"filter_median": 1}, {"disp_max": 300}, {"ipol_gap_width": 5000}):
+        p = jn.Elas.parameters(0, **kw)
+        h = C.c_void_p()
+        st = L.jn_elas_create(C.byref(p), 320, 180, 1, 0, 1, 1, C.byref(h))
+        assert st == _lib.JN_ERR_UNSUPPORTED and not h.value, kw
+    p = jn.Elas.parameters(0)
+    h = C.c_void_p()
+    assert L.jn_elas_create(C.byref(p), 8, 8, 1, 0, 1, 1, C.byref(h)) == _lib.JN_ERR_INVALID
+
+
+def test_no_device_fails_loudly(jn):
+    """Without a GPU the product must refuse to compute (there is no CPU fallback)."""
+    from jackal_navigation_amd import _lib
+    from jackal_navigation_amd.device import device_count
+    if device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.JnError) as e:
+        jn.Elas(jn.Elas.parameters(0), 320, 180)
+    assert e.value.status == _lib.JN_ERR_NO_DEVICE
+
+
+def test_product_does_not_reference_the_oracle():
+    """Nothing under the product package may import, link or dlopen anything under oracle/."""
+    pkg = os.path.join(ROOT, "jackal_navigation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_synth_generator_matches_appendix_a(jn, oracle):
+    import numpy as np
+    a = jn.node.synth_pair(320, 180, 48, 12345)
+    b = oracle.synth_pair(320, 180, 48, 12345)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c = jn.node.synth_pair(333, 77, 20, 99)
+    d = oracle.synth_pair(333, 77, 20, 99)
+    assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])

@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: two processes (gloo), rigs sharded across ranks, scans merged by the MIN
+all-reduce of jackal_navigation_amd.parallel — the only exchange step of the path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from jackal_navigation_amd import parallel
+    from oracle.binding import Oracle
+    r, w, _ = parallel.init("gloo")
+    assert (r, w) == (rank, world)
+    o = Oracle()
+    W, H, rigs = 160, 120, 5
+    lo, hi = parallel.shard(rigs, rank, world)
+    sp = o.scan_params(W, H)
+    lut = o.valid_lut(sp, W, H)
+    bins = np.full((1, sp.bins), 1e9)
+    meta = np.array([[400., -400., 1e9, -500.]])
+    for rig in range(lo, hi):                       # each rank scans its own rigs (checker as stand-in for the GPU path)
+        L, R = o.synth_pair(W, H, 24, 100 + rig)
+        _, D1, _ = o.process(o.params(0, disp_max=63), L, R)
+        b, m, _ = o.scan(sp, o.to_u8(D1), lut)
+        bins[0] = np.minimum(bins[0], b)
+        meta[0] = [min(meta[0, 0], m[0]), max(meta[0, 1], m[1]), min(meta[0, 2], m[2]), max(meta[0, 3], m[3])]
+    tb, tm = torch.from_numpy(bins.copy()), torch.from_numpy(meta.copy())
+    parallel.merge_scans(tb, tm)
+    np.save(os.path.join(out_dir, "bins%d.npy" % rank), tb.numpy())
+    np.save(os.path.join(out_dir, "meta%d.npy" % rank), tm.numpy())
+    np.save(os.path.join(out_dir, "local%d.npy" % rank), bins)
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_partition():
+    from jackal_navigation_amd import parallel
+    for n in (1, 5, 8, 33):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_scan_merge(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    b0, b1 = np.load(tmp_path / "bins0.npy"), np.load(tmp_path / "bins1.npy")
+    l0, l1 = np.load(tmp_path / "local0.npy"), np.load(tmp_path / "local1.npy")
+    m0, m1 = np.load(tmp_path / "meta0.npy"), np.load(tmp_path / "meta1.npy")
+    assert np.array_equal(b0, b1) and np.array_equal(m0, m1)                  # every rank holds the merged scan
+    assert np.array_equal(b0, np.minimum(l0, l1))                             # element-wise MIN over rigs
+    assert (b0 < 1e9 - 1).sum() >= max((l0 < 1e9 - 1).sum(), (l1 < 1e9 - 1).sum())
+    assert m0[0, 0] <= m0[0, 1] and m0[0, 2] <= m0[0, 3]
