@@ -101,7 +101,7 @@ struct Slot {
   hipEvent_t ev[EV_COUNT] = {};
   // device
   uint8_t* du = nullptr; uint8_t* dv = nullptr; uint4* desc = nullptr; int16_t* d_can = nullptr;
-  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* tri_map = nullptr; float* raw = nullptr;
+  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; int32_t* bin_list = nullptr; float* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
   std::vector<FrameScratch> scratch;
@@ -178,9 +178,9 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   if (any_ok) {
     launch_grid(st, dp, n, s.info, s.payload, (int64_t)cap, max_sup, s.mark, s.gridbits);
     launch_tri_setup(st, dp, n, s.info, s.payload, (int64_t)cap, max_tri, h->tri_cap, s.recs);
-    launch_raster(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.tri_map);
+    launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list);
     HIP_TRY(hipEventRecord(s.ev[EV_RASTER], st));
-    launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.gridbits, s.desc, s.tri_map, s.raw);
+    launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
     HIP_TRY(hipEventRecord(s.ev[EV_DENSE], st));
     launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
     HIP_TRY(hipEventRecord(s.ev[EV_LR], st));
@@ -314,7 +314,9 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     HIP_TRY(dmalloc(&s->desc, 2 * B * px));
     HIP_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
-    HIP_TRY(dmalloc(&s->tri_map, 2 * B * px)); HIP_TRY(dmalloc(&s->raw, 2 * B * px));
+    const size_t tiles = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    HIP_TRY(dmalloc(&s->bin_count, 2 * B * tiles)); HIP_TRY(dmalloc(&s->bin_list, 2 * B * tiles * kBinCap));
+    HIP_TRY(dmalloc(&s->raw, 2 * B * px));
     HIP_TRY(dmalloc(&s->tmp, B * px)); HIP_TRY(dmalloc(&s->label, B * px)); HIP_TRY(dmalloc(&s->size, B * px));
     const size_t grid_words = 2 * B * dp.gw * dp.gh * kGridWords;
     HIP_TRY(dmalloc(&s->mark, grid_words)); HIP_TRY(dmalloc(&s->gridbits, grid_words));
@@ -343,7 +345,7 @@ void jn_elas_destroy(jn_elas* h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
     hipFree(s->du); hipFree(s->dv); hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
-    hipFree(s->tri_map); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
+    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);

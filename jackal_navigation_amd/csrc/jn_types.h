@@ -12,11 +12,13 @@ struct TriRec {
   uint16_t flags;            // bit0: plane prior valid (elas.cpp:872)
   float ACa, ACb, ABa, ABb, BCa, BCb;   // edge lines v = a*u + b (elas.cpp:862-868)
   float pa, pb, pc;          // disparity plane of this side (elas.cpp:817-827)
-  int32_t pad;
+  int16_t vmin, vmax;        // conservative inclusive row range of the rasterised triangle (for binning)
 };
 static_assert(sizeof(TriRec) == 48, "TriRec layout");
 
 enum { kGridWords = 8 };     // 256-bit candidate set per grid cell (disp_max <= 255)
+enum { kTile = 16 };         // dense matching works on 16x16 pixel tiles = one workgroup
+enum { kBinCap = 64 };       // triangle candidates kept per tile; longer lists fall back to a full scan
 
 // Per-frame bookkeeping uploaded before GPU stage B.  The frame payload the host stage produces is
 //   [support points: nsup x (u,v,d) int32][left corners: ntri[0] x 3 int32][right corners: ntri[1] x 3 int32]

@@ -279,56 +279,92 @@ __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo
   o.ACb = __fsub_rn(tv[0], __fmul_rn(ACa, tu[0]));
   o.BCb = __fsub_rn(tv[1], __fmul_rn(BCa, tu[1]));
   o.Au = (int16_t)tu[0]; o.Bu = (int16_t)tu[1]; o.Cu = (int16_t)tu[2];
-  o.pad = 0;
+  o.vmin = (int16_t)(min(sv[0], min(sv[1], sv[2])) - 1);      // truncated line values can land one row above the top corner
+  o.vmax = (int16_t)max(sv[0], max(sv[1], sv[2]));
   recs[(size_t)(frame * 2 + side) * tri_cap + t] = o;
 }
 
 // ------------------------------------------------------------------------------------------------
-// Rasteriser: which triangle owns each pixel (loop structure of elas.cpp:874-901).  Eight lanes
-// share a triangle and take every 8th column.  Shared edges evaluate the identical float line and
-// spans are half-open, so triangles ALMOST tile the hull — but at a vertex column the two lines
-// of one triangle can round to different rows (a*u + (v - a*u) != v in float), so a few pixels
-// are claimed twice.  The reference visits triangles in list order and the last visitor's result
-// stays (findMatch's early-outs depend on the pixel only), hence atomicMax on the triangle index.
-__global__ void __launch_bounds__(256) k_raster(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
-                                                int tri_cap, int32_t* __restrict__ tri_map) {
+// Triangle binning: every triangle is appended to the candidate list of each 16x16 pixel tile its
+// bounding box touches.  Eight lanes share a triangle.  Lists are capped at kBinCap; the count keeps
+// growing past the cap so that the matcher can tell an overflowing tile and scan all triangles.
+__global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
+                                             int tri_cap, int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_list) {
   const int frame = blockIdx.y, side = blockIdx.z;
   const FrameInfo fi = info[frame];
   if (!fi.ok) return;
   const int t = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   if (t >= fi.ntri[side]) return;
-  const TriRec r = recs[(size_t)(frame * 2 + side) * tri_cap + t];
-  int32_t* map = tri_map + ((size_t)(frame * 2 + side) * dp.H) * dp.W;
-  const int W = dp.W, H = dp.H;
-  for (int part = 0; part < 2; part++) {
-    const int ua = part ? r.Bu : r.Au, ub = part ? r.Cu : r.Bu;
-    if (ua == ub) continue;                                               // :875 / :890
-    const float ea = part ? r.BCa : r.ABa, eb = part ? r.BCb : r.ABb;
-    for (int u = max(ua, 0) + sub; u < min(ub, W); u += 8) {
-      const float fu = (float)u;
-      const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(r.ACa, fu), r.ACb);   // :878 / :893
-      const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);         // :879 / :894
-      const int lo = max(min(v1, v2), 0), hi = min(max(v1, v2), H);
-      for (int v = lo; v < hi; v++) atomicMax(&map[(size_t)v * W + u], t);
-    }
+  const TriRec* r = recs + (size_t)(frame * 2 + side) * tri_cap + t;
+  const int u0 = max((int)r->Au, 0), u1 = min((int)r->Cu, dp.W) - 1;          // columns [Au, Cu)
+  const int v0 = max((int)r->vmin, 0), v1 = min((int)r->vmax, dp.H - 1);
+  if (u1 < u0 || v1 < v0) return;
+  const int tx0 = u0 / kTile, tx1 = u1 / kTile, ty0 = v0 / kTile, ty1 = v1 / kTile;
+  const int ntx = tx1 - tx0 + 1, total = ntx * (ty1 - ty0 + 1);
+  const int tiles_x = (dp.W + kTile - 1) / kTile, tiles_y = (dp.H + kTile - 1) / kTile;
+  const size_t base = (size_t)(frame * 2 + side) * tiles_x * tiles_y;
+  for (int k = sub; k < total; k += 8) {
+    const size_t bin = base + (size_t)(ty0 + k / ntx) * tiles_x + tx0 + k % ntx;
+    const int slot = atomicAdd(&bin_count[bin], 1);
+    if (slot < kBinCap) bin_list[bin * kBinCap + slot] = t;
   }
 }
 
+// Does triangle (Au,Bu,Cu, lines) cover pixel (u,v) under the reference's raster loops
+// (elas.cpp:874-901)?  Part 1 spans columns [Au,Bu) between lines AC and AB, part 2 spans [Bu,Cu)
+// between AC and BC; rows are the half-open interval between the truncated line values.
+DEV bool tri_covers(int Au, int Bu, int Cu, float ACa, float ACb, float ABa, float ABb, float BCa, float BCb, int u, int v) {
+  float ea, eb;
+  if (u < Bu) { if (Au == Bu || u < Au) return false; ea = ABa; eb = ABb; }
+  else        { if (Bu == Cu || u >= Cu) return false; ea = BCa; eb = BCb; }
+  const float fu = (float)u;
+  const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(ACa, fu), ACb);           // :878 / :893
+  const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);             // :879 / :894
+  return v >= min(v1, v2) && v < max(v1, v2);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Dense MAP matching (findMatch, elas.cpp:683-780).  One thread per pixel of one side.
+// Dense MAP matching (computeDisparity + findMatch, elas.cpp:683-907).  One workgroup per 16x16
+// tile and side.  The tile's candidate triangles are staged in LDS; every pixel takes the LAST
+// triangle in list order that covers it — at a vertex column the two float edge lines of one
+// triangle can round to different rows, so a few pixels are covered twice and the reference keeps
+// the later visitor's result (findMatch's early-outs depend on the pixel only).
 __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
-                                               const TriRec* __restrict__ recs, int tri_cap, const uint32_t* __restrict__ gridbits,
-                                               const uint4* __restrict__ desc, const int32_t* __restrict__ tri_map,
-                                               float* __restrict__ raw) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+                                               const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
+                                               const int32_t* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
+                                               const uint4* __restrict__ desc, float* __restrict__ raw) {
+  __shared__ int s_t[kBinCap], s_Au[kBinCap], s_Bu[kBinCap], s_Cu[kBinCap];
+  __shared__ float s_l[6][kBinCap];
   const int frame = blockIdx.z >> 1, side = blockIdx.z & 1;
-  if (u >= dp.W) return;
   const FrameInfo fi = info[frame];
   if (!fi.ok) return;
   const int W = dp.W, H = dp.H;
+  const int tid = threadIdx.x;
+  const int u = blockIdx.x * kTile + (tid & (kTile - 1)), v = blockIdx.y * kTile + (tid >> 4);
+  const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
+  const size_t bin = ((size_t)(frame * 2 + side) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int cnt = bin_count[bin];
+  if (cnt <= kBinCap && tid < cnt) {
+    const int t = bin_list[bin * kBinCap + tid];
+    const TriRec r = R[t];
+    s_t[tid] = t; s_Au[tid] = r.Au; s_Bu[tid] = r.Bu; s_Cu[tid] = r.Cu;
+    s_l[0][tid] = r.ACa; s_l[1][tid] = r.ACb; s_l[2][tid] = r.ABa; s_l[3][tid] = r.ABb; s_l[4][tid] = r.BCa; s_l[5][tid] = r.BCb;
+  }
+  __syncthreads();
+  if (u >= W || v >= H) return;
+  int t = -1;
+  if (cnt <= kBinCap) {
+    for (int c = 0; c < cnt; c++)
+      if (s_t[c] > t && tri_covers(s_Au[c], s_Bu[c], s_Cu[c], s_l[0][c], s_l[1][c], s_l[2][c], s_l[3][c], s_l[4][c], s_l[5][c], u, v))
+        t = s_t[c];
+  } else {                                                   // overflowing tile: scan every triangle of this side
+    for (int c = fi.ntri[side] - 1; c >= 0; c--) {
+      const TriRec* r = R + c;
+      if (tri_covers(r->Au, r->Bu, r->Cu, r->ACa, r->ACb, r->ABa, r->ABb, r->BCa, r->BCb, u, v)) { t = c; break; }
+    }
+  }
   const size_t pix = (size_t)v * W + u;
   float* out = raw + ((size_t)(frame * 2 + side) * H) * W;
-  const int t = tri_map[((size_t)(frame * 2 + side) * H) * W + pix];
   float result = -10.0f;                                                   // :797-798
   if (t >= 0 && u >= 2 && u < W - 2) {                                     // :697
     const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
@@ -336,7 +372,7 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
     const int vr = max(min(v, H - 3), 2);                                  // :701
     const uint4 a = A[(size_t)vr * W + u];
     if (texture16(a) >= dp.match_texture) {                                // :715-719
-      const TriRec* tr = recs + (size_t)(frame * 2 + side) * tri_cap + t;
+      const TriRec* tr = R + t;
       const float pa = tr->pa, pb = tr->pb, pc = tr->pc;
       const bool valid = tr->flags & 1;
       const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
@@ -481,6 +517,7 @@ __global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo
   if (u > 0) { const float e = row[u - 1]; conn = e >= 0 && fabsf(d - e) <= dp.speckle_sim; }
   const int start = conn ? L[p] : p;                        // a non-start pixel's label is never rewritten
   const int root = uf_find(L, start);
+  if (root != start) L[start] = root;                       // compress: k_ccl_apply then needs at most two hops
   atomicAdd(&sz[frame * plane + root], p - start + 1);
 }
 __global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo* __restrict__ info, float* __restrict__ D,
@@ -663,6 +700,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
   if (threadIdx.x < 4) lmeta[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;   // min slots start high, max slots low
   __syncthreads();
   const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  unsigned long long tmin = ~0ull, tmax = 0ull, rmin = ~0ull, rmax = 0ull;
   if (i < W) {
     const size_t p = ((size_t)frame * H + j) * W + i;
     int d;
@@ -673,11 +711,19 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
       const double th = atan2(Y, X);
       const double deg = __dmul_rn(th, 180.) / s.pi;
       const double r = sqrt(__dadd_rn(__dmul_rn(Y, Y), __dmul_rn(X, X)));
-      atomicMin(&lmeta[0], enc(th)); atomicMax(&lmeta[1], enc(th));
-      atomicMin(&lmeta[2], enc(r));  atomicMax(&lmeta[3], enc(r));
+      tmin = tmax = enc(th); rmin = rmax = enc(r);
       const double kf = floor(__dmul_rn((double)s.bins, __dadd_rn(s.fov / 2., -deg)) / s.fov);   // :263
       if (kf >= 0 && kf < (double)s.bins) atomicMin(&lbins[(int)kf], enc(r));
     }
+  }
+  // extrema: butterfly inside the wave, then one LDS atomic per wave
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    tmin = min(tmin, __shfl_xor(tmin, off)); tmax = max(tmax, __shfl_xor(tmax, off));
+    rmin = min(rmin, __shfl_xor(rmin, off)); rmax = max(rmax, __shfl_xor(rmax, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (tmin != ~0ull) { atomicMin(&lmeta[0], tmin); atomicMax(&lmeta[1], tmax); atomicMin(&lmeta[2], rmin); atomicMax(&lmeta[3], rmax); }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < s.bins; k += 256)
@@ -771,15 +817,17 @@ void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInf
   if (max_tri <= 0) return;
   hipLaunchKernelGGL(k_tri_setup, dim3((max_tri + 255) / 256, n, 2), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, tri_cap, recs);
 }
-void launch_raster(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                   int max_tri, int32_t* tri_map) {
-  hipMemsetAsync(tri_map, 0xFF, (size_t)n * 2 * dp.H * dp.W * sizeof(int32_t), st);
+void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                int max_tri, int32_t* bin_count, int32_t* bin_list) {
+  const int tiles = ((dp.W + kTile - 1) / kTile) * ((dp.H + kTile - 1) / kTile);
+  hipMemsetAsync(bin_count, 0, (size_t)n * 2 * tiles * sizeof(int32_t), st);
   if (max_tri <= 0) return;
-  hipLaunchKernelGGL(k_raster, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, tri_map);
+  hipLaunchKernelGGL(k_bin, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const uint32_t* gridbits, const uint4* desc, const int32_t* tri_map, float* raw) {
-  hipLaunchKernelGGL(k_dense, grid2d(dp.W, dp.H, 2 * n), dim3(256), 0, st, dp, n, info, recs, tri_cap, gridbits, desc, tri_map, raw);
+                  const int32_t* bin_count, const int32_t* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw) {
+  const dim3 grid((dp.W + kTile - 1) / kTile, (dp.H + kTile - 1) / kTile, 2 * n);
+  hipLaunchKernelGGL(k_dense, grid, dim3(256), 0, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw);
 }
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
   hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
