@@ -138,6 +138,68 @@ __global__ void __launch_bounds__(256) k_support(DevParams dp, int n, const uint
   if (lane == 0) d_can[(size_t)frame * dp.cw * dp.ch + cand] = out;
 }
 
+// LDS variant: one 1024-thread workgroup per lattice row.  The four descriptor rows the row's
+// candidates read (v-2 and v+2 of both images) are staged once in LDS (64*W bytes); four lanes share
+// a candidate and stride the disparity range, merged by two DPP-style shuffles.  Used when 64*W
+// bytes fit the 160 KB LDS; otherwise the global-memory kernel above runs.
+DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Ab, const uint4* __restrict__ Bt,
+                   const uint4* __restrict__ Bb, const uint4* __restrict__ Arow_v, int u, bool right, bool active, int j) {
+  const int W = dp.W;
+  bool ok = active && u >= 5 && u <= W - 6;                                   // :283 (rows checked by the caller)
+  if (ok) ok = texture16(Arow_v[u]) >= dp.support_texture;                    // :301-305
+  const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326
+  ok = ok && dmax >= 10;                                                      // :329
+  Best b{32767, -1, 32767};
+  if (ok) {
+    const uint4 a0 = At[u - 2], a1 = At[u + 2], a2 = Ab[u - 2], a3 = Ab[u + 2];
+    for (int d = j; d <= dmax; d += 4) {
+      const int uw = right ? u + d : u - d;
+      const int s = sad16(a0, Bt[uw - 2]) + sad16(a1, Bt[uw + 2]) + sad16(a2, Bb[uw - 2]) + sad16(a3, Bb[uw + 2]);
+      if (s < b.e1) { b.e2 = b.e1; b.e1 = s; b.d1 = d; }
+      else if (s < b.e2) b.e2 = s;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    const int e1 = __shfl_xor(b.e1, off), d1 = __shfl_xor(b.d1, off), e2 = __shfl_xor(b.e2, off);
+    b = merge(b, e1, d1, e2);
+  }
+  return (ok && b.d1 >= 0 && (float)b.e1 < dp.support_threshold * (float)b.e2) ? b.d1 : -1;   // :366
+}
+
+__global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can) {
+  extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], W each
+  const int vc = blockIdx.x, frame = blockIdx.y, W = dp.W;
+  const int v = vc * dp.step;
+  int16_t* out_row = d_can + ((size_t)frame * dp.ch + vc) * dp.cw;
+  const bool row_ok = vc >= 1 && v >= 5 && v <= dp.H - 6;
+  if (!row_ok) {                                        // row 0 keeps calloc's zeros, other out-of-range rows are -1
+    for (int uc = threadIdx.x; uc < dp.cw; uc += 1024) out_row[uc] = (vc == 0 || uc == 0) ? 0 : -1;
+    return;
+  }
+  const uint4* L = desc + (size_t)frame * dp.H * W;
+  const uint4* R = desc + (size_t)(n + frame) * dp.H * W;
+  uint4* Lt = rows; uint4* Lb = rows + W; uint4* Rt = rows + 2 * W; uint4* Rb = rows + 3 * W;
+  for (int i = threadIdx.x; i < W; i += 1024) {
+    Lt[i] = L[(size_t)(v - 2) * W + i]; Lb[i] = L[(size_t)(v + 2) * W + i];
+    Rt[i] = R[(size_t)(v - 2) * W + i]; Rb[i] = R[(size_t)(v + 2) * W + i];
+  }
+  __syncthreads();
+  const uint4* Lv = L + (size_t)v * W;                  // row v itself is only read for the texture test
+  const uint4* Rv = R + (size_t)v * W;
+  const int j = threadIdx.x & 3;
+  for (int uc0 = 0; uc0 < dp.cw; uc0 += 256) {
+    const int uc = uc0 + (threadIdx.x >> 2);
+    const bool active = uc >= 1 && uc < dp.cw;
+    const int u = uc * dp.step;
+    int res = -1;
+    const int d = quad_match(dp, Lt, Lb, Rt, Rb, Lv, u, false, active, j);
+    const int d2 = quad_match(dp, Rt, Rb, Lt, Lb, Rv, u - d, true, active && d >= 0, j);
+    if (d >= 0 && d2 >= 0 && abs(d - d2) <= dp.lr_threshold) res = d;         // :404-411
+    if (j == 0 && uc < dp.cw) out_row[uc] = (int16_t)(uc == 0 ? 0 : res);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Grid prior (createGrid, elas.cpp:579-659) as 256-bit candidate sets per 20x20 cell.
 // mark: every support point sets d-1..d+1 in its cell (left: column u, right: column u-d).
@@ -802,7 +864,17 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint
   hipLaunchKernelGGL(k_descriptor, grid2d(dp.W, dp.H, nimg), dim3(256), 0, st, dp, du, dv, desc);
 }
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
+  const size_t lds = (size_t)4 * dp.W * sizeof(uint4);
+  if (lds <= 160 * 1024) {
+    static bool configured = false;
+    if (!configured) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      configured = true;
+    }
+    hipLaunchKernelGGL(k_support_lds, dim3(dp.ch, n), dim3(1024), lds, st, dp, n, desc, d_can);
+  } else {
+    hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
+  }
 }
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                  int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits) {
