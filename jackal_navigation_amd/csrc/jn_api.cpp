@@ -101,7 +101,7 @@ struct Slot {
   hipEvent_t ev[EV_COUNT] = {};
   // device
   uint8_t* du = nullptr; uint8_t* dv = nullptr; uint4* desc = nullptr; int16_t* d_can = nullptr;
-  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; int32_t* bin_list = nullptr; float* raw = nullptr;
+  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; BinEntry* bin_list = nullptr; float* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
   std::vector<FrameScratch> scratch;
@@ -314,7 +314,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     HIP_TRY(dmalloc(&s->desc, 2 * B * px));
     HIP_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
-    const size_t tiles = (size_t)((W + kTile - 1) / kTile) * ((H + kTile - 1) / kTile);
+    const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
     HIP_TRY(dmalloc(&s->bin_count, 2 * B * tiles)); HIP_TRY(dmalloc(&s->bin_list, 2 * B * tiles * kBinCap));
     HIP_TRY(dmalloc(&s->raw, 2 * B * px));
     HIP_TRY(dmalloc(&s->tmp, B * px)); HIP_TRY(dmalloc(&s->label, B * px)); HIP_TRY(dmalloc(&s->size, B * px));

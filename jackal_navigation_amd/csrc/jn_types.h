@@ -17,8 +17,20 @@ struct TriRec {
 static_assert(sizeof(TriRec) == 48, "TriRec layout");
 
 enum { kGridWords = 8 };     // 256-bit candidate set per grid cell (disp_max <= 255)
-enum { kTile = 16 };         // dense matching works on 16x16 pixel tiles = one workgroup
+enum { kTileW = 32, kTileH = 8 };   // dense matching works on 32x8 pixel tiles = one 256-thread workgroup
 enum { kBinCap = 64 };       // triangle candidates kept per tile; longer lists fall back to a full scan
+
+// One candidate triangle of one 32x8 tile: byte x of `rows` has bit r set iff the reference's raster
+// loops (elas.cpp:874-901) visit pixel (tile_u0 + x, tile_v0 + r) for triangle t.
+struct BinEntry {
+  int32_t t;
+  uint32_t rows[kTileW / 4];
+  float pa, pb, pc;          // the triangle's disparity plane and validity flag ride along so that the
+  uint32_t flags;            // matcher needs no dependent TriRec fetch after the lookup
+};
+static_assert(sizeof(BinEntry) == 52, "BinEntry layout");
+enum { kBinWords = 13 };     // sizeof(BinEntry) / 4
+enum { kBinLds = 24 };       // list entries per tile kept in LDS by the matcher; longer lists are read from global memory
 
 // Per-frame bookkeeping uploaded before GPU stage B.  The frame payload the host stage produces is
 //   [support points: nsup x (u,v,d) int32][left corners: ntri[0] x 3 int32][right corners: ntri[1] x 3 int32]

@@ -27,12 +27,12 @@ void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* in
 // Plane fits + edge lines per triangle (elas.cpp:507-577, :847-872): recs [n][2][tri_cap].
 void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                       int64_t payload_stride, int max_tri, int tri_cap, TriRec* recs);
-// Triangle candidates per 16x16 tile: bin_count [n][2][tiles], bin_list [n][2][tiles][kBinCap].
+// Triangle candidates per 32x8 tile with their row masks: bin_count [n][2][tiles], bin_list [n][2][tiles][kBinCap].
 void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                int max_tri, int32_t* bin_count, int32_t* bin_list);
+                int max_tri, int32_t* bin_count, BinEntry* bin_list);
 // Dense MAP matching with in-kernel triangle lookup (elas.cpp:683-907): raw [n][2][H][W] float.
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const int32_t* bin_count, const int32_t* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw);
+                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw);
 // Left/right consistency (elas.cpp:909-979): raw -> D1, D2 (user buffers).
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2);
 // Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.

@@ -5,6 +5,7 @@
 // in the same order (built with -ffp-contract=off; products/sums that must not fuse use
 // __fmul_rn/__fadd_rn explicitly).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace jnav {
 
@@ -347,28 +348,57 @@ __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Triangle binning: every triangle is appended to the candidate list of each 16x16 pixel tile its
-// bounding box touches.  Eight lanes share a triangle.  Lists are capped at kBinCap; the count keeps
-// growing past the cap so that the matcher can tell an overflowing tile and scan all triangles.
+// Triangle binning + per-tile rasterisation.  Eight lanes share a triangle; each lane takes some of
+// the 32x8 tiles the triangle's bounding box touches, evaluates the reference's raster loops
+// (elas.cpp:874-901) for the tile's 32 columns and, if any pixel is covered, appends
+// {triangle, 32 row masks} to the tile's list.  Lists are capped at kBinCap; the count keeps growing
+// past the cap so that the matcher can tell an overflowing tile and scan all triangles instead.
 __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
-                                             int tri_cap, int32_t* __restrict__ bin_count, int32_t* __restrict__ bin_list) {
+                                             int tri_cap, int32_t* __restrict__ bin_count, BinEntry* __restrict__ bin_list) {
   const int frame = blockIdx.y, side = blockIdx.z;
   const FrameInfo fi = info[frame];
   if (!fi.ok) return;
   const int t = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   if (t >= fi.ntri[side]) return;
-  const TriRec* r = recs + (size_t)(frame * 2 + side) * tri_cap + t;
-  const int u0 = max((int)r->Au, 0), u1 = min((int)r->Cu, dp.W) - 1;          // columns [Au, Cu)
-  const int v0 = max((int)r->vmin, 0), v1 = min((int)r->vmax, dp.H - 1);
-  if (u1 < u0 || v1 < v0) return;
-  const int tx0 = u0 / kTile, tx1 = u1 / kTile, ty0 = v0 / kTile, ty1 = v1 / kTile;
+  const TriRec q = recs[(size_t)(frame * 2 + side) * tri_cap + t];
+  const int Au = q.Au, Bu = q.Bu, Cu = q.Cu;
+  const int c0 = max(Au, 0), c1 = min(Cu, dp.W) - 1;                          // columns [Au, Cu)
+  const int r0 = max((int)q.vmin, 0), r1 = min((int)q.vmax, dp.H - 1);
+  if (c1 < c0 || r1 < r0) return;
+  const int tx0 = c0 / kTileW, tx1 = c1 / kTileW, ty0 = r0 / kTileH, ty1 = r1 / kTileH;
   const int ntx = tx1 - tx0 + 1, total = ntx * (ty1 - ty0 + 1);
-  const int tiles_x = (dp.W + kTile - 1) / kTile, tiles_y = (dp.H + kTile - 1) / kTile;
+  const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
   const size_t base = (size_t)(frame * 2 + side) * tiles_x * tiles_y;
   for (int k = sub; k < total; k += 8) {
-    const size_t bin = base + (size_t)(ty0 + k / ntx) * tiles_x + tx0 + k % ntx;
+    const int tx = tx0 + k % ntx, ty = ty0 + k / ntx;
+    const int u0 = tx * kTileW, v0 = ty * kTileH;
+    BinEntry e; e.t = t; e.pa = q.pa; e.pb = q.pb; e.pc = q.pc; e.flags = q.flags;
+    uint32_t any = 0;
+#pragma unroll
+    for (int wd = 0; wd < kTileW / 4; wd++) {
+      uint32_t packed = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int uc = u0 + wd * 4 + b;
+        float ea = 0, eb = 0; bool in = false;
+        if (uc < Bu) { if (Au != Bu && uc >= Au) { in = true; ea = q.ABa; eb = q.ABb; } }       // :875-876
+        else         { if (Bu != Cu && uc < Cu)  { in = true; ea = q.BCa; eb = q.BCb; } }       // :890-891
+        uint32_t m = 0;
+        if (in && uc < dp.W) {
+          const float fu = (float)uc;
+          const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(q.ACa, fu), q.ACb);                 // :878 / :893
+          const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);                       // :879 / :894
+          const int lo = max(min(v1, v2) - v0, 0), hi = min(max(v1, v2) - v0, kTileH);         // rows [lo,hi) of this tile
+          if (hi > lo) m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        }
+        packed |= m << (8 * b);
+      }
+      e.rows[wd] = packed; any |= packed;
+    }
+    if (!any) continue;                                   // bounding box touched the tile, the triangle does not
+    const size_t bin = base + (size_t)ty * tiles_x + tx;
     const int slot = atomicAdd(&bin_count[bin], 1);
-    if (slot < kBinCap) bin_list[bin * kBinCap + slot] = t;
+    if (slot < kBinCap) bin_list[bin * kBinCap + slot] = e;
   }
 }
 
@@ -386,86 +416,162 @@ DEV bool tri_covers(int Au, int Bu, int Cu, float ACa, float ACb, float ABa, flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense MAP matching (computeDisparity + findMatch, elas.cpp:683-907).  One workgroup per 16x16
-// tile and side.  The tile's candidate triangles are staged in LDS; every pixel takes the LAST
-// triangle in list order that covers it — at a vertex column the two float edge lines of one
-// triangle can round to different rows, so a few pixels are covered twice and the reference keeps
-// the later visitor's result (findMatch's early-outs depend on the pixel only).
+// Dense MAP matching (computeDisparity + findMatch, elas.cpp:683-907).  One 256-thread workgroup
+// per 128x8 pixel strip and side; every thread owns 4 pixels (columns x, x+32, x+64, x+96 of its row).
+//  * The descriptors of the OTHER image that the strip can reach — 8 rows x (128 + disp_max)
+//    columns — are staged once in LDS with coalesced 16-byte loads (2 loads per pixel instead of
+//    one scattered 16-byte read per candidate disparity, ~13 per pixel); every candidate then
+//    costs one ds_read_b128 + four v_sad_u8.
+//  * Triangle lookup: k_bin left, per 32x8 tile, a list of {triangle, 8-bit row mask per tile
+//    column} (bit r set <=> the reference's raster loops, elas.cpp:874-901, visit pixel
+//    (u0+x, v0+r) for that triangle).  Every pixel takes the LAST covering triangle in list order
+//    — at a vertex column the two float edge lines of one triangle can round to different rows,
+//    so a few pixels are covered twice and the reference keeps the later visitor's result
+//    (findMatch's early-outs depend on the pixel only).
+//  * Candidate disparities: the cell's 256-bit set is pre-masked per 32-bit word with the plane
+//    range and the image-border range, so the inner loop is ctz -> read -> 4x v_sad_u8 -> select.
+DEV uint32_t range_mask(int lo, int hi, int w) {               // bits of word w (disparities 32w..32w+31) inside [lo,hi]
+  const int a = max(lo - 32 * w, 0), b = min(hi - 32 * w, 31);
+  if (a > b) return 0u;
+  return (0xFFFFFFFFu >> (31 - b)) & (0xFFFFFFFFu << a);
+}
+
+enum { kStripTiles = 4, kStripW = kStripTiles * kTileW };
+
 __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
                                                const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
-                                               const int32_t* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
+                                               const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
                                                const uint4* __restrict__ desc, float* __restrict__ raw) {
-  __shared__ int s_t[kBinCap], s_Au[kBinCap], s_Bu[kBinCap], s_Cu[kBinCap];
-  __shared__ float s_l[6][kBinCap];
+  __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
+  __shared__ int s_cnt[kStripTiles];
+  extern __shared__ uint4 s_B[];                             // [kTileH][kStripW + disp_max]
   const int frame = blockIdx.z >> 1, side = blockIdx.z & 1;
   const FrameInfo fi = info[frame];
   if (!fi.ok) return;
   const int W = dp.W, H = dp.H;
   const int tid = threadIdx.x;
-  const int u = blockIdx.x * kTile + (tid & (kTile - 1)), v = blockIdx.y * kTile + (tid >> 4);
+  const int u0 = blockIdx.x * kStripW, v0 = blockIdx.y * kTileH;
+  const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
+  const uint4* B = desc + (size_t)((side ? 0 : n) + frame) * H * W;      // image searched
   const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
-  const size_t bin = ((size_t)(frame * 2 + side) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  const int cnt = bin_count[bin];
-  if (cnt <= kBinCap && tid < cnt) {
-    const int t = bin_list[bin * kBinCap + tid];
-    const TriRec r = R[t];
-    s_t[tid] = t; s_Au[tid] = r.Au; s_Bu[tid] = r.Bu; s_Cu[tid] = r.Cu;
-    s_l[0][tid] = r.ACa; s_l[1][tid] = r.ACb; s_l[2][tid] = r.ABa; s_l[3][tid] = r.ABb; s_l[4][tid] = r.BCa; s_l[5][tid] = r.BCb;
+  const int tiles_x = (W + kTileW - 1) / kTileW;
+  const size_t bin_row = ((size_t)(frame * 2 + side) * gridDim.y + blockIdx.y) * tiles_x;
+  const int x = tid & (kTileW - 1), r = tid / kTileW;
+  const int v = v0 + r;
+  const int vr = max(min(v, H - 3), 2);                                    // :701
+  const int nwords = (dp.disp_max >> 5) + 1;
+
+  // ---- issue every global read of this thread up front ----
+  // (1) candidate lists: wave k copies tile k's list (cnt first, then its dwords)
+  {
+    const int k = tid >> 6, lane = tid & 63;
+    const int tx = blockIdx.x * kStripTiles + k;
+    int cnt = 0;
+    if (tx < tiles_x) {
+      const size_t bin = bin_row + tx;
+      cnt = bin_count[bin];
+      const int words = min(cnt, (int)kBinLds) * kBinWords;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
+      for (int i = lane; i < words; i += 64) s_list[k][i] = src[i];
+    }
+    if (lane == 0) s_cnt[k] = cnt;
   }
-  __syncthreads();
-  if (u >= W || v >= H) return;
-  int t = -1;
-  if (cnt <= kBinCap) {
-    for (int c = 0; c < cnt; c++)
-      if (s_t[c] > t && tri_covers(s_Au[c], s_Bu[c], s_Cu[c], s_l[0][c], s_l[1][c], s_l[2][c], s_l[3][c], s_l[4][c], s_l[5][c], u, v))
-        t = s_t[c];
-  } else {                                                   // overflowing tile: scan every triangle of this side
-    for (int c = fi.ntri[side] - 1; c >= 0; c--) {
-      const TriRec* r = R + c;
-      if (tri_covers(r->Au, r->Bu, r->Cu, r->ACa, r->ACb, r->ABa, r->ABb, r->BCa, r->BCb, u, v)) { t = c; break; }
+  // (2) own descriptors and grid-cell candidate sets of the thread's four pixels
+  uint4 a4[kStripTiles];
+  uint32_t cellw[kStripTiles][kGridWords];
+  const uint32_t* cells = gridbits + ((size_t)(frame * 2 + side) * dp.gw * dp.gh + (size_t)(min(v, H - 1) / dp.grid_size) * dp.gw) * kGridWords;
+#pragma unroll
+  for (int k = 0; k < kStripTiles; k++) {
+    const int u = min(u0 + k * kTileW + x, W - 1);
+    a4[k] = A[(size_t)vr * W + u];
+    const uint32_t* cell = cells + (size_t)(u / dp.grid_size) * kGridWords;
+#pragma unroll
+    for (int w = 0; w < kGridWords; w++) cellw[k][w] = w < nwords ? cell[w] : 0u;
+  }
+  // (3) the other image's descriptors the strip can reach
+  const int span = kStripW + dp.disp_max;                    // columns of B one strip row can reach
+  const int base = side ? u0 : u0 - dp.disp_max;             // left image looks left (u-d), right image looks right (u+d)
+#pragma unroll
+  for (int rr = 0; rr < kTileH; rr++) {
+    const uint4* src = B + (size_t)max(min(v0 + rr, H - 3), 2) * W;       // :701 row clamp
+    for (int c = tid; c < span; c += 256) {
+      const int col = base + c;
+      s_B[rr * span + c] = (col >= 0 && col < W) ? src[col] : make_uint4(0, 0, 0, 0);
     }
   }
-  const size_t pix = (size_t)v * W + u;
-  float* out = raw + ((size_t)(frame * 2 + side) * H) * W;
-  float result = -10.0f;                                                   // :797-798
-  if (t >= 0 && u >= 2 && u < W - 2) {                                     // :697
-    const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
-    const uint4* B = desc + (size_t)((side ? 0 : n) + frame) * H * W;      // image searched
-    const int vr = max(min(v, H - 3), 2);                                  // :701
-    const uint4 a = A[(size_t)vr * W + u];
-    if (texture16(a) >= dp.match_texture) {                                // :715-719
-      const TriRec* tr = R + t;
-      const float pa = tr->pa, pb = tr->pb, pc = tr->pc;
-      const bool valid = tr->flags & 1;
+  __syncthreads();
+  if (v >= H) return;
+
+  const uint4* Brow = s_B + r * span - base;                               // Brow[uw] = descriptor of column uw in row vr
+  float* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;
+
+#pragma unroll
+  for (int k = 0; k < kStripTiles; k++) {
+    const int u = u0 + k * kTileW + x;
+    if (u >= W) break;
+    // ---- which triangle owns this pixel: the last covering one in list order ----
+    const int cnt = s_cnt[k];
+    int t = -1; float pa = 0, pb = 0, pc = 0; bool valid = false;
+    if (cnt <= kBinLds) {
+      int hit = -1;
+      for (int c = 0; c < cnt; c++) {
+        const uint32_t* e = &s_list[k][c * kBinWords];
+        const unsigned m = (e[1 + (x >> 2)] >> ((x & 3) * 8)) & 0xFFu;
+        const int tc = (int)e[0];
+        if (((m >> r) & 1u) && tc > t) { t = tc; hit = c; }
+      }
+      if (hit >= 0) {
+        const uint32_t* e = &s_list[k][hit * kBinWords];
+        pa = __uint_as_float(e[9]); pb = __uint_as_float(e[10]); pc = __uint_as_float(e[11]); valid = e[12] & 1u;
+      }
+    } else {
+      if (cnt <= kBinCap) {                                  // long list: read it from global memory
+        const BinEntry* list = bin_list + (bin_row + blockIdx.x * kStripTiles + k) * kBinCap;
+        for (int c = 0; c < cnt; c++) {
+          const unsigned m = reinterpret_cast<const uint8_t*>(list[c].rows)[x];
+          const int tc = list[c].t;
+          if (((m >> r) & 1u) && tc > t) t = tc;
+        }
+      } else {                                               // overflowing tile: scan every triangle of this side
+        for (int c = fi.ntri[side] - 1; c >= 0; c--) {
+          const TriRec* q = R + c;
+          if (tri_covers(q->Au, q->Bu, q->Cu, q->ACa, q->ACb, q->ABa, q->ABb, q->BCa, q->BCb, u, v)) { t = c; break; }
+        }
+      }
+      if (t >= 0) { const TriRec* tr = R + t; pa = tr->pa; pb = tr->pb; pc = tr->pc; valid = tr->flags & 1; }
+    }
+    float result = -10.0f;                                                 // :797-798
+    const uint4 a = a4[k];
+    if (t >= 0 && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture) {   // :697, :715-719
       const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
       const int lo = max(d_plane - dp.radius, 0), hi = min(d_plane + dp.radius, dp.disp_max);                // :723-724
-      const uint32_t* cell = gridbits + ((size_t)(frame * 2 + side) * dp.gw * dp.gh +
-                                         (size_t)(v / dp.grid_size) * dp.gw + (u / dp.grid_size)) * kGridWords;   // :727-731
-      const uint4* Brow = B + (size_t)vr * W;
+      // disparities whose warped column stays inside [2, W-2) (:746, :753, :764, :771)
+      const int dmax_ok = side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
       int best = 10000, best_d = -1;                                       // :735-736
-      const int nwords = (dp.disp_max >> 5) + 1;
-      for (int w = 0; w < nwords; w++) {                                   // grid candidates outside the plane range (:742-750)
-        uint32_t bits = cell[w];
+#pragma unroll
+      for (int w = 0; w < kGridWords; w++) {                               // grid candidates outside the plane range (:742-750)
+        if (w >= nwords) break;
+        uint32_t bits = cellw[k][w] & range_mask(0, dmax_ok, w) & ~range_mask(lo, hi, w);
         while (bits) {
           const int d = (w << 5) + __builtin_ctz(bits);
           bits &= bits - 1;
-          if (d >= lo && d <= hi) continue;
-          const int uw = side ? u + d : u - d;
-          if (uw < 2 || uw >= W - 2) continue;
-          const int val = sad16(a, Brow[uw]);
+          const int val = sad16(a, Brow[side ? u + d : u - d]);
           if (val < best) { best = val; best_d = d; }
         }
       }
-      for (int d = lo; d <= hi; d++) {                                     // plane neighbourhood with prior (:751-756)
-        const int uw = side ? u + d : u - d;
-        if (uw < 2 || uw >= W - 2) continue;
-        const int val = sad16(a, Brow[uw]) + (valid ? dp.P[abs(d - d_plane)] : 0);
+      const int phi = min(hi, dmax_ok);
+      for (int d = lo; d <= phi; d++) {                                    // plane neighbourhood with prior (:751-756)
+        int val = sad16(a, Brow[side ? u + d : u - d]);
+        if (valid) {
+          const int kk = abs(d - d_plane);                                 // <= radius <= 7; select chain instead of indexed kernarg
+          val += kk == 0 ? dp.P[0] : kk == 1 ? dp.P[1] : kk == 2 ? dp.P[2] : kk == 3 ? dp.P[3] : kk == 4 ? dp.P[4] : kk == 5 ? dp.P[5] : kk == 6 ? dp.P[6] : dp.P[7];
+        }
         if (val < best) { best = val; best_d = d; }
       }
       result = best_d >= 0 ? (float)best_d : -1.0f;                        // :778-779
     }
+    out[u] = result;
   }
-  out[pix] = result;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -890,16 +996,17 @@ void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInf
   hipLaunchKernelGGL(k_tri_setup, dim3((max_tri + 255) / 256, n, 2), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, tri_cap, recs);
 }
 void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                int max_tri, int32_t* bin_count, int32_t* bin_list) {
-  const int tiles = ((dp.W + kTile - 1) / kTile) * ((dp.H + kTile - 1) / kTile);
+                int max_tri, int32_t* bin_count, BinEntry* bin_list) {
+  const int tiles = ((dp.W + kTileW - 1) / kTileW) * ((dp.H + kTileH - 1) / kTileH);
   hipMemsetAsync(bin_count, 0, (size_t)n * 2 * tiles * sizeof(int32_t), st);
   if (max_tri <= 0) return;
   hipLaunchKernelGGL(k_bin, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const int32_t* bin_count, const int32_t* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw) {
-  const dim3 grid((dp.W + kTile - 1) / kTile, (dp.H + kTile - 1) / kTile, 2 * n);
-  hipLaunchKernelGGL(k_dense, grid, dim3(256), 0, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw);
+                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw) {
+  const dim3 grid((dp.W + kStripW - 1) / kStripW, (dp.H + kTileH - 1) / kTileH, 2 * n);
+  const size_t lds = (size_t)kTileH * (kStripW + dp.disp_max) * sizeof(uint4);   // 32.6 KB at disp_max 127, 49 KB at 255
+  hipLaunchKernelGGL(k_dense, grid, dim3(256), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw);
 }
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
   hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
