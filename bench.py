@@ -84,8 +84,8 @@ def cpu_baseline(W, H, scene, disp, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--slots", type=int, default=3)
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (=RCCL, default) or gloo; gloo + --share-gpu lets two ranks dry-run the N>1 path on one GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses device 0")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,18 +110,24 @@ def main():
 
     import torch
     import jackal_navigation_amd as jn
-    from jackal_navigation_amd import node
+    from jackal_navigation_amd import node, parallel
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    on_gpu = a.dist_backend == "nccl"      # gloo reduces CPU tensors
 
     ncpu = os.cpu_count() or 1
     host_threads = a.host_threads or max(4, min(ncpu // max(world, 1) - 2, B * S))
@@ -150,8 +159,13 @@ def main():
             stage_acc.setdefault(k, []).append(v)
         node.disparity_scan(sp, B, D1[slot].data_ptr(), lut.ptr, W, H, U8[slot].data_ptr(), bins[slot].data_ptr(),
                             meta[slot].data_ptr(), device=local_rank)
-        if dist is not None:
-            dist.all_reduce(bins[slot], op=dist.ReduceOp.MIN)
+        if dist is not None:                      # the path's one exchange step: robot-level scan = MIN over rigs
+            if on_gpu:
+                parallel.merge_scans(bins[slot], meta[slot])
+            else:
+                b, m = bins[slot].cpu(), meta[slot].cpu()
+                parallel.merge_scans(b, m)
+                bins[slot].copy_(b); meta[slot].copy_(m)
 
     def run(steps):
         inflight = []
@@ -177,7 +191,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
