@@ -164,6 +164,36 @@ int32_t jn_compact_ranges(const double* bins, int32_t nbins, float* ranges);
 jn_status jn_point_cloud(int32_t device, const jn_scan_params* sp, const uint8_t* dDisp, int32_t width,
                          int32_t height, float* dXyz, int64_t* count);
 
+/* ---- rectification front end (OpenCV-side arithmetic: parity UNPINNED) ---- */
+
+/* The matrices `main` reads from the calibration YAML (point_cloud.cpp:530-536). */
+typedef struct jn_stereo_calib {
+  double K1[9], D1[5], K2[9], D2[5];   /* camera matrices, Brown distortion (k1,k2,p1,p2,k3) */
+  double R[9], T[3];                   /* pose of camera 2 w.r.t. camera 1 */
+  int32_t calib_width, calib_height;   /* calib_im_size, point_cloud.cpp:38 */
+} jn_stereo_calib;
+typedef struct jn_rectification { double R1[9], R2[9], P1[12], P2[12], Q[16]; } jn_rectification;
+
+/* calibration/amrl_jackal_webcam_stereo.yml:1-37 */
+void jn_stereo_calib_default(jn_stereo_calib* c);
+
+/* cv::stereoRectify(K1,D1,K2,D2,calib_size,R,T, R1,R2,P1,P2,Q, CV_CALIB_ZERO_DISPARITY, alpha=0,
+ * newImageSize) as called at point_cloud.cpp:543-544.  Host, double. */
+jn_status jn_stereo_rectify(const jn_stereo_calib* c, int32_t new_width, int32_t new_height, jn_rectification* out);
+
+/* cv::initUndistortRectifyMap(K, D, R, P, size, CV_32F, mapx, mapy) (point_cloud.cpp:553-554).
+ * dMapX/dMapY: device float [height][width]. */
+jn_status jn_init_undistort_rectify_map(int32_t device, const double K[9], const double D[5], const double R[9],
+                                        const double P[12], int32_t width, int32_t height, float* dMapX, float* dMapY);
+
+/* cv::remap(src, dst, mapx, mapy, INTER_LINEAR) with BORDER_CONSTANT 0 (point_cloud.cpp:440, :481)
+ * for n grey source frames (device).  Source coordinates are quantised to 1/32 pixel
+ * (round-half-even, as OpenCV does); the four taps are blended with exact 10-bit weights
+ * ((32-fx)(32-fy) ...)/1024, rounded to nearest. */
+jn_status jn_remap_bilinear(int32_t device, int32_t n, const uint8_t* dSrc, int32_t src_width, int32_t src_height,
+                            int32_t src_pitch, int64_t src_stride, const float* dMapX, const float* dMapY,
+                            uint8_t* dDst, int32_t width, int32_t height, int32_t dst_pitch, int64_t dst_stride);
+
 /* ---- utilities ---------------------------------------------------------------------------- */
 
 /* Synthetic rectified pair of the benchmark (SURVEY.md Appendix A generator), host buffers. */

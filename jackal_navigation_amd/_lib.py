@@ -42,6 +42,16 @@ class ScanParams(C.Structure):
                 ("fov_deg", C.c_double), ("bins", C.c_int32), ("pi_approx", C.c_double)]
 
 
+class StereoCalib(C.Structure):
+    """jn_stereo_calib: what main() reads from the calibration YAML (point_cloud.cpp:530-536)."""
+    _fields_ = [("K1", C.c_double * 9), ("D1", C.c_double * 5), ("K2", C.c_double * 9), ("D2", C.c_double * 5),
+                ("R", C.c_double * 9), ("T", C.c_double * 3), ("calib_width", C.c_int32), ("calib_height", C.c_int32)]
+
+
+class Rectification(C.Structure):
+    _fields_ = [("R1", C.c_double * 9), ("R2", C.c_double * 9), ("P1", C.c_double * 12), ("P2", C.c_double * 12), ("Q", C.c_double * 16)]
+
+
 class StageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("gpu_descriptor", "gpu_support", "d2h", "host_stage", "h2d", "gpu_matching",
                                          "gpu_lr", "gpu_speckle", "gpu_gap", "gpu_adaptive_mean", "total")]
@@ -57,6 +67,7 @@ EXPORTS = [
     "jn_build_valid_disp_lut", "jn_obstacle_scan", "jn_disparity_scan", "jn_compact_ranges", "jn_point_cloud",
     "jn_synth_pair", "jn_device_count", "jn_device_malloc", "jn_device_free", "jn_memcpy_h2d", "jn_memcpy_d2h",
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
+    "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
 ]
 
 _lib = None
@@ -98,6 +109,9 @@ def load():
     L.jn_memcpy_h2d.argtypes = [i32, vp, vp, i64]
     L.jn_memcpy_d2h.argtypes = [i32, vp, vp, i64]
     L.jn_device_synchronize.argtypes = [i32]
+    L.jn_stereo_rectify.argtypes = [C.POINTER(StereoCalib), i32, i32, C.POINTER(Rectification)]
+    L.jn_init_undistort_rectify_map.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp]
+    L.jn_remap_bilinear.argtypes = [i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, i32, i32, i32, i64]
     L.jn_host_triangulate.argtypes = [vp, vp, i32, vp]
     L.jn_host_stage.argtypes = [C.POINTER(ElasParams), i32, i32, vp, vp, i64, vp]
     L.jn_host_stage.restype = i64

@@ -506,6 +506,38 @@ jn_status jn_point_cloud(int32_t device, const jn_scan_params* sp, const uint8_t
   return JN_OK;
 }
 
+// ---- rectification front end -----------------------------------------------------------------------
+jn_status jn_init_undistort_rectify_map(int32_t device, const double K[9], const double D[5], const double R[9], const double P[12],
+                                        int32_t W, int32_t H, float* dMapX, float* dMapY) {
+  if (!K || !D || !R || !P || !dMapX || !dMapY || W < 1 || H < 1) return JN_ERR_INVALID;
+  // iR = inverse(P[:, :3] * R), by cofactors
+  double M[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M[3 * i + j] = P[4 * i] * R[j] + P[4 * i + 1] * R[3 + j] + P[4 * i + 2] * R[6 + j];
+  const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+  const double det = M[0] * c00 + M[1] * c01 + M[2] * c02;
+  if (det == 0.0) return JN_ERR_INVALID;
+  const double id = 1.0 / det;
+  const double iR[9] = {c00 * id, (M[2] * M[7] - M[1] * M[8]) * id, (M[1] * M[5] - M[2] * M[4]) * id,
+                        c01 * id, (M[0] * M[8] - M[2] * M[6]) * id, (M[2] * M[3] - M[0] * M[5]) * id,
+                        c02 * id, (M[1] * M[6] - M[0] * M[7]) * id, (M[0] * M[4] - M[1] * M[3]) * id};
+  HIP_TRY(hipSetDevice(device));
+  launch_undistort_map(nullptr, iR, K, D, W, H, dMapX, dMapY);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipGetLastError());
+  return JN_OK;
+}
+
+jn_status jn_remap_bilinear(int32_t device, int32_t n, const uint8_t* dSrc, int32_t sw, int32_t sh, int32_t spitch, int64_t sstride,
+                            const float* dMapX, const float* dMapY, uint8_t* dDst, int32_t W, int32_t H, int32_t dpitch, int64_t dstride) {
+  if (!dSrc || !dMapX || !dMapY || !dDst || n < 1 || sw < 1 || sh < 1 || W < 1 || H < 1 || spitch < sw || dpitch < W) return JN_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  launch_remap(nullptr, n, dSrc, sw, sh, spitch, sstride, dMapX, dMapY, dDst, W, H, dpitch, dstride);
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  HIP_TRY(hipGetLastError());
+  return JN_OK;
+}
+
 // ---- host-stage hooks -----------------------------------------------------------------------------
 int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri) {
   if (!x || !y || !tri || n < 0) return -1;

@@ -48,6 +48,10 @@ void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, ui
 // scratch: [n][4] uint64.  If dD != nullptr the u8 map is produced from it first (fused), else dDisp is read.
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
                  int W, int H, double* bins, double* meta, unsigned long long* scratch);
+// Rectification front end (point_cloud.cpp:440, :481, :553-554).
+void launch_undistort_map(hipStream_t st, const double iR[9], const double K[9], const double D[5], int W, int H, float* mapx, float* mapy);
+void launch_remap(hipStream_t st, int n, const uint8_t* src, int sw, int sh, int spitch, int64_t sstride, const float* mapx,
+                  const float* mapy, uint8_t* dst, int W, int H, int dpitch, int64_t dstride);
 // Point cloud (-g): counts per column, exclusive scan, scatter.  col_count: [W+1] int64 scratch.
 void launch_point_cloud(hipStream_t st, const jn_scan_params& sp, const uint8_t* disp, int W, int H, float* xyz,
                         long long* col_count);

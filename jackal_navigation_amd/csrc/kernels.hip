@@ -921,6 +921,43 @@ __global__ void k_scan_finish(int total_bins, int n, unsigned long long* gbins, 
   }
 }
 
+// initUndistortRectifyMap (point_cloud.cpp:553-554): for every rectified pixel the distorted source
+// position.  iR = inverse(P[:, :3] * R) comes from the host; the per-pixel math is OpenCV's, in
+// double, stored as float (the column walk is evaluated directly instead of by repeated addition).
+struct MapDev { double iR[9], k1, k2, p1, p2, k3, fx, fy, u0, v0; };
+__global__ void __launch_bounds__(256) k_undistort_map(MapDev m, int W, int H, float* __restrict__ mapx, float* __restrict__ mapy) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= W) return;
+  const double fj = (double)j, fi = (double)i;
+  const double _x = __dadd_rn(__dadd_rn(__dmul_rn(fj, m.iR[0]), __dmul_rn(fi, m.iR[1])), m.iR[2]);
+  const double _y = __dadd_rn(__dadd_rn(__dmul_rn(fj, m.iR[3]), __dmul_rn(fi, m.iR[4])), m.iR[5]);
+  const double _w = __dadd_rn(__dadd_rn(__dmul_rn(fj, m.iR[6]), __dmul_rn(fi, m.iR[7])), m.iR[8]);
+  const double w = __ddiv_rn(1.0, _w), x = __dmul_rn(_x, w), y = __dmul_rn(_y, w);
+  const double x2 = __dmul_rn(x, x), y2 = __dmul_rn(y, y), r2 = __dadd_rn(x2, y2), _2xy = __dmul_rn(__dmul_rn(2.0, x), y);
+  const double kr = __dadd_rn(1.0, __dmul_rn(__dadd_rn(__dmul_rn(__dadd_rn(__dmul_rn(m.k3, r2), m.k2), r2), m.k1), r2));
+  const double u = __dadd_rn(__dmul_rn(m.fx, __dadd_rn(__dadd_rn(__dmul_rn(x, kr), __dmul_rn(m.p1, _2xy)),
+                                                        __dmul_rn(m.p2, __dadd_rn(r2, __dmul_rn(2.0, x2))))), m.u0);
+  const double v = __dadd_rn(__dmul_rn(m.fy, __dadd_rn(__dadd_rn(__dmul_rn(y, kr), __dmul_rn(m.p1, __dadd_rn(r2, __dmul_rn(2.0, y2)))),
+                                                        __dmul_rn(m.p2, _2xy))), m.v0);
+  mapx[(size_t)i * W + j] = (float)u;
+  mapy[(size_t)i * W + j] = (float)v;
+}
+
+// remap, INTER_LINEAR, BORDER_CONSTANT 0 (point_cloud.cpp:440, :481)
+__global__ void __launch_bounds__(256) k_remap(const uint8_t* __restrict__ src, int sw, int sh, int spitch, long long sstride,
+                                               const float* __restrict__ mapx, const float* __restrict__ mapy,
+                                               uint8_t* __restrict__ dst, int W, int H, int dpitch, long long dstride) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+  if (x >= W) return;
+  const int sx = (int)rintf(__fmul_rn(mapx[(size_t)y * W + x], 32.0f)), sy = (int)rintf(__fmul_rn(mapy[(size_t)y * W + x], 32.0f));
+  const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+  const uint8_t* S = src + (long long)img * sstride;
+  auto tap = [&](int xx, int yy) -> int { return (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? S[(size_t)yy * spitch + xx] : 0; };
+  const int p00 = tap(ix, iy), p01 = tap(ix + 1, iy), p10 = tap(ix, iy + 1), p11 = tap(ix + 1, iy + 1);
+  const int acc = (32 - fx) * (32 - fy) * p00 + fx * (32 - fy) * p01 + (32 - fx) * fy * p10 + fx * fy * p11;
+  dst[(long long)img * dstride + (size_t)y * dpitch + x] = (uint8_t)((acc + 512) >> 10);
+}
+
 // Point cloud (-g, point_cloud.cpp:321-352): column-major order (i outer, j inner) with d >= 2.
 __global__ void __launch_bounds__(256) k_pc_count(const uint8_t* __restrict__ disp, int W, int H, long long* __restrict__ col_count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1042,6 +1079,18 @@ void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* d
   hipLaunchKernelGGL(k_scan_init, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch);
   hipLaunchKernelGGL(k_scan, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
   hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta);
+}
+void launch_undistort_map(hipStream_t st, const double iR[9], const double K[9], const double D[5], int W, int H, float* mapx, float* mapy) {
+  MapDev m;
+  for (int i = 0; i < 9; i++) m.iR[i] = iR[i];
+  m.k1 = D[0]; m.k2 = D[1]; m.p1 = D[2]; m.p2 = D[3]; m.k3 = D[4];
+  m.fx = K[0]; m.fy = K[4]; m.u0 = K[2]; m.v0 = K[5];
+  hipLaunchKernelGGL(k_undistort_map, grid2d(W, H, 1), dim3(256), 0, st, m, W, H, mapx, mapy);
+}
+void launch_remap(hipStream_t st, int n, const uint8_t* src, int sw, int sh, int spitch, int64_t sstride, const float* mapx,
+                  const float* mapy, uint8_t* dst, int W, int H, int dpitch, int64_t dstride) {
+  hipLaunchKernelGGL(k_remap, grid2d(W, H, n), dim3(256), 0, st, src, sw, sh, spitch, (long long)sstride, mapx, mapy, dst, W, H, dpitch,
+                     (long long)dstride);
 }
 void launch_point_cloud(hipStream_t st, const jn_scan_params& sp, const uint8_t* disp, int W, int H, float* xyz, long long* col_count) {
   const ScanDev s = to_dev(sp);

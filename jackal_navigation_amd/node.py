@@ -68,6 +68,36 @@ def point_cloud(sp, dDisp, width, height, device=0):
     return out
 
 
+def stereo_calib():
+    """K1,K2,D1,D2,R,T of calibration/amrl_jackal_webcam_stereo.yml (640x360)."""
+    c = _lib.StereoCalib()
+    _lib.load().jn_stereo_calib_default(C.byref(c))
+    return c
+
+
+def stereo_rectify(calib, new_width, new_height):
+    """cv::stereoRectify(..., CV_CALIB_ZERO_DISPARITY, 0, newImageSize) — point_cloud.cpp:543-544."""
+    r = _lib.Rectification()
+    _lib.check(_lib.load().jn_stereo_rectify(C.byref(calib), new_width, new_height, C.byref(r)), "jn_stereo_rectify")
+    return r
+
+
+def init_undistort_rectify_map(K, D, R, P, width, height, device=0):
+    """cv::initUndistortRectifyMap(K, D, R, P, size, CV_32F) — point_cloud.cpp:553-554; returns device float maps."""
+    mx = DeviceArray((height, width), np.float32, device)
+    my = DeviceArray((height, width), np.float32, device)
+    arr = [np.ascontiguousarray(np.asarray(a, np.float64)) for a in (K, D, R, P)]
+    _lib.check(_lib.load().jn_init_undistort_rectify_map(device, arr[0].ctypes.data, arr[1].ctypes.data, arr[2].ctypes.data,
+                                                         arr[3].ctypes.data, width, height, mx.ptr, my.ptr), "jn_init_undistort_rectify_map")
+    return mx, my
+
+
+def remap(n, dSrc, src_w, src_h, src_pitch, src_stride, dMapX, dMapY, dDst, width, height, dst_pitch, dst_stride, device=0):
+    """cv::remap(src, dst, mapx, mapy, INTER_LINEAR) — point_cloud.cpp:440, :481 (batched, device pointers)."""
+    _lib.check(_lib.load().jn_remap_bilinear(device, n, dSrc, src_w, src_h, src_pitch, src_stride, dMapX, dMapY, dDst, width, height,
+                                             dst_pitch, dst_stride), "jn_remap_bilinear")
+
+
 def synth_pair(width, height, scene_disp, seed=12345):
     L = np.zeros((height, width), np.uint8)
     R = np.zeros((height, width), np.uint8)

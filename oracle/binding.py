@@ -232,6 +232,21 @@ class Oracle:
         return bins, meta, used
 
 
+    def undistort_map(self, K, D, R, P, W, H):
+        arr = [np.ascontiguousarray(np.asarray(a, np.float64)) for a in (K, D, R, P)]
+        mx = np.zeros((H, W), np.float32); my = np.zeros((H, W), np.float32)
+        self.lib.orc_init_undistort_rectify_map(_p(arr[0]), _p(arr[1]), _p(arr[2]), _p(arr[3]), W, H, _p(mx), _p(my))
+        return mx, my
+
+    def remap(self, src, mx, my):
+        src = np.ascontiguousarray(src)
+        H, W = mx.shape
+        dst = np.zeros((H, W), np.uint8)
+        self.lib.orc_remap_bilinear(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(np.ascontiguousarray(mx)),
+                                    _p(np.ascontiguousarray(my)), _p(dst), W, H, W)
+        return dst
+
+
 class Reference:
     """The compiled reference (libelas from /root/reference), per stage."""
 

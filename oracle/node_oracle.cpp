@@ -165,3 +165,42 @@ extern "C" int64_t orc_obstacle_scan_points(const orc_scan_params* sp, const dou
   acc.meta(meta4);
   return used;
 }
+
+// ---- rectification front end (point_cloud.cpp:440, :481, :553-554) — definitions, PARITY UNPINNED ----
+// initUndistortRectifyMap: OpenCV's per-pixel formula in double, float maps; iR = inverse(P[:, :3]*R).
+extern "C" void orc_init_undistort_rectify_map(const double* K, const double* D, const double* R, const double* P, int32_t W,
+                                               int32_t H, float* mapx, float* mapy) {
+  double M[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M[3 * i + j] = P[4 * i] * R[j] + P[4 * i + 1] * R[3 + j] + P[4 * i + 2] * R[6 + j];
+  const double c00 = M[4] * M[8] - M[5] * M[7], c01 = M[5] * M[6] - M[3] * M[8], c02 = M[3] * M[7] - M[4] * M[6];
+  const double id = 1.0 / (M[0] * c00 + M[1] * c01 + M[2] * c02);
+  const double iR[9] = {c00 * id, (M[2] * M[7] - M[1] * M[8]) * id, (M[1] * M[5] - M[2] * M[4]) * id,
+                        c01 * id, (M[0] * M[8] - M[2] * M[6]) * id, (M[2] * M[3] - M[0] * M[5]) * id,
+                        c02 * id, (M[1] * M[6] - M[0] * M[7]) * id, (M[0] * M[4] - M[1] * M[3]) * id};
+  const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4], fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
+  for (int i = 0; i < H; i++)
+    for (int j = 0; j < W; j++) {
+      const double _x = j * iR[0] + i * iR[1] + iR[2], _y = j * iR[3] + i * iR[4] + iR[5], _w = j * iR[6] + i * iR[7] + iR[8];
+      const double w = 1. / _w, x = _x * w, y = _y * w;
+      const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+      const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+      const double u = fx * (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)) + u0;
+      const double v = fy * (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy) + v0;
+      mapx[(size_t)i * W + j] = (float)u; mapy[(size_t)i * W + j] = (float)v;
+    }
+}
+
+// remap INTER_LINEAR / BORDER_CONSTANT 0: 1/32-pixel coordinates (round-half-even), exact 10-bit weights.
+extern "C" void orc_remap_bilinear(const uint8_t* src, int32_t sw, int32_t sh, int32_t spitch, const float* mapx, const float* mapy,
+                                   uint8_t* dst, int32_t W, int32_t H, int32_t dpitch) {
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      const int sx = (int)std::nearbyintf(mapx[(size_t)y * W + x] * 32.0f), sy = (int)std::nearbyintf(mapy[(size_t)y * W + x] * 32.0f);
+      const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+      auto tap = [&](int xx, int yy) -> int { return (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * spitch + xx] : 0; };
+      const int acc = (32 - fx) * (32 - fy) * tap(ix, iy) + fx * (32 - fy) * tap(ix + 1, iy) + (32 - fx) * fy * tap(ix, iy + 1) +
+                      fx * fy * tap(ix + 1, iy + 1);
+      dst[(size_t)y * dpitch + x] = (uint8_t)((acc + 512) >> 10);
+    }
+}
