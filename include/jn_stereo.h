@@ -149,6 +149,13 @@ jn_status jn_build_valid_disp_lut(int32_t device, const jn_scan_params* sp, int3
 jn_status jn_obstacle_scan(int32_t device, const jn_scan_params* sp, int32_t n, const uint8_t* dDisp,
                            const uint8_t* dLut, int32_t width, int32_t height, double* dBins, double* dMeta);
 
+/* The -g flavour: publishPointCloud (point_cloud.cpp:321-352) followed by
+ * publishObstacleScan(vector<Point3d>) (:149-211) without materialising the cloud: every pixel with
+ * d >= 2 is reprojected (double), points on the ground model (:166-172) are dropped, the rest are
+ * binned.  Same outputs and divergence note as jn_obstacle_scan. */
+jn_status jn_obstacle_scan_cloud(int32_t device, const jn_scan_params* sp, int32_t n, const uint8_t* dDisp,
+                                 int32_t width, int32_t height, double* dBins, double* dMeta);
+
 /* Fused tail of the node: float disparity -> u8 map (published on /webcam/left/depth_map) -> scan. */
 jn_status jn_disparity_scan(int32_t device, const jn_scan_params* sp, int32_t n, const float* dD,
                             const uint8_t* dLut, int32_t width, int32_t height, uint8_t* dDispU8,

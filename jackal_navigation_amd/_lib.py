@@ -64,7 +64,7 @@ class StageTimes(C.Structure):
 EXPORTS = [
     "jn_elas_params_default", "jn_elas_create", "jn_elas_destroy", "jn_elas_process", "jn_elas_process_batch",
     "jn_elas_submit", "jn_elas_wait", "jn_elas_last_times", "jn_scan_params_default", "jn_disparity_to_u8",
-    "jn_build_valid_disp_lut", "jn_obstacle_scan", "jn_disparity_scan", "jn_compact_ranges", "jn_point_cloud",
+    "jn_build_valid_disp_lut", "jn_obstacle_scan", "jn_obstacle_scan_cloud", "jn_disparity_scan", "jn_compact_ranges", "jn_point_cloud",
     "jn_synth_pair", "jn_device_count", "jn_device_malloc", "jn_device_free", "jn_memcpy_h2d", "jn_memcpy_d2h",
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
@@ -99,6 +99,7 @@ def load():
     L.jn_disparity_to_u8.argtypes = [i32, vp, vp, i64]
     L.jn_build_valid_disp_lut.argtypes = [i32, C.POINTER(ScanParams), i32, i32, vp]
     L.jn_obstacle_scan.argtypes = [i32, C.POINTER(ScanParams), i32, vp, vp, i32, i32, vp, vp]
+    L.jn_obstacle_scan_cloud.argtypes = [i32, C.POINTER(ScanParams), i32, vp, i32, i32, vp, vp]
     L.jn_disparity_scan.argtypes = [i32, C.POINTER(ScanParams), i32, vp, vp, i32, i32, vp, vp, vp]
     L.jn_compact_ranges.argtypes = [vp, i32, vp]
     L.jn_point_cloud.argtypes = [i32, C.POINTER(ScanParams), vp, i32, i32, vp, C.POINTER(i64)]

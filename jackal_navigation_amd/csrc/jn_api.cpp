@@ -460,7 +460,7 @@ jn_status jn_build_valid_disp_lut(int32_t device, const jn_scan_params* sp, int3
 
 static jn_status scan_common(int32_t device, const jn_scan_params* sp, int32_t n, const float* dD, uint8_t* dDisp,
                              const uint8_t* dLut, int32_t W, int32_t H, double* dBins, double* dMeta) {
-  if (!sp || !dDisp || !dLut || !dBins || !dMeta || n < 1 || sp->bins < 1 || sp->bins > 1024) return JN_ERR_INVALID;
+  if (!sp || !dDisp || !dBins || !dMeta || n < 1 || sp->bins < 1 || sp->bins > 1024) return JN_ERR_INVALID;
   HIP_TRY(hipSetDevice(device));
   unsigned long long* scratch = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(unsigned long long) * 4 * n));
@@ -474,12 +474,18 @@ static jn_status scan_common(int32_t device, const jn_scan_params* sp, int32_t n
 
 jn_status jn_obstacle_scan(int32_t device, const jn_scan_params* sp, int32_t n, const uint8_t* dDisp, const uint8_t* dLut,
                            int32_t W, int32_t H, double* dBins, double* dMeta) {
+  if (!dLut) return JN_ERR_INVALID;
   return scan_common(device, sp, n, nullptr, const_cast<uint8_t*>(dDisp), dLut, W, H, dBins, dMeta);
+}
+
+jn_status jn_obstacle_scan_cloud(int32_t device, const jn_scan_params* sp, int32_t n, const uint8_t* dDisp, int32_t W, int32_t H,
+                                 double* dBins, double* dMeta) {
+  return scan_common(device, sp, n, nullptr, const_cast<uint8_t*>(dDisp), nullptr, W, H, dBins, dMeta);
 }
 
 jn_status jn_disparity_scan(int32_t device, const jn_scan_params* sp, int32_t n, const float* dD, const uint8_t* dLut,
                             int32_t W, int32_t H, uint8_t* dDispU8, double* dBins, double* dMeta) {
-  if (!dD) return JN_ERR_INVALID;
+  if (!dD || !dLut) return JN_ERR_INVALID;
   return scan_common(device, sp, n, dD, dDispU8, dLut, W, H, dBins, dMeta);
 }
 

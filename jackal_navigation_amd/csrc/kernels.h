@@ -46,6 +46,7 @@ void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const Fram
 void launch_to_u8(hipStream_t st, const float* D, uint8_t* out, int64_t count);
 void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, uint8_t* lut);
 // scratch: [n][4] uint64.  If dD != nullptr the u8 map is produced from it first (fused), else dDisp is read.
+// lut == nullptr selects the -g flavour (points with d >= 2 minus the ground model, point_cloud.cpp:149-211).
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
                  int W, int H, double* bins, double* meta, unsigned long long* scratch);
 // Rectification front end (point_cloud.cpp:440, :481, :553-554).

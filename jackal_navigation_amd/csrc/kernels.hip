@@ -857,6 +857,10 @@ __device__ __host__ inline double dec(unsigned long long k) {
 
 // publishObstacleScan(Mat&) (point_cloud.cpp:213-296).  Per block: bins and the four extrema are
 // reduced in LDS (64-bit integer atomics on order-encoded doubles), then merged into global memory.
+// kFromCloud selects the -g flavour (publishPointCloud + publishObstacleScan(vector<Point3d>),
+// point_cloud.cpp:321-352, :149-211): every pixel with d >= 2 becomes a point, points on the ground
+// model are dropped, the rest are binned — instead of the LUT test of the default path.
+template <bool kFromCloud>
 __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict__ dD, uint8_t* __restrict__ dDisp,
                                               const uint8_t* __restrict__ lut, int W, int H, unsigned long long* __restrict__ gbins,
                                               unsigned long long* __restrict__ gmeta) {
@@ -873,9 +877,14 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
     const size_t p = ((size_t)frame * H + j) * W + i;
     int d;
     if (dD) { const uint8_t q = f32_to_u8(dD[p]); dDisp[p] = q; d = q; } else d = dDisp[p];
-    const uint8_t l0 = lut[((size_t)j * W + i) * 2], l1 = lut[((size_t)j * W + i) * 2 + 1];
-    double X, Y, Z;
-    if (d >= l0 && d <= l1 && reproject(s, i, j, d, X, Y, Z)) {
+    bool take;
+    double X = 0, Y = 0, Z = 0;
+    if (kFromCloud) take = d >= 2 && reproject(s, i, j, d, X, Y, Z) && !is_ground(s, X, Z);      // :324, :166-172
+    else {
+      const uint8_t l0 = lut[((size_t)j * W + i) * 2], l1 = lut[((size_t)j * W + i) * 2 + 1];   // :234
+      take = d >= l0 && d <= l1 && reproject(s, i, j, d, X, Y, Z);
+    }
+    if (take) {
       const double th = atan2(Y, X);
       const double deg = __dmul_rn(th, 180.) / s.pi;
       const double r = sqrt(__dadd_rn(__dmul_rn(Y, Y), __dmul_rn(X, X)));
@@ -1077,7 +1086,8 @@ void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* d
   unsigned long long* gb = reinterpret_cast<unsigned long long*>(bins);
   const int total = n * s.bins, m = total > n * 4 ? total : n * 4;
   hipLaunchKernelGGL(k_scan_init, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch);
-  hipLaunchKernelGGL(k_scan, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
+  if (lut) hipLaunchKernelGGL(k_scan<false>, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
+  else     hipLaunchKernelGGL(k_scan<true>, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
   hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta);
 }
 void launch_undistort_map(hipStream_t st, const double iR[9], const double K[9], const double D[5], int W, int H, float* mapx, float* mapy) {

@@ -37,6 +37,11 @@ def obstacle_scan(sp, n, dDisp, dLut, width, height, dBins, dMeta, device=0):
     _lib.check(_lib.load().jn_obstacle_scan(device, C.byref(sp), n, dDisp, dLut, width, height, dBins, dMeta), "jn_obstacle_scan")
 
 
+def obstacle_scan_cloud(sp, n, dDisp, width, height, dBins, dMeta, device=0):
+    """-g mode: publishPointCloud + publishObstacleScan(vector<Point3d>) (point_cloud.cpp:321-352, :149-211)."""
+    _lib.check(_lib.load().jn_obstacle_scan_cloud(device, C.byref(sp), n, dDisp, width, height, dBins, dMeta), "jn_obstacle_scan_cloud")
+
+
 def disparity_scan(sp, n, dD, dLut, width, height, dDispU8, dBins, dMeta, device=0):
     _lib.check(_lib.load().jn_disparity_scan(device, C.byref(sp), n, dD, dLut, width, height, dDispU8, dBins, dMeta), "jn_disparity_scan")
 

@@ -232,6 +232,13 @@ class Oracle:
         return bins, meta, used
 
 
+    def scan_cloud(self, sp, disp):
+        H, W = disp.shape
+        bins = np.zeros(sp.bins, np.float64); meta = np.zeros(4, np.float64)
+        self.lib.orc_obstacle_scan_cloud.restype = C.c_int64
+        used = self.lib.orc_obstacle_scan_cloud(C.byref(sp), _p(np.ascontiguousarray(disp)), W, H, _p(bins), _p(meta))
+        return bins, meta, used
+
     def undistort_map(self, K, D, R, P, W, H):
         arr = [np.ascontiguousarray(np.asarray(a, np.float64)) for a in (K, D, R, P)]
         mx = np.zeros((H, W), np.float32); my = np.zeros((H, W), np.float32)

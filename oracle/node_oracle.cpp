@@ -166,6 +166,24 @@ extern "C" int64_t orc_obstacle_scan_points(const orc_scan_params* sp, const dou
   return used;
 }
 
+// -g mode end to end in double (point_cloud.cpp:321-352 then :149-211): the vector<Point3d> the
+// reference hands to the scan holds the double robot-frame points, not the float32 message copies.
+extern "C" int64_t orc_obstacle_scan_cloud(const orc_scan_params* sp, const uint8_t* disp, int32_t W, int32_t H, double* bins, double* meta4) {
+  ScanAcc acc; acc.init(bins, sp->bins);
+  int64_t used = 0;
+  for (int i = 0; i < W; i++)
+    for (int j = 0; j < H; j++) {
+      int d = disp[(size_t)j * W + i];
+      if (d < 2) continue;
+      P3 p;
+      if (!reproject(sp, i, j, d, p)) continue;
+      if (is_ground(sp, p.x, p.z)) continue;
+      acc.add(sp, p.x, p.y); used++;
+    }
+  acc.meta(meta4);
+  return used;
+}
+
 // ---- rectification front end (point_cloud.cpp:440, :481, :553-554) — definitions, PARITY UNPINNED ----
 // initUndistortRectifyMap: OpenCV's per-pixel formula in double, float maps; iR = inverse(P[:, :3]*R).
 extern "C" void orc_init_undistort_rectify_map(const double* K, const double* D, const double* R, const double* P, int32_t W,

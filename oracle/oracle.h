@@ -97,6 +97,7 @@ int64_t orc_point_cloud(const orc_scan_params* sp, const uint8_t* disp, int32_t 
 // robot-frame points given as doubles [n][3].
 int64_t orc_obstacle_scan_points(const orc_scan_params* sp, const double* xyz, int64_t n, double* bins, double* meta4);
 
+int64_t orc_obstacle_scan_cloud(const orc_scan_params* sp, const uint8_t* disp, int32_t W, int32_t H, double* bins, double* meta4);
 // rectification front end (definitions; OpenCV-side parity is unpinned)
 void orc_init_undistort_rectify_map(const double* K, const double* D, const double* R, const double* P, int32_t W, int32_t H,
                                     float* mapx, float* mapy);

@@ -189,6 +189,12 @@ def test_node_functions_vs_oracle(jn, oracle, same):
     bins2 = DeviceArray((n, sp.bins), np.float64); meta2 = DeviceArray((n, 4), np.float64)
     node.obstacle_scan(sp, n, du8.ptr, lut.ptr, W, H, bins2.ptr, meta2.ptr)
     assert same(bins2.numpy(), b_) and same(meta2.numpy(), m_)
+    bins3 = DeviceArray((n, sp.bins), np.float64); meta3 = DeviceArray((n, 4), np.float64)
+    node.obstacle_scan_cloud(sp, n, du8.ptr, W, H, bins3.ptr, meta3.ptr)          # -g flavour: d >= 2, ground model instead of the LUT
+    for b in range(n):
+        bo, mo, used = oracle.scan_cloud(spo, u8[b])
+        assert used > 0 and np.array_equal(bins3.numpy()[b] < 1e9 - 1, bo < 1e9 - 1)
+        assert np.allclose(bins3.numpy()[b], bo, rtol=0, atol=SCAN_TOL) and np.allclose(meta3.numpy()[b], mo, rtol=0, atol=SCAN_TOL)
     pc = node.point_cloud(sp, du8.ptr, W, H)            # first map
     pco = oracle.point_cloud(spo, u8[0])
     assert pc.shape == pco.shape and np.allclose(pc, pco, rtol=0, atol=SCAN_TOL)
