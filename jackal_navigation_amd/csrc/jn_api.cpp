@@ -58,7 +58,8 @@ class Pool {
       std::lock_guard<std::mutex> l(m_);
       for (int i = 0; i < n; i++) q_.push_back({&g, i});
     }
-    cv_.notify_all();
+    if (n >= (int)threads_.size()) cv_.notify_all();
+    else for (int i = 0; i < n; i++) cv_.notify_one();      // wake only as many workers as there are tasks
     std::unique_lock<std::mutex> l(g.m);
     g.cv.wait(l, [&g] { return g.left == 0; });
   }
