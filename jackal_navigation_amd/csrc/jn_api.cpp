@@ -101,7 +101,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev[EV_COUNT] = {};
   // device
-  uint8_t* du = nullptr; uint8_t* dv = nullptr; uint4* desc = nullptr; int16_t* d_can = nullptr;
+  uint4* desc = nullptr; int16_t* d_can = nullptr;
   FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; BinEntry* bin_list = nullptr; float* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
@@ -141,8 +141,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   HIP_TRY(hipSetDevice(h->device));
   auto t_begin = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(s.ev[EV_BEGIN], st));
-  launch_sobel(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.du, s.dv);
-  launch_descriptor(st, dp, 2 * n, s.du, s.dv, s.desc);
+  launch_descriptor(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
   HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
   launch_support(st, dp, n, s.desc, s.d_can);
   HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
@@ -311,7 +310,6 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     std::unique_ptr<Slot> s(new Slot());
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     for (int e = 0; e < EV_COUNT; e++) HIP_TRY(hipEventCreate(&s->ev[e]));
-    HIP_TRY(dmalloc(&s->du, 2 * B * H * dp.pitch)); HIP_TRY(dmalloc(&s->dv, 2 * B * H * dp.pitch));
     HIP_TRY(dmalloc(&s->desc, 2 * B * px));
     HIP_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
@@ -345,7 +343,7 @@ void jn_elas_destroy(jn_elas* h) {
   }
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
-    hipFree(s->du); hipFree(s->dv); hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
+    hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
     hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload);

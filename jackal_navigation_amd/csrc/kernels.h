@@ -11,12 +11,10 @@ namespace jnav {
 // frame-major with the strides given.
 
 // GPU stage A -------------------------------------------------------------------------------
-// Sobel responses (filter.cpp:372-416) of 2n images -> du/dv [H][pitch] each.
-// Image order in du/dv/desc: L0..L(n-1), R0..R(n-1).
-void launch_sobel(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
-                  int64_t in_stride, int n, uint8_t* du, uint8_t* dv);
-// 16-byte descriptors (descriptor.cpp:84-111): desc [2n][H][W] uint4; image order L0..L(n-1), R0..R(n-1).
-void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint8_t* du, const uint8_t* dv, uint4* desc);
+// Sobel + 16-byte descriptors (filter.cpp:372-416, descriptor.cpp:84-111), fused: desc [2n][H][W] uint4;
+// image order L0..L(n-1), R0..R(n-1).
+void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
+                       int64_t in_stride, int n, uint4* desc);
 // Support matching with back-check (elas.cpp:269-413): D_can [n][ch][cw] int16.
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can);
 

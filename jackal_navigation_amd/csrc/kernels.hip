@@ -30,48 +30,68 @@ DEV int texture16(const uint4& a) {   // sum |byte - 128| (elas.cpp:301-305, :71
 DEV int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
 // ------------------------------------------------------------------------------------------------
-// Sobel (filter.cpp:372-416, :227-267, :176-222).  One thread per output byte.
-//   S = I[v-1]+2I[v]+I[v+1], T = I[v-1]-I[v+1]            (int16 column pass)
+// Sobel + descriptor, fused (filter.cpp:372-416, :227-267, :176-222; descriptor.cpp:84-111).
+// One workgroup per 64x16 tile of descriptors: the (64+6)x(16+6) image patch is staged in LDS,
+//   S = I[v-1]+2I[v]+I[v+1], T = I[v-1]-I[v+1]                       (int16 column pass)
 //   du = sat(((S[u-1]-S[u+1])>>2)+128), dv = sat(((T[u-1]+2T[u]+T[u+1])>>2)+128)
-// Defined for rows 1..H-2, columns 1..W-2 (all the descriptor ever reads); 0 elsewhere.
-__global__ void __launch_bounds__(256) k_sobel(DevParams dp, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2,
-                                               int in_pitch, long long in_stride, int n, uint8_t* __restrict__ du,
-                                               uint8_t* __restrict__ dv) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, img = blockIdx.z;
-  if (u >= dp.pitch) return;
-  const uint8_t* I = (img < n ? I1 + (long long)img * in_stride : I2 + (long long)(img - n) * in_stride);
-  const size_t o = ((size_t)img * dp.H + v) * dp.pitch + u;
-  if (v < 1 || v > dp.H - 2 || u < 1 || u > dp.W - 2) { du[o] = 0; dv[o] = 0; return; }
-  const uint8_t* r0 = I + (size_t)(v - 1) * in_pitch + u;
-  const uint8_t* r1 = r0 + in_pitch;
-  const uint8_t* r2 = r1 + in_pitch;
-  const int a0 = r0[-1], a1 = r0[0], a2 = r0[1];
-  const int b0 = r1[-1], b2 = r1[1];
-  const int c0 = r2[-1], c1 = r2[0], c2 = r2[1];
-  const int Sl = a0 + 2 * b0 + c0, Sr = a2 + 2 * b2 + c2;
-  const int Tl = a0 - c0, Tm = a1 - c1, Tr = a2 - c2;
-  du[o] = (uint8_t)sat_u8(((Sl - Sr) >> 2) + 128);
-  dv[o] = (uint8_t)sat_u8(((Tl + 2 * Tm + Tr) >> 2) + 128);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Descriptor (descriptor.cpp:84-111): 12 du taps on a 5-row diamond + 4 dv taps, packed as uint4.
+// are formed in LDS for the (64+4)x(16+4) / (64+2)x(16+2) pixels the tile's descriptors tap
+// (du, dv defined on rows 1..H-2, columns 1..W-2, zero elsewhere: all the descriptor ever reads),
+// and each descriptor (12 du taps on a 5-row diamond + 4 dv taps) leaves as one 16-byte store.
 // Pixels outside u in [3,W-4], v in [3,H-4] get zeros (uninitialised in the reference).
-__global__ void __launch_bounds__(256) k_descriptor(DevParams dp, const uint8_t* __restrict__ du, const uint8_t* __restrict__ dv,
-                                                    uint4* __restrict__ desc) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, img = blockIdx.z;
-  if (u >= dp.W) return;
-  uint4 d = make_uint4(0, 0, 0, 0);
-  if (u >= 3 && u <= dp.W - 4 && v >= 3 && v <= dp.H - 4) {
-    const int P = dp.pitch;
-    const uint8_t* x = du + ((size_t)img * dp.H + v) * P + u;
-    const uint8_t* y = dv + ((size_t)img * dp.H + v) * P + u;
-    d.x = x[-2 * P] | (x[-P - 2] << 8) | (x[-P] << 16) | ((unsigned)x[-P + 2] << 24);
-    d.y = x[-1] | (x[0] << 8) | (x[0] << 16) | ((unsigned)x[1] << 24);
-    d.z = x[P - 2] | (x[P] << 8) | (x[P + 2] << 16) | ((unsigned)x[2 * P] << 24);
-    d.w = y[-P] | (y[-1] << 8) | (y[1] << 16) | ((unsigned)y[P] << 24);
+enum { kDescTW = 64, kDescTH = 16 };
+__global__ void __launch_bounds__(256) k_descriptor_fused(DevParams dp, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2,
+                                                          int in_pitch, long long in_stride, int n, uint4* __restrict__ desc) {
+  __shared__ uint8_t s_I[kDescTH + 6][kDescTW + 8];
+  __shared__ uint8_t s_du[kDescTH + 4][kDescTW + 4];
+  __shared__ uint8_t s_dv[kDescTH + 2][kDescTW + 4];
+  const int img = blockIdx.z, W = dp.W, H = dp.H;
+  const uint8_t* I = (img < n ? I1 + (long long)img * in_stride : I2 + (long long)(img - n) * in_stride);
+  const int u0 = blockIdx.x * kDescTW, v0 = blockIdx.y * kDescTH, tid = threadIdx.x;
+  for (int i = tid; i < (kDescTH + 6) * (kDescTW + 6); i += 256) {         // image rows v0-3.., columns u0-3..
+    const int r = i / (kDescTW + 6), c = i - r * (kDescTW + 6);
+    const int v = v0 - 3 + r, u = u0 - 3 + c;
+    s_I[r][c] = (v >= 0 && v < H && u >= 0 && u < W) ? I[(size_t)v * in_pitch + u] : 0;
   }
-  desc[((size_t)img * dp.H + v) * dp.W + u] = d;
+  __syncthreads();
+  for (int i = tid; i < (kDescTH + 4) * (kDescTW + 4); i += 256) {         // du rows v0-2.., columns u0-2..
+    const int r = i / (kDescTW + 4), c = i - r * (kDescTW + 4);
+    const int v = v0 - 2 + r, u = u0 - 2 + c;
+    int val = 0;
+    if (v >= 1 && v <= H - 2 && u >= 1 && u <= W - 2) {
+      const int Sl = s_I[r][c] + 2 * s_I[r + 1][c] + s_I[r + 2][c], Sr = s_I[r][c + 2] + 2 * s_I[r + 1][c + 2] + s_I[r + 2][c + 2];
+      val = sat_u8(((Sl - Sr) >> 2) + 128);
+    }
+    s_du[r][c] = (uint8_t)val;
+  }
+  for (int i = tid; i < (kDescTH + 2) * (kDescTW + 2); i += 256) {         // dv rows v0-1.., columns u0-1..
+    const int r = i / (kDescTW + 2), c = i - r * (kDescTW + 2);
+    const int v = v0 - 1 + r, u = u0 - 1 + c;
+    int val = 0;
+    if (v >= 1 && v <= H - 2 && u >= 1 && u <= W - 2) {
+      const int Tl = s_I[r + 1][c + 1] - s_I[r + 3][c + 1], Tm = s_I[r + 1][c + 2] - s_I[r + 3][c + 2], Tr = s_I[r + 1][c + 3] - s_I[r + 3][c + 3];
+      val = sat_u8(((Tl + 2 * Tm + Tr) >> 2) + 128);
+    }
+    s_dv[r][c] = (uint8_t)val;
+  }
+  __syncthreads();
+  const int x = tid & (kDescTW - 1), u = u0 + x;
+  if (u >= W) return;
+  uint4* out = desc + (size_t)img * H * W;
+#pragma unroll
+  for (int k = 0; k < kDescTH / 4; k++) {
+    const int y = (tid >> 6) + 4 * k, v = v0 + y;
+    if (v >= H) break;
+    uint4 d = make_uint4(0, 0, 0, 0);
+    if (u >= 3 && u <= W - 4 && v >= 3 && v <= H - 4) {
+      // s_du[y + 2 + dy][x + 2 + dx] = du(v + dy, u + dx); s_dv[y + 1 + dy][x + 1 + dx] = dv(v + dy, u + dx)
+      const uint8_t (*a)[kDescTW + 4] = s_du; const uint8_t (*b)[kDescTW + 4] = s_dv;
+      d.x = a[y][x + 2] | (a[y + 1][x] << 8) | (a[y + 1][x + 2] << 16) | ((unsigned)a[y + 1][x + 4] << 24);
+      d.y = a[y + 2][x + 1] | (a[y + 2][x + 2] << 8) | (a[y + 2][x + 2] << 16) | ((unsigned)a[y + 2][x + 3] << 24);
+      d.z = a[y + 3][x] | (a[y + 3][x + 2] << 8) | (a[y + 3][x + 4] << 16) | ((unsigned)a[y + 4][x + 2] << 24);
+      d.w = b[y][x + 1] | (b[y + 1][x] << 8) | (b[y + 1][x + 2] << 16) | ((unsigned)b[y + 2][x + 1] << 24);
+    }
+    out[(size_t)v * W + u] = d;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1008,12 +1028,10 @@ static ScanDev to_dev(const jn_scan_params& sp) {
   return s;
 }
 
-void launch_sobel(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
-                  int64_t in_stride, int n, uint8_t* du, uint8_t* dv) {
-  hipLaunchKernelGGL(k_sobel, grid2d(dp.pitch, dp.H, 2 * n), dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, du, dv);
-}
-void launch_descriptor(hipStream_t st, const DevParams& dp, int nimg, const uint8_t* du, const uint8_t* dv, uint4* desc) {
-  hipLaunchKernelGGL(k_descriptor, grid2d(dp.W, dp.H, nimg), dim3(256), 0, st, dp, du, dv, desc);
+void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
+                       int64_t in_stride, int n, uint4* desc) {
+  const dim3 grid((dp.W + kDescTW - 1) / kDescTW, (dp.H + kDescTH - 1) / kDescTH, 2 * n);
+  hipLaunchKernelGGL(k_descriptor_fused, grid, dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, desc);
 }
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
   const size_t lds = (size_t)4 * dp.W * sizeof(uint4);
