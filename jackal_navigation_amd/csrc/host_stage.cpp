@@ -11,7 +11,7 @@ HostWorker::HostWorker(const HostParams& hp) : hp_(hp) {}
 
 size_t HostWorker::payload_capacity(const HostParams& hp) {
   const size_t maxsup = (size_t)hp.cw * hp.ch;
-  return maxsup * 3 * sizeof(int32_t) + 2 * (2 * maxsup + 8) * 3 * sizeof(int32_t);
+  return maxsup * 3 * sizeof(int32_t) + 2 * (2 * maxsup + 8) * 3 * sizeof(int32_t) + 256;
 }
 
 // elas.cpp:153-179.  Column-major sweep over the lattice; a point survives if at least
@@ -81,34 +81,43 @@ void HostWorker::filter_redundant(int16_t* D, int max_dist, int thresh, bool ver
     }
 }
 
-void HostWorker::filter_and_list(int16_t* d_can, uint8_t* payload, FrameInfo* info, FrameScratch* fs) const {
+void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs) const {
   const int cw = hp_.cw, ch = hp_.ch, step = hp_.step;
   filter_inconsistent(d_can);                                    // elas.cpp:416
   filter_redundant(d_can, 5, 1, true);                           // elas.cpp:421
   filter_redundant(d_can, 5, 1, false);                          // elas.cpp:422
   fs->u.clear(); fs->v.clear(); fs->d.clear(); fs->x.clear();
-  int32_t* uvd = reinterpret_cast<int32_t*>(payload);
   for (int uc = 1; uc < cw; uc++)                                // elas.cpp:425-431 (u-major order)
     for (int vc = 1; vc < ch; vc++) {
       const int d = d_can[vc * cw + uc];
       if (d < 0) continue;
       const int u = uc * step, v = vc * step;
       fs->u.push_back(u); fs->v.push_back(v); fs->d.push_back(d); fs->x.push_back(u - d);
-      *uvd++ = u; *uvd++ = v; *uvd++ = d;
     }
   memset(info, 0, sizeof(*info));
-  const size_t n = fs->u.size();
-  info->nsup = (int32_t)n;
-  info->ok = n >= 3;                                             // elas.cpp:66-71
-  info->sup_offset = 0;
-  info->corner_offset[0] = (int64_t)(n * 3 * sizeof(int32_t));
-  info->corner_offset[1] = info->corner_offset[0] + (int64_t)((2 * n + 8) * 3 * sizeof(int32_t));
+  info->nsup = (int32_t)fs->u.size();
+  info->ok = fs->u.size() >= 3;                                  // elas.cpp:66-71
+}
+
+size_t HostWorker::place(FrameInfo* info, size_t base) {
+  if (!info->ok) return 0;
+  const size_t n = (size_t)info->nsup;
+  const size_t sup_bytes = n * 3 * sizeof(int32_t), side_bytes = (2 * n + 8) * 3 * sizeof(int32_t);   // <= 2n-5 triangles per side
+  info->sup_offset = (int64_t)base;
+  info->corner_offset[0] = (int64_t)(base + sup_bytes);
+  info->corner_offset[1] = (int64_t)(base + sup_bytes + side_bytes);
+  return (sup_bytes + 2 * side_bytes + 255) / 256 * 256;
 }
 
 void HostWorker::triangulate_side(int side, const FrameScratch& fs, uint8_t* payload, FrameInfo* info) {
   if (!info->ok) return;
+  const int n = (int)fs.u.size();
+  if (side == 0) {
+    int32_t* uvd = reinterpret_cast<int32_t*>(payload + info->sup_offset);
+    for (int i = 0; i < n; i++) { uvd[3 * i] = fs.u[i]; uvd[3 * i + 1] = fs.v[i]; uvd[3 * i + 2] = fs.d[i]; }
+  }
   int32_t* corners = reinterpret_cast<int32_t*>(payload + info->corner_offset[side]);
-  const int nt = dt_.run(side ? fs.x.data() : fs.u.data(), fs.v.data(), (int)fs.u.size(), corners);
+  const int nt = dt_.run(side ? fs.x.data() : fs.u.data(), fs.v.data(), n, corners);
   info->ntri[side] = nt < 0 ? 0 : nt;
 }
 

@@ -32,12 +32,16 @@ class HostWorker {
  public:
   explicit HostWorker(const HostParams& hp);
   // Phase 1 (one task per frame): filter this frame's candidate lattice d_can [ch][cw] in place
-  // (elas.cpp:416-422), list the support points (elas.cpp:425-431) into the payload and `fs`.
-  void filter_and_list(int16_t* d_can, uint8_t* payload, FrameInfo* info, FrameScratch* fs) const;
+  // (elas.cpp:416-422) and list the support points (elas.cpp:425-431) into `fs`; sets info->ok/nsup.
+  void filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs) const;
+  // Between the phases: give the frame its place in the batch payload (frames are packed back to
+  // back so that the whole batch goes to the GPU in one copy).  Returns the bytes the frame occupies.
+  static size_t place(FrameInfo* info, size_t base_offset);
   // Phase 2 (one task per frame and side): Delaunay triangulation (elas.cpp:445-505) of the points
-  // (u,v) for side 0 or (u-d,v) for side 1; corner indices go to the payload.
+  // (u,v) for side 0 or (u-d,v) for side 1; corner indices go to the payload (side 0 also writes
+  // the support points there).  `payload` is the base the offsets in `info` refer to.
   void triangulate_side(int side, const FrameScratch& fs, uint8_t* payload, FrameInfo* info);
-  static size_t payload_capacity(const HostParams& hp);
+  static size_t payload_capacity(const HostParams& hp);   // worst case for one frame
 
  private:
   HostParams hp_;

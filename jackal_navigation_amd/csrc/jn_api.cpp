@@ -151,13 +151,14 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   HIP_TRY(hipStreamSynchronize(st));
 
   auto t_host0 = std::chrono::steady_clock::now();
-  const size_t cap = h->payload_cap;
   h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: filters + support list, per frame
-    w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, s.h_payload + (size_t)i * cap, &s.h_info[i], &s.scratch[i]);
+    w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i]);
   });
+  size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
+  for (int i = 0; i < n; i++) payload_bytes += HostWorker::place(&s.h_info[i], payload_bytes);
   h->pool->run(2 * n, [&](HostWorker& w, int k) {        // phase 2: one triangulation per frame and side
     const int i = k >> 1;
-    w.triangulate_side(k & 1, s.scratch[i], s.h_payload + (size_t)i * cap, &s.h_info[i]);
+    w.triangulate_side(k & 1, s.scratch[i], s.h_payload, &s.h_info[i]);
   });
   auto t_host1 = std::chrono::steady_clock::now();
 
@@ -169,15 +170,14 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     if (j.status) j.status[i] = fi.ok ? JN_OK : JN_ERR_FEW_SUPPORT;
     if (!fi.ok) continue;
     any_ok = 1;
-    const size_t used = (size_t)fi.corner_offset[1] + (size_t)fi.ntri[1] * 3 * sizeof(int32_t);
-    HIP_TRY(hipMemcpyAsync(s.payload + (size_t)i * cap, s.h_payload + (size_t)i * cap, used, hipMemcpyHostToDevice, st));
     max_tri = std::max(max_tri, std::max(fi.ntri[0], fi.ntri[1]));
     max_sup = std::max(max_sup, fi.nsup);
   }
+  if (payload_bytes) HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(s.ev[EV_H2D], st));
   if (any_ok) {
-    launch_grid(st, dp, n, s.info, s.payload, (int64_t)cap, max_sup, s.mark, s.gridbits);
-    launch_tri_setup(st, dp, n, s.info, s.payload, (int64_t)cap, max_tri, h->tri_cap, s.recs);
+    launch_grid(st, dp, n, s.info, s.payload, 0, max_sup, s.mark, s.gridbits);      // offsets in FrameInfo are batch-absolute
+    launch_tri_setup(st, dp, n, s.info, s.payload, 0, max_tri, h->tri_cap, s.recs);
     launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list);
     HIP_TRY(hipEventRecord(s.ev[EV_RASTER], st));
     launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
@@ -565,7 +565,8 @@ int64_t jn_host_stage(const jn_elas_params* p, int32_t W, int32_t H, int16_t* d_
   HostWorker w(hp);
   FrameInfo fi;
   FrameScratch fs;
-  w.filter_and_list(d_can, payload, &fi, &fs);
+  w.filter_and_list(d_can, &fi, &fs);
+  HostWorker::place(&fi, 0);
   w.triangulate_side(0, fs, payload, &fi);
   w.triangulate_side(1, fs, payload, &fi);
   memcpy(info, &fi, sizeof(fi));
