@@ -148,7 +148,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
   HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipEventRecord(s.ev[EV_D2H], st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventSynchronize(s.ev[EV_D2H]));
 
   auto t_host0 = std::chrono::steady_clock::now();
   h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: filters + support list, per frame
@@ -198,7 +198,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   } else {
     for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(hipEventRecord(s.ev[e], st));
   }
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventSynchronize(s.ev[EV_AM]));
   HIP_TRY(hipGetLastError());
   auto t_end = std::chrono::steady_clock::now();
 
@@ -309,7 +309,9 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   for (int i = 0; i < slots; i++) {
     std::unique_ptr<Slot> s(new Slot());
     HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    for (int e = 0; e < EV_COUNT; e++) HIP_TRY(hipEventCreate(&s->ev[e]));
+    // blocking-sync events: the slot worker sleeps while the GPU runs instead of spinning on a core that
+    // the host stage (and, on a multi-GPU node, the other ranks) could use
+    for (int e = 0; e < EV_COUNT; e++) HIP_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
     HIP_TRY(dmalloc(&s->desc, 2 * B * px));
     HIP_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
@@ -461,12 +463,17 @@ static jn_status scan_common(int32_t device, const jn_scan_params* sp, int32_t n
                              const uint8_t* dLut, int32_t W, int32_t H, double* dBins, double* dMeta) {
   if (!sp || !dDisp || !dBins || !dMeta || n < 1 || sp->bins < 1 || sp->bins > 1024) return JN_ERR_INVALID;
   HIP_TRY(hipSetDevice(device));
-  unsigned long long* scratch = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&scratch), sizeof(unsigned long long) * 4 * n));
-  launch_scan(nullptr, *sp, n, dD, dDisp, dLut, W, H, dBins, dMeta, scratch);
-  hipError_t e = hipStreamSynchronize(nullptr);
-  hipFree(scratch);
-  HIP_TRY(e);
+  // grow-only scratch per device and calling thread: no hipMalloc/hipFree (a device-wide sync) per call
+  struct Scratch { unsigned long long* p = nullptr; int cap = 0; int dev = -1; };
+  static thread_local Scratch sc;
+  if (sc.dev != device || sc.cap < n) {
+    if (sc.p) { hipSetDevice(sc.dev); hipFree(sc.p); hipSetDevice(device); sc.p = nullptr; }
+    const int cap = n > 64 ? n : 64;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sc.p), sizeof(unsigned long long) * 4 * cap));
+    sc.cap = cap; sc.dev = device;
+  }
+  launch_scan(nullptr, *sp, n, dD, dDisp, dLut, W, H, dBins, dMeta, sc.p);
+  HIP_TRY(hipStreamSynchronize(nullptr));
   HIP_TRY(hipGetLastError());
   return JN_OK;
 }
