@@ -153,12 +153,14 @@ def main():
     torch.cuda.synchronize()
 
     stage_acc = {}
+    dense_ms = []
 
     def finish(slot):
         """Tail of a batch: wait for ELAS, then u8 map + scan, then the cross-rig MIN reduce."""
         elas.wait(slot)
         for k, v in elas.last_times(slot).items():
             stage_acc.setdefault(k, []).append(v)
+        dense_ms.append(elas.kernel_time(slot)[0])
         node.disparity_scan(sp, B, D1[slot].data_ptr(), lut.ptr, W, H, U8[slot].data_ptr(), bins[slot].data_ptr(),
                             meta[slot].data_ptr(), device=local_rank)
         if dist is not None:                      # the path's one exchange step: robot-level scan = MIN over rigs
@@ -188,6 +190,7 @@ def main():
     run(a.warmup)
     sync()
     stage_acc.clear()
+    del dense_ms[:]
     t0 = time.perf_counter()
     run(a.steps)
     sync()
@@ -201,16 +204,23 @@ def main():
     pairs = world * B * a.steps
     value = pairs / elapsed
 
-    # roofline of the dominant GPU stage: algorithmic bytes / measured stage time (HIP events
-    # recorded by the library on the stream the kernels run on)
+    # roofline of the dominant kernel, k_dense (26 % of GPU time, profiles/): algorithmic bytes per launch
+    # (dense L+R = 16 B per pixel per pair, one launch = the whole batch, both sides) over its average
+    # duration, measured with HIP events the library records around the kernel on the stream it runs on.
     stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
-    gpu_stages = {k: stage_ms[k] for k in STAGE_BYTES_PER_PX if k in stage_ms}
-    dom = max(gpu_stages, key=gpu_stages.get)
-    alg_bytes = STAGE_BYTES_PER_PX[dom] * W * H * B
-    achieved = alg_bytes / (gpu_stages[dom] * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "ms_per_launch": round(gpu_stages[dom], 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+    k_ms = float(np.mean(dense_ms))
+    alg_bytes = STAGE_BYTES_PER_PX["gpu_matching"] * W * H * B
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs) of the same workload
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if (W, H, B, a.disp) == (1280, 720, 32, 128):
+            traffic = pmc["k_dense"]["traffic_bytes"]
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "k_dense", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "ms_per_launch": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4)}
 
     if rank == 0:
