@@ -461,21 +461,34 @@ enum { kStripTiles = 4, kStripW = kStripTiles * kTileW };
 __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
                                                const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
                                                const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
-                                               const uint4* __restrict__ desc, float* __restrict__ raw) {
+                                               const uint4* __restrict__ desc, float* __restrict__ raw, int nbx, int nby, int xcd_order) {
   __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
   __shared__ int s_cnt[kStripTiles];
   extern __shared__ uint4 s_B[];                             // [kTileH][kStripW + disp_max]
-  const int frame = blockIdx.z >> 1, side = blockIdx.z & 1;
+  // XCD-aware work order.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
+  // its own 4 MB L2.  Workgroup b therefore takes logical item (b % 8) * per_xcd + b / 8, so that every
+  // XCD walks a contiguous run of items ordered (frame, strip row, strip column, side): the two sides of a
+  // strip read the same descriptor rows of both images back to back, and x-adjacent strips share their
+  // (128 + disp_max)-column staging windows — both now hit in that XCD's L2 instead of going to HBM again.
+  const int total = nbx * nby * 2 * n;
+  int item = blockIdx.x;
+  if (xcd_order) { const int per_xcd = (total + 7) / 8; item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); }
+  if (item >= total) return;
+  const int side = item & 1;
+  int rest = item >> 1;
+  const int bx = rest % nbx; rest /= nbx;
+  const int by = rest % nby;
+  const int frame = rest / nby;
   const FrameInfo fi = info[frame];
   if (!fi.ok) return;
   const int W = dp.W, H = dp.H;
   const int tid = threadIdx.x;
-  const int u0 = blockIdx.x * kStripW, v0 = blockIdx.y * kTileH;
+  const int u0 = bx * kStripW, v0 = by * kTileH;
   const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
   const uint4* B = desc + (size_t)((side ? 0 : n) + frame) * H * W;      // image searched
   const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
   const int tiles_x = (W + kTileW - 1) / kTileW;
-  const size_t bin_row = ((size_t)(frame * 2 + side) * gridDim.y + blockIdx.y) * tiles_x;
+  const size_t bin_row = ((size_t)(frame * 2 + side) * nby + by) * tiles_x;
   const int x = tid & (kTileW - 1), r = tid / kTileW;
   const int v = v0 + r;
   const int vr = max(min(v, H - 3), 2);                                    // :701
@@ -485,7 +498,7 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
   // (1) candidate lists: wave k copies tile k's list (cnt first, then its dwords)
   {
     const int k = tid >> 6, lane = tid & 63;
-    const int tx = blockIdx.x * kStripTiles + k;
+    const int tx = bx * kStripTiles + k;
     int cnt = 0;
     if (tx < tiles_x) {
       const size_t bin = bin_row + tx;
@@ -546,7 +559,7 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
       }
     } else {
       if (cnt <= kBinCap) {                                  // long list: read it from global memory
-        const BinEntry* list = bin_list + (bin_row + blockIdx.x * kStripTiles + k) * kBinCap;
+        const BinEntry* list = bin_list + (bin_row + bx * kStripTiles + k) * kBinCap;
         for (int c = 0; c < cnt; c++) {
           const unsigned m = reinterpret_cast<const uint8_t*>(list[c].rows)[x];
           const int tc = list[c].t;
@@ -1068,9 +1081,13 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
 }
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
                   const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw) {
-  const dim3 grid((dp.W + kStripW - 1) / kStripW, (dp.H + kTileH - 1) / kTileH, 2 * n);
+  const int nbx = (dp.W + kStripW - 1) / kStripW, nby = (dp.H + kTileH - 1) / kTileH;
+  const int total = nbx * nby * 2 * n;
+  static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
+  const int blocks = xcd_order ? (total + 7) / 8 * 8 : total;
   const size_t lds = (size_t)kTileH * (kStripW + dp.disp_max) * sizeof(uint4);   // 32.6 KB at disp_max 127, 49 KB at 255
-  hipLaunchKernelGGL(k_dense, grid, dim3(256), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw);
+  hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(256), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
+                     nbx, nby, xcd_order);
 }
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
   hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
