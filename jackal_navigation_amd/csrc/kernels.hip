@@ -436,15 +436,18 @@ DEV bool tri_covers(int Au, int Bu, int Cu, float ACa, float ACb, float ABa, flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense MAP matching (computeDisparity + findMatch, elas.cpp:683-907).  One 256-thread workgroup
-// per 128x8 pixel strip and side; every thread owns 4 pixels (columns x, x+32, x+64, x+96 of its row).
+// Dense MAP matching (computeDisparity + findMatch, elas.cpp:683-907).  One 512-thread workgroup
+// per 128x8 pixel strip and side; every thread owns 2 pixels of its row (64 columns apart), so that the
+// 36 KB of LDS a strip needs still allow 32 waves per CU.
 //  * The descriptors of the OTHER image that the strip can reach — 8 rows x (128 + disp_max)
 //    columns — are staged once in LDS with coalesced 16-byte loads (2 loads per pixel instead of
 //    one scattered 16-byte read per candidate disparity, ~13 per pixel); every candidate then
 //    costs one ds_read_b128 + four v_sad_u8.
 //  * Triangle lookup: k_bin left, per 32x8 tile, a list of {triangle, 8-bit row mask per tile
 //    column} (bit r set <=> the reference's raster loops, elas.cpp:874-901, visit pixel
-//    (u0+x, v0+r) for that triangle).  Every pixel takes the LAST covering triangle in list order
+//    (u0+x, v0+r) for that triangle).  The wave that stages a tile's list ranks its triangles and
+//    folds the masks into one 16-bit cover word per pixel, so a pixel finds its owner with one LDS
+//    read and a count-leading-zeros.  Every pixel takes the LAST covering triangle in list order
 //    — at a vertex column the two float edge lines of one triangle can round to different rows,
 //    so a few pixels are covered twice and the reference keeps the later visitor's result
 //    (findMatch's early-outs depend on the pixel only).
@@ -456,14 +459,16 @@ DEV uint32_t range_mask(int lo, int hi, int w) {               // bits of word w
   return (0xFFFFFFFFu >> (31 - b)) & (0xFFFFFFFFu << a);
 }
 
-enum { kStripTiles = 4, kStripW = kStripTiles * kTileW };
+enum { kStripTiles = 4, kStripW = kStripTiles * kTileW, kDenseThreads = 512, kPxPerThread = kStripTiles * kTileW * kTileH / kDenseThreads };
 
-__global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
+__global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
                                                const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
                                                const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
                                                const uint4* __restrict__ desc, float* __restrict__ raw, int nbx, int nby, int xcd_order) {
   __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
   __shared__ int s_cnt[kStripTiles];
+  __shared__ uint16_t s_cover[kStripTiles][kTileH][kTileW];       // per pixel: bit k set <=> the k-th smallest listed triangle covers it
+  __shared__ uint8_t s_slot[kStripTiles][kBinLds];                // rank -> list slot
   extern __shared__ uint4 s_B[];                             // [kTileH][kStripW + disp_max]
   // XCD-aware work order.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each with
   // its own 4 MB L2.  Workgroup b therefore takes logical item (b % 8) * per_xcd + b / 8, so that every
@@ -489,37 +494,40 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
   const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
   const int tiles_x = (W + kTileW - 1) / kTileW;
   const size_t bin_row = ((size_t)(frame * 2 + side) * nby + by) * tiles_x;
-  const int x = tid & (kTileW - 1), r = tid / kTileW;
+  const int x = tid & (kTileW - 1), r = (tid / kTileW) & (kTileH - 1), grp = tid / (kTileW * kTileH);   // grp 0: tiles 0,2; grp 1: tiles 1,3
   const int v = v0 + r;
   const int vr = max(min(v, H - 3), 2);                                    // :701
   const int nwords = (dp.disp_max >> 5) + 1;
 
-  // ---- issue every global read of this thread up front ----
-  // (1) candidate lists: wave k copies tile k's list (cnt first, then its dwords)
-  {
-    const int k = tid >> 6, lane = tid & 63;
-    const int tx = bx * kStripTiles + k;
-    int cnt = 0;
-    if (tx < tiles_x) {
-      const size_t bin = bin_row + tx;
-      cnt = bin_count[bin];
-      const int words = min(cnt, (int)kBinLds) * kBinWords;
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
-      for (int i = lane; i < words; i += 64) s_list[k][i] = src[i];
-    }
-    if (lane == 0) s_cnt[k] = cnt;
+  // ---- issue every global read of this thread up front, consume afterwards ----
+  // (1) candidate lists: wave k < 4 owns tile k (count, then up to 16 entries of 13 dwords)
+  const int lw = tid >> 6, lane = tid & 63;                  // waves 4..7 (second pixel pair) have no list duty
+  const bool list_wave = lw < kStripTiles && bx * kStripTiles + lw < tiles_x;
+  int cnt = 0, c16 = 0, myt = 0x7FFFFFFF;
+  uint32_t lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0;
+  if (list_wave) {
+    const size_t bin = bin_row + bx * kStripTiles + lw;
+    cnt = bin_count[bin];
+    c16 = min(cnt, (int)kBinLds);
+    const int words = c16 * kBinWords;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
+    if (lane < words) lw0 = src[lane];
+    if (lane + 64 < words) lw1 = src[lane + 64];
+    if (lane + 128 < words) lw2 = src[lane + 128];
+    if (lane + 192 < words) lw3 = src[lane + 192];
+    if (lane < c16) myt = (int)src[lane * kBinWords];
   }
-  // (2) own descriptors and grid-cell candidate sets of the thread's four pixels
-  uint4 a4[kStripTiles];
-  uint32_t cellw[kStripTiles][kGridWords];
+  // (2) own descriptors and grid-cell candidate sets of the thread's two pixels
+  uint4 a4[kPxPerThread];
+  uint32_t cellw[kPxPerThread][kGridWords];
   const uint32_t* cells = gridbits + ((size_t)(frame * 2 + side) * dp.gw * dp.gh + (size_t)(min(v, H - 1) / dp.grid_size) * dp.gw) * kGridWords;
 #pragma unroll
-  for (int k = 0; k < kStripTiles; k++) {
-    const int u = min(u0 + k * kTileW + x, W - 1);
-    a4[k] = A[(size_t)vr * W + u];
+  for (int q = 0; q < kPxPerThread; q++) {
+    const int u = min(u0 + (grp + 2 * q) * kTileW + x, W - 1);
+    a4[q] = A[(size_t)vr * W + u];
     const uint32_t* cell = cells + (size_t)(u / dp.grid_size) * kGridWords;
 #pragma unroll
-    for (int w = 0; w < kGridWords; w++) cellw[k][w] = w < nwords ? cell[w] : 0u;
+    for (int w = 0; w < kGridWords; w++) cellw[q][w] = w < nwords ? cell[w] : 0u;
   }
   // (3) the other image's descriptors the strip can reach
   const int span = kStripW + dp.disp_max;                    // columns of B one strip row can reach
@@ -527,11 +535,36 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
 #pragma unroll
   for (int rr = 0; rr < kTileH; rr++) {
     const uint4* src = B + (size_t)max(min(v0 + rr, H - 3), 2) * W;       // :701 row clamp
-    for (int c = tid; c < span; c += 256) {
+    for (int c = tid; c < span; c += kDenseThreads) {
       const int col = base + c;
       s_B[rr * span + c] = (col >= 0 && col < W) ? src[col] : make_uint4(0, 0, 0, 0);
     }
   }
+  // (1b) lists into LDS; rank the tile's triangles; fold the row masks into one cover word per pixel
+  if (list_wave) {
+    const int words = c16 * kBinWords;
+    if (lane < words) s_list[lw][lane] = lw0;
+    if (lane + 64 < words) s_list[lw][lane + 64] = lw1;
+    if (lane + 128 < words) s_list[lw][lane + 128] = lw2;
+    if (lane + 192 < words) s_list[lw][lane + 192] = lw3;
+    // rank among the listed triangles (indices are distinct): a pixel's owner is the covering triangle with the
+    // LARGEST index, i.e. the highest set bit of its cover word
+    int rank = 0;
+#pragma unroll
+    for (int jj = 0; jj < kBinLds; jj++) { const int tj = __shfl(myt, jj); rank += (jj < c16 && tj < myt) ? 1 : 0; }
+    if (lane < c16) s_slot[lw][rank] = (uint8_t)lane;
+    // lane (x, half) accumulates rows half*4 .. half*4+3 of column x over all listed candidates
+    const int xx = lane & (kTileW - 1), half = lane >> 5;
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (int c = 0; c < c16; c++) {
+      const unsigned m = ((s_list[lw][c * kBinWords + 1 + (xx >> 2)] >> ((xx & 3) * 8)) & 0xFFu) >> (half * 4);
+      const unsigned bit = 1u << __shfl(rank, c);
+      w0 |= (m & 1u) ? bit : 0u; w1 |= (m & 2u) ? bit : 0u; w2 |= (m & 4u) ? bit : 0u; w3 |= (m & 8u) ? bit : 0u;
+    }
+    s_cover[lw][half * 4 + 0][xx] = (uint16_t)w0; s_cover[lw][half * 4 + 1][xx] = (uint16_t)w1;
+    s_cover[lw][half * 4 + 2][xx] = (uint16_t)w2; s_cover[lw][half * 4 + 3][xx] = (uint16_t)w3;
+  }
+  if (lw < kStripTiles && lane == 0) s_cnt[lw] = cnt;
   __syncthreads();
   if (v >= H) return;
 
@@ -539,22 +572,18 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
   float* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;
 
 #pragma unroll
-  for (int k = 0; k < kStripTiles; k++) {
+  for (int q = 0; q < kPxPerThread; q++) {
+    const int k = grp + 2 * q;
     const int u = u0 + k * kTileW + x;
     if (u >= W) break;
     // ---- which triangle owns this pixel: the last covering one in list order ----
     const int cnt = s_cnt[k];
     int t = -1; float pa = 0, pb = 0, pc = 0; bool valid = false;
     if (cnt <= kBinLds) {
-      int hit = -1;
-      for (int c = 0; c < cnt; c++) {
-        const uint32_t* e = &s_list[k][c * kBinWords];
-        const unsigned m = (e[1 + (x >> 2)] >> ((x & 3) * 8)) & 0xFFu;
-        const int tc = (int)e[0];
-        if (((m >> r) & 1u) && tc > t) { t = tc; hit = c; }
-      }
-      if (hit >= 0) {
-        const uint32_t* e = &s_list[k][hit * kBinWords];
+      const unsigned cover = s_cover[k][r][x];
+      if (cover) {
+        const uint32_t* e = &s_list[k][s_slot[k][31 - __clz(cover)] * kBinWords];
+        t = (int)e[0];
         pa = __uint_as_float(e[9]); pb = __uint_as_float(e[10]); pc = __uint_as_float(e[11]); valid = e[12] & 1u;
       }
     } else {
@@ -574,7 +603,7 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
       if (t >= 0) { const TriRec* tr = R + t; pa = tr->pa; pb = tr->pb; pc = tr->pc; valid = tr->flags & 1; }
     }
     float result = -10.0f;                                                 // :797-798
-    const uint4 a = a4[k];
+    const uint4 a = a4[q];
     if (t >= 0 && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture) {   // :697, :715-719
       const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
       const int lo = max(d_plane - dp.radius, 0), hi = min(d_plane + dp.radius, dp.disp_max);                // :723-724
@@ -584,7 +613,7 @@ __global__ void __launch_bounds__(256) k_dense(DevParams dp, int n, const FrameI
 #pragma unroll
       for (int w = 0; w < kGridWords; w++) {                               // grid candidates outside the plane range (:742-750)
         if (w >= nwords) break;
-        uint32_t bits = cellw[k][w] & range_mask(0, dmax_ok, w) & ~range_mask(lo, hi, w);
+        uint32_t bits = cellw[q][w] & range_mask(0, dmax_ok, w) & ~range_mask(lo, hi, w);
         while (bits) {
           const int d = (w << 5) + __builtin_ctz(bits);
           bits &= bits - 1;
@@ -1086,7 +1115,7 @@ void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* i
   static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
   const int blocks = xcd_order ? (total + 7) / 8 * 8 : total;
   const size_t lds = (size_t)kTileH * (kStripW + dp.disp_max) * sizeof(uint4);   // 32.6 KB at disp_max 127, 49 KB at 255
-  hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(256), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
+  hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(kDenseThreads), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
                      nbx, nby, xcd_order);
 }
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
