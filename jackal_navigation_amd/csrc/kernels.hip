@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
 __global__ void __launch_bounds__(256) k_grid_mark(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
                                                    long long payload_stride, uint32_t* __restrict__ mark) {
   const int i = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
-  const FrameInfo fi = info[frame];
+  const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
   if (!fi.ok || i >= fi.nsup) return;
   const int32_t* s = reinterpret_cast<const int32_t*>(payload + (long long)frame * payload_stride + fi.sup_offset) + 3 * i;
   const int u = s[0], v = s[1], d = s[2];
@@ -326,7 +326,7 @@ DEV bool gauss_jordan3(double A[3][3], double b[3]) {
 __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
                                                    long long payload_stride, int tri_cap, TriRec* __restrict__ recs) {
   const int t = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y, side = blockIdx.z;
-  const FrameInfo fi = info[frame];
+  const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
   if (!fi.ok || t >= fi.ntri[side]) return;
   const uint8_t* fp = payload + (long long)frame * payload_stride;
   const int32_t* sup = reinterpret_cast<const int32_t*>(fp + fi.sup_offset);
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo
 __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
                                              int tri_cap, int32_t* __restrict__ bin_count, BinEntry* __restrict__ bin_list) {
   const int frame = blockIdx.y, side = blockIdx.z;
-  const FrameInfo fi = info[frame];
+  const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
   if (!fi.ok) return;
   const int t = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
   if (t >= fi.ntri[side]) return;
@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
   const int bx = rest % nbx; rest /= nbx;
   const int by = rest % nby;
   const int frame = rest / nby;
-  const FrameInfo fi = info[frame];
+  const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
   if (!fi.ok) return;
   const int W = dp.W, H = dp.H;
   const int tid = threadIdx.x;
