@@ -662,8 +662,15 @@ __global__ void __launch_bounds__(256) k_lr(DevParams dp, const FrameInfo* __res
 // speckle_size (and every invalid pixel, a "segment" of one) are set to -10.  The reference's
 // flood fill visits the same components, so the result is order-free.
 DEV int uf_find(int32_t* __restrict__ lab, int x) {
+  // path halving: every visited node is re-pointed at its grandparent.  Parents only ever move towards the
+  // root (smaller index), so the unsynchronised stores are benign; without them a tall region builds a
+  // chain of one hop per image row and a single find walks hundreds of dependent loads.
   int p = lab[x];
-  while (p != x) { x = p; p = lab[x]; }
+  while (p != x) {
+    const int g = lab[p];
+    if (g != p) lab[x] = g;
+    x = p; p = g;
+  }
   return x;
 }
 DEV void uf_union(int32_t* __restrict__ lab, int a, int b) {
