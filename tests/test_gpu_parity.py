@@ -46,6 +46,21 @@ def test_elas_bit_exact_vs_oracle(jn, oracle, same, W, H, sd, dmax, seed):
     assert same(D2, D2o), "%d differing pixels in D2" % int((D2 != D2o).sum())
 
 
+def test_full_hd_and_wide_images(jn, oracle, same):
+    """BASELINE config 5's frame (1920x1080, disparity range 256: the widest LDS windows) and an image wider than
+    2560 px, which takes the global-memory support-matching kernel instead of the LDS one."""
+    for (W, H, sd, dmax, seed) in ((1920, 1080, 256, 255, 12345), (2600, 200, 40, 63, 3)):
+        L, R = jn.node.synth_pair(W, H, sd, seed)
+        st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=dmax), L, R)
+        st_o, D1o, D2o = oracle.process(oracle.params(0, disp_max=dmax), L, R)
+        assert st == st_o == 0 and same(D1, D1o) and same(D2, D2o), (W, H)
+    import os
+    # SURVEY.md §8c known answer for 1920x1080, scene d<=256, disp_max=255 (measured there on the reference itself)
+    L, R = jn.node.synth_pair(1920, 1080, 256, 12345)
+    _, D1, _ = run_elas(jn, jn.Elas.parameters(0, disp_max=255), L, R)
+    assert oracle.fnv(D1) == 0xcd2740a7ac6afdf7
+
+
 def test_known_answer_hashes_on_gpu(jn, oracle):
     import os
     rows = [l.split() for l in open(os.path.join(os.path.dirname(__file__), "golden", "reference_hashes.txt")) if not l.startswith("#")]
