@@ -159,10 +159,14 @@ __global__ void __launch_bounds__(256) k_support(DevParams dp, int n, const uint
   if (lane == 0) d_can[(size_t)frame * dp.cw * dp.ch + cand] = out;
 }
 
-// LDS variant: one 1024-thread workgroup per lattice row.  The four descriptor rows the row's
-// candidates read (v-2 and v+2 of both images) are staged once in LDS (64*W bytes); four lanes share
-// a candidate and stride the disparity range, merged by two DPP-style shuffles.  Used when 64*W
-// bytes fit the 160 KB LDS; otherwise the global-memory kernel above runs.
+// LDS variant: one 1024-thread workgroup per lattice row stages the four descriptor rows its candidates
+// read (v-2 and v+2 of both images, 64*W bytes).  LANES lanes share a candidate and stride the disparity
+// range, merged by log2(LANES) xor-shuffles.  Measured at 720p/D=128: 4 lanes 416 us, 8 lanes 329 us,
+// 16 lanes 383 us, 1 lane (no merge, 256 threads) 447 us per 32-pair batch — 8 consecutive descriptors per
+// candidate spread the ds_read_b128 over more banks than 4 do, 16 pay more for the merge.  Used when
+// 64*W bytes fit the 160 KB LDS; otherwise the global-memory kernel above runs.
+enum { kSupportLanes = 8 };
+template <int LANES>
 DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Ab, const uint4* __restrict__ Bt,
                    const uint4* __restrict__ Bb, const uint4* __restrict__ Arow_v, int u, bool right, bool active, int j) {
   const int W = dp.W;
@@ -173,7 +177,7 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
   Best b{32767, -1, 32767};
   if (ok) {
     const uint4 a0 = At[u - 2], a1 = At[u + 2], a2 = Ab[u - 2], a3 = Ab[u + 2];
-    for (int d = j; d <= dmax; d += 4) {
+    for (int d = j; d <= dmax; d += LANES) {
       const int uw = right ? u + d : u - d;
       const int s = sad16(a0, Bt[uw - 2]) + sad16(a1, Bt[uw + 2]) + sad16(a2, Bb[uw - 2]) + sad16(a3, Bb[uw + 2]);
       if (s < b.e1) { b.e2 = b.e1; b.e1 = s; b.d1 = d; }
@@ -181,13 +185,14 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
     }
   }
 #pragma unroll
-  for (int off = 1; off <= 2; off <<= 1) {
+  for (int off = 1; off < LANES; off <<= 1) {
     const int e1 = __shfl_xor(b.e1, off), d1 = __shfl_xor(b.d1, off), e2 = __shfl_xor(b.e2, off);
     b = merge(b, e1, d1, e2);
   }
   return (ok && b.d1 >= 0 && (float)b.e1 < dp.support_threshold * (float)b.e2) ? b.d1 : -1;   // :366
 }
 
+template <int LANES>
 __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can) {
   extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], W each
   const int vc = blockIdx.x, frame = blockIdx.y, W = dp.W;
@@ -208,14 +213,14 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
   __syncthreads();
   const uint4* Lv = L + (size_t)v * W;                  // row v itself is only read for the texture test
   const uint4* Rv = R + (size_t)v * W;
-  const int j = threadIdx.x & 3;
-  for (int uc0 = 0; uc0 < dp.cw; uc0 += 256) {
-    const int uc = uc0 + (threadIdx.x >> 2);
+  const int j = threadIdx.x & (LANES - 1);
+  for (int uc0 = 0; uc0 < dp.cw; uc0 += 1024 / LANES) {
+    const int uc = uc0 + (threadIdx.x / LANES);
     const bool active = uc >= 1 && uc < dp.cw;
     const int u = uc * dp.step;
     int res = -1;
-    const int d = quad_match(dp, Lt, Lb, Rt, Rb, Lv, u, false, active, j);
-    const int d2 = quad_match(dp, Rt, Rb, Lt, Lb, Rv, u - d, true, active && d >= 0, j);
+    const int d = quad_match<LANES>(dp, Lt, Lb, Rt, Rb, Lv, u, false, active, j);
+    const int d2 = quad_match<LANES>(dp, Rt, Rb, Lt, Lb, Rv, u - d, true, active && d >= 0, j);
     if (d >= 0 && d2 >= 0 && abs(d - d2) <= dp.lr_threshold) res = d;         // :404-411
     if (j == 0 && uc < dp.cw) out_row[uc] = (int16_t)(uc == 0 ? 0 : res);
   }
@@ -1087,10 +1092,10 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
   if (lds <= 160 * 1024) {
     static bool configured = false;
     if (!configured) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       configured = true;
     }
-    hipLaunchKernelGGL(k_support_lds, dim3(dp.ch, n), dim3(1024), lds, st, dp, n, desc, d_can);
+    hipLaunchKernelGGL(k_support_lds<kSupportLanes>, dim3(dp.ch, n), dim3(1024), lds, st, dp, n, desc, d_can);
   } else {
     hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
   }
