@@ -967,14 +967,15 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
       if (kf >= 0 && kf < (double)s.bins) atomicMin(&lbins[(int)kf], enc(r));
     }
   }
-  // extrema: butterfly inside the wave, then one LDS atomic per wave
+  // extrema: butterfly inside the wave, then one LDS atomic per wave — skipped by the (many) waves in which
+  // no pixel passed the test
+  if (__ballot(tmin != ~0ull) != 0ull) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     tmin = min(tmin, __shfl_xor(tmin, off)); tmax = max(tmax, __shfl_xor(tmax, off));
     rmin = min(rmin, __shfl_xor(rmin, off)); rmax = max(rmax, __shfl_xor(rmax, off));
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (tmin != ~0ull) { atomicMin(&lmeta[0], tmin); atomicMax(&lmeta[1], tmax); atomicMin(&lmeta[2], rmin); atomicMax(&lmeta[3], rmax); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&lmeta[0], tmin); atomicMax(&lmeta[1], tmax); atomicMin(&lmeta[2], rmin); atomicMax(&lmeta[3], rmax); }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < s.bins; k += 256)
