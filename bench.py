@@ -223,6 +223,27 @@ def main():
                 "ms_per_launch": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4)}
 
+    # BASELINE config 2 beside the headline workload: 640x480, D=64, batch 1, latency mode (one synchronous
+    # call per pair on device pointers, nothing pipelined).  Informational; not part of `value`.
+    extra = None
+    if rank == 0 and world == 1:
+        w2, h2, d2, reps = 640, 480, 64, 50
+        l2, r2 = node.synth_pair(w2, h2, d2, 12345)
+        tl, tr = torch.from_numpy(l2).to(dev), torch.from_numpy(r2).to(dev)
+        o1 = torch.zeros((h2, w2), dtype=torch.float32, device=dev); o2 = torch.zeros_like(o1)
+        e2 = jn.Elas(jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=d2 - 1), w2, h2, max_batch=1, device=local_rank, host_threads=2, slots=1)
+        for _ in range(5):
+            e2.process_batch(1, tl.data_ptr(), tr.data_ptr(), w2, h2 * w2, o1.data_ptr(), o2.data_ptr())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            e2.process_batch(1, tl.data_ptr(), tr.data_ptr(), w2, h2 * w2, o1.data_ptr(), o2.data_ptr())
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / reps
+        e2.close()
+        extra = {"workload": "640x480 D=64 batch=1 latency mode (BASELINE config 2)", "ms_per_frame": round(lat * 1e3, 3),
+                 "pairs_per_sec": round(1.0 / lat, 1)}
+
     if rank == 0:
         out = {
             "metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
@@ -237,6 +258,7 @@ def main():
             "stage_ms_per_batch": {k: round(v, 3) for k, v in stage_ms.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "latency_config": extra,
         }
         print(json.dumps(out))
     elas.close()
