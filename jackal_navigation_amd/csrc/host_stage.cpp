@@ -81,11 +81,13 @@ void HostWorker::filter_redundant(int16_t* D, int max_dist, int thresh, bool ver
     }
 }
 
-void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs) const {
+void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs, bool filtered) const {
   const int cw = hp_.cw, ch = hp_.ch, step = hp_.step;
-  filter_inconsistent(d_can);                                    // elas.cpp:416
-  filter_redundant(d_can, 5, 1, true);                           // elas.cpp:421
-  filter_redundant(d_can, 5, 1, false);                          // elas.cpp:422
+  if (!filtered) {
+    filter_inconsistent(d_can);                                  // elas.cpp:416
+    filter_redundant(d_can, 5, 1, true);                         // elas.cpp:421
+    filter_redundant(d_can, 5, 1, false);                        // elas.cpp:422
+  }
   fs->u.clear(); fs->v.clear(); fs->d.clear(); fs->x.clear();
   for (int uc = 1; uc < cw; uc++)                                // elas.cpp:425-431 (u-major order)
     for (int vc = 1; vc < ch; vc++) {

@@ -33,7 +33,8 @@ class HostWorker {
   explicit HostWorker(const HostParams& hp);
   // Phase 1 (one task per frame): filter this frame's candidate lattice d_can [ch][cw] in place
   // (elas.cpp:416-422) and list the support points (elas.cpp:425-431) into `fs`; sets info->ok/nsup.
-  void filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs) const;
+  // `filtered`: the GPU already ran the filters (k_support_filters); only the list is built.
+  void filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs, bool filtered = false) const;
   // Between the phases: give the frame its place in the batch payload (frames are packed back to
   // back so that the whole batch goes to the GPU in one copy).  Returns the bytes the frame occupies.
   static size_t place(FrameInfo* info, size_t base_offset);

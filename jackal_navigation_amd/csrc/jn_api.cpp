@@ -73,6 +73,8 @@ struct jn_elas {
   int W = 0, H = 0, max_batch = 0, device = 0;
   size_t payload_cap = 0;
   int tri_cap = 0;
+  bool host_filters = false;        // JN_HOST_FILTERS at create time: support filters on the host workers (A/B switch; the
+                                    // host stage also takes over by itself when the lattice does not fit the filter kernel)
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
   // staging for the host-pointer drop-in call
@@ -92,6 +94,8 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   launch_descriptor(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
   HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
   launch_support(st, dp, n, s.desc, s.d_can);
+  const bool filtered = !h->host_filters &&
+      launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can);
   HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
   const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
   HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
@@ -100,7 +104,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
 
   auto t_host0 = std::chrono::steady_clock::now();
   h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: filters + support list, per frame
-    w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i]);
+    w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i], filtered);
   });
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
   for (int i = 0; i < n; i++) payload_bytes += HostWorker::place(&s.h_info[i], payload_bytes);
@@ -227,6 +231,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
 
   std::unique_ptr<jn_elas> h(new jn_elas());
   h->p = *p; h->W = W; h->H = H; h->max_batch = max_batch; h->device = device;
+  h->host_filters = getenv("JN_HOST_FILTERS") != nullptr;
   DevParams& dp = h->dp;
   memset(&dp, 0, sizeof(dp));
   dp.W = W; dp.H = H; dp.pitch = (W + 63) / 64 * 64;

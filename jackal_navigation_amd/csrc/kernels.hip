@@ -227,6 +227,112 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// Support-point filters on the candidate lattice, in place, with the reference's exact sequential
+// semantics (removeInconsistentSupportPoints, elas.cpp:153-179; removeRedundantSupportPoints
+// vertical then horizontal, elas.cpp:181-235, called at :416-422).  One workgroup per frame, the
+// lattice (int16 [ch][cw]) lives in LDS.
+//  * Inconsistency filter: the reference sweeps u-outer / v-inner and deletions act immediately, so
+//    a point sees earlier points of its (2w+1)^2 window already filtered and later ones untouched.
+//    With K = w+1, all points of equal t = K*u + v are independent (same-t points are >= K rows
+//    apart, earlier-in-sweep window points have smaller t, later ones larger), so the workgroup walks t
+//    as a skewed wavefront: sixteen lanes per point share the window, ~ch/K points per step.
+//  * Redundancy filters: the vertical pass only looks along a column, the horizontal pass only along
+//    a row, so columns resp. rows are independent and each thread sweeps one line sequentially.
+// The LDS copy carries a border of WIN invalid cells on every side, so no window needs bounds checks and the
+// (2*WIN+1)^2 loops unroll completely (the window size is a template parameter; the reference uses 5).
+// One line of a redundancy pass (removeRedundantSupportPoints, elas.cpp:181-235; max_dist 5, threshold 1):
+// a point goes when both directions along the line hold a point within 1 of it.  The sweep is in place,
+// so "before" sees this pass's deletions and "after" does not.  An 11-cell register window slides along
+// the line: one LDS read per step, issued a step ahead, and branch-free compares.
+__device__ __forceinline__ void redundant_line(int16_t* line, int stride, int n) {
+  int w[11];
+#pragma unroll
+  for (int k = 0; k < 11; k++) w[k] = line[(k - 5) * stride];
+  for (int i = 0; i < n; i++) {
+    const int nxt = line[min(i + 6, n + 4) * stride];
+    const int d = w[5];
+    const int lo = max(d - 1, 0);
+    const unsigned span = (unsigned)(d + 1 - lo);
+    bool before = false, after = false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) before |= (unsigned)(w[k] - lo) <= span;
+#pragma unroll
+    for (int k = 6; k < 11; k++) after |= (unsigned)(w[k] - lo) <= span;
+    if (d >= 0 && before && after) { line[i * stride] = -1; w[5] = -1; }
+#pragma unroll
+    for (int k = 0; k < 10; k++) w[k] = w[k + 1];
+    w[10] = nxt;
+  }
+}
+
+constexpr int kFilterThreads = 512, kFilterLanes = 16;              // 32 points per wavefront step, 16 lanes per point
+template <int WIN>
+__global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can) {
+  extern __shared__ int16_t s_lat[];                      // [(ch + 2*WIN)][(cw + 2*WIN)]
+  static_assert(WIN == 5, "redundant_line's window is the reference's fixed max_dist 5");
+  const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x;
+  const int pw = cw + 2 * WIN, ph = ch + 2 * WIN;
+  int16_t* g = d_can + (size_t)blockIdx.x * cw * ch;
+  for (int i = tid; i < pw * ph; i += kFilterThreads) {
+    const int r = i / pw - WIN, c = i % pw - WIN;
+    s_lat[i] = (r >= 0 && r < ch && c >= 0 && c < cw) ? g[r * cw + c] : (int16_t)-1;
+  }
+  __syncthreads();
+  int16_t* base = s_lat + WIN * pw + WIN;                  // base[v * pw + u] = lattice (u, v)
+  {
+    // 16 lanes per point: lane `part` takes window cells part, part+16, ... of the (2*WIN+1)^2 = 121; 32 points
+    // per step cover lattices up to 192 rows.  One barrier per step publishes the step's deletions.
+    constexpr int K = WIN + 1, CELLS = (2 * WIN + 1) * (2 * WIN + 1), L = kFilterLanes;
+    const int j = tid / L, part = tid % L;
+    constexpr int NC = (CELLS + L - 1) / L;
+    int off[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int cell = min(part + L * c, CELLS - 1);
+      off[c] = (cell / (2 * WIN + 1) - WIN) * pw + cell % (2 * WIN + 1) - WIN;
+    }
+    const bool tail = part + L * (NC - 1) < CELLS;         // whether this lane's last slot is a real cell
+    // step t = K*q + phase: point j sits at v = phase + K*j, u = q - j.  q and phase are wave-uniform, so the
+    // lane-dependent part of the address is the constant K*j*pw - j and the bounds are two compares.
+    const int lane_cell = K * j * pw - j, v_room = ch - K * j;
+    const int qmax = (K * (cw - 1) + ch - 1) / K;
+    for (int q = 0; q <= qmax; q++) {
+#pragma unroll
+      for (int phase = 0; phase < K; phase++) {
+        const bool on = phase < v_room && (unsigned)(q - j) < (unsigned)cw;
+        int16_t* p = base + (on ? lane_cell + phase * pw + q : 0);
+        const int d = on ? (int)p[0] : -1;
+        // all loads first, then branch-free arithmetic: a short-circuit on e >= 0 makes the compiler wait
+        // out every LDS read one at a time.  e in [max(d-tol,0), d+tol] as one unsigned compare.
+        int e[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) e[c] = p[off[c]];
+        const int lo = max(d - tol, 0);
+        const unsigned span = (unsigned)(d + tol - lo);
+        int count = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++)
+          count += (int)((unsigned)(e[c] - lo) <= span) & (int)(c < NC - 1 || tail);
+        count += __builtin_amdgcn_update_dpp(0, count, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+        count += __builtin_amdgcn_update_dpp(0, count, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+        count += __builtin_amdgcn_update_dpp(0, count, 0x141, 0xF, 0xF, false);   // row_half_mirror
+        count += __builtin_amdgcn_update_dpp(0, count, 0x140, 0xF, 0xF, false);   // row_mirror
+        // points of one step are K rows apart, outside each other's windows: their writes touch nothing
+        // this step reads, so one barrier (before the next step's reads) is enough.
+        if (d >= 0 && part == 0 && count < min_support) p[0] = -1;
+        __syncthreads();
+      }
+    }
+  }
+  __syncthreads();
+  for (int u = tid; u < cw; u += kFilterThreads) redundant_line(base + u, pw, ch);        // vertical pass (elas.cpp:421)
+  __syncthreads();
+  for (int v = tid; v < ch; v += kFilterThreads) redundant_line(base + v * pw, 1, cw);    // horizontal pass (elas.cpp:422)
+  __syncthreads();
+  for (int i = tid; i < cw * ch; i += kFilterThreads) g[i] = base[(i / cw) * pw + (i % cw)];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Grid prior (createGrid, elas.cpp:579-659) as 256-bit candidate sets per 20x20 cell.
 // mark: every support point sets d-1..d+1 in its cell (left: column u, right: column u-d).
 __global__ void __launch_bounds__(256) k_grid_mark(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
@@ -1100,6 +1206,19 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
   } else {
     hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
   }
+}
+bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can) {
+  constexpr int WIN = 5;                                            // the reference's incon_window_size (elas.h:97)
+  const size_t lds = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t);
+  // other window sizes, lattices beyond the LDS, or more than 32 points per wavefront step: the host stage filters
+  if (win != WIN || lds > 150 * 1024 || (dp.ch + WIN) / (WIN + 1) > 32) return false;   // 512 threads = 32 points x 16 lanes per step
+  static bool configured = false;
+  if (!configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    configured = true;
+  }
+  hipLaunchKernelGGL(k_support_filters<WIN>, dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can);
+  return true;
 }
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                  int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits) {
