@@ -1,7 +1,7 @@
 // delaunay.cpp — see delaunay.h.  Host stage of the stereo path (product code).
 //
 // Decision sequence reproduced (reference line numbers in src/elas/triangle.cpp):
-//   sort by (x,y) with LCG-pivot quicksort      :4045-4049, :5446-5500
+//   sort by (x,y) with LCG-pivot quicksort      :4045-4049, :5446-5500 (replayed only when vertices coincide)
 //   duplicates: first in sorted order survives   :6179-6194
 //   alternating-cut re-partition                 :5514-5606, :6197-6206 (same result, computed kd-style)
 //   2-/3-vertex bases, recursive hull zipping     :5638-5947, :5953-6103
@@ -41,8 +41,8 @@ unsigned Delaunay::draw(unsigned choices) {
 
 Delaunay::H Delaunay::fresh() {
   const int t = ntri_++;
-  link_[3 * t] = link_[3 * t + 1] = link_[3 * t + 2] = -1;
-  vert_[3 * t] = vert_[3 * t + 1] = vert_[3 * t + 2] = -1;
+  link_[4 * t] = link_[4 * t + 1] = link_[4 * t + 2] = -1;
+  vert_[4 * t] = vert_[4 * t + 1] = vert_[4 * t + 2] = -1;
   return (H)t << 2;
 }
 
@@ -65,6 +65,42 @@ void Delaunay::quicksort(int32_t* a, int n) {
   partition(a, n, 0, l, r);
   if (l > 1) quicksort(a, l);
   if (r < n - 2) quicksort(a + r + 1, n - r - 1);
+}
+
+// (x,y) order without replaying the quicksort.  With all keys distinct the sorted order is unique, so any
+// sort gives what the reference's does: nothing at all when the input is already ascending (the left
+// image's support list is, elas.cpp:425-431 walks u outer / v inner), else two stable counting passes (y,
+// then x).  Returns false when two vertices coincide; the caller then replays the reference's sort.
+bool Delaunay::sort_distinct(int32_t* a, int n) {
+  bool ascending = true;
+  int32_t xmin = x_[0], xmax = xmin, ymin = y_[0], ymax = ymin;
+  for (int i = 1; i < n; i++) {
+    const int32_t xi = x_[i], yi = y_[i];
+    ascending &= x_[i - 1] < xi || (x_[i - 1] == xi && y_[i - 1] < yi);
+    xmin = xi < xmin ? xi : xmin; xmax = xi > xmax ? xi : xmax;
+    ymin = yi < ymin ? yi : ymin; ymax = yi > ymax ? yi : ymax;
+  }
+  if (ascending) {
+    for (int i = 0; i < n; i++) a[i] = i;
+    return true;
+  }
+  const int xr = xmax - xmin + 1, yr = ymax - ymin + 1;
+  if ((int64_t)xr + yr > 8 * (int64_t)n + 4096) return false;        // sparse keys: buckets would cost more than the sort
+  const size_t need = (size_t)(xr > yr ? xr : yr) + 1;
+  if (bucket_.size() < need) bucket_.resize(need);
+  int32_t* b = bucket_.data();
+  int32_t* t = tmp_.data();
+  std::fill(b, b + yr + 1, 0);
+  for (int i = 0; i < n; i++) b[y_[i] - ymin + 1]++;
+  for (int i = 0; i < yr; i++) b[i + 1] += b[i];
+  for (int i = 0; i < n; i++) t[b[y_[i] - ymin]++] = i;
+  std::fill(b, b + xr + 1, 0);
+  for (int i = 0; i < n; i++) b[x_[i] - xmin + 1]++;
+  for (int i = 0; i < xr; i++) b[i + 1] += b[i];
+  for (int i = 0; i < n; i++) a[b[x_[t[i]] - xmin]++] = t[i];
+  for (int i = 1; i < n; i++)
+    if (x_[a[i - 1]] == x_[a[i]] && y_[a[i - 1]] == y_[a[i]]) return false;
+  return true;
 }
 
 // Alternating-cut arrangement (the effect of triangle.cpp:5514-5606, :6197-6206).  Triangle reaches it
@@ -294,22 +330,26 @@ int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
   if (n < 3) return -1;
   x_ = x; y_ = y; lcg_ = 1; ntri_ = 0;
   const size_t cap = (size_t)8 * n + 64;   // real + ghost triangles ever created (< 4n)
-  if (link_.size() < 3 * cap) { link_.resize(3 * cap); vert_.resize(3 * cap); }
+  if (link_.size() < 4 * cap) { link_.resize(4 * cap); vert_.resize(4 * cap); }
   if (order_.size() < (size_t)n) { order_.resize(n); by_y_.resize(n); tmp_.resize(n); left_.resize(n); }
   int32_t* a = order_.data();
-  for (int i = 0; i < n; i++) a[i] = i;
-  quicksort(a, n);
-  int k = 0;
-  for (int j = 1; j < n; j++)
-    if (x[a[k]] != x[a[j]] || y[a[k]] != y[a[j]]) a[++k] = a[j];
-  ++k;
+  int k = n;
+  if (!sort_distinct(a, n)) {
+    // duplicate vertices: which of them survives depends on the reference's quicksort, pivot draws included
+    for (int i = 0; i < n; i++) a[i] = i;
+    quicksort(a, n);
+    k = 0;
+    for (int j = 1; j < n; j++)
+      if (x[a[k]] != x[a[j]] || y[a[k]] != y[a[j]]) a[++k] = a[j];
+    ++k;
+  }
   if (k < 2) return -1;
   arrange(a, k);
   H hl, hr;
   conquer(a, k, 0, hl, hr);
   int out = 0;
   for (int t = 0; t < ntri_; t++) {
-    const int32_t* c = &vert_[3 * t];
+    const int32_t* c = &vert_[4 * t];
     if ((c[0] | c[1] | c[2]) < 0) continue;       // ghost
     tri[3 * out] = c[1]; tri[3 * out + 1] = c[2]; tri[3 * out + 2] = c[0];
     out++;

@@ -25,23 +25,23 @@ class Delaunay {
   typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge
   const int32_t* x_ = nullptr;
   const int32_t* y_ = nullptr;
-  std::vector<int32_t> link_;               // 3 per triangle: handle across that edge
-  std::vector<int32_t> vert_;               // 3 per triangle: vertex or -1 (ghost corner)
+  std::vector<int32_t> link_;               // 4 per triangle (3 used): handle across that edge; indexed by the handle itself
+  std::vector<int32_t> vert_;               // 4 per triangle (3 used): vertex or -1 (ghost corner)
   std::vector<int32_t> order_, by_y_, tmp_, bucket_;
   std::vector<uint8_t> left_;
   int ntri_ = 0;
   uint64_t lcg_ = 1;
 
   H fresh();
-  inline H across(H h) const { return (H)link_[3 * (h >> 2) + (h & 3)]; }
+  inline H across(H h) const { return (H)link_[h]; }
   static inline unsigned up(unsigned e) { return e == 2 ? 0u : e + 1u; }      // edge 0->1->2->0
   static inline unsigned down(unsigned e) { return e == 0 ? 2u : e - 1u; }    // edge 0->2->1->0
   static inline H ccw_edge(H h) { return (h & ~3u) | up(h & 3); }
   static inline H cw_edge(H h)  { return (h & ~3u) | down(h & 3); }
-  inline int32_t& v_org(H h)  { return vert_[3 * (h >> 2) + up(h & 3)]; }
-  inline int32_t& v_dest(H h) { return vert_[3 * (h >> 2) + down(h & 3)]; }
-  inline int32_t& v_apex(H h) { return vert_[3 * (h >> 2) + (h & 3)]; }
-  inline void glue(H a, H b) { link_[3 * (a >> 2) + (a & 3)] = (int32_t)b; link_[3 * (b >> 2) + (b & 3)] = (int32_t)a; }
+  inline int32_t& v_org(H h)  { return vert_[ccw_edge(h)]; }
+  inline int32_t& v_dest(H h) { return vert_[cw_edge(h)]; }
+  inline int32_t& v_apex(H h) { return vert_[h]; }
+  inline void glue(H a, H b) { link_[a] = (int32_t)b; link_[b] = (int32_t)a; }
 
   inline int orient(int a, int b, int c) const;
   inline int in_circle(int a, int b, int c, int d) const;
@@ -49,6 +49,7 @@ class Delaunay {
   unsigned draw(unsigned choices);
   void partition(int32_t* a, int n, int axis, int& l, int& r);
   void quicksort(int32_t* a, int n);
+  bool sort_distinct(int32_t* a, int n);
   void arrange(int32_t* a, int n);
   void split(int lo, int hi, int axis);
   void conquer(int32_t* a, int n, int axis, H& farleft, H& farright);
