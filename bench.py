@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency-config", action="store_true",
+                    help="skip the informational 640x480 batch-1 leg (profiles then hold the headline workload's launches only)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (=RCCL, default) or gloo; gloo + --share-gpu lets two ranks dry-run the N>1 path on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses device 0")
@@ -226,7 +228,7 @@ def main():
     # BASELINE config 2 beside the headline workload: 640x480, D=64, batch 1, latency mode (one synchronous
     # call per pair on device pointers, nothing pipelined).  Informational; not part of `value`.
     extra = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not a.no_latency_config:
         w2, h2, d2, reps = 640, 480, 64, 50
         l2, r2 = node.synth_pair(w2, h2, d2, 12345)
         tl, tr = torch.from_numpy(l2).to(dev), torch.from_numpy(r2).to(dev)

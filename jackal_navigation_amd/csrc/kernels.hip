@@ -1040,6 +1040,7 @@ __device__ __host__ inline double dec(unsigned long long k) {
 // kFromCloud selects the -g flavour (publishPointCloud + publishObstacleScan(vector<Point3d>),
 // point_cloud.cpp:321-352, :149-211): every pixel with d >= 2 becomes a point, points on the ground
 // model are dropped, the rest are binned — instead of the LUT test of the default path.
+constexpr int kScanRows = 16;
 template <bool kFromCloud>
 __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict__ dD, uint8_t* __restrict__ dDisp,
                                               const uint8_t* __restrict__ lut, int W, int H, unsigned long long* __restrict__ gbins,
@@ -1051,9 +1052,14 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
   for (int k = threadIdx.x; k < s.bins; k += 256) lbins[k] = ~0ull;
   if (threadIdx.x < 4) lmeta[threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;   // min slots start high, max slots low
   __syncthreads();
-  const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+  // One thread walks kScanRows rows of one column.  The bearing of a pixel hardly depends on its row or
+  // disparity, so consecutive rows fall in the same bin: the running minimum stays in registers and reaches the
+  // LDS only when the bin changes (same-address LDS atomics from a whole wave would serialise otherwise).
+  const int i = blockIdx.x * 256 + threadIdx.x, j0 = blockIdx.y * kScanRows;
   unsigned long long tmin = ~0ull, tmax = 0ull, rmin = ~0ull, rmax = 0ull;
-  if (i < W) {
+  int cur_bin = -1;
+  unsigned long long cur_min = ~0ull;
+  if (i < W) for (int j = j0; j < min(j0 + kScanRows, H); j++) {
     const size_t p = ((size_t)frame * H + j) * W + i;
     int d;
     if (dD) { const uint8_t q = f32_to_u8(dD[p]); dDisp[p] = q; d = q; } else d = dDisp[p];
@@ -1068,11 +1074,19 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
       const double th = atan2(Y, X);
       const double deg = __dmul_rn(th, 180.) / s.pi;
       const double r = sqrt(__dadd_rn(__dmul_rn(Y, Y), __dmul_rn(X, X)));
-      tmin = tmax = enc(th); rmin = rmax = enc(r);
+      const unsigned long long et = enc(th), er = enc(r);
+      tmin = min(tmin, et); tmax = max(tmax, et); rmin = min(rmin, er); rmax = max(rmax, er);
       const double kf = floor(__dmul_rn((double)s.bins, __dadd_rn(s.fov / 2., -deg)) / s.fov);   // :263
-      if (kf >= 0 && kf < (double)s.bins) atomicMin(&lbins[(int)kf], enc(r));
+      if (kf >= 0 && kf < (double)s.bins) {
+        const int k = (int)kf;
+        if (k != cur_bin) {
+          if (cur_bin >= 0) atomicMin(&lbins[cur_bin], cur_min);
+          cur_bin = k; cur_min = er;
+        } else cur_min = min(cur_min, er);
+      }
     }
   }
+  if (cur_bin >= 0) atomicMin(&lbins[cur_bin], cur_min);
   // extrema: butterfly inside the wave, then one LDS atomic per wave — skipped by the (many) waves in which
   // no pixel passed the test
   if (__ballot(tmin != ~0ull) != 0ull) {
@@ -1282,8 +1296,9 @@ void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* d
   unsigned long long* gb = reinterpret_cast<unsigned long long*>(bins);
   const int total = n * s.bins, m = total > n * 4 ? total : n * 4;
   hipLaunchKernelGGL(k_scan_init, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch);
-  if (lut) hipLaunchKernelGGL(k_scan<false>, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
-  else     hipLaunchKernelGGL(k_scan<true>, grid2d(W, H, n), dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
+  const dim3 sg((W + 255) / 256, (H + kScanRows - 1) / kScanRows, n);
+  if (lut) hipLaunchKernelGGL(k_scan<false>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
+  else     hipLaunchKernelGGL(k_scan<true>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
   hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta);
 }
 void launch_undistort_map(hipStream_t st, const double iR[9], const double K[9], const double D[5], int W, int H, float* mapx, float* mapy) {
