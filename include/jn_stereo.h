@@ -244,6 +244,41 @@ typedef struct jn_host_frame_info {
 int64_t jn_host_stage(const jn_elas_params* p, int32_t width, int32_t height, int16_t* d_can, uint8_t* payload,
                       int64_t payload_cap, jn_host_frame_info* info);
 
+/* ---------------------------------------------------------------------------------------------
+ * Scan consumer: the decision navigate.cpp takes from one LaserScan.  Host code;
+ * present so that scans from this library can be checked to drive the same stop / turn decisions.
+ * The reference keeps this state in file-scope globals (navigate.cpp:22-24, :44-45); here the caller
+ * owns it. */
+#define JN_NAV_MAX_HISTORY 64
+typedef struct jn_nav_params {
+  double clear_front;        /* navigate.cpp:37  0.24 + 0.8 */
+  double clear_side;         /* :38  0.3 */
+  double stop_dist;          /* :125 0.5: any return closer than this is an obstacle */
+  int32_t laser_pt_thresh;   /* :42  8 */
+  int32_t history;           /* :129 20 votes kept */
+  int32_t history_votes;     /* :146 more than 2 positives in the history => obstacle */
+  int32_t reserved;
+} jn_nav_params;
+typedef struct jn_nav_state {
+  int32_t votes[JN_NAV_MAX_HISTORY];
+  int32_t head, filled, positives;
+  int32_t last_dir;          /* :45 */
+} jn_nav_state;
+typedef struct jn_nav_decision {
+  int32_t points_inside;     /* `count` of :108-111 */
+  int32_t points;            /* laserPoints.size() */
+  int32_t obstacle;          /* checkObstacle's return value */
+  int32_t direction;         /* 0 none, 1 left, 2 right (chooseDirection; 0 when no obstacle, :252) */
+  double closest;            /* closestObst */
+  double confidence;         /* `conf` of :149 */
+} jn_nav_decision;
+void jn_nav_params_default(jn_nav_params* p);
+void jn_nav_state_reset(jn_nav_state* s);
+/* laserScanCallback (navigate.cpp:344-363): ranges[i] at angle i*(max-min)/n + min -> xy[2*i], xy[2*i+1]. */
+int32_t jn_scan_to_points(const float* ranges, int32_t n, float angle_min, float angle_max, double* xy);
+/* checkObstacle (:101-153) followed by obstacleAvoidMode's use of chooseDirection (:232-235, :252). */
+jn_status jn_nav_vote(const jn_nav_params* p, jn_nav_state* s, const double* xy, int32_t n, jn_nav_decision* out);
+
 #ifdef __cplusplus
 }
 #endif

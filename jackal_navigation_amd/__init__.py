@@ -7,4 +7,4 @@ compute lives in csrc/.  Importing the compute API requires the built library; t
 """
 from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # noqa: F401
 from .elas import Elas  # noqa: F401
-from . import node, device, parallel  # noqa: F401
+from . import node, device, parallel, navigate  # noqa: F401

@@ -52,6 +52,25 @@ class Rectification(C.Structure):
     _fields_ = [("R1", C.c_double * 9), ("R2", C.c_double * 9), ("P1", C.c_double * 12), ("P2", C.c_double * 12), ("Q", C.c_double * 16)]
 
 
+NAV_MAX_HISTORY = 64
+
+
+class NavParams(C.Structure):
+    """jn_nav_params: the constants checkObstacle / chooseDirection read (navigate.cpp:37-42, :125-146)."""
+    _fields_ = [("clear_front", C.c_double), ("clear_side", C.c_double), ("stop_dist", C.c_double),
+                ("laser_pt_thresh", C.c_int32), ("history", C.c_int32), ("history_votes", C.c_int32), ("reserved", C.c_int32)]
+
+
+class NavState(C.Structure):
+    _fields_ = [("votes", C.c_int32 * NAV_MAX_HISTORY), ("head", C.c_int32), ("filled", C.c_int32), ("positives", C.c_int32),
+                ("last_dir", C.c_int32)]
+
+
+class NavDecision(C.Structure):
+    _fields_ = [("points_inside", C.c_int32), ("points", C.c_int32), ("obstacle", C.c_int32), ("direction", C.c_int32),
+                ("closest", C.c_double), ("confidence", C.c_double)]
+
+
 class StageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("gpu_descriptor", "gpu_support", "d2h", "host_stage", "h2d", "gpu_matching",
                                          "gpu_lr", "gpu_speckle", "gpu_gap", "gpu_adaptive_mean", "total")]
@@ -68,6 +87,7 @@ EXPORTS = [
     "jn_synth_pair", "jn_device_count", "jn_device_malloc", "jn_device_free", "jn_memcpy_h2d", "jn_memcpy_d2h",
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
+    "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote",
 ]
 
 _lib = None
@@ -116,6 +136,12 @@ def load():
     L.jn_host_triangulate.argtypes = [vp, vp, i32, vp]
     L.jn_host_stage.argtypes = [C.POINTER(ElasParams), i32, i32, vp, vp, i64, vp]
     L.jn_host_stage.restype = i64
+    L.jn_nav_params_default.argtypes = [C.POINTER(NavParams)]
+    L.jn_nav_params_default.restype = None
+    L.jn_nav_state_reset.argtypes = [C.POINTER(NavState)]
+    L.jn_nav_state_reset.restype = None
+    L.jn_scan_to_points.argtypes = [vp, i32, C.c_float, C.c_float, vp]
+    L.jn_nav_vote.argtypes = [C.POINTER(NavParams), C.POINTER(NavState), vp, i32, C.POINTER(NavDecision)]
     _lib = L
     return L
 

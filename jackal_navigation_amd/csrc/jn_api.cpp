@@ -146,6 +146,10 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
       if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
     }
+    if (h->p.filter_median) {                                                            // elas.cpp:133-139
+      launch_median(st, dp, n, s.info, j.dD1, s.tmp);
+      if (!h->p.postprocess_only_left) launch_median(st, dp, n, s.info, j.dD2, s.tmp);
+    }
     HIP_TRY(hipEventRecord(s.ev[EV_AM], st));
   } else {
     for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(hipEventRecord(s.ev[e], st));
@@ -221,7 +225,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (!p || !out || W < 32 || H < 32 || W > 8192 || H > 8192 || max_batch < 1 || slots < 1) return JN_ERR_INVALID;
   *out = nullptr;
   const int radius = (int)std::max((float)std::ceil(p->sigma * p->sradius), 2.0f);        // elas.cpp:806
-  if (p->subsampling || p->add_corners || p->filter_median || p->disp_max > 255 || p->disp_max < 10 ||
+  if (p->subsampling || p->add_corners || p->disp_max > 255 || p->disp_max < 10 ||
       p->disp_min != 0 || p->ipol_gap_width > 64 || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
       p->grid_size < 1 || radius > 7 || p->incon_window_size < 0)
     return JN_ERR_UNSUPPORTED;

@@ -43,6 +43,7 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
 // Adaptive mean (elas.cpp:1287-1492): horizontal D->tmp, vertical tmp->D.
 void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
+void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
 
 // Node side (point_cloud.cpp) -------------------------------------------------------------------
 void launch_to_u8(hipStream_t st, const float* D, uint8_t* out, int64_t count);

@@ -963,6 +963,39 @@ __global__ void __launch_bounds__(256) k_adaptive_mean(DevParams dp, const Frame
 }
 
 // ------------------------------------------------------------------------------------------------
+// Median filter (elas.cpp:1494-1560): separable 7-tap median on valid pixels of the interior
+// u in [3,W-4], v in [3,H-4].  The horizontal pass writes a calloc'ed scratch image, so the scratch border
+// is 0 and takes part in the vertical windows; the vertical pass tests D itself and reads the scratch.
+// The reference insertion-sorts the window and takes element 3; the 4th smallest is the same value.
+DEV float median7(float x0, float x1, float x2, float x3, float x4, float x5, float x6) {
+  float v[7] = {x0, x1, x2, x3, x4, x5, x6};
+#pragma unroll
+  for (int pass = 0; pass < 4; pass++)                 // four selection passes put the 4 smallest in front
+#pragma unroll
+    for (int k = 6; k > pass; k--) {
+      const float lo = fminf(v[k - 1], v[k]), hi = fmaxf(v[k - 1], v[k]);
+      v[k - 1] = lo; v[k] = hi;
+    }
+  return v[3];
+}
+template <bool kHorizontal>
+__global__ void __launch_bounds__(256) k_median(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
+                                                float* __restrict__ D, float* __restrict__ out) {
+  // horizontal: in = D, out = tmp (0 outside the interior); vertical: in = tmp, out = D (interior only)
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W, H = dp.H;
+  const size_t plane = (size_t)H * W, p = (size_t)v * W + u;
+  const bool interior = u >= 3 && u < W - 3 && v >= 3 && v < H - 3;
+  if (!interior) { if (kHorizontal) out[frame * plane + p] = 0.0f; return; }
+  const float c = D[frame * plane + p];
+  if (!(c >= 0)) { if (kHorizontal) out[frame * plane + p] = c; return; }
+  const float* I = in + frame * plane + p;
+  const long long st = kHorizontal ? 1 : W;
+  out[frame * plane + p] = median7(I[-3 * st], I[-2 * st], I[-st], I[0], I[st], I[2 * st], I[3 * st]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Node side.  convertTo(CV_8U) (point_cloud.cpp:422) = round-half-even + saturate.
 DEV uint8_t f32_to_u8(float x) {
   const float r = rintf(x);
@@ -1283,6 +1316,11 @@ void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const Fram
   const dim3 g = grid2d(dp.W, dp.H, n);
   hipLaunchKernelGGL(k_adaptive_mean<true>, g, dim3(256), 0, st, dp, info, D, D, tmp);
   hipLaunchKernelGGL(k_adaptive_mean<false>, g, dim3(256), 0, st, dp, info, tmp, D, D);
+}
+void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
+  const dim3 g = grid2d(dp.W, dp.H, n);
+  hipLaunchKernelGGL(k_median<true>, g, dim3(256), 0, st, dp, info, D, D, tmp);
+  hipLaunchKernelGGL(k_median<false>, g, dim3(256), 0, st, dp, info, tmp, D, D);
 }
 void launch_to_u8(hipStream_t st, const float* D, uint8_t* out, int64_t count) {
   hipLaunchKernelGGL(k_to_u8, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, D, out, (long long)count);

@@ -232,6 +232,28 @@ class Oracle:
         return bins, meta, used
 
 
+    def scan_to_points(self, ranges, angle_min, angle_max):
+        ranges = np.ascontiguousarray(ranges, np.float32)
+        xy = np.zeros((len(ranges), 2), np.float64)
+        self.lib.orc_scan_to_points(_p(ranges), len(ranges), C.c_float(angle_min), C.c_float(angle_max), _p(xy))
+        return xy
+
+    def check_obstacle(self, xy, history, clear_front=0.24 + 0.8, clear_side=0.3, laser_pt_thresh=8):
+        """history: python list standing in for navigate.cpp's deque `commands`; updated in place."""
+        xy = np.ascontiguousarray(xy, np.float64)
+        h = np.zeros(20, np.int32); h[:len(history)] = history
+        n = C.c_int32(len(history)); count = C.c_int32(0); closest = C.c_double(0); conf = C.c_double(0)
+        self.lib.orc_check_obstacle.restype = C.c_int32
+        obst = self.lib.orc_check_obstacle(_p(xy), len(xy), _p(h), C.byref(n), C.c_double(clear_front), C.c_double(clear_side),
+                                           laser_pt_thresh, C.byref(count), C.byref(closest), C.byref(conf))
+        history[:] = [int(v) for v in h[:n.value]]
+        return obst, count.value, closest.value, conf.value
+
+    def choose_direction(self, xy, last_dir, clear_front=0.24 + 0.8):
+        xy = np.ascontiguousarray(xy, np.float64)
+        self.lib.orc_choose_direction.restype = C.c_int32
+        return self.lib.orc_choose_direction(_p(xy), len(xy), C.c_double(clear_front), last_dir)
+
     def scan_cloud(self, sp, disp):
         H, W = disp.shape
         bins = np.zeros(sp.bins, np.float64); meta = np.zeros(4, np.float64)

@@ -222,3 +222,67 @@ extern "C" void orc_remap_bilinear(const uint8_t* src, int32_t sw, int32_t sh, i
       dst[(size_t)y * dpitch + x] = (uint8_t)((acc + 512) >> 10);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Scan consumer: how navigate.cpp turns the published LaserScan into a stop/turn
+// decision.  Parity unpinned like the rest of the node side (ROS absent); restated line by line.
+//
+// navigate.cpp:344-363 laserScanCallback: ranges[i] sits at angle i*(max-min)/n + min (message floats widened
+// to double), point = range * (cos, sin).
+extern "C" void orc_scan_to_points(const float* ranges, int32_t n, float angle_min, float angle_max, double* xy) {
+  const double minAngle = angle_min, maxAngle = angle_max;
+  // The reference is built without optimisation (CMakeLists.txt has no -O flag), so it calls libm's cos and sin
+  // separately; an optimising GCC would merge them into one sincos() whose results can differ in the last bit.
+  double (*volatile call_cos)(double) = cos;
+  double (*volatile call_sin)(double) = sin;
+  for (int i = 0; i < n; i++) {
+    const double angle = (double)i * (maxAngle - minAngle) / (double)(unsigned)n + minAngle;
+    xy[2 * i] = ranges[i] * call_cos(angle);
+    xy[2 * i + 1] = ranges[i] * call_sin(angle);
+  }
+}
+// navigate.cpp:101-153 checkObstacle: spatial vote (> laser_pt_thresh points inside the clearance box, or
+// anything closer than 0.5 m), then the last-20 history (more than 2 positives => obstacle).
+// history: the deque `commands` (oldest first), *len its size.  out: {count, is_obstacle}, closest, confidence.
+extern "C" int32_t orc_check_obstacle(const double* xy, int32_t n, int32_t* history, int32_t* len, double clear_front,
+                                      double clear_side, int32_t laser_pt_thresh, int32_t* count_out, double* closest_out,
+                                      double* conf_out) {
+  int count = 0, isObstacle = 0;
+  double closestObst = 1000000000;                       // const int INF = 1e9 (:47)
+  for (int i = 0; i < n; i++) {
+    const double x = xy[2 * i], y = xy[2 * i + 1];
+    const double dist = sqrt(x * x + y * y);
+    closestObst = std::min(closestObst, dist);
+    if (x > 0. && x < clear_front && y > -clear_side && y < clear_side) count++;
+  }
+  if (count > laser_pt_thresh) isObstacle = 1;
+  if (closestObst < 0.5) isObstacle = 1;
+  if (*len < 20) history[(*len)++] = isObstacle;
+  else {
+    for (int i = 1; i < 20; i++) history[i - 1] = history[i];      // pop_front, push_back
+    history[19] = isObstacle;
+  }
+  int one = 0, zero = 0;
+  for (int i = 0; i < *len; i++) { if (history[i] == 1) one++; else zero++; }
+  if (one > 2) isObstacle = 1;
+  *count_out = count; *closest_out = closestObst; *conf_out = (double)one / (double)(one + zero);
+  return isObstacle;
+}
+// navigate.cpp:155-197 chooseDirection: side with fewer points in front wins, with hysteresis on last_dir.
+extern "C" int32_t orc_choose_direction(const double* xy, int32_t n, double clear_front, int32_t last_dir) {
+  int left_count = 0, right_count = 0;
+  for (int i = 0; i < n; i++)
+    if (xy[2 * i] > 0. && xy[2 * i] < clear_front) { if (xy[2 * i + 1] < 0) right_count++; else left_count++; }
+  if (left_count + right_count < 2) return 0;
+  const double conf_left = 2. * (double)right_count / (double)(left_count + right_count);
+  const double conf_right = 2. * (double)left_count / (double)(left_count + right_count);
+  int dir = 0;
+  if (conf_left > conf_right) {
+    if (last_dir != 1) dir = (conf_left - conf_right > 0.5) ? 1 : last_dir;
+    else dir = 1;
+  } else {
+    if (last_dir != 2) dir = (conf_right - conf_left > 0.5) ? 2 : last_dir;
+    else dir = 2;
+  }
+  return dir;
+}

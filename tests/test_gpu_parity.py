@@ -74,6 +74,7 @@ def test_known_answer_hashes_on_gpu(jn, oracle):
     {"postprocess_only_left": 0}, {"filter_adaptive_mean": 0}, {"ipol_gap_width": 7}, {"speckle_size": 50, "speckle_sim_threshold": 2.0},
     {"support_threshold": 0.95, "support_texture": 20}, {"lr_threshold": 1, "match_texture": 5}, {"grid_size": 16, "sradius": 3.0},
     {"candidate_stepsize": 4, "incon_window_size": 3, "incon_min_support": 3}, {"gamma": 5.0, "beta": 0.03, "sigma": 1.5},
+    {"filter_median": 1}, {"filter_median": 1, "filter_adaptive_mean": 0, "postprocess_only_left": 0},
 ])
 def test_parameter_variations(jn, oracle, same, kw):
     W, H = 320, 240
@@ -232,6 +233,41 @@ def test_node_functions_vs_oracle(jn, oracle, same):
     assert pc.shape == pco.shape and np.allclose(pc, pco, rtol=0, atol=SCAN_TOL)
     msg = node.laser_scan_message(b_[0], m_[0], seq=3)
     assert msg["header"]["frame_id"] == "jackal" and len(msg["ranges"]) == int((b_[0] < 1e9 - 1).sum())
+
+
+def test_scans_drive_the_same_navigation_decisions(jn, oracle):
+    """raw pairs -> HIP ELAS -> u8 -> scan -> LaserScan -> navigate.cpp's consumer, beside the same
+    chain on the oracle.  Scans agree to 1e-4 (device atan2/sqrt), the decisions taken from them must be equal."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node, navigate
+    W, H, n = 320, 180, 12
+    sp, spo = node.scan_params(W, H), oracle.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    luto = oracle.valid_lut(spo, W, H)
+    pairs = [node.synth_pair(W, H, 30 + 18 * (b % 4), 900 + b) for b in range(n)]        # scenes at several depths
+    Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    dD1 = DeviceArray((n, H, W), np.float32); dD2 = DeviceArray((n, H, W), np.float32)
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=n) as e:
+        assert e.process_batch(n, dL.ptr, dR.ptr, W, H * W, dD1.ptr, dD2.ptr) == [0] * n
+    du8 = DeviceArray((n, H, W), np.uint8); bins = DeviceArray((n, sp.bins), np.float64); meta = DeviceArray((n, 4), np.float64)
+    node.disparity_scan(sp, n, dD1.ptr, lut.ptr, W, H, du8.ptr, bins.ptr, meta.ptr)
+    b_, m_ = bins.numpy(), meta.numpy()
+    nav = navigate.Navigator()
+    history, last_dir, obstacles = [], 0, 0
+    for b in range(n):
+        msg = node.laser_scan_message(b_[b], m_[b], seq=b)
+        nav.scan_callback(msg)
+        d = nav.obstacle_avoid_step()
+        _, D1o, _ = oracle.process(oracle.params(0), Ls[b], Rs[b])
+        bo, mo, _ = oracle.scan(spo, oracle.to_u8(D1o), luto)
+        xy = oracle.scan_to_points(oracle.compact(bo), np.float32(mo[0]), np.float32(mo[1]))
+        obst, count, closest, conf = oracle.check_obstacle(xy, history)
+        last_dir = oracle.choose_direction(xy, last_dir) if obst else 0
+        assert (d["obstacle"], d["points_inside"], d["direction"], d["points"]) == (obst, count, last_dir, len(xy)), b
+        assert abs(d["closest"] - closest) <= SCAN_TOL and d["confidence"] == conf
+        obstacles += obst
+    assert 0 < obstacles
 
 
 def test_scan_with_empty_and_saturated_maps(jn, oracle):

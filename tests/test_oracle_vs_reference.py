@@ -17,6 +17,19 @@ def test_process_bit_exact(oracle, reference, same, W, H, sd, dmax, seed, both):
     assert st == 0 and same(D1, D1r) and same(D2, D2r)
 
 
+@pytest.mark.parametrize("kw", [
+    {"filter_median": 1}, {"filter_median": 1, "filter_adaptive_mean": 0, "postprocess_only_left": 0},
+    {"incon_window_size": 3, "incon_min_support": 3}, {"ipol_gap_width": 7, "speckle_size": 50},
+])
+def test_process_bit_exact_with_other_parameters(oracle, reference, same, kw):
+    """The optional median filter (elas.cpp:1494-1560, off in the node's preset) and a few non-default tunables."""
+    L, R = oracle.synth_pair(320, 240, 40, 21)
+    p = oracle.params(0, disp_max=79, **kw)
+    st, D1, D2 = oracle.process(p, L, R)
+    D1r, D2r = reference.process(p, L, R)
+    assert st == 0 and same(D1, D1r) and same(D2, D2r), kw
+
+
 def test_stagewise_bit_exact_720p(oracle, reference, same):
     W, H = 1280, 720
     L, R = oracle.synth_pair(W, H, 128, 12345)
