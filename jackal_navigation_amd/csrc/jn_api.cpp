@@ -73,8 +73,11 @@ struct jn_elas {
   int W = 0, H = 0, max_batch = 0, device = 0;
   size_t payload_cap = 0;
   int tri_cap = 0;
-  bool host_filters = false;        // JN_HOST_FILTERS at create time: support filters on the host workers (A/B switch; the
-                                    // host stage also takes over by itself when the lattice does not fit the filter kernel)
+  // Where the support filters run.  The wavefront kernel is a serial chain of ~6*cw steps on one workgroup per
+  // frame: a win for throughput (it overlaps other slots' kernels and frees the host pool), a loss for the latency
+  // of a lone pair, where one host core is faster.  JN_HOST_FILTERS at create time: unset = device for batches of
+  // >= 4 pairs, "1" = always host, "0" = always device.  The host also takes over when the lattice does not fit.
+  int filter_min_batch = 4;
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
   // staging for the host-pointer drop-in call
@@ -94,7 +97,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   launch_descriptor(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
   HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
   launch_support(st, dp, n, s.desc, s.d_can);
-  const bool filtered = !h->host_filters &&
+  const bool filtered = n >= h->filter_min_batch &&
       launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can);
   HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
   const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -235,7 +238,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
 
   std::unique_ptr<jn_elas> h(new jn_elas());
   h->p = *p; h->W = W; h->H = H; h->max_batch = max_batch; h->device = device;
-  h->host_filters = getenv("JN_HOST_FILTERS") != nullptr;
+  if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   DevParams& dp = h->dp;
   memset(&dp, 0, sizeof(dp));
   dp.W = W; dp.H = H; dp.pitch = (W + 63) / 64 * 64;

@@ -86,17 +86,15 @@ def test_parameter_variations(jn, oracle, same, kw):
 
 def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypatch):
     """The support-point filters run in k_support_filters when the lattice fits its LDS wavefront and on the host
-    workers otherwise (JN_HOST_FILTERS forces the latter at create time).  Both routes must give the oracle's maps,
+    workers otherwise; by default lone pairs also go to the host, which is faster for latency (JN_HOST_FILTERS=0/1 forces a route
+    at create time).  Both routes must give the oracle's maps,
     also with a non-default tolerance / support count and with a window size the kernel does not take."""
     W, H = 640, 360
     L, R = jn.node.synth_pair(W, H, 64, 77)
     for kw in ({}, {"incon_threshold": 3, "incon_min_support": 9}, {"incon_window_size": 4}):
         _, D1o, D2o = oracle.process(oracle.params(0, disp_max=95, **kw), L, R)
         for host in (False, True):
-            if host:
-                monkeypatch.setenv("JN_HOST_FILTERS", "1")
-            else:
-                monkeypatch.delenv("JN_HOST_FILTERS", raising=False)
+            monkeypatch.setenv("JN_HOST_FILTERS", "1" if host else "0")      # unset = by batch size
             st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=95, **kw), L, R)
             assert st == 0 and same(D1, D1o) and same(D2, D2o), (kw, host)
 
