@@ -145,8 +145,8 @@ def main():
     D1 = [torch.zeros((B, H, W), dtype=torch.float32, device=dev) for _ in range(S)]
     D2 = [torch.zeros((B, H, W), dtype=torch.float32, device=dev) for _ in range(S)]
     U8 = [torch.zeros((B, H, W), dtype=torch.uint8, device=dev) for _ in range(S)]
-    bins = [torch.zeros((B, 90), dtype=torch.float64, device=dev) for _ in range(S)]
-    meta = [torch.zeros((B, 4), dtype=torch.float64, device=dev) for _ in range(S)]
+    scans = [parallel.ScanBuffer(B, 90, dev) for _ in range(S)]            # bins + extrema of a batch in one buffer
+    bins = [s.bins for s in scans]; meta = [s.meta for s in scans]
     status = [(C.c_int32 * B)() for _ in range(S)]
 
     p = jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=a.disp - 1)          # point_cloud.cpp:416-417 + D
@@ -166,13 +166,14 @@ def main():
         dense_ms.append(elas.kernel_time(slot)[0])
         node.disparity_scan(sp, B, D1[slot].data_ptr(), lut.ptr, W, H, U8[slot].data_ptr(), bins[slot].data_ptr(),
                             meta[slot].data_ptr(), device=local_rank)
-        if dist is not None:                      # the path's one exchange step: robot-level scan = MIN over rigs
-            if on_gpu:
-                parallel.merge_scans(bins[slot], meta[slot])
+        if dist is not None:                      # the path's one exchange step: robot-level scan = MIN over rigs,
+            if on_gpu:                            # one all-reduce per batch
+                scans[slot].merge()
             else:
-                b, m = bins[slot].cpu(), meta[slot].cpu()
-                parallel.merge_scans(b, m)
-                bins[slot].copy_(b); meta[slot].copy_(m)
+                host = parallel.ScanBuffer(B, 90, "cpu")
+                host.flat.copy_(scans[slot].flat)
+                host.merge()
+                scans[slot].flat.copy_(host.flat)
 
     def run(steps):
         inflight = []

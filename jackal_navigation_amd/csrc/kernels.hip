@@ -940,26 +940,81 @@ __global__ void __launch_bounds__(256) k_adaptive_mean(DevParams dp, const Frame
   const bool line_ok = kHorizontal ? (v >= 3 && v < H - 3) : (u >= 3 && u < W - 3);
   if (line_ok && pos >= 4 && pos <= len - 4) {
     const int stride = kHorizontal ? 1 : W;
-    float val[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int q = pos - 4 + k;                       // window [c-4, c+3]
-      float x = I[p + (long long)(k - 4) * stride];
-      if (kHorizontal && x < 0) x = -10.0f;            // elas.cpp:1304-1309
-      // place into ring slot q mod 8 (static indexing via the select chain below)
-      const int slot = q & 7;
-#pragma unroll
-      for (int s = 0; s < 8; s++) if (s == slot) val[s] = x;
-    }
     float c = I[p]; if (kHorizontal && c < 0) c = -10.0f;
-    float w[8], f[8];
+    // Window [c-4, c+3]; the reference keeps it in an 8-slot ring (slot = position mod 8) and sums lane l =
+    // slot l + slot l+4, then ((l0+l1)+l2)+l3.  Window taps k and k+4 always share a lane, so with pair sums
+    // P_j = tap j + tap j+4 (addition commutes) lane l holds P[(l - pos) & 3]: a rotation by pos & 3.
+    float pw[4], pf[4];
 #pragma unroll
-    for (int s = 0; s < 8; s++) { w[s] = am_weight(val[s], c); f[s] = __fmul_rn(val[s], w[s]); }
-    const float ws = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(w[0], w[4]), __fadd_rn(w[1], w[5])), __fadd_rn(w[2], w[6])), __fadd_rn(w[3], w[7]));
-    const float fs = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(f[0], f[4]), __fadd_rn(f[1], f[5])), __fadd_rn(f[2], f[6])), __fadd_rn(f[3], f[7]));
+    for (int k = 0; k < 4; k++) {
+      float x0 = I[p + (long long)(k - 4) * stride], x1 = I[p + (long long)k * stride];
+      if (kHorizontal) { if (x0 < 0) x0 = -10.0f; if (x1 < 0) x1 = -10.0f; }       // elas.cpp:1304-1309
+      const float w0 = am_weight(x0, c), w1 = am_weight(x1, c);
+      pw[k] = __fadd_rn(w0, w1);
+      pf[k] = __fadd_rn(__fmul_rn(x0, w0), __fmul_rn(x1, w1));
+    }
+    const int r = pos & 3;
+    if (r & 1) {
+      const float tw = pw[3], tf = pf[3];
+      pw[3] = pw[2]; pw[2] = pw[1]; pw[1] = pw[0]; pw[0] = tw;
+      pf[3] = pf[2]; pf[2] = pf[1]; pf[1] = pf[0]; pf[0] = tf;
+    }
+    if (r & 2) {
+      float t = pw[0]; pw[0] = pw[2]; pw[2] = t; t = pw[1]; pw[1] = pw[3]; pw[3] = t;
+      t = pf[0]; pf[0] = pf[2]; pf[2] = t; t = pf[1]; pf[1] = pf[3]; pf[3] = t;
+    }
+    const float ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[0], pw[1]), pw[2]), pw[3]);
+    const float fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[0], pf[1]), pf[2]), pf[3]);
     if (ws > 0) { const float d = fs / ws; if (d >= 0) res = d; }
   }
   out[frame * plane + p] = res;
+}
+
+// Vertical pass, one thread per column walking kAmRows rows with the 8-tap window in registers: 1.4 row reads per
+// output instead of 8 (the per-row variant above is bound by L2 requests, not by arithmetic).  Same arithmetic as
+// k_adaptive_mean<false>: in = tmp (horizontal result), D = keep and output.
+constexpr int kAmRows = 16;
+__global__ void __launch_bounds__(256) k_adaptive_mean_v(DevParams dp, const FrameInfo* __restrict__ info,
+                                                         const float* __restrict__ in, float* __restrict__ D) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v0 = blockIdx.y * kAmRows, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W, H = dp.H;
+  const size_t plane = (size_t)H * W;
+  const float* I = in + frame * plane + u;
+  float* O = D + frame * plane + u;
+  if (u < 3 || u >= W - 3) return;                       // columns the pass leaves as they are (out == keep)
+  float x[8];
+#pragma unroll
+  for (int k = 0; k < 7; k++) { const int row = v0 - 4 + k; x[k] = (row >= 0 && row < H) ? I[(size_t)row * W] : 0.0f; }
+  const int v1 = min(v0 + kAmRows, H);
+  for (int v = v0; v < v1; v++) {
+    x[7] = (v + 3 < H) ? I[(size_t)(v + 3) * W] : 0.0f;
+    if (v >= 4 && v <= H - 4) {
+      const float c = x[4];
+      float pw[4], pf[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float w0 = am_weight(x[k], c), w1 = am_weight(x[k + 4], c);
+        pw[k] = __fadd_rn(w0, w1);
+        pf[k] = __fadd_rn(__fmul_rn(x[k], w0), __fmul_rn(x[k + 4], w1));
+      }
+      const int r = v & 3;                               // wave-uniform: lane l of the reference's ring = P[(l - v) & 3]
+      if (r & 1) {
+        const float tw = pw[3], tf = pf[3];
+        pw[3] = pw[2]; pw[2] = pw[1]; pw[1] = pw[0]; pw[0] = tw;
+        pf[3] = pf[2]; pf[2] = pf[1]; pf[1] = pf[0]; pf[0] = tf;
+      }
+      if (r & 2) {
+        float t = pw[0]; pw[0] = pw[2]; pw[2] = t; t = pw[1]; pw[1] = pw[3]; pw[3] = t;
+        t = pf[0]; pf[0] = pf[2]; pf[2] = t; t = pf[1]; pf[1] = pf[3]; pf[3] = t;
+      }
+      const float ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[0], pw[1]), pw[2]), pw[3]);
+      const float fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[0], pf[1]), pf[2]), pf[3]);
+      if (ws > 0) { const float d = fs / ws; if (d >= 0) O[(size_t)v * W] = d; }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) x[k] = x[k + 1];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1315,7 +1370,7 @@ void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
 void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);
   hipLaunchKernelGGL(k_adaptive_mean<true>, g, dim3(256), 0, st, dp, info, D, D, tmp);
-  hipLaunchKernelGGL(k_adaptive_mean<false>, g, dim3(256), 0, st, dp, info, tmp, D, D);
+  hipLaunchKernelGGL(k_adaptive_mean_v, dim3((dp.W + 255) / 256, (dp.H + kAmRows - 1) / kAmRows, n), dim3(256), 0, st, dp, info, tmp, D);
 }
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);

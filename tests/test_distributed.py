@@ -35,6 +35,10 @@ def _worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, "bins%d.npy" % rank), tb.numpy())
     np.save(os.path.join(out_dir, "meta%d.npy" % rank), tm.numpy())
     np.save(os.path.join(out_dir, "local%d.npy" % rank), bins)
+    sb = parallel.ScanBuffer(1, sp.bins)            # the same merge as ONE collective (what bench.py uses)
+    sb.bins.copy_(torch.from_numpy(bins)); sb.meta.copy_(torch.from_numpy(meta))
+    sb.merge()
+    assert torch.equal(sb.bins, tb) and torch.equal(sb.meta, tm)
     torch.distributed.destroy_process_group()
 
 
