@@ -74,9 +74,11 @@ struct jn_elas {
   size_t payload_cap = 0;
   int tri_cap = 0;
   // Where the support filters run.  The wavefront kernel is a serial chain of ~6*cw steps on one workgroup per
-  // frame: a win for throughput (it overlaps other slots' kernels and frees the host pool), a loss for the latency
-  // of a lone pair, where one host core is faster.  JN_HOST_FILTERS at create time: unset = device for batches of
-  // >= 4 pairs, "1" = always host, "0" = always device.  The host also takes over when the lattice does not fit.
+  // frame, so its duration does not depend on the batch size; the host filters take one pool round per
+  // `threads` frames.  The device wins once a batch needs more than one round (and it frees the pool for Delaunay);
+  // for a lone pair or a batch the pool swallows at once the host is quicker.  JN_HOST_FILTERS at create time:
+  // unset = device when the batch exceeds the pool size, "1" = always host, "0" = always device.  The host also
+  // takes over when the kernel cannot take the lattice.
   int filter_min_batch = 4;
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
@@ -238,7 +240,6 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
 
   std::unique_ptr<jn_elas> h(new jn_elas());
   h->p = *p; h->W = W; h->H = H; h->max_batch = max_batch; h->device = device;
-  if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   DevParams& dp = h->dp;
   memset(&dp, 0, sizeof(dp));
   dp.W = W; dp.H = H; dp.pitch = (W + 63) / 64 * 64;
@@ -264,6 +265,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (nthreads < 1) nthreads = 1;
   nthreads = std::min(nthreads, std::max(1, max_batch * slots));
   h->pool.reset(new Pool(nthreads, hp));
+  h->filter_min_batch = nthreads + 1;
+  if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
   for (int i = 0; i < slots; i++) {

@@ -265,71 +265,129 @@ __device__ __forceinline__ void redundant_line(int16_t* line, int stride, int n)
   }
 }
 
-constexpr int kFilterThreads = 512, kFilterLanes = 16;              // 32 points per wavefront step, 16 lanes per point
-template <int WIN>
-__global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can) {
-  extern __shared__ int16_t s_lat[];                      // [(ch + 2*WIN)][(cw + 2*WIN)]
+constexpr int kFilterThreads = 512;
+// Copy lattice columns [c0,c1) x rows [r0,r1) (cells outside the lattice read as invalid) into an LDS block of
+// pitch pw, and the interior back.
+__device__ __forceinline__ void lattice_load(int16_t* s, const int16_t* g, int cw, int ch, int c0, int c1, int r0, int r1, int pw) {
+  const int w = c1 - c0, n = w * (r1 - r0);
+  for (int i = threadIdx.x; i < n; i += kFilterThreads) {
+    const int r = r0 + i / w, c = c0 + i % w;
+    s[(r - r0) * pw + (c - c0)] = (r >= 0 && r < ch && c >= 0 && c < cw) ? g[r * cw + c] : (int16_t)-1;
+  }
+}
+__device__ __forceinline__ void lattice_store(const int16_t* base, int16_t* g, int cw, int u0, int u1, int v0, int v1, int pw) {
+  const int w = u1 - u0, n = w * (v1 - v0);                 // base[(v - v0) * pw + (u - u0)] = lattice (u, v)
+  for (int i = threadIdx.x; i < n; i += kFilterThreads) {
+    const int v = v0 + i / w, u = u0 + i % w;
+    g[v * cw + u] = base[(v - v0) * pw + (u - u0)];
+  }
+}
+// The skewed wavefront of the inconsistency filter over columns [0,ncols) of an LDS block (base = cell (0,0),
+// a border of WIN cells readable on every side).  L lanes per point share the (2*WIN+1)^2 window cells;
+// kFilterThreads / L points per step cover lattices of up to K * kFilterThreads / L rows.
+template <int WIN, int L>
+__device__ __forceinline__ void incon_wavefront(int16_t* base, int pw, int ncols, int ch, int tol, int min_support) {
+  constexpr int K = WIN + 1, CELLS = (2 * WIN + 1) * (2 * WIN + 1);
+  const int tid = threadIdx.x, j = tid / L, part = tid % L;
+  constexpr int NC = (CELLS + L - 1) / L;
+  int off[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) {
+    const int cell = min(part + L * c, CELLS - 1);
+    off[c] = (cell / (2 * WIN + 1) - WIN) * pw + cell % (2 * WIN + 1) - WIN;
+  }
+  const bool tail = part + L * (NC - 1) < CELLS;         // whether this lane's last slot is a real cell
+  // step t = K*q + phase: point j sits at v = phase + K*j, u = q - j.  q and phase are wave-uniform, so the
+  // lane-dependent part of the address is the constant K*j*pw - j and the bounds are two compares.
+  const int lane_cell = K * j * pw - j, v_room = ch - K * j;
+  const int qmax = (K * (ncols - 1) + ch - 1) / K;
+  for (int q = 0; q <= qmax; q++) {
+#pragma unroll
+    for (int phase = 0; phase < K; phase++) {
+      const bool on = phase < v_room && (unsigned)(q - j) < (unsigned)ncols;
+      int16_t* p = base + (on ? lane_cell + phase * pw + q : 0);
+      const int d = on ? (int)p[0] : -1;
+      // all loads first, then branch-free arithmetic: a short-circuit on e >= 0 makes the compiler wait
+      // out every LDS read one at a time.  e in [max(d-tol,0), d+tol] as one unsigned compare.
+      int e[NC];
+#pragma unroll
+      for (int c = 0; c < NC; c++) e[c] = p[off[c]];
+      const int lo = max(d - tol, 0);
+      const unsigned span = (unsigned)(d + tol - lo);
+      int count = 0;
+#pragma unroll
+      for (int c = 0; c < NC; c++)
+        count += (int)((unsigned)(e[c] - lo) <= span) & (int)(c < NC - 1 || tail);
+      count += __builtin_amdgcn_update_dpp(0, count, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+      count += __builtin_amdgcn_update_dpp(0, count, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+      count += __builtin_amdgcn_update_dpp(0, count, 0x141, 0xF, 0xF, false);   // row_half_mirror
+      if (L == 16) count += __builtin_amdgcn_update_dpp(0, count, 0x140, 0xF, 0xF, false);   // row_mirror
+      // points of one step are K rows apart, outside each other's windows: their writes touch nothing
+      // this step reads, so one barrier (before the next step's reads) is enough.
+      if (d >= 0 && part == 0 && count < min_support) p[0] = -1;
+      __syncthreads();
+    }
+  }
+}
+// seg_c == 0: the whole lattice (plus border) sits in LDS for all three passes.  Otherwise the lattice is larger
+// than the LDS and every pass streams it through in pieces, global memory holding the state in between: the
+// inconsistency filter by column segments [u0,u1) — the sweep is column-major, so a segment only needs the final
+// values of the WIN columns before it and the untouched WIN columns after it — the vertical redundancy pass by
+// the same column segments, the horizontal one by row segments of seg_r rows.
+template <int WIN, int L>
+__global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can,
+                                                                    int seg_c, int seg_r) {
+  extern __shared__ int16_t s_lat[];
   static_assert(WIN == 5, "redundant_line's window is the reference's fixed max_dist 5");
+  static_assert(L == 16 || L == 8, "the DPP reduction covers 8 or 16 lanes");
   const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x;
-  const int pw = cw + 2 * WIN, ph = ch + 2 * WIN;
   int16_t* g = d_can + (size_t)blockIdx.x * cw * ch;
-  for (int i = tid; i < pw * ph; i += kFilterThreads) {
-    const int r = i / pw - WIN, c = i % pw - WIN;
-    s_lat[i] = (r >= 0 && r < ch && c >= 0 && c < cw) ? g[r * cw + c] : (int16_t)-1;
+  if (seg_c == 0) {
+    const int pw = cw + 2 * WIN;
+    lattice_load(s_lat, g, cw, ch, -WIN, cw + WIN, -WIN, ch + WIN, pw);
+    __syncthreads();
+    int16_t* base = s_lat + WIN * pw + WIN;                  // base[v * pw + u] = lattice (u, v)
+    incon_wavefront<WIN, L>(base, pw, cw, ch, tol, min_support);
+    __syncthreads();
+    for (int u = tid; u < cw; u += kFilterThreads) redundant_line(base + u, pw, ch);        // vertical pass (elas.cpp:421)
+    __syncthreads();
+    for (int v = tid; v < ch; v += kFilterThreads) redundant_line(base + v * pw, 1, cw);    // horizontal pass (elas.cpp:422)
+    __syncthreads();
+    lattice_store(base, g, cw, 0, cw, 0, ch, pw);
+    return;
   }
-  __syncthreads();
-  int16_t* base = s_lat + WIN * pw + WIN;                  // base[v * pw + u] = lattice (u, v)
-  {
-    // 16 lanes per point: lane `part` takes window cells part, part+16, ... of the (2*WIN+1)^2 = 121; 32 points
-    // per step cover lattices up to 192 rows.  One barrier per step publishes the step's deletions.
-    constexpr int K = WIN + 1, CELLS = (2 * WIN + 1) * (2 * WIN + 1), L = kFilterLanes;
-    const int j = tid / L, part = tid % L;
-    constexpr int NC = (CELLS + L - 1) / L;
-    int off[NC];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-      const int cell = min(part + L * c, CELLS - 1);
-      off[c] = (cell / (2 * WIN + 1) - WIN) * pw + cell % (2 * WIN + 1) - WIN;
-    }
-    const bool tail = part + L * (NC - 1) < CELLS;         // whether this lane's last slot is a real cell
-    // step t = K*q + phase: point j sits at v = phase + K*j, u = q - j.  q and phase are wave-uniform, so the
-    // lane-dependent part of the address is the constant K*j*pw - j and the bounds are two compares.
-    const int lane_cell = K * j * pw - j, v_room = ch - K * j;
-    const int qmax = (K * (cw - 1) + ch - 1) / K;
-    for (int q = 0; q <= qmax; q++) {
-#pragma unroll
-      for (int phase = 0; phase < K; phase++) {
-        const bool on = phase < v_room && (unsigned)(q - j) < (unsigned)cw;
-        int16_t* p = base + (on ? lane_cell + phase * pw + q : 0);
-        const int d = on ? (int)p[0] : -1;
-        // all loads first, then branch-free arithmetic: a short-circuit on e >= 0 makes the compiler wait
-        // out every LDS read one at a time.  e in [max(d-tol,0), d+tol] as one unsigned compare.
-        int e[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) e[c] = p[off[c]];
-        const int lo = max(d - tol, 0);
-        const unsigned span = (unsigned)(d + tol - lo);
-        int count = 0;
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-          count += (int)((unsigned)(e[c] - lo) <= span) & (int)(c < NC - 1 || tail);
-        count += __builtin_amdgcn_update_dpp(0, count, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-        count += __builtin_amdgcn_update_dpp(0, count, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-        count += __builtin_amdgcn_update_dpp(0, count, 0x141, 0xF, 0xF, false);   // row_half_mirror
-        count += __builtin_amdgcn_update_dpp(0, count, 0x140, 0xF, 0xF, false);   // row_mirror
-        // points of one step are K rows apart, outside each other's windows: their writes touch nothing
-        // this step reads, so one barrier (before the next step's reads) is enough.
-        if (d >= 0 && part == 0 && count < min_support) p[0] = -1;
-        __syncthreads();
-      }
-    }
+  const int pwc = seg_c + 2 * WIN;
+  int16_t* cbase = s_lat + WIN * pwc + WIN;
+  for (int u0 = 0; u0 < cw; u0 += seg_c) {                   // inconsistency filter (elas.cpp:416)
+    const int u1 = min(u0 + seg_c, cw);
+    lattice_load(s_lat, g, cw, ch, u0 - WIN, u1 + WIN, -WIN, ch + WIN, pwc);
+    __syncthreads();
+    incon_wavefront<WIN, L>(cbase, pwc, u1 - u0, ch, tol, min_support);
+    __syncthreads();
+    lattice_store(cbase, g, cw, u0, u1, 0, ch, pwc);
+    __threadfence();                                         // the next piece reads these columns back from memory
+    __syncthreads();
   }
-  __syncthreads();
-  for (int u = tid; u < cw; u += kFilterThreads) redundant_line(base + u, pw, ch);        // vertical pass (elas.cpp:421)
-  __syncthreads();
-  for (int v = tid; v < ch; v += kFilterThreads) redundant_line(base + v * pw, 1, cw);    // horizontal pass (elas.cpp:422)
-  __syncthreads();
-  for (int i = tid; i < cw * ch; i += kFilterThreads) g[i] = base[(i / cw) * pw + (i % cw)];
+  for (int u0 = 0; u0 < cw; u0 += seg_c) {                   // vertical redundancy pass (elas.cpp:421)
+    const int u1 = min(u0 + seg_c, cw);
+    lattice_load(s_lat, g, cw, ch, u0 - WIN, u1 + WIN, -WIN, ch + WIN, pwc);
+    __syncthreads();
+    for (int u = tid; u < u1 - u0; u += kFilterThreads) redundant_line(cbase + u, pwc, ch);
+    __syncthreads();
+    lattice_store(cbase, g, cw, u0, u1, 0, ch, pwc);
+    __threadfence();
+    __syncthreads();
+  }
+  const int pwr = cw + 2 * WIN;
+  for (int v0 = 0; v0 < ch; v0 += seg_r) {                   // horizontal redundancy pass (elas.cpp:422)
+    const int v1 = min(v0 + seg_r, ch);
+    lattice_load(s_lat, g, cw, ch, -WIN, cw + WIN, v0, v1, pwr);
+    __syncthreads();
+    for (int v = tid; v < v1 - v0; v += kFilterThreads) redundant_line(s_lat + v * pwr + WIN, 1, cw);
+    __syncthreads();
+    lattice_store(s_lat + WIN, g, cw, 0, cw, v0, v1, pwr);
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1310,16 +1368,33 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
   }
 }
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can) {
-  constexpr int WIN = 5;                                            // the reference's incon_window_size (elas.h:97)
-  const size_t lds = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t);
-  // other window sizes, lattices beyond the LDS, or more than 32 points per wavefront step: the host stage filters
-  if (win != WIN || lds > 150 * 1024 || (dp.ch + WIN) / (WIN + 1) > 32) return false;   // 512 threads = 32 points x 16 lanes per step
+  constexpr int WIN = 5, K = WIN + 1;                               // the reference's incon_window_size (elas.h:97)
+  if (win != WIN) return false;                                     // other window sizes: the host stage filters
+  // LDS budget in int16 cells (JN_FILTER_LDS_KB shrinks it: a test hook that forces the streamed variant)
+  const char* env = getenv("JN_FILTER_LDS_KB");
+  const int budget = (env ? atoi(env) : 150) * 1024 / (int)sizeof(int16_t);
+  const int cw = dp.cw, ch = dp.ch, ph = ch + 2 * WIN, pwr = cw + 2 * WIN;
+  int seg_c = 0, seg_r = 0, cells = pwr * ph;
+  if (cells > budget) {                                             // stream the lattice through the LDS in pieces
+    seg_c = budget / ph - 2 * WIN;
+    seg_r = budget / pwr;
+    if (seg_c < 8 || seg_r < 1) return false;
+    const int nc = (cw + seg_c - 1) / seg_c, nr = (ch + seg_r - 1) / seg_r;
+    seg_c = (cw + nc - 1) / nc; seg_r = (ch + nr - 1) / nr;         // balanced pieces
+    cells = max((seg_c + 2 * WIN) * ph, pwr * seg_r);
+  }
+  const int points = (ch + K - 1) / K;                              // points per wavefront step
+  const int lanes = points <= kFilterThreads / 16 ? 16 : (points <= kFilterThreads / 8 ? 8 : 0);
+  if (!lanes) return false;
   static bool configured = false;
   if (!configured) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     configured = true;
   }
-  hipLaunchKernelGGL(k_support_filters<WIN>, dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can);
+  const size_t lds = (size_t)cells * sizeof(int16_t);
+  if (lanes == 16) hipLaunchKernelGGL((k_support_filters<WIN, 16>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r);
+  else             hipLaunchKernelGGL((k_support_filters<WIN, 8>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r);
   return true;
 }
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,

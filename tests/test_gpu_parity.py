@@ -97,6 +97,14 @@ def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypat
             monkeypatch.setenv("JN_HOST_FILTERS", "1" if host else "0")      # unset = by batch size
             st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=95, **kw), L, R)
             assert st == 0 and same(D1, D1o) and same(D2, D2o), (kw, host)
+    # lattices larger than the LDS are streamed through it in column / row pieces (1920x1080 does that for real);
+    # a small LDS budget forces the same code on this small image, with 2 and with 5 column pieces
+    monkeypatch.setenv("JN_HOST_FILTERS", "0")
+    _, D1o, D2o = oracle.process(oracle.params(0, disp_max=95), L, R)
+    for kb in ("16", "6"):
+        monkeypatch.setenv("JN_FILTER_LDS_KB", kb)
+        st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=95), L, R)
+        assert st == 0 and same(D1, D1o) and same(D2, D2o), kb
 
 
 def test_pitch_larger_than_width(jn, oracle, same):
