@@ -22,14 +22,17 @@ enum { kBinCap = 64 };       // triangle candidates kept per tile; longer lists 
 
 // One candidate triangle of one 32x8 tile: byte x of `rows` has bit r set iff the reference's raster
 // loops (elas.cpp:874-901) visit pixel (tile_u0 + x, tile_v0 + r) for triangle t.
-struct BinEntry {
+// Padded to 64 bytes and 16-byte aligned: an entry is written as four 16-byte stores into one cache line
+// (13 scattered dword stores per entry made k_bin store-bound).
+struct alignas(16) BinEntry {
   int32_t t;
   uint32_t rows[kTileW / 4];
   float pa, pb, pc;          // the triangle's disparity plane and validity flag ride along so that the
   uint32_t flags;            // matcher needs no dependent TriRec fetch after the lookup
+  uint32_t pad[3];
 };
-static_assert(sizeof(BinEntry) == 52, "BinEntry layout");
-enum { kBinWords = 13 };     // sizeof(BinEntry) / 4
+static_assert(sizeof(BinEntry) == 64, "BinEntry layout");
+enum { kBinWords = 16 };     // sizeof(BinEntry) / 4
 enum { kBinLds = 16 };       // list entries per tile the matcher resolves from LDS (one 16-bit cover word per pixel); longer lists (never seen: mean 7, max 17 per 32x8 tile at 720p) are read from global memory
 
 // Per-frame bookkeeping uploaded before GPU stage B.  The frame payload the host stage produces is

@@ -589,49 +589,83 @@ __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo
 // (elas.cpp:874-901) for the tile's 32 columns and, if any pixel is covered, appends
 // {triangle, 32 row masks} to the tile's list.  Lists are capped at kBinCap; the count keeps growing
 // past the cap so that the matcher can tell an overflowing tile and scan all triangles instead.
+// Row masks of triangle q inside the 32x8 tile at (u0, v0): byte x of rows[] has bit r set iff the reference's
+// raster loops visit pixel (u0 + x, v0 + r).  Returns false when the triangle misses the tile.
+DEV bool bin_entry(const DevParams& dp, const TriRec& q, int t, int u0, int v0, int c0, int c1, BinEntry& e) {
+  const int Au = q.Au, Bu = q.Bu, Cu = q.Cu;
+  e.t = t; e.pa = q.pa; e.pb = q.pb; e.pc = q.pc; e.flags = q.flags; e.pad[0] = e.pad[1] = e.pad[2] = 0;
+  uint32_t any = 0;
+#pragma unroll
+  for (int wd = 0; wd < kTileW / 4; wd++) {
+    uint32_t packed = 0;
+    if (u0 + wd * 4 + 3 >= c0 && u0 + wd * 4 <= c1)        // most of a tile's columns lie outside a ~10 px wide triangle
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int uc = u0 + wd * 4 + b;
+      float ea = 0, eb = 0; bool in = false;
+      if (uc < Bu) { if (Au != Bu && uc >= Au) { in = true; ea = q.ABa; eb = q.ABb; } }       // :875-876
+      else         { if (Bu != Cu && uc < Cu)  { in = true; ea = q.BCa; eb = q.BCb; } }       // :890-891
+      uint32_t m = 0;
+      if (in && uc < dp.W) {
+        const float fu = (float)uc;
+        const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(q.ACa, fu), q.ACb);                 // :878 / :893
+        const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);                       // :879 / :894
+        const int lo = max(min(v1, v2) - v0, 0), hi = min(max(v1, v2) - v0, kTileH);         // rows [lo,hi) of this tile
+        if (hi > lo) m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+      }
+      packed |= m << (8 * b);
+    }
+    e.rows[wd] = packed; any |= packed;
+  }
+  return any != 0;                                        // bounding box touched the tile, the triangle may not
+}
+// 32 triangles per workgroup.  Most triangles touch a handful of tiles, but Delaunay hulls carry a few long, thin
+// ones whose bounding boxes span hundreds; any fixed lanes-per-triangle split lets those set the kernel's duration.
+// So the (triangle, tile) pairs of the workgroup's triangles are numbered consecutively (prefix sum of the box
+// sizes in LDS) and the 256 threads stride over that flat list.
+enum { kBinTris = 32 };
 __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
                                              int tri_cap, int32_t* __restrict__ bin_count, BinEntry* __restrict__ bin_list) {
-  const int frame = blockIdx.y, side = blockIdx.z;
+  __shared__ int s_first[kBinTris + 1];                    // first flat index of each triangle's tiles
+  __shared__ int s_box[kBinTris][3];                       // tx0, ty0, ntx of the bounding box in tiles
+  __shared__ int s_cols[kBinTris][2];                      // c0, c1
+  const int frame = blockIdx.y, side = blockIdx.z, tid = threadIdx.x;
   const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
   if (!fi.ok) return;
-  const int t = blockIdx.x * 32 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
-  if (t >= fi.ntri[side]) return;
-  const TriRec q = recs[(size_t)(frame * 2 + side) * tri_cap + t];
-  const int Au = q.Au, Bu = q.Bu, Cu = q.Cu;
-  const int c0 = max(Au, 0), c1 = min(Cu, dp.W) - 1;                          // columns [Au, Cu)
-  const int r0 = max((int)q.vmin, 0), r1 = min((int)q.vmax, dp.H - 1);
-  if (c1 < c0 || r1 < r0) return;
-  const int tx0 = c0 / kTileW, tx1 = c1 / kTileW, ty0 = r0 / kTileH, ty1 = r1 / kTileH;
-  const int ntx = tx1 - tx0 + 1, total = ntx * (ty1 - ty0 + 1);
   const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
   const size_t base = (size_t)(frame * 2 + side) * tiles_x * tiles_y;
-  for (int k = sub; k < total; k += 8) {
-    const int tx = tx0 + k % ntx, ty = ty0 + k / ntx;
-    const int u0 = tx * kTileW, v0 = ty * kTileH;
-    BinEntry e; e.t = t; e.pa = q.pa; e.pb = q.pb; e.pc = q.pc; e.flags = q.flags;
-    uint32_t any = 0;
-#pragma unroll
-    for (int wd = 0; wd < kTileW / 4; wd++) {
-      uint32_t packed = 0;
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int uc = u0 + wd * 4 + b;
-        float ea = 0, eb = 0; bool in = false;
-        if (uc < Bu) { if (Au != Bu && uc >= Au) { in = true; ea = q.ABa; eb = q.ABb; } }       // :875-876
-        else         { if (Bu != Cu && uc < Cu)  { in = true; ea = q.BCa; eb = q.BCb; } }       // :890-891
-        uint32_t m = 0;
-        if (in && uc < dp.W) {
-          const float fu = (float)uc;
-          const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(q.ACa, fu), q.ACb);                 // :878 / :893
-          const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);                       // :879 / :894
-          const int lo = max(min(v1, v2) - v0, 0), hi = min(max(v1, v2) - v0, kTileH);         // rows [lo,hi) of this tile
-          if (hi > lo) m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-        }
-        packed |= m << (8 * b);
+  const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
+  const int t0 = blockIdx.x * kBinTris;
+  if (tid < kBinTris) {
+    int total = 0;
+    const int t = t0 + tid;
+    if (t < fi.ntri[side]) {
+      const TriRec& q = R[t];
+      const int c0 = max(q.Au, 0), c1 = min(q.Cu, dp.W) - 1;                  // columns [Au, Cu)
+      const int r0 = max((int)q.vmin, 0), r1 = min((int)q.vmax, dp.H - 1);
+      if (c1 >= c0 && r1 >= r0) {
+        const int tx0 = c0 / kTileW, ty0 = r0 / kTileH, ntx = c1 / kTileW - tx0 + 1;
+        total = ntx * (r1 / kTileH - ty0 + 1);
+        s_box[tid][0] = tx0; s_box[tid][1] = ty0; s_box[tid][2] = ntx;
+        s_cols[tid][0] = c0; s_cols[tid][1] = c1;
       }
-      e.rows[wd] = packed; any |= packed;
     }
-    if (!any) continue;                                   // bounding box touched the tile, the triangle does not
+    int incl = total;                                       // inclusive scan over the 32 lanes
+#pragma unroll
+    for (int off = 1; off < kBinTris; off <<= 1) { const int o = __shfl_up(incl, off); if (tid >= off) incl += o; }
+    s_first[tid + 1] = incl;
+    if (tid == 0) s_first[0] = 0;
+  }
+  __syncthreads();
+  const int items = s_first[kBinTris];
+  for (int idx = tid; idx < items; idx += 256) {
+    int j = 0;                                              // triangle whose range holds idx (5-step binary search)
+#pragma unroll
+    for (int step = kBinTris / 2; step >= 1; step >>= 1) if (s_first[j + step] <= idx) j += step;
+    const int k = idx - s_first[j], ntx = s_box[j][2];
+    const int tx = s_box[j][0] + k % ntx, ty = s_box[j][1] + k / ntx;
+    BinEntry e;
+    if (!bin_entry(dp, R[t0 + j], t0 + j, tx * kTileW, ty * kTileH, s_cols[j][0], s_cols[j][1], e)) continue;
     const size_t bin = base + (size_t)ty * tiles_x + tx;
     const int slot = atomicAdd(&bin_count[bin], 1);
     if (slot < kBinCap) bin_list[bin * kBinCap + slot] = e;
@@ -1464,7 +1498,7 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
   const int tiles = ((dp.W + kTileW - 1) / kTileW) * ((dp.H + kTileH - 1) / kTileH);
   hipMemsetAsync(bin_count, 0, (size_t)n * 2 * tiles * sizeof(int32_t), st);
   if (max_tri <= 0) return;
-  hipLaunchKernelGGL(k_bin, dim3((max_tri + 31) / 32, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
+  hipLaunchKernelGGL(k_bin, dim3((max_tri + kBinTris - 1) / kBinTris, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
                   const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw) {
