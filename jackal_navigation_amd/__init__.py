@@ -5,6 +5,13 @@ Rectified stereo pair -> ELAS disparity -> u8 depth map -> Q reprojection -> gro
 libjn_stereo.so).  This package is the thin host-side mirror of the reference interfaces; all
 compute lives in csrc/.  Importing the compute API requires the built library; there is no CPU path.
 """
+import os as _os
+
+# One hardware queue per slot stream: the HIP runtime multiplexes streams onto 4 hardware queues by default, so with
+# 4 slots + the caller's stream two slots share a queue and serialise (measured: -10 % pairs/s).  Must be in the
+# environment before the HIP runtime initialises; an explicit setting by the user wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # noqa: F401
 from .elas import Elas  # noqa: F401
 from . import node, device, parallel, navigate  # noqa: F401

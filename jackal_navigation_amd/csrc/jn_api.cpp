@@ -89,6 +89,11 @@ struct jn_elas {
 
 namespace {
 
+// Runs when the library is loaded.  The HIP runtime multiplexes streams onto 4 hardware queues by default; with one
+// stream per slot plus the caller's, two slots then share a queue and serialise.  Ask for 8 unless the user chose a
+// value; it only takes effect if the HIP runtime has not initialised yet (load this library first, or export it).
+__attribute__((constructor)) void prefer_one_queue_per_slot() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const DevParams& dp = h->dp;
   const int n = j.n;
