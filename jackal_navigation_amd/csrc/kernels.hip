@@ -19,6 +19,12 @@ DEV int sad16(const uint4& a, const uint4& b) {
   s = __builtin_amdgcn_sad_u8(a.w, b.w, s);
   return (int)s;
 }
+DEV unsigned sad16_acc(const uint4& a, const uint4& b, unsigned s) {   // the same, continuing a running sum
+  s = __builtin_amdgcn_sad_u8(a.x, b.x, s);
+  s = __builtin_amdgcn_sad_u8(a.y, b.y, s);
+  s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
+  return __builtin_amdgcn_sad_u8(a.w, b.w, s);
+}
 DEV int texture16(const uint4& a) {   // sum |byte - 128| (elas.cpp:301-305, :715-719)
   const unsigned k = 0x80808080u;
   unsigned s = __builtin_amdgcn_sad_u8(a.x, k, 0u);
@@ -213,35 +219,52 @@ __global__ void __launch_bounds__(256) k_support(DevParams dp, int n, const uint
 // candidate spread the ds_read_b128 over more banks than 4 do, 16 pay more for the merge.  Used when
 // 64*W bytes fit the 160 KB LDS; otherwise the global-memory kernel above runs.
 enum { kSupportLanes = 8 };
-template <int LANES>
-DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Ab, const uint4* __restrict__ Bt,
-                   const uint4* __restrict__ Bb, const uint4* __restrict__ Arow_v, int u, bool right, bool active, int j) {
+// LDS layout of k_support_lds: four descriptor rows [Ltop | Lbot | Rtop | Rbot] of PITCH columns each, PITCH a
+// compile-time constant so that the four taps of a candidate (u-2 / u+2, top / bottom) sit at immediate offsets
+// 0, 64, 16*PITCH, 16*PITCH + 64 from one address and a disparity step costs one pointer update.  (Interleaving
+// top and bottom per column gives the same immediates but a 32-byte lane stride: all eight candidates of a wave
+// then fall on the same 32 banks and the kernel gets 30 % slower.  Re-using the leading tap pair of disparity d as
+// the trailing pair of d+4 halves the LDS reads but was 9 % slower: the kernel is bound by issuing the 16 v_sad_u8
+// per disparity, not by LDS bandwidth.)
+// The running best / second best (reference: strict `<`, first d wins, elas.cpp:354-362) are kept as packed keys
+// energy << 8 | d: E1 = smallest key's energy with the smallest d attaining it, E2 = second smallest key's energy =
+// second smallest energy of the multiset (two disparities sharing the minimum give E2 = E1, as in the reference).
+template <int LANES, int PITCH>
+DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Bt,
+                   const uint4* __restrict__ Arow_v, int u, bool right, bool active, int j) {
   const int W = dp.W;
   bool ok = active && u >= 5 && u <= W - 6;                                   // :283 (rows checked by the caller)
   if (ok) ok = texture16(Arow_v[u]) >= dp.support_texture;                    // :301-305
   const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326
   ok = ok && dmax >= 10;                                                      // :329
-  Best b{32767, -1, 32767};
+  constexpr unsigned kNone = 0x7FFFFFFFu;
+  unsigned k1 = kNone, k2 = kNone;
   if (ok) {
-    const uint4 a0 = At[u - 2], a1 = At[u + 2], a2 = Ab[u - 2], a3 = Ab[u + 2];
-    for (int d = j; d <= dmax; d += LANES) {
-      const int uw = right ? u + d : u - d;
-      const int s = sad16(a0, Bt[uw - 2]) + sad16(a1, Bt[uw + 2]) + sad16(a2, Bb[uw - 2]) + sad16(a3, Bb[uw + 2]);
-      if (s < b.e1) { b.e2 = b.e1; b.e1 = s; b.d1 = d; }
-      else if (s < b.e2) b.e2 = s;
+    const uint4* a = At + (u - 2);
+    const uint4 a0 = a[0], a1 = a[4], a2 = a[PITCH], a3 = a[PITCH + 4];       // (top,u-2) (top,u+2) (bottom,u-2) (bottom,u+2)
+    const uint4* b = Bt + ((right ? u + j : u - j) - 2);
+    const int step = right ? LANES : -LANES;
+    for (int d = j; d <= dmax; d += LANES, b += step) {
+      // two accumulate chains (the adder is part of v_sad_u8) joined by one add
+      const unsigned s = sad16_acc(a1, b[4], sad16_acc(a0, b[0], 0u)) + sad16_acc(a3, b[PITCH + 4], sad16_acc(a2, b[PITCH], 0u));
+      const unsigned key = (s << 8) | (unsigned)d;
+      k2 = min(k2, max(k1, key));
+      k1 = min(k1, key);
     }
   }
 #pragma unroll
   for (int off = 1; off < LANES; off <<= 1) {
-    const int e1 = __shfl_xor(b.e1, off), d1 = __shfl_xor(b.d1, off), e2 = __shfl_xor(b.e2, off);
-    b = merge(b, e1, d1, e2);
+    const unsigned o1 = __shfl_xor(k1, off), o2 = __shfl_xor(k2, off);
+    k2 = min(max(k1, o1), min(k2, o2));
+    k1 = min(k1, o1);
   }
-  return (ok && b.d1 >= 0 && (float)b.e1 < dp.support_threshold * (float)b.e2) ? b.d1 : -1;   // :366
+  const int e1 = (int)(k1 >> 8), d1 = (int)(k1 & 255u), e2 = k2 == kNone ? 32767 : (int)(k2 >> 8);
+  return (ok && k1 != kNone && (float)e1 < dp.support_threshold * (float)e2) ? d1 : -1;   // :366
 }
 
-template <int LANES>
+template <int LANES, int PITCH>
 __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can) {
-  extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], W each
+  extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], PITCH each
   const int vc = blockIdx.x, frame = blockIdx.y, W = dp.W;
   const int v = vc * dp.step;
   int16_t* out_row = d_can + ((size_t)frame * dp.ch + vc) * dp.cw;
@@ -252,10 +275,10 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
   }
   const uint4* L = desc + (size_t)frame * dp.H * W;
   const uint4* R = desc + (size_t)(n + frame) * dp.H * W;
-  uint4* Lt = rows; uint4* Lb = rows + W; uint4* Rt = rows + 2 * W; uint4* Rb = rows + 3 * W;
+  uint4* Lt = rows; uint4* Rt = rows + 2 * PITCH;
   for (int i = threadIdx.x; i < W; i += 1024) {
-    Lt[i] = L[(size_t)(v - 2) * W + i]; Lb[i] = L[(size_t)(v + 2) * W + i];
-    Rt[i] = R[(size_t)(v - 2) * W + i]; Rb[i] = R[(size_t)(v + 2) * W + i];
+    Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i];
+    Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i];
   }
   __syncthreads();
   const uint4* Lv = L + (size_t)v * W;                  // row v itself is only read for the texture test
@@ -266,8 +289,8 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
     const bool active = uc >= 1 && uc < dp.cw;
     const int u = uc * dp.step;
     int res = -1;
-    const int d = quad_match<LANES>(dp, Lt, Lb, Rt, Rb, Lv, u, false, active, j);
-    const int d2 = quad_match<LANES>(dp, Rt, Rb, Lt, Lb, Rv, u - d, true, active && d >= 0, j);
+    const int d = quad_match<LANES, PITCH>(dp, Lt, Rt, Lv, u, false, active, j);
+    const int d2 = quad_match<LANES, PITCH>(dp, Rt, Lt, Rv, u - d, true, active && d >= 0, j);
     if (d >= 0 && d2 >= 0 && abs(d - d2) <= dp.lr_threshold) res = d;         // :404-411
     if (j == 0 && uc < dp.cw) out_row[uc] = (int16_t)(uc == 0 ? 0 : res);
   }
@@ -1437,18 +1460,23 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, c
   const dim3 grid((dp.W + kDescTW - 1) / kDescTW, (dp.H + kDescTH - 1) / kDescTH, 2 * n);
   hipLaunchKernelGGL(k_descriptor_fused, grid, dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, desc);
 }
-void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  const size_t lds = (size_t)4 * dp.W * sizeof(uint4);
-  if (lds <= 160 * 1024) {
-    static bool configured = false;
-    if (!configured) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      configured = true;
-    }
-    hipLaunchKernelGGL(k_support_lds<kSupportLanes>, dim3(dp.ch, n), dim3(1024), lds, st, dp, n, desc, d_can);
-  } else {
-    hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
+template <int PITCH>
+static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
+  static bool configured = false;
+  if (!configured) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    configured = true;
   }
+  hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n), dim3(1024), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can);
+}
+void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
+  // the LDS row pitch is a template constant (immediate tap offsets): smallest bucket that holds the image width;
+  // 1280 columns = 80 KB, two workgroups per CU; 2560 = the whole 160 KB
+  if (dp.W <= 320) launch_support_pitch<320>(st, dp, n, desc, d_can);
+  else if (dp.W <= 640) launch_support_pitch<640>(st, dp, n, desc, d_can);
+  else if (dp.W <= 1280) launch_support_pitch<1280>(st, dp, n, desc, d_can);
+  else if (dp.W <= 2560) launch_support_pitch<2560>(st, dp, n, desc, d_can);
+  else hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can) {
   constexpr int WIN = 5, K = WIN + 1;                               // the reference's incon_window_size (elas.h:97)
