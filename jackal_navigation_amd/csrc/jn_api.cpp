@@ -257,6 +257,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   const float two_sigma_sq = 2 * p->sigma * p->sigma;
   for (int dd = 0; dd <= radius; dd++)                                                    // elas.cpp:802-805 (float math)
     dp.P[dd] = (int32_t)((-std::log(p->gamma + std::exp(-dd * dd / two_sigma_sq)) + std::log(p->gamma)) / p->beta);
+  for (int dd = 0; dd <= radius; dd++)            // k_dense packs cost + prior into 24 bits of a key (bias 2^20)
+    if (dp.P[dd] <= -(1 << 19) || dp.P[dd] >= (1 << 19)) return JN_ERR_UNSUPPORTED;
   dp.speckle_sim = p->speckle_sim_threshold; dp.speckle_size = p->speckle_size; dp.gap_width = p->ipol_gap_width;
 
   HostParams& hp = h->hp;

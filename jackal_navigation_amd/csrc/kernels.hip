@@ -810,7 +810,9 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
     const uint4* src = B + (size_t)max(min(v0 + rr, H - 3), 2) * W;       // :701 row clamp
     for (int c = tid; c < span; c += kDenseThreads) {
       const int col = base + c;
-      s_B[rr * span + c] = (col >= 0 && col < W) ? src[col] : make_uint4(0, 0, 0, 0);
+      // the left image's window is stored mirrored, so that on both sides the descriptor matched at disparity d
+      // sits d slots after the one matched at d = 0
+      s_B[rr * span + (side ? c : span - 1 - c)] = (col >= 0 && col < W) ? src[col] : make_uint4(0, 0, 0, 0);
     }
   }
   // (1b) lists into LDS; rank the tile's triangles; fold the row masks into one cover word per pixel
@@ -841,7 +843,10 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
   __syncthreads();
   if (v >= H) return;
 
-  const uint4* Brow = s_B + r * span - base;                               // Brow[uw] = descriptor of column uw in row vr
+  // Bzero + u + d = descriptor of the column matched at disparity d for pixel column u (u - d left, u + d right)
+  const uint4* Bzero = side ? s_B + r * span - base : s_B + r * span + span - 1 + base;
+  constexpr unsigned kNoKey = 0xFFFFFFFFu;
+  constexpr int kBias = 1 << 20;                             // makes cost + prior non-negative inside a key
   float* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;
 
 #pragma unroll
@@ -882,7 +887,11 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
       const int lo = max(d_plane - dp.radius, 0), hi = min(d_plane + dp.radius, dp.disp_max);                // :723-724
       // disparities whose warped column stays inside [2, W-2) (:746, :753, :764, :771)
       const int dmax_ok = side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
-      int best = 10000, best_d = -1;                                       // :735-736
+      // The reference keeps (min_val, min_d) with a strict `<` over candidates in evaluation order (:735-756).  Within
+      // one phase disparities ascend, so the minimum of the keys (cost << 8 | d) is the same choice; the plane phase
+      // comes second and only wins with a strictly smaller cost.
+      const uint4* Bu = side ? Bzero + u : Bzero - u;
+      unsigned best1 = kNoKey, best2 = kNoKey;
 #pragma unroll
       for (int w = 0; w < kGridWords; w++) {                               // grid candidates outside the plane range (:742-750)
         if (w >= nwords) break;
@@ -890,19 +899,23 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
         while (bits) {
           const int d = (w << 5) + __builtin_ctz(bits);
           bits &= bits - 1;
-          const int val = sad16(a, Brow[side ? u + d : u - d]);
-          if (val < best) { best = val; best_d = d; }
+          const unsigned val = sad16_acc(a, Bu[d], (unsigned)kBias);      // the bias rides in the accumulator operand
+          best1 = min(best1, (val << 8) | (unsigned)d);
         }
       }
       const int phi = min(hi, dmax_ok);
-      for (int d = lo; d <= phi; d++) {                                    // plane neighbourhood with prior (:751-756)
-        int val = sad16(a, Brow[side ? u + d : u - d]);
-        if (valid) {
-          const int kk = abs(d - d_plane);                                 // <= radius <= 7; select chain instead of indexed kernarg
-          val += kk == 0 ? dp.P[0] : kk == 1 ? dp.P[1] : kk == 2 ? dp.P[2] : kk == 3 ? dp.P[3] : kk == 4 ? dp.P[4] : kk == 5 ? dp.P[5] : kk == 6 ? dp.P[6] : dp.P[7];
+      const unsigned prior_on = valid ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int off = -7; off <= 7; off++) {                                // plane neighbourhood with prior (:751-756); radius <= 7
+        if ((off < 0 ? -off : off) > dp.radius) continue;                  // uniform
+        const int d = d_plane + off;
+        if (d >= lo && d <= phi) {
+          const unsigned val = sad16_acc(a, Bu[d], (unsigned)kBias + ((unsigned)dp.P[off < 0 ? -off : off] & prior_on));
+          best2 = min(best2, (val << 8) | (unsigned)d);
         }
-        if (val < best) { best = val; best_d = d; }
       }
+      const unsigned best = (best2 >> 8) < (best1 >> 8) ? best2 : best1;
+      const int best_d = best == kNoKey ? -1 : (int)(best & 255u);
       result = best_d >= 0 ? (float)best_d : -1.0f;                        // :778-779
     }
     out[u] = result;
