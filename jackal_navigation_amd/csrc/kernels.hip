@@ -1099,38 +1099,32 @@ DEV float am_weight(float x, float c) {
   const float m = __uint_as_float(__float_as_uint(__fsub_rn(x, c)) & 0x4F000000u);
   return fmaxf(0.0f, __fsub_rn(4.0f, m));
 }
-template <bool kHorizontal>
-__global__ void __launch_bounds__(256) k_adaptive_mean(DevParams dp, const FrameInfo* __restrict__ info,
-                                                       const float* __restrict__ in, const float* __restrict__ keep,
-                                                       float* __restrict__ out) {
-  // horizontal: in = D (negatives read as -10), out = tmp, default = clamped centre
-  // vertical:   in = tmp, keep = D, out = D, default = keep
+// Horizontal pass: in = D (negatives read as -10, elas.cpp:1304-1309), out = tmp; rows 3..H-4, centres 4..W-4.
+__global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const FrameInfo* __restrict__ info,
+                                                         const float* __restrict__ in, float* __restrict__ out) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
   if (u >= dp.W || !info[frame].ok) return;
   const int W = dp.W, H = dp.H;
   const size_t plane = (size_t)H * W;
   const float* I = in + frame * plane;
   const size_t p = (size_t)v * W + u;
-  float res;
-  if (kHorizontal) { res = I[p]; if (res < 0) res = -10.0f; } else res = keep[frame * plane + p];
-  const int pos = kHorizontal ? u : v, len = kHorizontal ? W : H;
-  const bool line_ok = kHorizontal ? (v >= 3 && v < H - 3) : (u >= 3 && u < W - 3);
-  if (line_ok && pos >= 4 && pos <= len - 4) {
-    const int stride = kHorizontal ? 1 : W;
-    float c = I[p]; if (kHorizontal && c < 0) c = -10.0f;
+  float c = I[p]; if (c < 0) c = -10.0f;
+  float res = c;
+  if (v >= 3 && v < H - 3 && u >= 4 && u <= W - 4) {
     // Window [c-4, c+3]; the reference keeps it in an 8-slot ring (slot = position mod 8) and sums lane l =
     // slot l + slot l+4, then ((l0+l1)+l2)+l3.  Window taps k and k+4 always share a lane, so with pair sums
     // P_j = tap j + tap j+4 (addition commutes) lane l holds P[(l - pos) & 3]: a rotation by pos & 3.
     float pw[4], pf[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      float x0 = I[p + (long long)(k - 4) * stride], x1 = I[p + (long long)k * stride];
-      if (kHorizontal) { if (x0 < 0) x0 = -10.0f; if (x1 < 0) x1 = -10.0f; }       // elas.cpp:1304-1309
+      float x0 = I[p + k - 4], x1 = I[p + k];
+      if (x0 < 0) x0 = -10.0f;
+      if (x1 < 0) x1 = -10.0f;
       const float w0 = am_weight(x0, c), w1 = am_weight(x1, c);
       pw[k] = __fadd_rn(w0, w1);
       pf[k] = __fadd_rn(__fmul_rn(x0, w0), __fmul_rn(x1, w1));
     }
-    const int r = pos & 3;
+    const int r = u & 3;
     if (r & 1) {
       const float tw = pw[3], tf = pf[3];
       pw[3] = pw[2]; pw[2] = pw[1]; pw[1] = pw[0]; pw[0] = tw;
@@ -1148,8 +1142,8 @@ __global__ void __launch_bounds__(256) k_adaptive_mean(DevParams dp, const Frame
 }
 
 // Vertical pass, one thread per column walking kAmRows rows with the 8-tap window in registers: 1.4 row reads per
-// output instead of 8 (the per-row variant above is bound by L2 requests, not by arithmetic).  Same arithmetic as
-// k_adaptive_mean<false>: in = tmp (horizontal result), D = keep and output.
+// output instead of 8 (a thread-per-pixel variant is bound by L2 requests, not by arithmetic).  Same arithmetic as the
+// horizontal pass on columns 3..W-4, centres 4..H-4: in = tmp (horizontal result); D keeps its value where no mean forms.
 constexpr int kAmRows = 16;
 __global__ void __launch_bounds__(256) k_adaptive_mean_v(DevParams dp, const FrameInfo* __restrict__ info,
                                                          const float* __restrict__ in, float* __restrict__ D) {
@@ -1568,7 +1562,7 @@ void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
 }
 void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);
-  hipLaunchKernelGGL(k_adaptive_mean<true>, g, dim3(256), 0, st, dp, info, D, D, tmp);
+  hipLaunchKernelGGL(k_adaptive_mean_h, g, dim3(256), 0, st, dp, info, D, tmp);
   hipLaunchKernelGGL(k_adaptive_mean_v, dim3((dp.W + 255) / 256, (dp.H + kAmRows - 1) / kAmRows, n), dim3(256), 0, st, dp, info, tmp, D);
 }
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
