@@ -1043,7 +1043,11 @@ __global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo
   const int start = conn ? L[p] : p;                        // a non-start pixel's label is never rewritten
   const int root = uf_find(L, start);
   if (root != start) L[start] = root;                       // compress: k_ccl_apply then needs at most two hops
-  atomicAdd(&sz[frame * plane + root], p - start + 1);
+  // Only "at least speckle_size or not" matters (elas.cpp:1083): once a component is seen to have reached the
+  // threshold, further runs skip the add.  The scene's few huge components would otherwise take ~10^5 atomic adds
+  // each on one address.  A stale read only means one add too many.
+  int32_t* total = &sz[frame * plane + root];
+  if (*total < dp.speckle_size) atomicAdd(total, p - start + 1);
 }
 __global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo* __restrict__ info, float* __restrict__ D,
                                                    const int32_t* __restrict__ lab, const int32_t* __restrict__ sz) {
