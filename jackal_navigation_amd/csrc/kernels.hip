@@ -218,20 +218,21 @@ __global__ void __launch_bounds__(256) k_support(DevParams dp, int n, const uint
 // 16 lanes 383 us, 1 lane (no merge, 256 threads) 447 us per 32-pair batch — 8 consecutive descriptors per
 // candidate spread the ds_read_b128 over more banks than 4 do, 16 pay more for the merge.  Used when
 // 64*W bytes fit the 160 KB LDS; otherwise the global-memory kernel above runs.
-enum { kSupportLanes = 8 };
+enum { kSupportLanes = 4 };
 // LDS layout of k_support_lds: four descriptor rows [Ltop | Lbot | Rtop | Rbot] of PITCH columns each, PITCH a
-// compile-time constant so that the four taps of a candidate (u-2 / u+2, top / bottom) sit at immediate offsets
-// 0, 64, 16*PITCH, 16*PITCH + 64 from one address and a disparity step costs one pointer update.  (Interleaving
-// top and bottom per column gives the same immediates but a 32-byte lane stride: all eight candidates of a wave
-// then fall on the same 32 banks and the kernel gets 30 % slower.  Re-using the leading tap pair of disparity d as
-// the trailing pair of d+4 halves the LDS reads but was 9 % slower: the kernel is bound by issuing the 16 v_sad_u8
-// per disparity, not by LDS bandwidth.)
+// compile-time constant so that a candidate's taps (u-2 / u+2, top / bottom) sit at immediate offsets from one
+// address.  Four lanes per candidate, lane j taking the disparities j, j+4, ...: consecutive columns per lane and
+// 5-column steps between candidates spread a wave's 16-byte reads evenly over the 64 banks.  (Interleaving top and
+// bottom per column, or splitting the range between two lane groups 64 columns apart, puts the groups on the same
+// banks and costs 10-30 %.)  PMC: 21 M ds_read_b128 per launch at 8 lanes x 4 reads per disparity = 277 us of LDS
+// pipe time out of 317 us; with the tap-pair re-use below it is half that and the kernel runs in 262 us.
 // The running best / second best (reference: strict `<`, first d wins, elas.cpp:354-362) are kept as packed keys
 // energy << 8 | d: E1 = smallest key's energy with the smallest d attaining it, E2 = second smallest key's energy =
 // second smallest energy of the multiset (two disparities sharing the minimum give E2 = E1, as in the reference).
 template <int LANES, int PITCH>
 DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Bt,
                    const uint4* __restrict__ Arow_v, int u, bool right, bool active, int j) {
+  static_assert(LANES == 4, "lane j walks the disparities j, j+4, j+8, ...");
   const int W = dp.W;
   bool ok = active && u >= 5 && u <= W - 6;                                   // :283 (rows checked by the caller)
   if (ok) ok = texture16(Arow_v[u]) >= dp.support_texture;                    // :301-305
@@ -239,18 +240,40 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
   ok = ok && dmax >= 10;                                                      // :329
   constexpr unsigned kNone = 0x7FFFFFFFu;
   unsigned k1 = kNone, k2 = kNone;
-  if (ok) {
+  if (ok && j <= dmax) {
+    // Stepping d by 4 moves the matched column by 4 = the distance between the two tap columns, so the tap pair that
+    // led (column +/- 2 in the direction of motion) is the trailing pair of the next step: one new (top, bottom) pair
+    // is read from LDS per disparity instead of two.  Three register sets rotate through lead / trail / prefetch,
+    // hence the loop unrolled by three.  (The kernel was bound by LDS bandwidth: 4 x 16 B per lane and disparity.)
+    const int dir = right ? 1 : -1;
     const uint4* a = At + (u - 2);
-    const uint4 a0 = a[0], a1 = a[4], a2 = a[PITCH], a3 = a[PITCH + 4];       // (top,u-2) (top,u+2) (bottom,u-2) (bottom,u+2)
-    const uint4* b = Bt + ((right ? u + j : u - j) - 2);
-    const int step = right ? LANES : -LANES;
-    for (int d = j; d <= dmax; d += LANES, b += step) {
-      // two accumulate chains (the adder is part of v_sad_u8) joined by one add
-      const unsigned s = sad16_acc(a1, b[4], sad16_acc(a0, b[0], 0u)) + sad16_acc(a3, b[PITCH + 4], sad16_acc(a2, b[PITCH], 0u));
-      const unsigned key = (s << 8) | (unsigned)d;
-      k2 = min(k2, max(k1, key));
-      k1 = min(k1, key);
+    const uint4 am_t = a[0], ap_t = a[4], am_b = a[PITCH], ap_b = a[PITCH + 4];  // descriptors at u-2 / u+2, top / bottom row
+    const uint4 aL_t = right ? ap_t : am_t, aL_b = right ? ap_b : am_b;       // partner of the leading pair
+    const uint4 aT_t = right ? am_t : ap_t, aT_b = right ? am_b : ap_b;       // partner of the trailing pair
+    int d = j;
+    const uint4* b = Bt + (u + dir * d);                                      // column matched at disparity d
+    uint4 p0_t = b[-2 * dir], p0_b = b[PITCH - 2 * dir];                      // trailing pair
+    uint4 p1_t = b[2 * dir], p1_b = b[PITCH + 2 * dir];                       // leading pair
+    uint4 p2_t, p2_b;
+    const uint4* nx = b + 6 * dir;                                            // leading column of the next step
+#define JN_STEP(LD, TR, NX)                                                                                   \
+    {                                                                                                         \
+      const bool more = d + 4 <= dmax;                                                                        \
+      const uint4* q = more ? nx : b;                         /* a harmless address when there is no next step */ \
+      NX##_t = q[0]; NX##_b = q[PITCH];                                                                       \
+      const unsigned s = sad16_acc(aT_t, TR##_t, sad16_acc(aL_t, LD##_t, 0u)) + sad16_acc(aT_b, TR##_b, sad16_acc(aL_b, LD##_b, 0u)); \
+      const unsigned key = (s << 8) | (unsigned)d;                                                            \
+      k2 = min(k2, max(k1, key));                                                                             \
+      k1 = min(k1, key);                                                                                      \
+      if (!more) break;                                                                                       \
+      d += 4; nx += 4 * dir;                                                                                  \
     }
+    for (;;) {
+      JN_STEP(p1, p0, p2)
+      JN_STEP(p2, p1, p0)
+      JN_STEP(p0, p2, p1)
+    }
+#undef JN_STEP
   }
 #pragma unroll
   for (int off = 1; off < LANES; off <<= 1) {
