@@ -146,8 +146,8 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipEventRecord(s.ev[EV_DENSE], st));
     launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
     HIP_TRY(hipEventRecord(s.ev[EV_LR], st));
-    launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size);
-    if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size);
+    launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
+    if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
     HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
     launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
     if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);

@@ -38,7 +38,8 @@ void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* i
 // Left/right consistency (elas.cpp:909-979): raw -> D1, D2 (user buffers).
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2);
 // Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.
-void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size);
+void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size,
+                    void* scratch);
 // Gap interpolation (elas.cpp:1101-1284): rows D->tmp, columns tmp->D.
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
 // Adaptive mean (elas.cpp:1287-1492): horizontal D->tmp, vertical tmp->D.

@@ -993,99 +993,119 @@ DEV void uf_union(int32_t* __restrict__ lab, int a, int b) {
   }
 }
 // Row pass: every maximal horizontal run of connected pixels gets the flat index of its first pixel
-// as label (no atomics: a block-wide max-scan of "run starts here" positions per image row).
+// as label (no atomics: a max-scan of "run starts here" positions along the image row), and the row's runs are
+// listed compactly — run k of the row spans columns [starts[k], ends[k]] — so that the later passes that work per
+// run (sizes, removal) touch ~4 % as many items as there are pixels and never read the image.
+struct RunLists { uint16_t* starts; uint16_t* ends; int32_t* count; int pitch; };   // [n*H][pitch], [n*H]
+// One wave per image row, walking it in 64-pixel chunks: the carries (latest run start, runs so far) are wave-uniform,
+// so there is no LDS and no barrier, and the next chunk's pixels are loaded before the current one is processed.
 __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
-                                                  int32_t* __restrict__ lab, int32_t* __restrict__ sz) {
-  __shared__ int wave_max[4];
-  const int v = blockIdx.x, frame = blockIdx.y;
-  if (!info[frame].ok) return;
-  const int W = dp.W;
+                                                  int32_t* __restrict__ lab, int32_t* __restrict__ sz, RunLists runs) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
+  if (v >= dp.H || !info[frame].ok) return;
+  const int W = dp.W, lane = threadIdx.x & 63;
   const size_t base = (size_t)frame * dp.H * W + (size_t)v * W;
+  const size_t rbase = ((size_t)frame * dp.H + v) * runs.pitch;
   const float* row = D + base;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float sim = dp.speckle_sim;
   int carry = -1;                                           // last run start seen in earlier chunks
-  for (int u0 = 0; u0 < W; u0 += 256) {
-    const int u = u0 + threadIdx.x;
-    const float d = u < W ? row[u] : -10.0f;
+  int carry_cnt = 0;                                        // runs started in earlier chunks
+  float left = -10.0f;                                      // pixel just before the chunk
+  float d = lane < W ? row[lane] : -10.0f;
+  for (int u0 = 0; u0 < W; u0 += 64) {
+    const int u = u0 + lane;
+    const float nxt = u + 64 < W ? row[u + 64] : -10.0f;    // next chunk, in flight while this one is processed
+    float prev = __shfl_up(d, 1), foll = __shfl_down(d, 1);
+    if (lane == 0) prev = left;
+    if (lane == 63) foll = __shfl(nxt, 0);
     const bool valid = d >= 0;
-    bool conn = false;
-    if (valid && u > 0) { const float e = row[u - 1]; conn = e >= 0 && fabsf(d - e) <= dp.speckle_sim; }
-    const bool start = valid && !conn;
+    const bool conn = valid && prev >= 0 && fabsf(d - prev) <= sim;
+    const bool conn_next = valid && foll >= 0 && fabsf(foll - d) <= sim;
+    const bool start = valid && !conn, last = valid && !conn_next;
     int s = start ? u : -1;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(s, off); if (lane >= off) s = max(s, o); }
-    if (lane == 63) wave_max[wave] = s;
-    __syncthreads();
-    int pre = carry;
-    for (int w = 0; w < wave; w++) pre = max(pre, wave_max[w]);
-    s = max(s, pre);
-    const int chunk_last = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    s = max(s, carry);
+    const unsigned long long starts = __ballot(start);
+    const int k = carry_cnt + __popcll(starts & (~0ull >> (63 - lane))) - 1;   // ordinal of the run this pixel belongs to
     if (u < W) lab[base + u] = valid ? v * W + s : -1;
-    if (start) sz[base + u] = 0;                            // sizes are only ever read and added to at roots, and roots are run starts
-    carry = max(carry, chunk_last);
-    __syncthreads();
+    if (start) { sz[base + u] = 0; runs.starts[rbase + k] = (uint16_t)u; }    // sizes live at roots, and roots are run starts
+    if (last) runs.ends[rbase + k] = (uint16_t)u;
+    carry = __shfl(s, 63);
+    carry_cnt += __popcll(starts);
+    left = __shfl(d, 63);
+    d = nxt;
   }
+  if (lane == 0) runs.count[(size_t)frame * dp.H + v] = carry_cnt;
 }
 // Column pass: unite vertically adjacent runs.  A pixel issues the union only if it is the first
 // column of the contact between its run and the run below (the pixel to its left belongs to the
 // same two runs otherwise), which removes almost all redundant atomics.
 __global__ void __launch_bounds__(256) k_ccl_merge(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
                                                    int32_t* __restrict__ lab) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (u >= dp.W || v + 1 >= dp.H || !info[frame].ok) return;
-  const int W = dp.W;
+  // one wave per pair of rows (v, v+1), 64 columns at a time; left neighbours come from the lane below
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
+  if (v + 1 >= dp.H || !info[frame].ok) return;
+  const int W = dp.W, lane = threadIdx.x & 63;
   const size_t plane = (size_t)dp.H * W;
   const float* r0 = D + frame * plane + (size_t)v * W;
   const float* r1 = r0 + W;
+  int32_t* L = lab + frame * plane;
   const float sim = dp.speckle_sim;
-  const float a = r0[u], b = r1[u];
-  if (!(a >= 0 && b >= 0 && fabsf(a - b) <= sim)) return;
-  if (u > 0) {
-    const float a0 = r0[u - 1], b0 = r1[u - 1];
+  float a_left = -10.0f, b_left = -10.0f;                   // column just before the chunk
+  float a = lane < W ? r0[lane] : -10.0f, b = lane < W ? r1[lane] : -10.0f;
+  for (int u0 = 0; u0 < W; u0 += 64) {
+    const int u = u0 + lane;
+    const float an = u + 64 < W ? r0[u + 64] : -10.0f, bn = u + 64 < W ? r1[u + 64] : -10.0f;   // next chunk in flight
+    float a0 = __shfl_up(a, 1), b0 = __shfl_up(b, 1);
+    if (lane == 0) { a0 = a_left; b0 = b_left; }
+    const bool contact = a >= 0 && b >= 0 && fabsf(a - b) <= sim;
     const bool same_pair = a0 >= 0 && b0 >= 0 && fabsf(a0 - b0) <= sim && fabsf(a - a0) <= sim && fabsf(b - b0) <= sim;
-    if (same_pair) return;
+    if (contact && !same_pair) uf_union(L, L[v * W + u], L[(v + 1) * W + u]);
+    a_left = __shfl(a, 63); b_left = __shfl(b, 63);
+    a = an; b = bn;
   }
-  int32_t* L = lab + frame * plane;
-  uf_union(L, L[v * W + u] , L[(v + 1) * W + u]);
 }
-// One atomic per run: its last pixel adds the run length to the component root.
-__global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
-                                                   int32_t* __restrict__ lab, int32_t* __restrict__ sz) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (u >= dp.W || !info[frame].ok) return;
+// One atomic per run: the run length goes to the component root.  Four rows per workgroup, one wave per row
+// striding over that row's run list.
+__global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo* __restrict__ info, int32_t* __restrict__ lab,
+                                                   int32_t* __restrict__ sz, RunLists runs) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
+  if (v >= dp.H || !info[frame].ok) return;
   const int W = dp.W;
-  const size_t plane = (size_t)dp.H * W;
-  const float* row = D + frame * plane + (size_t)v * W;
-  const float d = row[u];
-  if (!(d >= 0)) return;
-  if (u + 1 < W) { const float e = row[u + 1]; if (e >= 0 && fabsf(e - d) <= dp.speckle_sim) return; }   // not the run's last pixel
+  const size_t plane = (size_t)dp.H * W, rrow = (size_t)frame * dp.H + v;
   int32_t* L = lab + frame * plane;
-  const int p = v * W + u;
-  bool conn = false;
-  if (u > 0) { const float e = row[u - 1]; conn = e >= 0 && fabsf(d - e) <= dp.speckle_sim; }
-  const int start = conn ? L[p] : p;                        // a non-start pixel's label is never rewritten
-  const int root = uf_find(L, start);
-  if (root != start) L[start] = root;                       // compress: k_ccl_apply then needs at most two hops
-  // Only "at least speckle_size or not" matters (elas.cpp:1083): once a component is seen to have reached the
-  // threshold, further runs skip the add.  The scene's few huge components would otherwise take ~10^5 atomic adds
-  // each on one address.  A stale read only means one add too many.
-  int32_t* total = &sz[frame * plane + root];
-  if (*total < dp.speckle_size) atomicAdd(total, p - start + 1);
-}
-__global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo* __restrict__ info, float* __restrict__ D,
-                                                   const int32_t* __restrict__ lab, const int32_t* __restrict__ sz) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (u >= dp.W || !info[frame].ok) return;
-  const size_t plane = (size_t)dp.H * dp.W;
-  const int32_t* L = lab + frame * plane;
-  const int p = v * dp.W + u;
-  int count = 1;                                            // an invalid pixel is a segment of one
-  if (L[p] >= 0) {
-    int x = p, q = L[x];
-    while (q != x) { x = q; q = L[x]; }
-    count = sz[frame * plane + x];
+  const int cnt = runs.count[rrow];
+  for (int k = threadIdx.x & 63; k < cnt; k += 64) {
+    const int start = v * W + runs.starts[rrow * runs.pitch + k], len = runs.ends[rrow * runs.pitch + k] - runs.starts[rrow * runs.pitch + k] + 1;
+    const int root = uf_find(L, start);
+    if (root != start) L[start] = root;                     // compress: k_ccl_apply then needs at most two hops
+    // Only "at least speckle_size or not" matters (elas.cpp:1083): once a component is seen to have reached the
+    // threshold, further runs skip the add.  The scene's few huge components would otherwise take ~10^5 atomic adds
+    // each on one address.  A stale read only means one add too many.
+    int32_t* total = &sz[frame * plane + root];
+    if (*total < dp.speckle_size) atomicAdd(total, len);
   }
-  if (count < dp.speckle_size) D[frame * plane + p] = -10.0f;
+}
+// Runs of components smaller than speckle_size are set to -10 (invalid pixels already are: every invalid value the
+// L/R check leaves is -10, the "segment of one" of elas.cpp:1075-1090 changes nothing for them).
+__global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo* __restrict__ info, float* __restrict__ D,
+                                                   const int32_t* __restrict__ lab, const int32_t* __restrict__ sz, RunLists runs) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
+  if (v >= dp.H || !info[frame].ok) return;
+  const int W = dp.W;
+  const size_t plane = (size_t)dp.H * W, rrow = (size_t)frame * dp.H + v;
+  const int32_t* L = lab + frame * plane;
+  const int cnt = runs.count[rrow];
+  for (int k = threadIdx.x & 63; k < cnt; k += 64) {
+    const int us = runs.starts[rrow * runs.pitch + k], ue = runs.ends[rrow * runs.pitch + k];
+    int x = v * W + us, q = L[x];
+    while (q != x) { x = q; q = L[x]; }
+    if (sz[frame * plane + x] < dp.speckle_size) {
+      float* row = D + frame * plane + (size_t)v * W;
+      for (int u = us; u <= ue; u++) row[u] = -10.0f;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1575,12 +1595,20 @@ void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* i
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
   hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
 }
-void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size) {
-  const dim3 g = grid2d(dp.W, dp.H, n);
-  hipLaunchKernelGGL(k_ccl_rows, dim3(dp.H, n), dim3(256), 0, st, dp, info, D, label, size);
-  hipLaunchKernelGGL(k_ccl_merge, g, dim3(256), 0, st, dp, info, D, label);
-  hipLaunchKernelGGL(k_ccl_count, g, dim3(256), 0, st, dp, info, D, label, size);
-  hipLaunchKernelGGL(k_ccl_apply, g, dim3(256), 0, st, dp, info, D, label, size);
+void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size,
+                    void* scratch) {
+  // run lists live in the (currently idle) float scratch image: 2 x uint16 [n*H][W/2 + 2] + int32 [n*H] < n*H*W*4 bytes
+  RunLists runs;
+  runs.pitch = (dp.W / 2 + 2) & ~1;                          // a row of W pixels holds at most ceil(W/2) runs
+  const size_t rows = (size_t)n * dp.H;
+  runs.starts = reinterpret_cast<uint16_t*>(scratch);
+  runs.ends = runs.starts + rows * runs.pitch;
+  runs.count = reinterpret_cast<int32_t*>(runs.ends + rows * runs.pitch);
+  const dim3 gr((dp.H + 3) / 4, n);                          // one wave per image row
+  hipLaunchKernelGGL(k_ccl_rows, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
+  hipLaunchKernelGGL(k_ccl_merge, gr, dim3(256), 0, st, dp, info, D, label);
+  hipLaunchKernelGGL(k_ccl_count, gr, dim3(256), 0, st, dp, info, label, size, runs);
+  hipLaunchKernelGGL(k_ccl_apply, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
 }
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);
