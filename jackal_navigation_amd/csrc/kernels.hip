@@ -1146,7 +1146,7 @@ DEV float am_weight(float x, float c) {
   const float m = __uint_as_float(__float_as_uint(__fsub_rn(x, c)) & 0x4F000000u);
   return fmaxf(0.0f, __fsub_rn(4.0f, m));
 }
-// Horizontal pass: in = D (negatives read as -10, elas.cpp:1304-1309), out = tmp; rows 3..H-4, centres 4..W-4.
+// Horizontal pass: in = D, out = tmp; rows 3..H-4, centres 4..W-4.
 __global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const FrameInfo* __restrict__ info,
                                                          const float* __restrict__ in, float* __restrict__ out) {
   const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
@@ -1155,7 +1155,10 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const Fra
   const size_t plane = (size_t)H * W;
   const float* I = in + frame * plane;
   const size_t p = (size_t)v * W + u;
-  float c = I[p]; if (c < 0) c = -10.0f;
+  // The reference first copies D with negatives replaced by -10 (elas.cpp:1304-1309).  Here every invalid pixel
+  // already holds exactly -10 when this pass runs: k_lr writes -10 for everything it rejects, speckle removal writes
+  // -10, gap interpolation only ever turns invalid pixels into valid ones.  So the copy is the identity.
+  const float c = I[p];
   float res = c;
   if (v >= 3 && v < H - 3 && u >= 4 && u <= W - 4) {
     // Window [c-4, c+3]; the reference keeps it in an 8-slot ring (slot = position mod 8) and sums lane l =
@@ -1164,9 +1167,7 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const Fra
     float pw[4], pf[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      float x0 = I[p + k - 4], x1 = I[p + k];
-      if (x0 < 0) x0 = -10.0f;
-      if (x1 < 0) x1 = -10.0f;
+      const float x0 = I[p + k - 4], x1 = I[p + k];
       const float w0 = am_weight(x0, c), w1 = am_weight(x1, c);
       pw[k] = __fadd_rn(w0, w1);
       pf[k] = __fadd_rn(__fmul_rn(x0, w0), __fmul_rn(x1, w1));

@@ -160,6 +160,34 @@ def test_batch_device_pointers_with_a_failing_frame(jn, oracle, same):
         assert same(D1[b], D1o) and same(D2[b], D2o), b
 
 
+def test_slots_in_flight_do_not_interfere(jn, oracle, same):
+    """Three batches of different pairs in flight on three slots (their kernels and host stages overlap, as in
+    bench.py), for several rounds: every output equals what the same batch gives when it runs alone."""
+    from jackal_navigation_amd.device import DeviceArray
+    W, H, n, S = 320, 240, 6, 3
+    p = jn.Elas.parameters(0, disp_max=79)
+    batches = []
+    for s in range(S):
+        Ls = np.stack([jn.node.synth_pair(W, H, 30 + 10 * s, 7000 + 10 * s + b)[0] for b in range(n)])
+        Rs = np.stack([jn.node.synth_pair(W, H, 30 + 10 * s, 7000 + 10 * s + b)[1] for b in range(n)])
+        batches.append((Ls, Rs, DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)))
+    with jn.Elas(p, W, H, max_batch=n, host_threads=4, slots=S) as e:      # 6 pairs > 4 pool threads: device filters
+        alone = []
+        for Ls, Rs, dL, dR in batches:
+            d1 = DeviceArray((n, H, W), np.float32); d2 = DeviceArray((n, H, W), np.float32)
+            assert e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr) == [0] * n
+            alone.append((d1.numpy(), d2.numpy()))
+        outs = [(DeviceArray((n, H, W), np.float32), DeviceArray((n, H, W), np.float32)) for _ in range(S)]
+        for rounds in range(4):
+            for s in range(S):
+                e.submit(s, n, batches[s][2].ptr, batches[s][3].ptr, W, H * W, outs[s][0].ptr, outs[s][1].ptr)
+            for s in range(S):
+                e.wait(s)
+                assert same(outs[s][0].numpy(), alone[s][0]) and same(outs[s][1].numpy(), alone[s][1]), (rounds, s)
+    _, D1o, D2o = oracle.process(oracle.params(0, disp_max=79), batches[1][0][3], batches[1][1][3])
+    assert same(alone[1][0][3], D1o) and same(alone[1][1][3], D2o)
+
+
 def test_full_size_batch_properties(jn, oracle, same):
     """BASELINE config 3 at full size (1280x720, D=128, batch 32): three frames bit-checked against the
     oracle (frame 4 has pixels claimed by two triangles: the reference's visiting order decides), every frame checked through size-independent properties — determinism (two runs agree),
