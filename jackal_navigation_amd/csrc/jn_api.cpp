@@ -50,7 +50,7 @@ struct Slot {
   hipEvent_t ev[EV_COUNT] = {};
   // device
   uint4* desc = nullptr; int16_t* d_can = nullptr;
-  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; BinEntry* bin_list = nullptr; float* raw = nullptr;
+  FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; BinEntry* bin_list = nullptr; int16_t* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
   std::vector<FrameScratch> scratch;

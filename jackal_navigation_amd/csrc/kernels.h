@@ -34,9 +34,9 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
                 int max_tri, int32_t* bin_count, BinEntry* bin_list);
 // Dense MAP matching with in-kernel triangle lookup (elas.cpp:683-907): raw [n][2][H][W] float.
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw);
+                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, int16_t* raw);
 // Left/right consistency (elas.cpp:909-979): raw -> D1, D2 (user buffers).
-void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2);
+void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2);
 // Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.
 void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size,
                     void* scratch);

@@ -760,7 +760,7 @@ enum { kStripTiles = 4, kStripW = kStripTiles * kTileW, kDenseThreads = 512, kPx
 __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, const FrameInfo* __restrict__ info,
                                                const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
                                                const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
-                                               const uint4* __restrict__ desc, float* __restrict__ raw, int nbx, int nby, int xcd_order) {
+                                               const uint4* __restrict__ desc, int16_t* __restrict__ raw, int nbx, int nby, int xcd_order) {
   __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
   __shared__ int s_cnt[kStripTiles];
   __shared__ uint16_t s_cover[kStripTiles][kTileH][kTileW];       // per pixel: bit k set <=> the k-th smallest listed triangle covers it
@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
   const uint4* Bzero = side ? s_B + r * span - base : s_B + r * span + span - 1 + base;
   constexpr unsigned kNoKey = 0xFFFFFFFFu;
   constexpr int kBias = 1 << 20;                             // makes cost + prior non-negative inside a key
-  float* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;
+  int16_t* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;   // integer disparity, -1 no match, -10 not visited (:797-798)
 
 #pragma unroll
   for (int q = 0; q < kPxPerThread; q++) {
@@ -941,28 +941,39 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
       const int best_d = best == kNoKey ? -1 : (int)(best & 255u);
       result = best_d >= 0 ? (float)best_d : -1.0f;                        // :778-779
     }
-    out[u] = result;
+    out[u] = (int16_t)result;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Left/right consistency (elas.cpp:909-979), out of place: raw -> D1/D2.
-__global__ void __launch_bounds__(256) k_lr(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ raw,
+__global__ void __launch_bounds__(256) k_lr(DevParams dp, const FrameInfo* __restrict__ info, const int16_t* __restrict__ raw,
                                             float* __restrict__ D1, float* __restrict__ D2) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
-  if (u >= dp.W || !info[frame].ok) return;
+  // One workgroup per image row: both raw rows go to LDS with coalesced loads, the data-dependent look-ups
+  // (the partner pixel u -/+ d in the other image's row) then hit LDS instead of scattering over the row in memory.
+  // The matcher's output is integer valued, so it travels as int16.
+  extern __shared__ int16_t s_raw[];                     // [2][W]
+  const int v = blockIdx.x, frame = blockIdx.y;
+  if (!info[frame].ok) return;
   const int W = dp.W;
   const size_t plane = (size_t)dp.H * W;
-  const float* r1 = raw + (size_t)(frame * 2) * plane + (size_t)v * W;
-  const float* r2 = r1 + plane;
-  const float d1 = r1[u], d2 = r2[u];
+  const int16_t* r1 = raw + (size_t)(frame * 2) * plane + (size_t)v * W;
+  const int16_t* r2 = r1 + plane;
+  int16_t* s1 = s_raw; int16_t* s2 = s_raw + W;
+  for (int u = threadIdx.x; u < W; u += 256) { s1[u] = r1[u]; s2[u] = r2[u]; }
+  __syncthreads();
   const float thr = (float)dp.lr_threshold;
-  float o1 = d1, o2 = d2;
-  const float w1 = (float)u - d1, w2 = (float)u + d2;
-  if (d1 >= 0 && w1 >= 0 && w1 < (float)W) { if (fabsf(r2[(int)w1] - d1) > thr) o1 = -10.0f; } else o1 = -10.0f;
-  if (d2 >= 0 && w2 >= 0 && w2 < (float)W) { if (fabsf(r1[(int)w2] - d2) > thr) o2 = -10.0f; } else o2 = -10.0f;
-  D1[(size_t)frame * plane + (size_t)v * W + u] = o1;
-  D2[(size_t)frame * plane + (size_t)v * W + u] = o2;
+  float* o1row = D1 + (size_t)frame * plane + (size_t)v * W;
+  float* o2row = D2 + (size_t)frame * plane + (size_t)v * W;
+  for (int u = threadIdx.x; u < W; u += 256) {
+    const float d1 = (float)s1[u], d2 = (float)s2[u];
+    float o1 = d1, o2 = d2;
+    const float w1 = (float)u - d1, w2 = (float)u + d2;
+    if (d1 >= 0 && w1 >= 0 && w1 < (float)W) { if (fabsf((float)s2[(int)w1] - d1) > thr) o1 = -10.0f; } else o1 = -10.0f;
+    if (d2 >= 0 && w2 >= 0 && w2 < (float)W) { if (fabsf((float)s1[(int)w2] - d2) > thr) o2 = -10.0f; } else o2 = -10.0f;
+    o1row[u] = o1;
+    o2row[u] = o2;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1584,7 +1595,7 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
   hipLaunchKernelGGL(k_bin, dim3((max_tri + kBinTris - 1) / kBinTris, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, float* raw) {
+                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, int16_t* raw) {
   const int nbx = (dp.W + kStripW - 1) / kStripW, nby = (dp.H + kTileH - 1) / kTileH;
   const int total = nbx * nby * 2 * n;
   static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
@@ -1593,8 +1604,8 @@ void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* i
   hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(kDenseThreads), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
                      nbx, nby, xcd_order);
 }
-void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* raw, float* D1, float* D2) {
-  hipLaunchKernelGGL(k_lr, grid2d(dp.W, dp.H, n), dim3(256), 0, st, dp, info, raw, D1, D2);
+void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2) {
+  hipLaunchKernelGGL(k_lr, dim3(dp.H, n), dim3(256), (size_t)2 * dp.W * sizeof(int16_t), st, dp, info, raw, D1, D2);
 }
 void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size,
                     void* scratch) {
