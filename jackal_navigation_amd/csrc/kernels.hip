@@ -49,7 +49,8 @@ DEV int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 // du/dv are only ever tapped at rows 1..H-2, columns 1..W-2 (descriptors exist for u in [3,W-4], v in [3,H-4]),
 // so whatever the patch border produces elsewhere is never looked at.  Pixels outside that range get zeros
 // (uninitialised in the reference).
-enum { kDescTW = 64, kDescTH = 16, kDescIW = (kDescTW + 8) / 4, kDescDW = (kDescTW + 4) / 4 };   // dwords per LDS row
+enum { kDescTW = 64, kDescTH = 16, kDescIW = (kDescTW + 8) / 4, kDescDW = (kDescTW + 4) / 4,   // dwords per LDS row
+       kDescTiles = 2 };                                                                        // tiles per workgroup
 typedef short pk16 __attribute__((ext_vector_type(2)));
 DEV pk16 as_pk(uint32_t x) { union { uint32_t u; pk16 p; } c; c.u = x; return c.p; }
 DEV uint32_t as_u32(pk16 p) { union { uint32_t u; pk16 p; } c; c.p = p; return c.u; }
@@ -66,21 +67,42 @@ __global__ void __launch_bounds__(256) k_descriptor_fused(DevParams dp, const ui
   __shared__ uint4 s_out[kDescTW * kDescTH];              // finished descriptors, swizzled (see below)
   const int img = blockIdx.z, W = dp.W, H = dp.H;
   const uint8_t* I = (img < n ? I1 + (long long)img * in_stride : I2 + (long long)(img - n) * in_stride);
-  const int u0 = blockIdx.x * kDescTW, v0 = blockIdx.y * kDescTH, tid = threadIdx.x;
+  const int v0 = blockIdx.y * kDescTH, tid = threadIdx.x;
   const bool aligned = ((reinterpret_cast<uintptr_t>(I) | (uintptr_t)in_pitch) & 3) == 0;
-  for (int i = tid; i < (kDescTH + 6) * kDescIW; i += 256) {
-    const int r = i / kDescIW, k = i - r * kDescIW;
-    const int v = v0 - 3 + r, u = u0 - 4 + 4 * k;
-    uint32_t w = 0;
-    if (v >= 0 && v < H) {
-      const uint8_t* src = I + (size_t)v * in_pitch + u;
-      if (aligned && u >= 0 && u + 3 < W) w = *reinterpret_cast<const uint32_t*>(src);
-      else
+  // A workgroup walks kDescTiles tiles of its tile row.  The image words of the next tile are fetched into
+  // registers while the current tile is computed: with one tile per workgroup the chain load -> Sobel -> assemble
+  // -> transpose -> store (three barriers) is latency bound even at 7 workgroups per CU (compute alone 128 us,
+  // stores alone 138 us, one after the other 235 us); 2 tiles per workgroup: 184 us, 4: 189 us, 10: 217 us.
+  constexpr int kWords = ((kDescTH + 6) * kDescIW + 255) / 256;            // patch words per thread
+  auto fetch = [&](int u0, uint32_t (&w)[kWords]) {
 #pragma unroll
-        for (int b = 0; b < 4; b++) if (u + b >= 0 && u + b < W) w |= (uint32_t)src[b] << (8 * b);
+    for (int q = 0; q < kWords; q++) {
+      const int i = tid + 256 * q;
+      const int r = i / kDescIW, k = i - r * kDescIW;
+      const int v = v0 - 3 + r, u = u0 - 4 + 4 * k;
+      uint32_t x = 0;
+      if (i < (kDescTH + 6) * kDescIW && v >= 0 && v < H) {
+        const uint8_t* src = I + (size_t)v * in_pitch + u;
+        if (aligned && u >= 0 && u + 3 < W) x = *reinterpret_cast<const uint32_t*>(src);
+        else
+#pragma unroll
+          for (int b = 0; b < 4; b++) if (u + b >= 0 && u + b < W) x |= (uint32_t)src[b] << (8 * b);
+      }
+      w[q] = x;
     }
-    s_I[r][k] = w;
+  };
+  const int tile0 = blockIdx.x * kDescTiles, tiles_x = (W + kDescTW - 1) / kDescTW;
+  const int tile1 = min(tile0 + kDescTiles, tiles_x);
+  uint32_t patch[kWords];
+  fetch(tile0 * kDescTW, patch);
+  for (int tile = tile0; tile < tile1; tile++) {
+  const int u0 = tile * kDescTW;
+#pragma unroll
+  for (int q = 0; q < kWords; q++) {
+    const int i = tid + 256 * q;
+    if (i < (kDescTH + 6) * kDescIW) s_I[i / kDescIW][i % kDescIW] = patch[q];
   }
+  if (tile + 1 < tile1) fetch(u0 + kDescTW, patch);                        // in flight during this tile's work
   __syncthreads();
   // bytes b0..b7 = image columns u0-4+4k .. +7 of one patch row; pair(j) = (b_j, b_j+1) as two 16-bit halves
 #define JN_PAIR(hi, lo, j) __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(j) | ((uint32_t)((j) + 1) << 16))
@@ -145,6 +167,7 @@ __global__ void __launch_bounds__(256) k_descriptor_fused(DevParams dp, const ui
     const int p = 256 * k + tid, vv = v0 + (p >> 6), uu = u0 + (p & 63);
     if (vv < H && uu < W) desc[((size_t)img * H + vv) * W + uu] = s_out[p ^ ((p >> 4) & 3)];
   }
+  }   // next tile: the two barriers before s_out is written again order these reads before those writes
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1523,7 +1546,8 @@ static ScanDev to_dev(const jn_scan_params& sp) {
 
 void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
                        int64_t in_stride, int n, uint4* desc) {
-  const dim3 grid((dp.W + kDescTW - 1) / kDescTW, (dp.H + kDescTH - 1) / kDescTH, 2 * n);
+  const int tiles_x = (dp.W + kDescTW - 1) / kDescTW;
+  const dim3 grid((tiles_x + kDescTiles - 1) / kDescTiles, (dp.H + kDescTH - 1) / kDescTH, 2 * n);
   hipLaunchKernelGGL(k_descriptor_fused, grid, dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, desc);
 }
 template <int PITCH>
