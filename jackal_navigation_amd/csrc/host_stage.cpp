@@ -17,12 +17,13 @@ size_t HostWorker::payload_capacity(const HostParams& hp) {
 // elas.cpp:153-179.  Column-major sweep over the lattice; a point survives if at least
 // incon_min_support lattice points (itself included) in the (2w+1)^2 window agree within
 // incon_threshold.  Deletions take effect immediately, so the sweep order is part of the result.
-// The window rows are contiguous int16, so each row is one masked 16-lane compare (AVX2).
+// The window rows are contiguous int16: each row is one 16-lane compare (AVX2) whose 0/-1 lanes are
+// subtracted into a lane-wise counter; one horizontal sum per point.
 void HostWorker::filter_inconsistent(int16_t* D) const {
   const int cw = hp_.cw, ch = hp_.ch, win = hp_.incon_window_size, tol = hp_.incon_threshold;
   const bool simd = (2 * win + 1) <= 16;
   const __m256i lanes = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-  const __m256i vtol = _mm256_set1_epi16((short)tol), vneg = _mm256_set1_epi16(-1);
+  const __m256i vtol = _mm256_set1_epi16((short)tol), vneg = _mm256_set1_epi16(-1), ones = _mm256_set1_epi16(1);
   for (int u = 0; u < cw; u++) {
     const int u0 = std::max(u - win, 0), u1 = std::min(u + win, cw - 1);
     const int span = u1 - u0 + 1;
@@ -34,13 +35,17 @@ void HostWorker::filter_inconsistent(int16_t* D) const {
       int agree = 0;
       if (simd && u0 + 16 <= cw) {
         const __m256i vd = _mm256_set1_epi16((short)d);
+        __m256i acc = _mm256_setzero_si256();
         for (int vv = v0; vv <= v1; vv++) {
           const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(D + vv * cw + u0));
           const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(vd, e));
           const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vtol), _mm256_cmpgt_epi16(e, vneg));
-          agree += __builtin_popcount((unsigned)_mm256_movemask_epi8(_mm256_and_si256(ok, in_span)));
+          acc = _mm256_sub_epi16(acc, ok);             // agreeing lanes are -1
         }
-        agree >>= 1;                                   // movemask yields two bits per int16 lane
+        const __m256i s32 = _mm256_madd_epi16(_mm256_and_si256(acc, in_span), ones);      // 8 x int32 pair sums
+        const __m128i s4 = _mm_add_epi32(_mm256_castsi256_si128(s32), _mm256_extracti128_si256(s32, 1));
+        const __m128i s2 = _mm_add_epi32(s4, _mm_shuffle_epi32(s4, 0x4E));
+        agree = _mm_cvtsi128_si32(_mm_add_epi32(s2, _mm_shuffle_epi32(s2, 0xB1)));
       } else {
         for (int vv = v0; vv <= v1; vv++) {
           const int16_t* row = D + vv * cw;
@@ -56,29 +61,61 @@ void HostWorker::filter_inconsistent(int16_t* D) const {
 }
 
 // elas.cpp:181-235.  A point is redundant when, walking up to max_dist lattice steps in BOTH
-// directions along one axis, a point within `thresh` disparity is met.
+// directions along one axis, a point within `thresh` disparity is met.  The sweep is in place: steps
+// "before" the point see this pass's deletions, steps "after" it do not.
+// Lines across the axis are independent, so `rows x cols` is walked row by row, 16 columns per AVX2 op
+// (the vertical pass as is; the horizontal pass on a transposed copy).
+static void redundant_down_rows(int16_t* D, int rows, int cols, int max_dist, int thresh) {
+  const __m256i vneg = _mm256_set1_epi16(-1), vth = _mm256_set1_epi16((short)thresh);
+  for (int r = 0; r < rows; r++) {
+    int16_t* row = D + (size_t)r * cols;
+    int c = 0;
+    for (; c + 16 <= cols; c += 16) {
+      const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(row + c));
+      __m256i before = _mm256_setzero_si256(), after = before;
+      for (int k = 1; k <= max_dist; k++) {
+        if (r - k >= 0) {
+          const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(row + c - (ptrdiff_t)k * cols));
+          before = _mm256_or_si256(before, _mm256_andnot_si256(_mm256_cmpgt_epi16(_mm256_abs_epi16(_mm256_sub_epi16(d, e)), vth),
+                                                               _mm256_cmpgt_epi16(e, vneg)));
+        }
+        if (r + k < rows) {
+          const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(row + c + (ptrdiff_t)k * cols));
+          after = _mm256_or_si256(after, _mm256_andnot_si256(_mm256_cmpgt_epi16(_mm256_abs_epi16(_mm256_sub_epi16(d, e)), vth),
+                                                             _mm256_cmpgt_epi16(e, vneg)));
+        }
+      }
+      const __m256i kill = _mm256_and_si256(_mm256_and_si256(before, after), _mm256_cmpgt_epi16(d, vneg));
+      _mm256_storeu_si256(reinterpret_cast<__m256i*>(row + c), _mm256_blendv_epi8(d, vneg, kill));
+    }
+    for (; c < cols; c++) {                                  // columns past the last full vector
+      const int d = row[c];
+      if (d < 0) continue;
+      bool before = false, after = false;
+      for (int k = 1; k <= max_dist; k++) {
+        if (r - k >= 0) { const int e = row[c - (ptrdiff_t)k * cols]; before |= e >= 0 && std::abs(d - e) <= thresh; }
+        if (r + k < rows) { const int e = row[c + (ptrdiff_t)k * cols]; after |= e >= 0 && std::abs(d - e) <= thresh; }
+      }
+      if (before && after) row[c] = -1;
+    }
+  }
+}
+static void transpose16(const int16_t* src, int rows, int cols, int16_t* dst) {   // dst [cols][rows]
+  constexpr int B = 32;
+  for (int r0 = 0; r0 < rows; r0 += B)
+    for (int c0 = 0; c0 < cols; c0 += B) {
+      const int r1 = std::min(r0 + B, rows), c1 = std::min(c0 + B, cols);
+      for (int r = r0; r < r1; r++)
+        for (int c = c0; c < c1; c++) dst[(size_t)c * rows + r] = src[(size_t)r * cols + c];
+    }
+}
 void HostWorker::filter_redundant(int16_t* D, int max_dist, int thresh, bool vertical) const {
   const int cw = hp_.cw, ch = hp_.ch;
-  const int stride = vertical ? cw : 1;
-  for (int u = 0; u < cw; u++)
-    for (int v = 0; v < ch; v++) {
-      int16_t* p = D + v * cw + u;
-      const int d = *p;
-      if (d < 0) continue;
-      const int pos = vertical ? v : u, len = vertical ? ch : cw;
-      bool both = true;
-      for (int dir = -1; dir <= 1 && both; dir += 2) {
-        bool found = false;
-        for (int j = 1; j <= max_dist; j++) {
-          const int q = pos + dir * j;
-          if (q < 0 || q >= len) break;
-          const int e = p[dir * j * stride];
-          if (e >= 0 && std::abs(d - e) <= thresh) { found = true; break; }
-        }
-        both = found;
-      }
-      if (both) *p = -1;
-    }
+  if (vertical) { redundant_down_rows(D, ch, cw, max_dist, thresh); return; }
+  tr_.resize((size_t)cw * ch);
+  transpose16(D, ch, cw, tr_.data());                        // lattice columns become rows
+  redundant_down_rows(tr_.data(), cw, ch, max_dist, thresh);
+  transpose16(tr_.data(), cw, ch, D);
 }
 
 void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs, bool filtered) const {

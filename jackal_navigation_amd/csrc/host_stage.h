@@ -47,6 +47,7 @@ class HostWorker {
  private:
   HostParams hp_;
   Delaunay dt_;
+  mutable std::vector<int16_t> tr_;              // transposed lattice for the horizontal redundancy pass
   void filter_inconsistent(int16_t* D) const;
   void filter_redundant(int16_t* D, int max_dist, int thresh, bool vertical) const;
 };
