@@ -17,35 +17,37 @@ size_t HostWorker::payload_capacity(const HostParams& hp) {
 // elas.cpp:153-179.  Column-major sweep over the lattice; a point survives if at least
 // incon_min_support lattice points (itself included) in the (2w+1)^2 window agree within
 // incon_threshold.  Deletions take effect immediately, so the sweep order is part of the result.
-// The window rows are contiguous int16: each row is one 16-lane compare (AVX2) whose 0/-1 lanes are
-// subtracted into a lane-wise counter; one horizontal sum per point.
+// The window rows are contiguous int16: each row is one masked 16-lane compare (AVX2).
 void HostWorker::filter_inconsistent(int16_t* D) const {
   const int cw = hp_.cw, ch = hp_.ch, win = hp_.incon_window_size, tol = hp_.incon_threshold;
   const bool simd = (2 * win + 1) <= 16;
-  const __m256i lanes = _mm256_setr_epi16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-  const __m256i vtol = _mm256_set1_epi16((short)tol), vneg = _mm256_set1_epi16(-1), ones = _mm256_set1_epi16(1);
+  const __m256i vtol = _mm256_set1_epi16((short)tol), vneg = _mm256_set1_epi16(-1);
   for (int u = 0; u < cw; u++) {
     const int u0 = std::max(u - win, 0), u1 = std::min(u + win, cw - 1);
     const int span = u1 - u0 + 1;
-    const __m256i in_span = _mm256_cmpgt_epi16(_mm256_set1_epi16((short)span), lanes);
     for (int v = 0; v < ch; v++) {
       const int d = D[v * cw + u];
       if (d < 0) continue;
       const int v0 = std::max(v - win, 0), v1 = std::min(v + win, ch - 1);
       int agree = 0;
       if (simd && u0 + 16 <= cw) {
+        // Only "at least incon_min_support or not" matters, so the rows are visited from the point's own row outwards
+        // and the scan stops as soon as the threshold is reached — after one or two rows wherever the lattice is
+        // dense; only the sparse points that end up deleted see all 2w+1 rows.
         const __m256i vd = _mm256_set1_epi16((short)d);
-        __m256i acc = _mm256_setzero_si256();
-        for (int vv = v0; vv <= v1; vv++) {
-          const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(D + vv * cw + u0));
-          const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(vd, e));
-          const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vtol), _mm256_cmpgt_epi16(e, vneg));
-          acc = _mm256_sub_epi16(acc, ok);             // agreeing lanes are -1
-        }
-        const __m256i s32 = _mm256_madd_epi16(_mm256_and_si256(acc, in_span), ones);      // 8 x int32 pair sums
-        const __m128i s4 = _mm_add_epi32(_mm256_castsi256_si128(s32), _mm256_extracti128_si256(s32, 1));
-        const __m128i s2 = _mm_add_epi32(s4, _mm_shuffle_epi32(s4, 0x4E));
-        agree = _mm_cvtsi128_si32(_mm_add_epi32(s2, _mm_shuffle_epi32(s2, 0xB1)));
+        const unsigned span_bits = span >= 16 ? 0xFFFFFFFFu : ((1u << (2 * span)) - 1u);   // two mask bits per int16 lane
+        const int need2 = 2 * hp_.incon_min_support;
+        int agree2 = 0;
+        for (int k = 0; k <= win && agree2 < need2; k++)
+          for (int sgn = 0; sgn < (k ? 2 : 1); sgn++) {
+            const int vv = sgn ? v + k : v - k;
+            if (vv < v0 || vv > v1) continue;
+            const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(D + vv * cw + u0));
+            const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(vd, e));
+            const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vtol), _mm256_cmpgt_epi16(e, vneg));
+            agree2 += __builtin_popcount((unsigned)_mm256_movemask_epi8(ok) & span_bits);
+          }
+        agree = agree2 >> 1;
       } else {
         for (int vv = v0; vv <= v1; vv++) {
           const int16_t* row = D + vv * cw;
