@@ -105,7 +105,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
   launch_support(st, dp, n, s.desc, s.d_can);
   const bool filtered = n >= h->filter_min_batch &&
-      launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can);
+      launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
   HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
   const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
   HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));

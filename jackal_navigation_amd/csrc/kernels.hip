@@ -398,6 +398,37 @@ __device__ __forceinline__ void lattice_store(const int16_t* base, int16_t* g, i
     g[v * cw + u] = base[(v - v0) * pw + (u - u0)];
   }
 }
+// Whole-lattice variants for widths that are multiples of 8: 16-byte global accesses, all of a thread's loads in
+// flight together (the generic loops above wait out one 2-byte load per iteration), the border written separately.
+__device__ __forceinline__ void lattice_load_all(int16_t* s, const int16_t* g, int cw, int ch, int win, int pw) {
+  const int ph = ch + 2 * win;
+  if (cw & 7) { lattice_load(s, g, cw, ch, -win, cw + win, -win, ch + win, pw); return; }
+  for (int i = threadIdx.x; i < pw * ph; i += kFilterThreads) {            // border cells
+    const int r = i / pw, c = i - r * pw;
+    if (r < win || r >= ch + win || c < win || c >= cw + win) s[i] = -1;
+  }
+  const int per_row = cw >> 3, total = per_row * ch;
+  const uint4* g4 = reinterpret_cast<const uint4*>(g);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < total; i += kFilterThreads) {
+    const int r = i / per_row, c = (i - r * per_row) << 3;
+    const uint4 x = g4[i];
+    int16_t* d = s + (r + win) * pw + win + c;
+    d[0] = (int16_t)(x.x & 0xFFFF); d[1] = (int16_t)(x.x >> 16); d[2] = (int16_t)(x.y & 0xFFFF); d[3] = (int16_t)(x.y >> 16);
+    d[4] = (int16_t)(x.z & 0xFFFF); d[5] = (int16_t)(x.z >> 16); d[6] = (int16_t)(x.w & 0xFFFF); d[7] = (int16_t)(x.w >> 16);
+  }
+}
+__device__ __forceinline__ void lattice_store_all(const int16_t* s, int16_t* g, int cw, int ch, int win, int pw) {
+  if (cw & 7) { lattice_store(s + win * pw + win, g, cw, 0, cw, 0, ch, pw); return; }
+  const int per_row = cw >> 3, total = per_row * ch;
+  uint4* g4 = reinterpret_cast<uint4*>(g);
+#pragma unroll 4
+  for (int i = threadIdx.x; i < total; i += kFilterThreads) {
+    const int r = i / per_row, c = (i - r * per_row) << 3;
+    const uint16_t* d = reinterpret_cast<const uint16_t*>(s + (r + win) * pw + win + c);
+    g4[i] = make_uint4(d[0] | ((uint32_t)d[1] << 16), d[2] | ((uint32_t)d[3] << 16), d[4] | ((uint32_t)d[5] << 16), d[6] | ((uint32_t)d[7] << 16));
+  }
+}
 // The skewed wavefront of the inconsistency filter over columns [0,ncols) of an LDS block (base = cell (0,0),
 // a border of WIN cells readable on every side).  L lanes per point share the (2*WIN+1)^2 window cells;
 // kFilterThreads / L points per step cover lattices of up to K * kFilterThreads / L rows.
@@ -445,6 +476,146 @@ __device__ __forceinline__ void incon_wavefront(int16_t* base, int pw, int ncols
     }
   }
 }
+// ---- The inconsistency filter without the serial sweep --------------------------------------------------------
+// When the sweep reaches a point p, the points after p (in sweep order) still hold their original values, so they
+// contribute later(p) = #{q in window, q after p, agreeing} no matter what happened before; the points before p
+// contribute only if they survived.  Hence, from the ORIGINAL lattice alone:
+//   1 + later(p) >= min_support                 p survives for sure
+//   1 + later(p) + earlier0(p) < min_support    p is deleted for sure   (earlier0 = agreeing points before p)
+// and only the rest — a few per cent, at the rims of sparse regions — depends on the fate of earlier points.
+// k_filter_classify computes that in parallel over all points and frames (code: 0 dead or invalid, 255 survivor,
+// otherwise 1 + later(p), the part of the count that is already certain).  k_filter_resolve then walks the undecided
+// points of a frame in sweep order with one wave: each looks up which of its earlier agreeing neighbours survived
+// (all decided by then), one lane per window cell.  Exactly the reference's result, ~30 dependent steps per frame
+// instead of 6*cw.
+template <int WIN>
+__global__ void __launch_bounds__(256) k_filter_classify(DevParams dp, int tol, int min_support, const int16_t* __restrict__ d_can,
+                                                         uint8_t* __restrict__ code) {
+  constexpr int T = 16, TW = T + 2 * WIN;
+  __shared__ int16_t s_t[TW][TW + 2];
+  const int cw = dp.cw, ch = dp.ch, frame = blockIdx.z;
+  const int u0 = blockIdx.x * T, v0 = blockIdx.y * T;
+  const int16_t* g = d_can + (size_t)frame * cw * ch;
+  for (int i = threadIdx.x; i < TW * TW; i += 256) {
+    const int r = i / TW, c = i - r * TW, v = v0 - WIN + r, u = u0 - WIN + c;
+    s_t[r][c] = (v >= 0 && v < ch && u >= 0 && u < cw) ? g[v * cw + u] : (int16_t)-1;
+  }
+  __syncthreads();
+  const int x = threadIdx.x & (T - 1), y = threadIdx.x / T, u = u0 + x, v = v0 + y;
+  if (u >= cw || v >= ch) return;
+  const int d = s_t[y + WIN][x + WIN];
+  int out = 0;
+  if (d >= 0) {
+    const int lo = max(d - tol, 0);
+    const unsigned span = (unsigned)(d + tol - lo);
+    int later = 0, earlier = 0;
+#pragma unroll
+    for (int du = -WIN; du <= WIN; du++)
+#pragma unroll
+      for (int dv = -WIN; dv <= WIN; dv++) {
+        if (du == 0 && dv == 0) continue;
+        const int hit = (unsigned)((int)s_t[y + WIN + dv][x + WIN + du] - lo) <= span ? 1 : 0;
+        if (du > 0 || (du == 0 && dv > 0)) later += hit; else earlier += hit;      // sweep order: u outer, v inner
+      }
+    const int sure = 1 + later;
+    out = sure >= min_support ? 255 : (sure + earlier < min_support ? 0 : sure);
+  }
+  code[(size_t)frame * cw * ch + (size_t)u * ch + v] = (uint8_t)out;             // column-major = sweep order
+}
+constexpr int kFilterTodo = 2048;                                   // undecided points listed per frame (more: in-order scan)
+template <int WIN>
+__global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can,
+                                                                   const uint8_t* __restrict__ code) {
+  extern __shared__ int16_t s_lat[];                      // lattice with a border of WIN cells, then the codes
+  static_assert(WIN == 5, "redundant_line's window is the reference's fixed max_dist 5");
+  const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x, N = cw * ch;
+  const int pw = cw + 2 * WIN, ph = ch + 2 * WIN;
+  int16_t* g = d_can + (size_t)blockIdx.x * N;
+  uint8_t* s_code = reinterpret_cast<uint8_t*>(s_lat + (size_t)pw * ph);
+  lattice_load_all(s_lat, g, cw, ch, WIN, pw);
+  {
+    const uint8_t* src = code + (size_t)blockIdx.x * N;
+    if ((N & 3) == 0 && ((pw * ph) & 1) == 0) {                          // dword copy: frame offset and LDS offset are multiples of 4
+      const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src);
+      uint32_t* d4 = reinterpret_cast<uint32_t*>(s_code);
+#pragma unroll 4
+      for (int i = tid; i < (N >> 2); i += kFilterThreads) d4[i] = s4[i];
+    } else
+      for (int i = tid; i < N; i += kFilterThreads) s_code[i] = src[i];
+  }
+  __syncthreads();
+  int16_t* base = s_lat + WIN * pw + WIN;                  // base[v * pw + u] = lattice (u, v)
+  // List the undecided points in sweep order: every thread owns a contiguous stretch of the (column-major) codes,
+  // counts its undecided points, an exclusive scan over the threads gives its place in the list.  Points that are
+  // dead for sure leave the lattice on the way (the resolution below never looks at the value of a dead point).
+  __shared__ int s_off[kFilterThreads + 1];
+  __shared__ uint16_t s_todo[kFilterTodo];
+  const int per = (N + kFilterThreads - 1) / kFilterThreads, i_lo = min(tid * per, N), i_hi = min(i_lo + per, N);
+  int mine = 0;
+  {
+    int u = i_lo / ch, v = i_lo - u * ch;
+    for (int i = i_lo; i < i_hi; i++) {
+      const int c = s_code[i];
+      mine += (c != 0 && c != 255) ? 1 : 0;
+      if (c == 0) base[v * pw + u] = -1;
+      if (++v == ch) { v = 0; u++; }
+    }
+  }
+  s_off[tid + 1] = mine;
+  if (tid == 0) s_off[0] = 0;
+  __syncthreads();
+  for (int step = 1; step < kFilterThreads; step <<= 1) {    // inclusive scan of s_off[1..]
+    const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
+    __syncthreads();
+    s_off[tid + 1] += add;
+    __syncthreads();
+  }
+  const int total = s_off[kFilterThreads];
+  if (total <= kFilterTodo) {
+    int at = s_off[tid];
+    for (int i = i_lo; i < i_hi; i++) { const int c = s_code[i]; if (c != 0 && c != 255) s_todo[at++] = (uint16_t)i; }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // lane -> one of the 60 window cells that precede the point in sweep order: 5 columns to the left (11 rows each),
+    // then the 5 cells above in its own column
+    constexpr int ROWS = 2 * WIN + 1, LEFT = WIN * ROWS;
+    const int du = tid < LEFT ? tid / ROWS - WIN : 0;
+    const int dv = tid < LEFT ? tid % ROWS - WIN : tid - LEFT - WIN;
+    const bool cell = tid < LEFT + WIN;
+    auto resolve = [&](int pidx) {
+      const int u = pidx / ch, v = pidx - u * ch;
+      const int d = base[v * pw + u], sure = s_code[pidx];
+      bool hit = false;
+      if (cell) {
+        const int e = base[(v + dv) * pw + (u + du)];        // the border reads as invalid
+        if (e >= 0 && abs(d - e) <= tol) hit = s_code[(u + du) * ch + (v + dv)] == 255;
+      }
+      const int count = sure + __popcll(__ballot(hit));
+      if (tid == 0) {
+        const bool lives = count >= min_support;
+        s_code[pidx] = lives ? 255 : 0;
+        if (!lives) base[v * pw + u] = -1;
+      }
+    };
+    if (total <= kFilterTodo) {
+      for (int k = 0; k < total; k++) resolve(s_todo[k]);
+    } else {                                                 // more undecided points than the list holds: scan the codes in order
+      for (int i0 = 0; i0 < N; i0 += 64) {
+        const int c = i0 + tid < N ? (int)s_code[i0 + tid] : 0;
+        unsigned long long todo = __ballot(c != 0 && c != 255);
+        while (todo) { const int bit = __builtin_ctzll(todo); todo &= todo - 1; resolve(i0 + bit); }
+      }
+    }
+  }
+  __syncthreads();
+  for (int u = tid; u < cw; u += kFilterThreads) redundant_line(base + u, pw, ch);        // vertical pass (elas.cpp:421)
+  __syncthreads();
+  for (int v = tid; v < ch; v += kFilterThreads) redundant_line(base + v * pw, 1, cw);    // horizontal pass (elas.cpp:422)
+  __syncthreads();
+  lattice_store_all(s_lat, g, cw, ch, WIN, pw);
+}
+
 // seg_c == 0: the whole lattice (plus border) sits in LDS for all three passes.  Otherwise the lattice is larger
 // than the LDS and every pass streams it through in pieces, global memory holding the state in between: the
 // inconsistency filter by column segments [u0,u1) — the sweep is column-major, so a segment only needs the final
@@ -1568,9 +1739,29 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
   else if (dp.W <= 2560) launch_support_pitch<2560>(st, dp, n, desc, d_can);
   else hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
-bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can) {
+bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,
+                            void* scratch) {
   constexpr int WIN = 5, K = WIN + 1;                               // the reference's incon_window_size (elas.h:97)
   if (win != WIN) return false;                                     // other window sizes: the host stage filters
+  {
+    // classify + resolve when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
+    // skewed-wavefront kernel below (A/B and test hook), which also serves lattices that need streaming
+    static const bool wavefront_only = getenv("JN_FILTER_WAVEFRONT") != nullptr && atoi(getenv("JN_FILTER_WAVEFRONT")) != 0;
+    const char* kb = getenv("JN_FILTER_LDS_KB");
+    const size_t budget_bytes = (size_t)(kb ? atoi(kb) : 150) * 1024;
+    const size_t need = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
+    if (!wavefront_only && need <= budget_bytes && min_support >= 1 && min_support <= 254 && scratch) {
+      static bool configured_fast = false;
+      if (!configured_fast) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
+        configured_fast = true;
+      }
+      uint8_t* code = reinterpret_cast<uint8_t*>(scratch);          // [n][cw*ch], column-major
+      hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
+      hipLaunchKernelGGL(k_filter_resolve<WIN>, dim3(n), dim3(kFilterThreads), need, st, dp, tol, min_support, d_can, code);
+      return true;
+    }
+  }
   // LDS budget in int16 cells (JN_FILTER_LDS_KB shrinks it: a test hook that forces the streamed variant)
   const char* env = getenv("JN_FILTER_LDS_KB");
   const int budget = (env ? atoi(env) : 150) * 1024 / (int)sizeof(int16_t);

@@ -97,6 +97,9 @@ def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypat
             monkeypatch.setenv("JN_HOST_FILTERS", "1" if host else "0")      # unset = by batch size
             st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=95, **kw), L, R)
             assert st == 0 and same(D1, D1o) and same(D2, D2o), (kw, host)
+    # the device route has two forms: classification + in-order resolution of the undecided points (default when
+    # lattice and codes fit the LDS) and the skewed wavefront (JN_FILTER_WAVEFRONT=1, read once per process, so the
+    # wavefront is exercised through the LDS budget below, which the default form does not fit)
     # lattices larger than the LDS are streamed through it in column / row pieces (1920x1080 does that for real);
     # a small LDS budget forces the same code on this small image, with 2 and with 5 column pieces
     monkeypatch.setenv("JN_HOST_FILTERS", "0")
