@@ -77,9 +77,11 @@ struct jn_elas {
   // frame, so its duration does not depend on the batch size; the host filters take one pool round per
   // `threads` frames.  The device wins once a batch needs more than one round (and it frees the pool for Delaunay);
   // for a lone pair or a batch the pool swallows at once the host is quicker.  JN_HOST_FILTERS at create time:
-  // unset = device when the batch exceeds the pool size, "1" = always host, "0" = always device.  The host also
-  // takes over when the kernel cannot take the lattice.
+  // unset = device when the classify + resolve kernels apply (no serial sweep; lattice and codes fit the LDS) or the
+  // batch exceeds the pool size, "1" = always host, "0" = always device.  The host also takes over when no kernel can
+  // take the lattice.
   int filter_min_batch = 4;
+  bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
   // staging for the host-pointer drop-in call
@@ -104,7 +106,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   launch_descriptor(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
   HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
   launch_support(st, dp, n, s.desc, s.d_can);
-  const bool filtered = n >= h->filter_min_batch &&
+  const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
       launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
   HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
   const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -273,6 +275,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   nthreads = std::min(nthreads, std::max(1, max_batch * slots));
   h->pool.reset(new Pool(nthreads, hp));
   h->filter_min_batch = nthreads + 1;
+  h->filters_fast = support_filters_fast(h->dp, p->incon_window_size, p->incon_min_support);
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;

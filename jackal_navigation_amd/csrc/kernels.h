@@ -20,6 +20,8 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
 
 // In-place support-point filters (elas.cpp:153-235 as called at :416-422) on d_can.  Returns false (nothing
 // launched) when the lattice does not fit the LDS; the host stage then runs them.
+// true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
+bool support_filters_fast(const DevParams& dp, int win, int min_support);
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,
                             void* scratch);
 

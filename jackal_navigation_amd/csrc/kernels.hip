@@ -1247,21 +1247,24 @@ __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo*
 // column of the contact between its run and the run below (the pixel to its left belongs to the
 // same two runs otherwise), which removes almost all redundant atomics.
 __global__ void __launch_bounds__(256) k_ccl_merge(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
-                                                   int32_t* __restrict__ lab) {
-  // one wave per pair of rows (v, v+1), 64 columns at a time; left neighbours come from the lane below
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
+                                                   int32_t* __restrict__ lab, int segs) {
+  // one wave per pair of rows (v, v+1) — per column segment of it when a small batch has few rows to offer —
+  // 64 columns at a time; left neighbours come from the lane below
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), v = wave / segs, seg = wave - v * segs, frame = blockIdx.y;
   if (v + 1 >= dp.H || !info[frame].ok) return;
   const int W = dp.W, lane = threadIdx.x & 63;
+  const int seg_len = ((W + segs - 1) / segs + 63) & ~63, c0 = seg * seg_len, c1 = min(c0 + seg_len, W);
+  if (c0 >= W) return;
   const size_t plane = (size_t)dp.H * W;
   const float* r0 = D + frame * plane + (size_t)v * W;
   const float* r1 = r0 + W;
   int32_t* L = lab + frame * plane;
   const float sim = dp.speckle_sim;
-  float a_left = -10.0f, b_left = -10.0f;                   // column just before the chunk
-  float a = lane < W ? r0[lane] : -10.0f, b = lane < W ? r1[lane] : -10.0f;
-  for (int u0 = 0; u0 < W; u0 += 64) {
+  float a_left = c0 > 0 ? r0[c0 - 1] : -10.0f, b_left = c0 > 0 ? r1[c0 - 1] : -10.0f;      // column just before the chunk
+  float a = c0 + lane < c1 ? r0[c0 + lane] : -10.0f, b = c0 + lane < c1 ? r1[c0 + lane] : -10.0f;
+  for (int u0 = c0; u0 < c1; u0 += 64) {
     const int u = u0 + lane;
-    const float an = u + 64 < W ? r0[u + 64] : -10.0f, bn = u + 64 < W ? r1[u + 64] : -10.0f;   // next chunk in flight
+    const float an = u + 64 < c1 ? r0[u + 64] : -10.0f, bn = u + 64 < c1 ? r1[u + 64] : -10.0f;   // next chunk in flight
     float a0 = __shfl_up(a, 1), b0 = __shfl_up(b, 1);
     if (lane == 0) { a0 = a_left; b0 = b_left; }
     const bool contact = a >= 0 && b >= 0 && fabsf(a - b) <= sim;
@@ -1739,18 +1742,22 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
   else if (dp.W <= 2560) launch_support_pitch<2560>(st, dp, n, desc, d_can);
   else hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
+// classify + resolve applies when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
+// skewed-wavefront kernel (A/B and test hook), which also serves lattices that need streaming
+bool support_filters_fast(const DevParams& dp, int win, int min_support) {
+  static const bool wavefront_only = getenv("JN_FILTER_WAVEFRONT") != nullptr && atoi(getenv("JN_FILTER_WAVEFRONT")) != 0;
+  const char* kb = getenv("JN_FILTER_LDS_KB");
+  const size_t budget_bytes = (size_t)(kb ? atoi(kb) : 150) * 1024;
+  const size_t need = (size_t)(dp.cw + 10) * (dp.ch + 10) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
+  return win == 5 && !wavefront_only && need <= budget_bytes && min_support >= 1 && min_support <= 254;
+}
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,
                             void* scratch) {
   constexpr int WIN = 5, K = WIN + 1;                               // the reference's incon_window_size (elas.h:97)
   if (win != WIN) return false;                                     // other window sizes: the host stage filters
   {
-    // classify + resolve when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
-    // skewed-wavefront kernel below (A/B and test hook), which also serves lattices that need streaming
-    static const bool wavefront_only = getenv("JN_FILTER_WAVEFRONT") != nullptr && atoi(getenv("JN_FILTER_WAVEFRONT")) != 0;
-    const char* kb = getenv("JN_FILTER_LDS_KB");
-    const size_t budget_bytes = (size_t)(kb ? atoi(kb) : 150) * 1024;
     const size_t need = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
-    if (!wavefront_only && need <= budget_bytes && min_support >= 1 && min_support <= 254 && scratch) {
+    if (support_filters_fast(dp, win, min_support) && scratch) {
       static bool configured_fast = false;
       if (!configured_fast) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
@@ -1833,7 +1840,10 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
   runs.count = reinterpret_cast<int32_t*>(runs.ends + rows * runs.pitch);
   const dim3 gr((dp.H + 3) / 4, n);                          // one wave per image row
   hipLaunchKernelGGL(k_ccl_rows, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
-  hipLaunchKernelGGL(k_ccl_merge, gr, dim3(256), 0, st, dp, info, D, label);
+  // enough waves to fill the GPU even for a lone small pair: split the rows of the merge pass into column segments
+  const int row_waves = dp.H * n, chunks = (dp.W + 63) / 64;
+  const int segs = row_waves >= 4096 ? 1 : max(1, min(chunks, 4096 / max(row_waves, 1)));
+  hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs);
   hipLaunchKernelGGL(k_ccl_count, gr, dim3(256), 0, st, dp, info, label, size, runs);
   hipLaunchKernelGGL(k_ccl_apply, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
 }
