@@ -616,6 +616,80 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
   lattice_store_all(s_lat, g, cw, ch, WIN, pw);
 }
 
+// The same resolution for lattices too large to sit in LDS next to their codes (1920x1080: 166 KB + 83 KB): only the
+// codes are in LDS, candidate values come from memory (a few dozen undecided points x 60 cells), deaths are written
+// straight to the lattice; the redundancy passes follow in k_support_filters with the sweep switched off.
+template <int WIN>
+__global__ void __launch_bounds__(kFilterThreads) k_filter_resolve_big(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can,
+                                                                       const uint8_t* __restrict__ code) {
+  extern __shared__ int16_t s_lat[];
+  uint8_t* s_code = reinterpret_cast<uint8_t*>(s_lat);
+  __shared__ int s_off[kFilterThreads + 1];
+  __shared__ uint32_t s_todo[kFilterTodo / 2];             // 32-bit indices: these lattices can exceed 65536 points
+  const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x, N = cw * ch;
+  int16_t* g = d_can + (size_t)blockIdx.x * N;
+  const uint8_t* src = code + (size_t)blockIdx.x * N;
+  for (int i = tid; i < N; i += kFilterThreads) s_code[i] = src[i];
+  __syncthreads();
+  const int per = (N + kFilterThreads - 1) / kFilterThreads, i_lo = min(tid * per, N), i_hi = min(i_lo + per, N);
+  int mine = 0;
+  {
+    int u = i_lo / ch, v = i_lo - u * ch;
+    for (int i = i_lo; i < i_hi; i++) {
+      const int c = s_code[i];
+      mine += (c != 0 && c != 255) ? 1 : 0;
+      if (c == 0) g[v * cw + u] = -1;                        // dead for sure (or invalid already)
+      if (++v == ch) { v = 0; u++; }
+    }
+  }
+  s_off[tid + 1] = mine;
+  if (tid == 0) s_off[0] = 0;
+  __syncthreads();
+  for (int step = 1; step < kFilterThreads; step <<= 1) {
+    const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
+    __syncthreads();
+    s_off[tid + 1] += add;
+    __syncthreads();
+  }
+  const int total = s_off[kFilterThreads];
+  const bool listed = total <= kFilterTodo / 2;
+  if (listed) {
+    int at = s_off[tid];
+    for (int i = i_lo; i < i_hi; i++) { const int c = s_code[i]; if (c != 0 && c != 255) s_todo[at++] = (uint32_t)i; }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  constexpr int ROWS = 2 * WIN + 1, LEFT = WIN * ROWS;
+  const int du = tid < LEFT ? tid / ROWS - WIN : 0;
+  const int dv = tid < LEFT ? tid % ROWS - WIN : tid - LEFT - WIN;
+  const bool cell = tid < LEFT + WIN;
+  auto resolve = [&](int pidx) {
+    const int u = pidx / ch, v = pidx - u * ch;
+    const int d = g[v * cw + u], sure = s_code[pidx];
+    bool hit = false;
+    const int uu = u + du, vv = v + dv;
+    if (cell && uu >= 0 && uu < cw && vv >= 0 && vv < ch && s_code[uu * ch + vv] == 255) {   // survivors keep their value
+      const int e = g[vv * cw + uu];
+      hit = abs(d - e) <= tol;
+    }
+    const int count = sure + __popcll(__ballot(hit));
+    if (tid == 0) {
+      const bool lives = count >= min_support;
+      s_code[pidx] = lives ? 255 : 0;
+      if (!lives) g[v * cw + u] = -1;
+    }
+  };
+  if (listed) {
+    for (int k = 0; k < total; k++) resolve((int)s_todo[k]);
+  } else {
+    for (int i0 = 0; i0 < N; i0 += 64) {
+      const int c = i0 + tid < N ? (int)s_code[i0 + tid] : 0;
+      unsigned long long todo = __ballot(c != 0 && c != 255);
+      while (todo) { const int bit = __builtin_ctzll(todo); todo &= todo - 1; resolve(i0 + bit); }
+    }
+  }
+}
+
 // seg_c == 0: the whole lattice (plus border) sits in LDS for all three passes.  Otherwise the lattice is larger
 // than the LDS and every pass streams it through in pieces, global memory holding the state in between: the
 // inconsistency filter by column segments [u0,u1) — the sweep is column-major, so a segment only needs the final
@@ -623,7 +697,9 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
 // the same column segments, the horizontal one by row segments of seg_r rows.
 template <int WIN, int L>
 __global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can,
-                                                                    int seg_c, int seg_r) {
+                                                                    int seg_c, int seg_r, int sweep) {
+  // sweep == 0: the inconsistency filter has been applied already (k_filter_classify + k_filter_resolve_big); only
+  // the two redundancy passes run
   extern __shared__ int16_t s_lat[];
   static_assert(WIN == 5, "redundant_line's window is the reference's fixed max_dist 5");
   static_assert(L == 16 || L == 8, "the DPP reduction covers 8 or 16 lanes");
@@ -634,7 +710,7 @@ __global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp
     lattice_load(s_lat, g, cw, ch, -WIN, cw + WIN, -WIN, ch + WIN, pw);
     __syncthreads();
     int16_t* base = s_lat + WIN * pw + WIN;                  // base[v * pw + u] = lattice (u, v)
-    incon_wavefront<WIN, L>(base, pw, cw, ch, tol, min_support);
+    if (sweep) incon_wavefront<WIN, L>(base, pw, cw, ch, tol, min_support);
     __syncthreads();
     for (int u = tid; u < cw; u += kFilterThreads) redundant_line(base + u, pw, ch);        // vertical pass (elas.cpp:421)
     __syncthreads();
@@ -645,7 +721,7 @@ __global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp
   }
   const int pwc = seg_c + 2 * WIN;
   int16_t* cbase = s_lat + WIN * pwc + WIN;
-  for (int u0 = 0; u0 < cw; u0 += seg_c) {                   // inconsistency filter (elas.cpp:416)
+  for (int u0 = 0; sweep && u0 < cw; u0 += seg_c) {          // inconsistency filter (elas.cpp:416)
     const int u1 = min(u0 + seg_c, cw);
     lattice_load(s_lat, g, cw, ch, u0 - WIN, u1 + WIN, -WIN, ch + WIN, pwc);
     __syncthreads();
@@ -1744,20 +1820,24 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
 }
 // classify + resolve applies when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
 // skewed-wavefront kernel (A/B and test hook), which also serves lattices that need streaming
-bool support_filters_fast(const DevParams& dp, int win, int min_support) {
+// 2: lattice and codes fit the LDS together (k_filter_resolve), 1: only the codes do (k_filter_resolve_big), 0: neither
+static int support_filters_form(const DevParams& dp, int win, int min_support) {
   static const bool wavefront_only = getenv("JN_FILTER_WAVEFRONT") != nullptr && atoi(getenv("JN_FILTER_WAVEFRONT")) != 0;
   const char* kb = getenv("JN_FILTER_LDS_KB");
   const size_t budget_bytes = (size_t)(kb ? atoi(kb) : 150) * 1024;
-  const size_t need = (size_t)(dp.cw + 10) * (dp.ch + 10) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
-  return win == 5 && !wavefront_only && need <= budget_bytes && min_support >= 1 && min_support <= 254;
+  const size_t codes = (size_t)dp.cw * dp.ch, both = (size_t)(dp.cw + 10) * (dp.ch + 10) * sizeof(int16_t) + codes;
+  if (win != 5 || wavefront_only || min_support < 1 || min_support > 254) return 0;
+  return both <= budget_bytes ? 2 : (codes <= budget_bytes ? 1 : 0);
 }
+bool support_filters_fast(const DevParams& dp, int win, int min_support) { return support_filters_form(dp, win, min_support) != 0; }
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,
                             void* scratch) {
   constexpr int WIN = 5, K = WIN + 1;                               // the reference's incon_window_size (elas.h:97)
   if (win != WIN) return false;                                     // other window sizes: the host stage filters
+  const int form = scratch ? support_filters_form(dp, win, min_support) : 0;
   {
     const size_t need = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
-    if (support_filters_fast(dp, win, min_support) && scratch) {
+    if (form == 2) {
       static bool configured_fast = false;
       if (!configured_fast) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
@@ -1792,8 +1872,20 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
     configured = true;
   }
   const size_t lds = (size_t)cells * sizeof(int16_t);
-  if (lanes == 16) hipLaunchKernelGGL((k_support_filters<WIN, 16>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r);
-  else             hipLaunchKernelGGL((k_support_filters<WIN, 8>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r);
+  int sweep = 1;
+  if (form == 1) {                                                  // classify + resolve from memory; the kernel below only runs the redundancy passes
+    static bool configured_big = false;
+    if (!configured_big) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve_big<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
+      configured_big = true;
+    }
+    uint8_t* code = reinterpret_cast<uint8_t*>(scratch);
+    hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
+    hipLaunchKernelGGL(k_filter_resolve_big<WIN>, dim3(n), dim3(kFilterThreads), ((size_t)cw * ch + 3) & ~(size_t)3, st, dp, tol, min_support, d_can, code);
+    sweep = 0;
+  }
+  if (lanes == 16) hipLaunchKernelGGL((k_support_filters<WIN, 16>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r, sweep);
+  else             hipLaunchKernelGGL((k_support_filters<WIN, 8>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r, sweep);
   return true;
 }
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,

@@ -104,7 +104,7 @@ def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypat
     # a small LDS budget forces the same code on this small image, with 2 and with 5 column pieces
     monkeypatch.setenv("JN_HOST_FILTERS", "0")
     _, D1o, D2o = oracle.process(oracle.params(0, disp_max=95), L, R)
-    for kb in ("16", "6"):
+    for kb in ("16", "12", "6"):          # 16: codes + lattice do not fit, codes alone do (resolution from memory); 6: wavefront in pieces
         monkeypatch.setenv("JN_FILTER_LDS_KB", kb)
         st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=95), L, R)
         assert st == 0 and same(D1, D1o) and same(D2, D2o), kb
