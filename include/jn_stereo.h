@@ -244,6 +244,13 @@ typedef struct jn_host_frame_info {
 int64_t jn_host_stage(const jn_elas_params* p, int32_t width, int32_t height, int16_t* d_can, uint8_t* payload,
                       int64_t payload_cap, jn_host_frame_info* info);
 
+/* The GPU's support filters on their own (elas.cpp:416-422 on n candidate lattices [n][ch][cw], host memory, filtered in
+ * place), exposed so that the kernels can be verified on arbitrary lattices.  form: 0 = whatever jn_elas would use,
+ * 1 = skewed wavefront, 2 = classification + resolution.  Returns JN_ERR_UNSUPPORTED when no kernel takes the lattice
+ * (jn_elas then filters on the host). */
+jn_status jn_device_support_filters(int32_t device, const jn_elas_params* p, int32_t width, int32_t height, int32_t n,
+                                    int16_t* d_can, int32_t form);
+
 /* ---------------------------------------------------------------------------------------------
  * Scan consumer: the decision navigate.cpp takes from one LaserScan.  Host code;
  * present so that scans from this library can be checked to drive the same stop / turn decisions.

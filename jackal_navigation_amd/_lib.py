@@ -87,7 +87,7 @@ EXPORTS = [
     "jn_synth_pair", "jn_device_count", "jn_device_malloc", "jn_device_free", "jn_memcpy_h2d", "jn_memcpy_d2h",
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
-    "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote",
+    "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote", "jn_device_support_filters",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def load():
     L.jn_host_triangulate.argtypes = [vp, vp, i32, vp]
     L.jn_host_stage.argtypes = [C.POINTER(ElasParams), i32, i32, vp, vp, i64, vp]
     L.jn_host_stage.restype = i64
+    L.jn_device_support_filters.argtypes = [i32, C.POINTER(ElasParams), i32, i32, i32, vp, i32]
     L.jn_nav_params_default.argtypes = [C.POINTER(NavParams)]
     L.jn_nav_params_default.restype = None
     L.jn_nav_state_reset.argtypes = [C.POINTER(NavState)]

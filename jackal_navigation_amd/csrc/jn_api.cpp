@@ -530,6 +530,35 @@ int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32
   return dt.run(x, y, n, tri);
 }
 
+jn_status jn_device_support_filters(int32_t device, const jn_elas_params* p, int32_t W, int32_t H, int32_t n, int16_t* d_can,
+                                    int32_t form) {
+  if (!p || !d_can || n < 1 || W < 1 || H < 1 || p->candidate_stepsize < 1 || form < 0 || form > 2) return JN_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  DevParams dp;
+  memset(&dp, 0, sizeof(dp));
+  dp.W = W; dp.H = H; dp.step = p->candidate_stepsize;
+  dp.cw = (W + dp.step - 1) / dp.step; dp.ch = (H + dp.step - 1) / dp.step;
+  const size_t cells = (size_t)n * dp.cw * dp.ch;
+  if (form == 2 && !support_filters_fast(dp, p->incon_window_size, p->incon_min_support)) return JN_ERR_UNSUPPORTED;
+  int16_t* d = nullptr; uint8_t* scratch = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), cells * sizeof(int16_t)));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), cells);
+  if (e != hipSuccess) { hipFree(d); HIP_TRY(e); }
+  e = hipMemcpy(d, d_can, cells * sizeof(int16_t), hipMemcpyHostToDevice);
+  bool ran = false;
+  if (e == hipSuccess) {
+    ran = launch_support_filters(nullptr, dp, n, p->incon_window_size, p->incon_threshold, p->incon_min_support, d,
+                                 form == 1 ? nullptr : scratch);       // no scratch: only the wavefront kernel can run
+    if (ran) e = hipMemcpy(d_can, d, cells * sizeof(int16_t), hipMemcpyDeviceToHost);
+  }
+  hipFree(d); hipFree(scratch);
+  HIP_TRY(e);
+  HIP_TRY(hipGetLastError());
+  return ran ? JN_OK : JN_ERR_UNSUPPORTED;
+}
+
 static_assert(sizeof(jn_host_frame_info) == sizeof(FrameInfo), "jn_host_frame_info mirrors FrameInfo");
 
 int64_t jn_host_stage(const jn_elas_params* p, int32_t W, int32_t H, int16_t* d_can, uint8_t* payload, int64_t payload_cap,

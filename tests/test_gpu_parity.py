@@ -110,6 +110,32 @@ def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypat
         assert st == 0 and same(D1, D1o) and same(D2, D2o), kb
 
 
+@pytest.mark.parametrize("form", [1, 2])
+def test_device_filters_on_random_lattices(jn, oracle, same, form):
+    """The filter kernels alone (jn_device_support_filters) on random lattices, where — unlike in stereo scenes —
+    a large share of the points is undecided after classification and deletions cascade along the sweep: sparse, medium
+    and dense lattices, several tolerances and support counts, a batch of different lattices at once."""
+    from jackal_navigation_amd import _lib
+    rng = np.random.default_rng(17 + form)
+    L = jn.load()
+    for (cw, ch, tol, sup, dmax) in ((80, 60, 5, 5, 60), (128, 96, 5, 5, 20), (67, 41, 3, 9, 40), (256, 144, 5, 5, 128), (50, 50, 1, 3, 8)):
+        n = 6
+        D = rng.integers(0, dmax, (n, ch, cw)).astype(np.int16)
+        for b in range(n):
+            D[b][rng.random((ch, cw)) < (0.05, 0.3, 0.5, 0.7, 0.85, 0.95)[b]] = -1     # from dense to almost empty
+        D[:, 0, :] = 0; D[:, :, 0] = 0                                                   # elas.cpp:388-397
+        p = jn.Elas.parameters(0, incon_threshold=tol, incon_min_support=sup)
+        po = oracle.params(0, incon_threshold=tol, incon_min_support=sup)
+        out = np.ascontiguousarray(D.copy())
+        st = L.jn_device_support_filters(0, C.byref(p), cw * 5, ch * 5, n, out.ctypes.data, form)
+        assert st == _lib.JN_OK, (cw, ch, form, st)
+        for b in range(n):
+            exp = oracle.remove_inconsistent(po, D[b])
+            exp = oracle.remove_redundant(exp, 5, 1, True)
+            exp = oracle.remove_redundant(exp, 5, 1, False)
+            assert same(out[b], exp), (cw, ch, tol, sup, b, int((out[b] != exp).sum()))
+
+
 def test_pitch_larger_than_width(jn, oracle, same):
     W, H, pitch = 300, 160, 352
     L, R = jn.node.synth_pair(W, H, 30, 4)
