@@ -140,6 +140,18 @@ void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* 
   info->ok = fs->u.size() >= 3;                                  // elas.cpp:66-71
 }
 
+void HostWorker::take_list(const int16_t* t, int count, FrameInfo* info, FrameScratch* fs) const {
+  const int step = hp_.step;
+  fs->u.resize(count); fs->v.resize(count); fs->d.resize(count); fs->x.resize(count);
+  for (int i = 0; i < count; i++) {
+    const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
+    fs->u[i] = u; fs->v[i] = v; fs->d[i] = d; fs->x[i] = u - d;
+  }
+  memset(info, 0, sizeof(*info));
+  info->nsup = count;
+  info->ok = count >= 3;                                         // elas.cpp:66-71
+}
+
 size_t HostWorker::place(FrameInfo* info, size_t base) {
   if (!info->ok) return 0;
   const size_t n = (size_t)info->nsup;

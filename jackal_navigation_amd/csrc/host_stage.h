@@ -35,6 +35,9 @@ class HostWorker {
   // (elas.cpp:416-422) and list the support points (elas.cpp:425-431) into `fs`; sets info->ok/nsup.
   // `filtered`: the GPU already ran the filters (k_support_filters); only the list is built.
   void filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs, bool filtered = false) const;
+  // Phase 1 when the GPU has filtered the lattice and listed the support points itself (k_support_list): take the
+  // (uc, vc, d) triples over.
+  void take_list(const int16_t* triples, int count, FrameInfo* info, FrameScratch* fs) const;
   // Between the phases: give the frame its place in the batch payload (frames are packed back to
   // back so that the whole batch goes to the GPU in one copy).  Returns the bytes the frame occupies.
   static size_t place(FrameInfo* info, size_t base_offset);

@@ -56,6 +56,7 @@ struct Slot {
   std::vector<FrameScratch> scratch;
   // pinned host
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
+  int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
   // worker
   std::thread th; std::mutex m; std::condition_variable cv;
   bool has_job = false, busy = false, quit = false;
@@ -109,14 +110,20 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
       launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
   HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
-  const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
-  HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
+  const int list_cap = dp.cw * dp.ch;
+  if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
+    launch_support_list(st, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
+  } else {
+    const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
+    HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(hipEventRecord(s.ev[EV_D2H], st));
   HIP_TRY(hipEventSynchronize(s.ev[EV_D2H]));
 
   auto t_host0 = std::chrono::steady_clock::now();
-  h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: filters + support list, per frame
-    w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i], filtered);
+  h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: support list (after the filters, if they are the host's), per frame
+    if (filtered) w.take_list(s.h_list + (size_t)i * list_cap * 3, std::min(s.h_cnt[i], list_cap), &s.h_info[i], &s.scratch[i]);
+    else w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i], false);
   });
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
   for (int i = 0; i < n; i++) payload_bytes += HostWorker::place(&s.h_info[i], payload_bytes);
@@ -299,6 +306,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_can), B * dp.cw * dp.ch * sizeof(int16_t), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), B * sizeof(FrameInfo), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_list), B * dp.cw * dp.ch * 3 * sizeof(int16_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_cnt), B * sizeof(int32_t), hipHostMallocDefault));
     h->slots.push_back(std::move(s));
   }
   h->s_pitch = dp.pitch;
@@ -321,7 +330,7 @@ void jn_elas_destroy(jn_elas* h) {
     hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
     hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
-    hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload);
+    hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
     if (s->stream) hipStreamDestroy(s->stream);
   }

@@ -20,6 +20,9 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
 
 // In-place support-point filters (elas.cpp:153-235 as called at :416-422) on d_can.  Returns false (nothing
 // launched) when the lattice does not fit the LDS; the host stage then runs them.
+// (uc, vc, d) int16 triples of the support points of each frame in the reference's order + their counts; `list` and
+// `count` may be pinned host memory
+void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,

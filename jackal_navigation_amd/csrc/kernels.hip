@@ -690,6 +690,47 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve_big(DevParams
   }
 }
 
+// Support list (elas.cpp:425-431) straight from the filtered lattice: lattice points with uc >= 1, vc >= 1 and a valid
+// disparity, in the reference's order (u outer, v inner), as (uc, vc, d) int16 triples plus their count, written by
+// the GPU into pinned host memory — the candidate lattice itself then never travels to the host.
+// One workgroup per frame; every thread owns a contiguous stretch of the column-major index range.
+__global__ void __launch_bounds__(kFilterThreads) k_support_list(DevParams dp, const int16_t* __restrict__ d_can, int16_t* __restrict__ list,
+                                                                 int32_t* __restrict__ count, int cap) {
+  __shared__ int s_off[kFilterThreads + 1];
+  const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x, N = cw * ch;
+  const int16_t* g = d_can + (size_t)blockIdx.x * N;
+  int16_t* out = list + (size_t)blockIdx.x * cap * 3;
+  const int per = (N + kFilterThreads - 1) / kFilterThreads, i_lo = min(tid * per, N), i_hi = min(i_lo + per, N);
+  int mine = 0;
+  {
+    int u = i_lo / ch, v = i_lo - u * ch;
+    for (int i = i_lo; i < i_hi; i++) {
+      mine += (u >= 1 && v >= 1 && g[v * cw + u] >= 0) ? 1 : 0;
+      if (++v == ch) { v = 0; u++; }
+    }
+  }
+  s_off[tid + 1] = mine;
+  if (tid == 0) s_off[0] = 0;
+  __syncthreads();
+  for (int step = 1; step < kFilterThreads; step <<= 1) {
+    const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
+    __syncthreads();
+    s_off[tid + 1] += add;
+    __syncthreads();
+  }
+  int at = s_off[tid];
+  int u = i_lo / ch, v = i_lo - u * ch;
+  for (int i = i_lo; i < i_hi; i++) {
+    const int d = g[v * cw + u];
+    if (u >= 1 && v >= 1 && d >= 0) {
+      if (at < cap) { out[3 * at] = (int16_t)u; out[3 * at + 1] = (int16_t)v; out[3 * at + 2] = (int16_t)d; }
+      at++;
+    }
+    if (++v == ch) { v = 0; u++; }
+  }
+  if (tid == 0) count[blockIdx.x] = s_off[kFilterThreads];
+}
+
 // seg_c == 0: the whole lattice (plus border) sits in LDS for all three passes.  Otherwise the lattice is larger
 // than the LDS and every pass streams it through in pieces, global memory holding the state in between: the
 // inconsistency filter by column segments [u0,u1) — the sweep is column-major, so a segment only needs the final
@@ -1887,6 +1928,9 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
   if (lanes == 16) hipLaunchKernelGGL((k_support_filters<WIN, 16>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r, sweep);
   else             hipLaunchKernelGGL((k_support_filters<WIN, 8>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r, sweep);
   return true;
+}
+void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap) {
+  hipLaunchKernelGGL(k_support_list, dim3(n), dim3(kFilterThreads), 0, st, dp, d_can, list, count, cap);
 }
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                  int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits) {
