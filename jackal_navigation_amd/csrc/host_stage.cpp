@@ -140,18 +140,6 @@ void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* 
   info->ok = fs->u.size() >= 3;                                  // elas.cpp:66-71
 }
 
-void HostWorker::take_list(const int16_t* t, int count, FrameInfo* info, FrameScratch* fs) const {
-  const int step = hp_.step;
-  fs->u.resize(count); fs->v.resize(count); fs->d.resize(count); fs->x.resize(count);
-  for (int i = 0; i < count; i++) {
-    const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
-    fs->u[i] = u; fs->v[i] = v; fs->d[i] = d; fs->x[i] = u - d;
-  }
-  memset(info, 0, sizeof(*info));
-  info->nsup = count;
-  info->ok = count >= 3;                                         // elas.cpp:66-71
-}
-
 size_t HostWorker::place(FrameInfo* info, size_t base) {
   if (!info->ok) return 0;
   const size_t n = (size_t)info->nsup;
@@ -171,6 +159,25 @@ void HostWorker::triangulate_side(int side, const FrameScratch& fs, uint8_t* pay
   }
   int32_t* corners = reinterpret_cast<int32_t*>(payload + info->corner_offset[side]);
   const int nt = dt_.run(side ? fs.x.data() : fs.u.data(), fs.v.data(), n, corners);
+  info->ntri[side] = nt < 0 ? 0 : nt;
+}
+
+void HostWorker::triangulate_side_from_list(int side, const int16_t* t, uint8_t* payload, FrameInfo* info) {
+  if (!info->ok) return;
+  const int n = info->nsup, step = hp_.step;
+  xs_.resize(n); ys_.resize(n);
+  if (side == 0) {
+    int32_t* uvd = reinterpret_cast<int32_t*>(payload + info->sup_offset);
+    for (int i = 0; i < n; i++) {
+      const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
+      uvd[3 * i] = u; uvd[3 * i + 1] = v; uvd[3 * i + 2] = d;
+      xs_[i] = u; ys_[i] = v;
+    }
+  } else {
+    for (int i = 0; i < n; i++) { xs_[i] = t[3 * i] * step - t[3 * i + 2]; ys_[i] = t[3 * i + 1] * step; }   // (u - d, v), elas.cpp:466-467
+  }
+  int32_t* corners = reinterpret_cast<int32_t*>(payload + info->corner_offset[side]);
+  const int nt = dt_.run(xs_.data(), ys_.data(), n, corners);
   info->ntri[side] = nt < 0 ? 0 : nt;
 }
 

@@ -35,9 +35,6 @@ class HostWorker {
   // (elas.cpp:416-422) and list the support points (elas.cpp:425-431) into `fs`; sets info->ok/nsup.
   // `filtered`: the GPU already ran the filters (k_support_filters); only the list is built.
   void filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* fs, bool filtered = false) const;
-  // Phase 1 when the GPU has filtered the lattice and listed the support points itself (k_support_list): take the
-  // (uc, vc, d) triples over.
-  void take_list(const int16_t* triples, int count, FrameInfo* info, FrameScratch* fs) const;
   // Between the phases: give the frame its place in the batch payload (frames are packed back to
   // back so that the whole batch goes to the GPU in one copy).  Returns the bytes the frame occupies.
   static size_t place(FrameInfo* info, size_t base_offset);
@@ -45,11 +42,16 @@ class HostWorker {
   // (u,v) for side 0 or (u-d,v) for side 1; corner indices go to the payload (side 0 also writes
   // the support points there).  `payload` is the base the offsets in `info` refer to.
   void triangulate_side(int side, const FrameScratch& fs, uint8_t* payload, FrameInfo* info);
+  // The same from the GPU's list (k_support_list), with no shared scratch: the task builds the coordinates it needs from
+  // the (uc, vc, d) triples itself, so a batch is one flat set of frame-side tasks.  `info` must hold ok / nsup and
+  // its payload offsets already.
+  void triangulate_side_from_list(int side, const int16_t* triples, uint8_t* payload, FrameInfo* info);
   static size_t payload_capacity(const HostParams& hp);   // worst case for one frame
 
  private:
   HostParams hp_;
   Delaunay dt_;
+  std::vector<int32_t> xs_, ys_;                 // coordinates of one frame side (triangulate_side_from_list)
   mutable std::vector<int16_t> tr_;              // transposed lattice for the horizontal redundancy pass
   void filter_inconsistent(int16_t* D) const;
   void filter_redundant(int16_t* D, int max_dist, int thresh, bool vertical) const;

@@ -121,16 +121,30 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   HIP_TRY(hipEventSynchronize(s.ev[EV_D2H]));
 
   auto t_host0 = std::chrono::steady_clock::now();
-  h->pool->run(n, [&](HostWorker& w, int i) {            // phase 1: support list (after the filters, if they are the host's), per frame
-    if (filtered) w.take_list(s.h_list + (size_t)i * list_cap * 3, std::min(s.h_cnt[i], list_cap), &s.h_info[i], &s.scratch[i]);
-    else w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i], false);
-  });
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
-  for (int i = 0; i < n; i++) payload_bytes += HostWorker::place(&s.h_info[i], payload_bytes);
-  h->pool->run(2 * n, [&](HostWorker& w, int k) {        // phase 2: one triangulation per frame and side
-    const int i = k >> 1;
-    w.triangulate_side(k & 1, s.scratch[i], s.h_payload, &s.h_info[i]);
-  });
+  if (filtered) {
+    // the counts are known, so the frames can be placed at once and the batch is one flat set of frame-side tasks
+    for (int i = 0; i < n; i++) {
+      FrameInfo& fi = s.h_info[i];
+      memset(&fi, 0, sizeof(fi));
+      fi.nsup = std::min(s.h_cnt[i], list_cap);
+      fi.ok = fi.nsup >= 3;                              // elas.cpp:66-71
+      payload_bytes += HostWorker::place(&fi, payload_bytes);
+    }
+    h->pool->run(2 * n, [&](HostWorker& w, int k) {
+      const int i = k >> 1;
+      w.triangulate_side_from_list(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i]);
+    });
+  } else {
+    h->pool->run(n, [&](HostWorker& w, int i) {          // phase 1: filters + support list, per frame
+      w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i], false);
+    });
+    for (int i = 0; i < n; i++) payload_bytes += HostWorker::place(&s.h_info[i], payload_bytes);
+    h->pool->run(2 * n, [&](HostWorker& w, int k) {      // phase 2: one triangulation per frame and side
+      const int i = k >> 1;
+      w.triangulate_side(k & 1, s.scratch[i], s.h_payload, &s.h_info[i]);
+    });
+  }
   auto t_host1 = std::chrono::steady_clock::now();
 
   HIP_TRY(hipEventRecord(s.ev[EV_H2D0], st));
