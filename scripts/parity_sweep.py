@@ -1,0 +1,68 @@
+"""Wide parity sweep of the HIP path against the CPU oracle (run on the GPU box): many seeds, sizes, scene depths and
+parameter sets, batches through the pipelined device-pointer API; every D1 / D2 must be bit-identical.
+Usage: python3 scripts/parity_sweep.py [pairs_per_config]   (the oracle is run in a process pool)"""
+import os
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def oracle_job(args):
+    W, H, sd, dmax, seed, kw = args
+    from oracle.binding import Oracle
+    o = Oracle()
+    L, R = o.synth_pair(W, H, sd, seed)
+    st, D1, D2 = o.process(o.params(0, disp_max=dmax, **kw), L, R)
+    return st, D1, D2
+
+
+def main():
+    per = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+    configs = [
+        (1280, 720, 128, 127, {}), (1280, 720, 40, 127, {}), (640, 480, 64, 63, {}), (320, 180, 48, 255, {}),
+        (333, 201, 30, 95, {}), (1920, 1080, 200, 255, {}), (800, 600, 90, 127, {"postprocess_only_left": 0}),
+        (640, 360, 64, 95, {"filter_median": 1, "speckle_size": 100}), (512, 384, 50, 79, {"incon_min_support": 8, "incon_threshold": 3}),
+    ]
+    with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as pool:
+        futures = []
+        for ci, (W, H, sd, dmax, kw) in enumerate(configs):
+            n = per if W * H <= 1280 * 720 else max(4, per // 3)
+            futures.append([pool.submit(oracle_job, (W, H, sd, dmax, 31000 + 100 * ci + b, kw)) for b in range(n)])
+        import jackal_navigation_amd as jn          # GPU side in the parent only (after the workers were forked)
+        from jackal_navigation_amd.device import DeviceArray
+        bad = 0
+        for ci, (W, H, sd, dmax, kw) in enumerate(configs):
+            n = len(futures[ci])
+            Ls = np.stack([jn.node.synth_pair(W, H, sd, 31000 + 100 * ci + b)[0] for b in range(n)])
+            Rs = np.stack([jn.node.synth_pair(W, H, sd, 31000 + 100 * ci + b)[1] for b in range(n)])
+            dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+            d1 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32)); d2 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32))
+            t0 = time.time()
+            with jn.Elas(jn.Elas.parameters(0, disp_max=dmax, **kw), W, H, max_batch=n, host_threads=8) as e:
+                status = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
+            t_gpu = time.time() - t0
+            D1, D2 = d1.numpy(), d2.numpy()
+            wrong = 0
+            for b in range(n):
+                st, D1o, D2o = futures[ci][b].result()
+                if st != status[b]:
+                    wrong += 1
+                elif st == 0 and not (np.array_equal(D1[b].view(np.uint32), D1o.view(np.uint32)) and
+                                      np.array_equal(D2[b].view(np.uint32), D2o.view(np.uint32))):
+                    wrong += 1
+            bad += wrong
+            print("%4dx%-4d scene<=%-3d disp_max=%-3d %-45s %3d pairs  %s  (gpu %.2f s)" %
+                  (W, H, sd, dmax, kw, n, "all bit-identical" if wrong == 0 else "%d MISMATCH" % wrong, t_gpu), flush=True)
+            for a in (dL, dR, d1, d2):
+                a.free()
+    print("sweep", "PASSED" if bad == 0 else "FAILED (%d)" % bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
