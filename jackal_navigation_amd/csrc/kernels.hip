@@ -976,11 +976,11 @@ DEV bool bin_entry(const DevParams& dp, const TriRec& q, int t, int u0, int v0, 
   }
   return any != 0;                                        // bounding box touched the tile, the triangle may not
 }
-// 32 triangles per workgroup.  Most triangles touch a handful of tiles, but Delaunay hulls carry a few long, thin
+// 64 triangles per workgroup (one wave scans their box sizes).  Most triangles touch a handful of tiles, but Delaunay hulls carry a few long, thin
 // ones whose bounding boxes span hundreds; any fixed lanes-per-triangle split lets those set the kernel's duration.
 // So the (triangle, tile) pairs of the workgroup's triangles are numbered consecutively (prefix sum of the box
 // sizes in LDS) and the 256 threads stride over that flat list.
-enum { kBinTris = 32 };
+enum { kBinTris = 64 };
 __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
                                              int tri_cap, int32_t* __restrict__ bin_count, BinEntry* __restrict__ bin_list) {
   __shared__ int s_first[kBinTris + 1];                    // first flat index of each triangle's tiles
