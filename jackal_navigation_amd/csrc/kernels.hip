@@ -1337,9 +1337,10 @@ __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo*
   for (int u0 = 0; u0 < W; u0 += 64) {
     const int u = u0 + lane;
     const float nxt = u + 64 < W ? row[u + 64] : -10.0f;    // next chunk, in flight while this one is processed
-    float prev = __shfl_up(d, 1), foll = __shfl_down(d, 1);
+    const float nxt0 = __shfl(nxt, 0);                      // read with all lanes active: a shuffle inside `if (lane == 63)` would
+    float prev = __shfl_up(d, 1), foll = __shfl_down(d, 1); // pull from an inactive lane
     if (lane == 0) prev = left;
-    if (lane == 63) foll = __shfl(nxt, 0);
+    if (lane == 63) foll = nxt0;
     const bool valid = d >= 0;
     const bool conn = valid && prev >= 0 && fabsf(d - prev) <= sim;
     const bool conn_next = valid && foll >= 0 && fabsf(foll - d) <= sim;

@@ -1,0 +1,49 @@
+"""Synthetic stereo scenes beyond the survey's plane-and-box generator, for parity tests: they stress other parts of
+the path (occlusions and disparity jumps -> L/R failures, speckles, gaps; textureless patches -> texture tests and
+sparse support; photometric differences -> ambiguous matches; slanted surfaces -> non-constant planes)."""
+import numpy as np
+
+KINDS = ("strips", "patches", "slanted", "photometric", "blobs")
+
+
+def _texture(rng, H, W, cell=3):
+    t = rng.integers(0, 256, ((H + cell - 1) // cell, (W + 512 + cell - 1) // cell)).astype(np.uint8)
+    return np.kron(t, np.ones((cell, cell), np.uint8))[:H, :W + 512]
+
+
+def make_scene(kind, W, H, dmax, seed):
+    """Returns (L, R) uint8 images; R is the texture, L samples it at x - d(x, y) (as the survey's generator does)."""
+    rng = np.random.default_rng(seed)
+    tex = _texture(rng, H, W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    if kind == "strips":                                   # vertical strips at very different depths
+        edges = np.sort(rng.integers(0, W, 7))
+        d = np.full((H, W), 3, np.int64)
+        for i, e in enumerate(edges):
+            d[:, e:] = int(rng.integers(2, max(3, int(dmax * 0.8))))
+    elif kind == "patches":                                # plane with textureless rectangles painted over both images
+        d = (yy * (0.5 * dmax) / H).astype(np.int64) + 2
+    elif kind == "slanted":                                # disparity grows along x and y
+        d = (2 + xx * (0.35 * dmax) / W + yy * (0.3 * dmax) / H).astype(np.int64)
+    elif kind == "photometric":
+        d = (yy * (0.6 * dmax) / H).astype(np.int64) + 2
+    elif kind == "blobs":                                  # random ellipses at random depths over a far background
+        d = np.full((H, W), 2, np.int64)
+        for _ in range(25):
+            cx, cy = rng.integers(0, W), rng.integers(0, H)
+            ax, ay = rng.integers(10, max(11, W // 6)), rng.integers(8, max(9, H // 6))
+            d[((xx - cx) / ax) ** 2 + ((yy - cy) / ay) ** 2 < 1] = int(rng.integers(2, max(3, int(dmax * 0.7))))
+    else:
+        raise ValueError(kind)
+    R = tex[:, 256:256 + W].copy()
+    L = tex[yy, np.clip(xx - d + 256, 0, tex.shape[1] - 1)].copy()
+    if kind == "patches":
+        for _ in range(12):
+            x0, y0 = int(rng.integers(0, W - 20)), int(rng.integers(0, H - 20))
+            w, h = int(rng.integers(15, max(16, W // 5))), int(rng.integers(10, max(11, H // 5)))
+            g = int(rng.integers(0, 256))
+            L[y0:y0 + h, x0:x0 + w] = g; R[y0:y0 + h, max(0, x0 - 10):x0 + w] = g
+    if kind == "photometric":
+        R = np.clip(R.astype(np.float64) * 0.8 + 25 + rng.normal(0, 6, R.shape), 0, 255).astype(np.uint8)
+        L = np.clip(L.astype(np.float64) + rng.normal(0, 4, L.shape), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(L), np.ascontiguousarray(R)

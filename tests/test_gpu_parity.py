@@ -46,6 +46,29 @@ def test_elas_bit_exact_vs_oracle(jn, oracle, same, W, H, sd, dmax, seed):
     assert same(D2, D2o), "%d differing pixels in D2" % int((D2 != D2o).sum())
 
 
+@pytest.mark.parametrize("kind", ["strips", "patches", "slanted", "photometric", "blobs"])
+def test_other_scenes_bit_exact_vs_oracle(jn, oracle, same, kind):
+    """Scenes unlike the survey's plane-and-box generator (tests/scenes.py; the oracle is pinned against the reference
+    on them in test_oracle_vs_reference.py): occlusions and depth jumps, textureless patches, slanted surfaces,
+    photometric differences, random blobs — as a batch through the pipelined API, one of them at 1280x720."""
+    from scenes import make_scene
+    from jackal_navigation_amd.device import DeviceArray
+    for (W, H, dmax, n) in ((320, 240, 79, 5), (640, 360, 95, 3), (1280, 720, 127, 2)):
+        pairs = [make_scene(kind, W, H, dmax, 50 + b) for b in range(n)]
+        Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+        dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+        d1 = DeviceArray((n, H, W), np.float32); d2 = DeviceArray((n, H, W), np.float32)
+        with jn.Elas(jn.Elas.parameters(0, disp_max=dmax, postprocess_only_left=0), W, H, max_batch=n, host_threads=2) as e:
+            assert e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr) == [0] * n
+        D1, D2 = d1.numpy(), d2.numpy()
+        po = oracle.params(0, disp_max=dmax, postprocess_only_left=0)
+        for b in range(n):
+            _, D1o, D2o = oracle.process(po, Ls[b], Rs[b])
+            assert same(D1[b], D1o) and same(D2[b], D2o), (kind, W, H, b, int((D1[b] != D1o).sum()), int((D2[b] != D2o).sum()))
+        for a in (dL, dR, d1, d2):
+            a.free()
+
+
 def test_full_hd_and_wide_images(jn, oracle, same):
     """BASELINE config 5's frame (1920x1080, disparity range 256: the widest LDS windows) and an image wider than
     2560 px, which takes the global-memory support-matching kernel instead of the LDS one."""

@@ -30,6 +30,19 @@ def test_process_bit_exact_with_other_parameters(oracle, reference, same, kw):
     assert st == 0 and same(D1, D1r) and same(D2, D2r), kw
 
 
+@pytest.mark.parametrize("kind", ["strips", "patches", "slanted", "photometric", "blobs"])
+def test_process_bit_exact_on_other_scenes(oracle, reference, same, kind):
+    """Scenes unlike the survey's plane-and-box generator (tests/scenes.py): depth jumps and occlusions, textureless
+    patches, slanted surfaces, gain / offset / noise between the images, random blobs."""
+    from scenes import make_scene
+    for (W, H, dmax, seed) in ((320, 240, 79, 5), (400, 304, 127, 6)):
+        L, R = make_scene(kind, W, H, dmax, seed)
+        p = oracle.params(0, disp_max=dmax, postprocess_only_left=0)
+        st, D1, D2 = oracle.process(p, L, R)
+        D1r, D2r = reference.process(p, L, R)
+        assert st == 0 and same(D1, D1r) and same(D2, D2r), (kind, W, H)
+
+
 def test_stagewise_bit_exact_720p(oracle, reference, same):
     W, H = 1280, 720
     L, R = oracle.synth_pair(W, H, 128, 12345)
