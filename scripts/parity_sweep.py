@@ -10,13 +10,23 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def make_pair(W, H, sd, dmax, seed):
+    """sd: largest scene disparity of the survey's generator, or the name of a scene kind of tests/scenes.py"""
+    if isinstance(sd, str):
+        from scenes import make_scene
+        return make_scene(sd, W, H, dmax, seed)
+    from oracle.binding import Oracle
+    return Oracle().synth_pair(W, H, sd, seed)
 
 
 def oracle_job(args):
     W, H, sd, dmax, seed, kw = args
     from oracle.binding import Oracle
     o = Oracle()
-    L, R = o.synth_pair(W, H, sd, seed)
+    L, R = make_pair(W, H, sd, dmax, seed)
     st, D1, D2 = o.process(o.params(0, disp_max=dmax, **kw), L, R)
     return st, D1, D2
 
@@ -28,6 +38,9 @@ def main():
         (333, 201, 30, 95, {}), (1920, 1080, 200, 255, {}), (800, 600, 90, 127, {"postprocess_only_left": 0}),
         (640, 360, 64, 95, {"filter_median": 1, "speckle_size": 100}), (512, 384, 50, 79, {"incon_min_support": 8, "incon_threshold": 3}),
     ]
+    for kind in ("strips", "patches", "slanted", "photometric", "blobs"):
+        configs += [(320, 240, kind, 79, {"postprocess_only_left": 0}), (640, 480, kind, 127, {"postprocess_only_left": 0}),
+                    (1280, 720, kind, 127, {}), (448, 333, kind, 255, {"postprocess_only_left": 0, "ipol_gap_width": 7})]
     with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as pool:
         futures = []
         for ci, (W, H, sd, dmax, kw) in enumerate(configs):
@@ -38,8 +51,8 @@ def main():
         bad = 0
         for ci, (W, H, sd, dmax, kw) in enumerate(configs):
             n = len(futures[ci])
-            Ls = np.stack([jn.node.synth_pair(W, H, sd, 31000 + 100 * ci + b)[0] for b in range(n)])
-            Rs = np.stack([jn.node.synth_pair(W, H, sd, 31000 + 100 * ci + b)[1] for b in range(n)])
+            pairs = [make_pair(W, H, sd, dmax, 31000 + 100 * ci + b) for b in range(n)]
+            Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
             dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
             d1 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32)); d2 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32))
             t0 = time.time()
@@ -56,7 +69,7 @@ def main():
                                       np.array_equal(D2[b].view(np.uint32), D2o.view(np.uint32))):
                     wrong += 1
             bad += wrong
-            print("%4dx%-4d scene<=%-3d disp_max=%-3d %-45s %3d pairs  %s  (gpu %.2f s)" %
+            print("%4dx%-4d scene %-11s disp_max=%-3d %-45s %3d pairs  %s  (gpu %.2f s)" %
                   (W, H, sd, dmax, kw, n, "all bit-identical" if wrong == 0 else "%d MISMATCH" % wrong, t_gpu), flush=True)
             for a in (dL, dR, d1, d2):
                 a.free()
