@@ -38,7 +38,7 @@ def main():
         (333, 201, 30, 95, {}), (1920, 1080, 200, 255, {}), (800, 600, 90, 127, {"postprocess_only_left": 0}),
         (640, 360, 64, 95, {"filter_median": 1, "speckle_size": 100}), (512, 384, 50, 79, {"incon_min_support": 8, "incon_threshold": 3}),
     ]
-    for kind in ("strips", "patches", "slanted", "photometric", "blobs"):
+    for kind in ("strips", "patches", "slanted", "photometric", "blobs", "shallow"):
         configs += [(320, 240, kind, 79, {"postprocess_only_left": 0}), (640, 480, kind, 127, {"postprocess_only_left": 0}),
                     (1280, 720, kind, 127, {}), (448, 333, kind, 255, {"postprocess_only_left": 0, "ipol_gap_width": 7})]
     with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as pool:

@@ -3,7 +3,7 @@ the path (occlusions and disparity jumps -> L/R failures, speckles, gaps; textur
 sparse support; photometric differences -> ambiguous matches; slanted surfaces -> non-constant planes)."""
 import numpy as np
 
-KINDS = ("strips", "patches", "slanted", "photometric", "blobs")
+KINDS = ("strips", "patches", "slanted", "photometric", "blobs", "shallow")
 
 
 def _texture(rng, H, W, cell=3):
@@ -33,6 +33,8 @@ def make_scene(kind, W, H, dmax, seed):
             cx, cy = rng.integers(0, W), rng.integers(0, H)
             ax, ay = rng.integers(10, max(11, W // 6)), rng.integers(8, max(9, H // 6))
             d[((xx - cx) / ax) ** 2 + ((yy - cy) / ay) ** 2 < 1] = int(rng.integers(2, max(3, int(dmax * 0.7))))
+    elif kind == "shallow":                                # disparities 0, 1, 2 only: the far field, where d - 1 and u - d hit their limits
+        d = ((xx // 37 + yy // 29) % 3).astype(np.int64)
     else:
         raise ValueError(kind)
     R = tex[:, 256:256 + W].copy()

@@ -46,7 +46,7 @@ def test_elas_bit_exact_vs_oracle(jn, oracle, same, W, H, sd, dmax, seed):
     assert same(D2, D2o), "%d differing pixels in D2" % int((D2 != D2o).sum())
 
 
-@pytest.mark.parametrize("kind", ["strips", "patches", "slanted", "photometric", "blobs"])
+@pytest.mark.parametrize("kind", ["strips", "patches", "slanted", "photometric", "blobs", "shallow"])
 def test_other_scenes_bit_exact_vs_oracle(jn, oracle, same, kind):
     """Scenes unlike the survey's plane-and-box generator (tests/scenes.py; the oracle is pinned against the reference
     on them in test_oracle_vs_reference.py): occlusions and depth jumps, textureless patches, slanted surfaces,
