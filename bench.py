@@ -63,7 +63,7 @@ def cpu_baseline_worker(args):
 def cpu_baseline(W, H, scene, disp, budget_s=20.0):
     """Reference CPU path on a bounded sample, one process per core (Triangle is not thread-safe)."""
     import multiprocessing as mp
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the CPUs this process may use
     procs = max(1, min(ncpu // 2, 64))
     # single-core probe first (also the figure quoted per core)
     t1, kind = cpu_baseline_worker((W, H, scene, disp, 12345, 2))
@@ -134,7 +134,7 @@ def main():
     torch.cuda.set_device(dev)
     on_gpu = a.dist_backend == "nccl"      # gloo reduces CPU tensors
 
-    ncpu = os.cpu_count() or 1
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the CPUs this process may use
     # measured on the 2x64-core EPYC box: 16 pool threads per GPU keep the host stage hidden behind the
     # kernels of the other slots; more threads only add wake-up and cache traffic
     host_threads = a.host_threads or max(4, min(ncpu // max(world, 1) - 2, 16))
