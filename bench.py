@@ -161,13 +161,11 @@ def main():
     dense_ms = []
 
     def finish(slot):
-        """Tail of a batch: wait for ELAS, then u8 map + scan, then the cross-rig MIN reduce."""
-        elas.wait(slot)
+        """Tail of a batch: wait for ELAS + u8 map + scan, then the cross-rig MIN reduce."""
+        elas.wait(slot)                           # ELAS and the node's tail (u8 map + scan) ran on the slot's stream
         for k, v in elas.last_times(slot).items():
             stage_acc.setdefault(k, []).append(v)
         dense_ms.append(elas.kernel_time(slot)[0])
-        node.disparity_scan(sp, B, D1[slot].data_ptr(), lut.ptr, W, H, U8[slot].data_ptr(), bins[slot].data_ptr(),
-                            meta[slot].data_ptr(), device=local_rank)
         if dist is not None:                      # the path's one exchange step: robot-level scan = MIN over rigs,
             if on_gpu:                            # one all-reduce per batch
                 scans[slot].merge()
@@ -183,7 +181,8 @@ def main():
             slot = i % S
             if len(inflight) == S:
                 finish(inflight.pop(0))
-            elas.submit(slot, B, dL.data_ptr(), dR.data_ptr(), W, H * W, D1[slot].data_ptr(), D2[slot].data_ptr(), status[slot])
+            elas.submit_scan(slot, B, dL.data_ptr(), dR.data_ptr(), W, H * W, D1[slot].data_ptr(), D2[slot].data_ptr(), sp, lut.ptr,
+                             U8[slot].data_ptr(), bins[slot].data_ptr(), meta[slot].data_ptr(), status[slot])
             inflight.append(slot)
         while inflight:
             finish(inflight.pop(0))

@@ -161,6 +161,15 @@ jn_status jn_disparity_scan(int32_t device, const jn_scan_params* sp, int32_t n,
                             const uint8_t* dLut, int32_t width, int32_t height, uint8_t* dDispU8,
                             double* dBins, double* dMeta);
 
+/* jn_elas_submit followed by the node's tail on the same stream: convertTo(CV_8U) of D1 (point_cloud.cpp:422) and
+ * publishObstacleScan(Mat&) (:213-296) with the cached LUT — i.e. what jn_disparity_scan does, without a second
+ * call or a host round trip in between.  After jn_elas_wait: dD1/dD2 as for jn_elas_submit, dDispU8 [n][H][W],
+ * dBins [n][bins], dMeta [n][4].  Frames that fail (status != 0) leave dD1 untouched, and the tail then scans
+ * whatever dD1 held (the reference publishes its zero-initialised map in that case, point_cloud.cpp:414-428). */
+jn_status jn_elas_submit_scan(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch,
+                              int64_t image_stride, float* dD1, float* dD2, const jn_scan_params* sp, const uint8_t* dLut,
+                              uint8_t* dDispU8, double* dBins, double* dMeta, int32_t* status);
+
 /* The `ranges` compaction of point_cloud.cpp:278-282 (host): bins < 1e9-1, pushed from the last
  * bin to the first, as float32.  Returns the count. */
 int32_t jn_compact_ranges(const double* bins, int32_t nbins, float* ranges);

@@ -41,9 +41,11 @@ namespace {
 struct Job {
   int n = 0; const uint8_t* dI1 = nullptr; const uint8_t* dI2 = nullptr; int pitch = 0; int64_t stride = 0;
   float* dD1 = nullptr; float* dD2 = nullptr; int32_t* status = nullptr;
+  // optional tail of the node on the same stream (jn_elas_submit_scan): u8 map + LUT scan of D1
+  bool scan = false; jn_scan_params sp = {}; const uint8_t* dLut = nullptr; uint8_t* dDispU8 = nullptr; double* dBins = nullptr; double* dMeta = nullptr;
 };
 
-enum { EV_BEGIN, EV_DESC, EV_SUPPORT, EV_D2H, EV_H2D0, EV_H2D, EV_RASTER, EV_DENSE, EV_LR, EV_SPECKLE, EV_GAP, EV_AM, EV_COUNT };
+enum { EV_BEGIN, EV_DESC, EV_SUPPORT, EV_D2H, EV_H2D0, EV_H2D, EV_RASTER, EV_DENSE, EV_LR, EV_SPECKLE, EV_GAP, EV_AM, EV_END, EV_COUNT };
 
 struct Slot {
   hipStream_t stream = nullptr;
@@ -53,6 +55,7 @@ struct Slot {
   FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; BinEntry* bin_list = nullptr; int16_t* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
+  unsigned long long* scan_scratch = nullptr;                 // extrema of the scan tail, 4 per frame
   std::vector<FrameScratch> scratch;
   // pinned host
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
@@ -187,7 +190,10 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   } else {
     for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(hipEventRecord(s.ev[e], st));
   }
-  HIP_TRY(hipEventSynchronize(s.ev[EV_AM]));
+  if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
+    launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
+  HIP_TRY(hipEventRecord(s.ev[EV_END], st));
+  HIP_TRY(hipEventSynchronize(s.ev[EV_END]));
   HIP_TRY(hipGetLastError());
   auto t_end = std::chrono::steady_clock::now();
 
@@ -313,6 +319,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     HIP_TRY(dmalloc(&s->bin_count, 2 * B * tiles)); HIP_TRY(dmalloc(&s->bin_list, 2 * B * tiles * kBinCap));
     HIP_TRY(dmalloc(&s->raw, 2 * B * px));
     HIP_TRY(dmalloc(&s->tmp, B * px)); HIP_TRY(dmalloc(&s->label, B * px)); HIP_TRY(dmalloc(&s->size, B * px));
+    HIP_TRY(dmalloc(&s->scan_scratch, B * 4));
     const size_t grid_words = 2 * B * dp.gw * dp.gh * kGridWords;
     HIP_TRY(dmalloc(&s->mark, grid_words)); HIP_TRY(dmalloc(&s->gridbits, grid_words));
     HIP_TRY(dmalloc(&s->recs, 2 * B * (size_t)h->tri_cap));
@@ -342,7 +349,7 @@ void jn_elas_destroy(jn_elas* h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
     hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
-    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size);
+    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
@@ -363,6 +370,24 @@ jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1
     std::unique_lock<std::mutex> l(s.m);
     s.cv.wait(l, [&] { return !s.busy; });
     s.job = Job{n, dI1, dI2, pitch, image_stride, dD1, dD2, status};
+    s.has_job = true; s.busy = true;
+  }
+  s.cv.notify_all();
+  return JN_OK;
+}
+
+jn_status jn_elas_submit_scan(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch,
+                              int64_t image_stride, float* dD1, float* dD2, const jn_scan_params* sp, const uint8_t* dLut,
+                              uint8_t* dDispU8, double* dBins, double* dMeta, int32_t* status) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dD1 || !dD2 ||
+      pitch < h->W || !sp || !dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024)
+    return JN_ERR_INVALID;
+  Slot& s = *h->slots[slot];
+  {
+    std::unique_lock<std::mutex> l(s.m);
+    s.cv.wait(l, [&] { return !s.busy; });
+    s.job = Job{n, dI1, dI2, pitch, image_stride, dD1, dD2, status};
+    s.job.scan = true; s.job.sp = *sp; s.job.dLut = dLut; s.job.dDispU8 = dDispU8; s.job.dBins = dBins; s.job.dMeta = dMeta;
     s.has_job = true; s.busy = true;
   }
   s.cv.notify_all();

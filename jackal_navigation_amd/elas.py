@@ -80,6 +80,11 @@ class Elas:
     def submit(self, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, status=None):
         _lib.check(self._L.jn_elas_submit(self._h, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, status), "jn_elas_submit")
 
+    def submit_scan(self, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, sp, dLut, dDispU8, dBins, dMeta, status=None):
+        """submit() plus the node's tail (u8 depth map + LUT obstacle scan of D1) on the same stream."""
+        _lib.check(self._L.jn_elas_submit_scan(self._h, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, C.byref(sp), dLut,
+                                               dDispU8, dBins, dMeta, status), "jn_elas_submit_scan")
+
     def wait(self, slot):
         _lib.check(self._L.jn_elas_wait(self._h, slot), "jn_elas_wait")
 

@@ -390,6 +390,36 @@ def test_scan_on_other_scenes(jn, oracle, same, kind):
         assert np.allclose(b2[b], bc, rtol=0, atol=SCAN_TOL) and np.allclose(m2[b], mc, rtol=0, atol=SCAN_TOL)
 
 
+def test_fused_submit_scan_equals_separate_calls(jn, same):
+    """jn_elas_submit_scan = jn_elas_submit followed by jn_disparity_scan, bit for bit (a failing frame included)."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node
+    W, H, n = 320, 180, 5
+    rng = np.random.default_rng(2)
+    Ls = np.stack([node.synth_pair(W, H, 48, 70 + b)[0] for b in range(n)]); Rs = np.stack([node.synth_pair(W, H, 48, 70 + b)[1] for b in range(n)])
+    Ls[3] = rng.integers(0, 255, (H, W)); Rs[3] = rng.integers(0, 255, (H, W))          # frame 3 fails
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    outs = []
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=n, slots=2) as e:
+        for fused in (False, True):
+            d1 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32)); d2 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32))
+            u8 = DeviceArray((n, H, W), np.uint8); bins = DeviceArray((n, sp.bins), np.float64); meta = DeviceArray((n, 4), np.float64)
+            st = (C.c_int32 * n)()
+            if fused:
+                e.submit_scan(1, n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr, sp, lut.ptr, u8.ptr, bins.ptr, meta.ptr, st)
+                e.wait(1)
+            else:
+                e.submit(0, n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr, st)
+                e.wait(0)
+                node.disparity_scan(sp, n, d1.ptr, lut.ptr, W, H, u8.ptr, bins.ptr, meta.ptr)
+            outs.append((list(st), d1.numpy(), d2.numpy(), u8.numpy(), bins.numpy(), meta.numpy()))
+    assert outs[0][0] == outs[1][0] == [0, 0, 0, 1, 0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert same(a, b)
+
+
 def test_scan_with_empty_and_saturated_maps(jn, oracle):
     from jackal_navigation_amd.device import DeviceArray
     from jackal_navigation_amd import node
