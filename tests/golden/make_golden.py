@@ -65,6 +65,20 @@ def main():
     with open(os.path.join(here, "reference_hashes.txt"), "w") as f:
         f.write("# W H scene_disp disp_max fnv1a64(D1) fnv1a64(D2) -- reference src/elas, ROBOTICS params, seed 12345, D pre-filled 0\n")
         f.write("\n".join(lines) + "\n")
+    # the other scene kinds (tests/scenes.py), both sides post-processed
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene, KINDS
+    lines = []
+    for kind in KINDS:
+        for (W, H, dmax, seed) in ((320, 240, 79, 11), (640, 360, 127, 12)):
+            L, R = make_scene(kind, W, H, dmax, seed)
+            D1, D2 = r.process(r.params(0, disp_max=dmax, postprocess_only_left=0), L, R)
+            lines.append("%s %d %d %d %d %016x %016x" % (kind, W, H, dmax, seed, o.fnv(D1), o.fnv(D2)))
+            print(lines[-1])
+    with open(os.path.join(here, "reference_scene_hashes.txt"), "w") as f:
+        f.write("# kind W H disp_max seed fnv1a64(D1) fnv1a64(D2) -- reference src/elas, ROBOTICS params with postprocess_only_left=0,\n"
+                "# tests/scenes.py make_scene(kind, W, H, disp_max, seed), D pre-filled 0\n")
+        f.write("\n".join(lines) + "\n")
 
 
 if __name__ == "__main__":

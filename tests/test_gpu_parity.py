@@ -93,6 +93,19 @@ def test_known_answer_hashes_on_gpu(jn, oracle):
         assert st == 0 and oracle.fnv(D1) == int(h1, 16) and oracle.fnv(D2) == int(h2, 16), (W, H)
 
 
+def test_known_answer_hashes_on_other_scenes_on_gpu(jn, oracle):
+    """HIP path against the REFERENCE's own hashes (tests/golden/reference_scene_hashes.txt) on the scene kinds of
+    tests/scenes.py, both sides post-processed."""
+    import os
+    from scenes import make_scene
+    rows = [l.split() for l in open(os.path.join(os.path.dirname(__file__), "golden", "reference_scene_hashes.txt")) if not l.startswith("#")]
+    assert len(rows) >= 12
+    for kind, W, H, dmax, seed, h1, h2 in rows:
+        L, R = make_scene(kind, int(W), int(H), int(dmax), int(seed))
+        st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=int(dmax), postprocess_only_left=0), L, R)
+        assert st == 0 and oracle.fnv(D1) == int(h1, 16) and oracle.fnv(D2) == int(h2, 16), (kind, W, H)
+
+
 @pytest.mark.parametrize("kw", [
     {"postprocess_only_left": 0}, {"filter_adaptive_mean": 0}, {"ipol_gap_width": 7}, {"speckle_size": 50, "speckle_sim_threshold": 2.0},
     {"support_threshold": 0.95, "support_texture": 20}, {"lr_threshold": 1, "match_texture": 5}, {"grid_size": 16, "sradius": 3.0},
