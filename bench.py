@@ -209,7 +209,7 @@ def main():
     pairs = world * B * a.steps
     value = pairs / elapsed
 
-    # roofline of the dominant kernel, k_dense (26 % of GPU time, profiles/): algorithmic bytes per launch
+    # roofline of the dominant kernel, k_dense (31 % of GPU time, profiles/): algorithmic bytes per launch
     # (dense L+R = 16 B per pixel per pair, one launch = the whole batch, both sides) over its average
     # duration, measured with HIP events the library records around the kernel on the stream it runs on.
     stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
@@ -217,16 +217,23 @@ def main():
     alg_bytes = STAGE_BYTES_PER_PX["gpu_matching"] * W * H * B
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic = None
+    extra_roof = {}
     try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs) of the same workload
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if (W, H, B, a.disp) == (1280, 720, 32, 128):
             traffic = pmc["k_dense"]["traffic_bytes"]
+            extra_roof = {"alone_ms_per_launch": pmc["k_dense"].get("alone_ms_per_launch"),
+                          "valu_issue_frac_alone": pmc["k_dense"].get("valu_issue_frac_alone"),
+                          "note": "k_dense is bound by vector-instruction issue, not by HBM: running alone it uses the stated fraction of "
+                                  "its VALU issue slots (PMC, profiles/r01_pmc_traffic.json); ms_per_launch above is the duration "
+                                  "stretched by the other slots' kernels sharing the GPU"}
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": "k_dense", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "ms_per_launch": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4)}
+    roofline.update(extra_roof)
 
     # BASELINE config 2 beside the headline workload: 640x480, D=64, batch 1, latency mode (one synchronous
     # call per pair on device pointers, nothing pipelined).  Informational; not part of `value`.
