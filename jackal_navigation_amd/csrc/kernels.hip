@@ -993,11 +993,21 @@ __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __re
   const size_t base = (size_t)(frame * 2 + side) * tiles_x * tiles_y;
   const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
   const int t0 = blockIdx.x * kBinTris;
+  // the workgroup's triangle records go to LDS in one coalesced sweep: read field by field from memory, every
+  // item would wait out a dozen dependent global loads
+  __shared__ TriRec s_rec[kBinTris];
+  {
+    const int ntri_here = min(kBinTris, fi.ntri[side] - t0);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(R + t0);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_rec);
+    for (int i = tid; i < ntri_here * (int)(sizeof(TriRec) / 4); i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
   if (tid < kBinTris) {
     int total = 0;
     const int t = t0 + tid;
     if (t < fi.ntri[side]) {
-      const TriRec& q = R[t];
+      const TriRec& q = s_rec[tid];
       const int c0 = max(q.Au, 0), c1 = min(q.Cu, dp.W) - 1;                  // columns [Au, Cu)
       const int r0 = max((int)q.vmin, 0), r1 = min((int)q.vmax, dp.H - 1);
       if (c1 >= c0 && r1 >= r0) {
@@ -1022,7 +1032,7 @@ __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __re
     const int k = idx - s_first[j], ntx = s_box[j][2];
     const int tx = s_box[j][0] + k % ntx, ty = s_box[j][1] + k / ntx;
     BinEntry e;
-    if (!bin_entry(dp, R[t0 + j], t0 + j, tx * kTileW, ty * kTileH, s_cols[j][0], s_cols[j][1], e)) continue;
+    if (!bin_entry(dp, s_rec[j], t0 + j, tx * kTileW, ty * kTileH, s_cols[j][0], s_cols[j][1], e)) continue;
     const size_t bin = base + (size_t)ty * tiles_x + tx;
     const int slot = atomicAdd(&bin_count[bin], 1);
     if (slot < kBinCap) bin_list[bin * kBinCap + slot] = e;
