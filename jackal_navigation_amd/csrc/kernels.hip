@@ -1702,17 +1702,25 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
   unsigned long long tmin = ~0ull, tmax = 0ull, rmin = ~0ull, rmax = 0ull;
   int cur_bin = -1;
   unsigned long long cur_min = ~0ull;
-  if (i < W) for (int j = j0; j < min(j0 + kScanRows, H); j++) {
+  const int jend = min(j0 + kScanRows, H);
+  // the next row's disparity and LUT entry are fetched before this row's double-precision work starts
+  auto fetch = [&](int j, float& fd, int& ud, int& l0, int& l1) {
     const size_t p = ((size_t)frame * H + j) * W + i;
+    if (dD) fd = dD[p]; else ud = dDisp[p];
+    if (!kFromCloud) { const uint16_t l = reinterpret_cast<const uint16_t*>(lut)[(size_t)j * W + i]; l0 = l & 0xFF; l1 = l >> 8; }   // :234
+  };
+  float fd_n = 0; int ud_n = 0, l0_n = 0, l1_n = 0;
+  if (i < W && j0 < jend) fetch(j0, fd_n, ud_n, l0_n, l1_n);
+  if (i < W) for (int j = j0; j < jend; j++) {
+    const size_t p = ((size_t)frame * H + j) * W + i;
+    const float fd = fd_n; const int ud = ud_n, l0 = l0_n, l1 = l1_n;
+    if (j + 1 < jend) fetch(j + 1, fd_n, ud_n, l0_n, l1_n);
     int d;
-    if (dD) { const uint8_t q = f32_to_u8(dD[p]); dDisp[p] = q; d = q; } else d = dDisp[p];
+    if (dD) { const uint8_t q = f32_to_u8(fd); dDisp[p] = q; d = q; } else d = ud;
     bool take;
     double X = 0, Y = 0, Z = 0;
     if (kFromCloud) take = d >= 2 && reproject(s, i, j, d, X, Y, Z) && !is_ground(s, X, Z);      // :324, :166-172
-    else {
-      const uint8_t l0 = lut[((size_t)j * W + i) * 2], l1 = lut[((size_t)j * W + i) * 2 + 1];   // :234
-      take = d >= l0 && d <= l1 && reproject(s, i, j, d, X, Y, Z);
-    }
+    else take = d >= l0 && d <= l1 && reproject(s, i, j, d, X, Y, Z);
     if (take) {
       const double th = atan2(Y, X);
       const double deg = __dmul_rn(th, 180.) / s.pi;
