@@ -1525,6 +1525,43 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const Fra
   out[frame * plane + p] = res;
 }
 
+// Horizontal pass, four consecutive pixels per thread (widths that are multiples of 4): the 11 values their windows
+// span arrive as three 16-byte loads, and because u & 3 is then known at compile time the ring order is a
+// straight-line case per pixel instead of a lane-wise rotation.  Same arithmetic as k_adaptive_mean_h.
+__global__ void __launch_bounds__(64) k_adaptive_mean_h4(DevParams dp, const FrameInfo* __restrict__ info,
+                                                          const float* __restrict__ in, float* __restrict__ out) {
+  const int u0 = (blockIdx.x * 64 + threadIdx.x) * 4, v = blockIdx.y, frame = blockIdx.z;
+  if (u0 >= dp.W || !info[frame].ok) return;
+  const int W = dp.W, H = dp.H;
+  const size_t row = ((size_t)frame * H + v) * W;
+  const float4* I4 = reinterpret_cast<const float4*>(in + row);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 a = u0 >= 4 ? I4[u0 / 4 - 1] : zero, b = I4[u0 / 4], c4 = u0 + 4 < W ? I4[u0 / 4 + 1] : zero;
+  const float x[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x, c4.y, c4.z, c4.w};   // x[k] = pixel u0 - 4 + k
+  float res[4] = {b.x, b.y, b.z, b.w};
+  if (v >= 3 && v < H - 3) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int u = u0 + i;
+      if (u < 4 || u > W - 4) continue;
+      const float c = x[4 + i];
+      float pw[4], pf[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float x0 = x[i + k], x1 = x[i + k + 4];
+        const float w0 = am_weight(x0, c), w1 = am_weight(x1, c);
+        pw[k] = __fadd_rn(w0, w1);
+        pf[k] = __fadd_rn(__fmul_rn(x0, w0), __fmul_rn(x1, w1));
+      }
+      // ring lane l = P[(l - u) & 3] with u & 3 == i
+      const float ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[(0 - i) & 3], pw[(1 - i) & 3]), pw[(2 - i) & 3]), pw[(3 - i) & 3]);
+      const float fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[(0 - i) & 3], pf[(1 - i) & 3]), pf[(2 - i) & 3]), pf[(3 - i) & 3]);
+      if (ws > 0) { const float d = fs / ws; if (d >= 0) res[i] = d; }
+    }
+  }
+  reinterpret_cast<float4*>(out + row)[u0 / 4] = make_float4(res[0], res[1], res[2], res[3]);
+}
+
 // Vertical pass, one thread per column walking kAmRows rows with the 8-tap window in registers: 1.4 row reads per
 // output instead of 8 (a thread-per-pixel variant is bound by L2 requests, not by arithmetic).  Same arithmetic as the
 // horizontal pass on columns 3..W-4, centres 4..H-4: in = tmp (horizontal result); D keeps its value where no mean forms.
@@ -1553,18 +1590,15 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_v(DevParams dp, const Fra
         pw[k] = __fadd_rn(w0, w1);
         pf[k] = __fadd_rn(__fmul_rn(x[k], w0), __fmul_rn(x[k + 4], w1));
       }
-      const int r = v & 3;                               // wave-uniform: lane l of the reference's ring = P[(l - v) & 3]
-      if (r & 1) {
-        const float tw = pw[3], tf = pf[3];
-        pw[3] = pw[2]; pw[2] = pw[1]; pw[1] = pw[0]; pw[0] = tw;
-        pf[3] = pf[2]; pf[2] = pf[1]; pf[1] = pf[0]; pf[0] = tf;
+      // lane l of the reference's ring holds P[(l - v) & 3]; v is the same for the whole wave, so the four possible
+      // orders are four straight-line cases instead of a lane-wise rotation
+      float ws, fs;
+      switch (v & 3) {
+        case 0:  ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[0], pw[1]), pw[2]), pw[3]); fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[0], pf[1]), pf[2]), pf[3]); break;
+        case 1:  ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[3], pw[0]), pw[1]), pw[2]); fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[3], pf[0]), pf[1]), pf[2]); break;
+        case 2:  ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[2], pw[3]), pw[0]), pw[1]); fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[2], pf[3]), pf[0]), pf[1]); break;
+        default: ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[1], pw[2]), pw[3]), pw[0]); fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[1], pf[2]), pf[3]), pf[0]); break;
       }
-      if (r & 2) {
-        float t = pw[0]; pw[0] = pw[2]; pw[2] = t; t = pw[1]; pw[1] = pw[3]; pw[3] = t;
-        t = pf[0]; pf[0] = pf[2]; pf[2] = t; t = pf[1]; pf[1] = pf[3]; pf[3] = t;
-      }
-      const float ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[0], pw[1]), pw[2]), pw[3]);
-      const float fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[0], pf[1]), pf[2]), pf[3]);
       if (ws > 0) { const float d = fs / ws; if (d >= 0) O[(size_t)v * W] = d; }
     }
 #pragma unroll
@@ -2009,7 +2043,8 @@ void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
 }
 void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);
-  hipLaunchKernelGGL(k_adaptive_mean_h, g, dim3(256), 0, st, dp, info, D, tmp);
+  if ((dp.W & 3) == 0) hipLaunchKernelGGL(k_adaptive_mean_h4, dim3((dp.W / 4 + 63) / 64, dp.H, n), dim3(64), 0, st, dp, info, D, tmp);
+  else hipLaunchKernelGGL(k_adaptive_mean_h, g, dim3(256), 0, st, dp, info, D, tmp);
   hipLaunchKernelGGL(k_adaptive_mean_v, dim3((dp.W + 255) / 256, (dp.H + kAmRows - 1) / kAmRows, n), dim3(256), 0, st, dp, info, tmp, D);
 }
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
