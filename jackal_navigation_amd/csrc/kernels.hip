@@ -1473,6 +1473,34 @@ __global__ void __launch_bounds__(256) k_gap(DevParams dp, const FrameInfo* __re
   out[frame * plane + p] = val;
 }
 
+// Four pixels per thread (widths that are multiples of 4): most pixels are valid and just pass through, so the common
+// case is one 16-byte load and one 16-byte store; only invalid pixels look along their line.
+DEV float gap_fill(const DevParams& dp, const float* I, size_t p, int stride, int pos, int len) {
+  int a = 0, b = 0;
+  for (int k = 1; k <= dp.gap_width && pos - k >= 0; k++) if (I[p - (size_t)k * stride] >= 0) { a = k; break; }
+  if (!a) return I[p];
+  for (int k = 1; k <= dp.gap_width - a + 1 && pos + k < len; k++) if (I[p + (size_t)k * stride] >= 0) { b = k; break; }
+  if (!b) return I[p];
+  const float d1 = I[p - (size_t)a * stride], d2 = I[p + (size_t)b * stride];
+  return fabsf(d1 - d2) < 3.0f ? __fadd_rn(d1, d2) / 2 : fminf(d1, d2);     // :1149-1150
+}
+template <bool kRows>
+__global__ void __launch_bounds__(64) k_gap4(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
+                                             float* __restrict__ out) {
+  const int u0 = (blockIdx.x * 64 + threadIdx.x) * 4, v = blockIdx.y, frame = blockIdx.z;
+  if (u0 >= dp.W || !info[frame].ok) return;
+  const int W = dp.W;
+  const size_t plane = (size_t)dp.H * W;
+  const float* I = in + frame * plane;
+  const size_t p0 = (size_t)v * W + u0;
+  const float4 x = *reinterpret_cast<const float4*>(I + p0);
+  float r[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (!(r[i] >= 0)) r[i] = gap_fill(dp, I, p0 + i, kRows ? 1 : W, kRows ? u0 + i : v, kRows ? W : dp.H);
+  *reinterpret_cast<float4*>(out + frame * plane + p0) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Adaptive mean (elas.cpp:1287-1492, full-resolution branch).  The reference's "abs mask" is
 // _mm_set1_ps(0x7FFFFFFF) = 2^31 as a float (0x4F000000), so the weight keeps a few exponent
@@ -2038,6 +2066,12 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
 }
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);
+  if ((dp.W & 3) == 0) {
+    const dim3 g4((dp.W / 4 + 63) / 64, dp.H, n);
+    hipLaunchKernelGGL(k_gap4<true>, g4, dim3(64), 0, st, dp, info, D, tmp);
+    hipLaunchKernelGGL(k_gap4<false>, g4, dim3(64), 0, st, dp, info, tmp, D);
+    return;
+  }
   hipLaunchKernelGGL(k_gap<true>, g, dim3(256), 0, st, dp, info, D, tmp);
   hipLaunchKernelGGL(k_gap<false>, g, dim3(256), 0, st, dp, info, tmp, D);
 }
