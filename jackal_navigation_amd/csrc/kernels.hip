@@ -5,6 +5,7 @@
 // in the same order (built with -ffp-contract=off; products/sums that must not fuse use
 // __fmul_rn/__fadd_rn explicitly).
 #include "kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 namespace jnav {
@@ -1904,6 +1905,14 @@ __global__ void __launch_bounds__(256) k_pc_scatter(ScanDev s, const uint8_t* __
 // ================================================================================================
 // launchers
 static inline dim3 grid2d(int W, int H, int z) { return dim3((W + 255) / 256, H, z); }
+// kernel attributes (dynamic LDS limits) are per device: true the first time a launcher runs on the current device;
+// slot workers of several handles may get here at the same time
+static bool first_time_on_device(std::atomic<uint64_t>& seen) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  return !(seen.fetch_or(bit) & bit);
+}
 
 static ScanDev to_dev(const jn_scan_params& sp) {
   ScanDev s;
@@ -1924,10 +1933,9 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, c
 }
 template <int PITCH>
 static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  static bool configured = false;
-  if (!configured) {
+  static std::atomic<uint64_t> configured{0};
+  if (first_time_on_device(configured)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    configured = true;
   }
   hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n), dim3(1024), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can);
 }
@@ -1960,10 +1968,9 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
   {
     const size_t need = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
     if (form == 2) {
-      static bool configured_fast = false;
-      if (!configured_fast) {
+      static std::atomic<uint64_t> configured_fast{0};
+      if (first_time_on_device(configured_fast)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
-        configured_fast = true;
       }
       uint8_t* code = reinterpret_cast<uint8_t*>(scratch);          // [n][cw*ch], column-major
       hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
@@ -1987,19 +1994,17 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
   const int points = (ch + K - 1) / K;                              // points per wavefront step
   const int lanes = points <= kFilterThreads / 16 ? 16 : (points <= kFilterThreads / 8 ? 8 : 0);
   if (!lanes) return false;
-  static bool configured = false;
-  if (!configured) {
+  static std::atomic<uint64_t> configured{0};
+  if (first_time_on_device(configured)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    configured = true;
   }
   const size_t lds = (size_t)cells * sizeof(int16_t);
   int sweep = 1;
   if (form == 1) {                                                  // classify + resolve from memory; the kernel below only runs the redundancy passes
-    static bool configured_big = false;
-    if (!configured_big) {
+    static std::atomic<uint64_t> configured_big{0};
+    if (first_time_on_device(configured_big)) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve_big<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
-      configured_big = true;
     }
     uint8_t* code = reinterpret_cast<uint8_t*>(scratch);
     hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
