@@ -6,23 +6,36 @@ reprojection -> 90-bin obstacle scan), 1280x720, disp range 128, batch 32 per GP
 
 One "step" = one batch of `--batch` synthetic pairs (SURVEY.md Appendix A generator, seed 12345+b)
 through the whole path with inputs already resident in HBM.  Steps are pipelined over `--slots`
-library slots (GPU stage A / host stage / GPU stage B of different batches overlap).  For N>1 the
-driver launches one rank per GPU (torch.distributed, backend nccl = RCCL); every rank processes its
-own rigs (weak scaling) and the per-step exchange is the element-wise MIN all-reduce of the scan
-bins, the only cross-rig step the path has.
+library slots (GPU stage A / host stage / GPU stage B of different batches overlap).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+N > 1: one rank (process) per GPU.  Under torchrun the ranks are already there (RANK / WORLD_SIZE in
+the environment); started plainly as `python bench.py --gpus N` this process spawns N fresh rank
+processes itself BEFORE anything touches the GPU and relays rank 0's line.  Every rank processes its
+own rigs (weak scaling); the per-step exchange is the element-wise MIN all-reduce of the scan bins
+(+ extrema), the only cross-rig step the path has, issued through the library's C-ABI
+(`jn_scan_allreduce`, RCCL over xGMI).  Each rank is pinned to its own physical cores on its GPU's
+NUMA node (jackal_navigation_amd/parallel.py).
+
+The timed region is EXACTLY `--steps` steps between barrier + synchronize pairs; it is repeated until
+at least `--min-time` seconds have been timed and the MEDIAN region decides `value` (the spread is
+reported).  Rank 0 prints ONE JSON line with `roofline`, `cpu_baseline` and `check` (FNV-1a-64 of D1 of
+frame 0 against the reference's golden hash; a mismatch exits non-zero).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises: one hardware queue per slot stream (see jackal_navigation_amd/__init__.py)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -38,6 +51,8 @@ STAGE_BYTES_PER_PX = {
     "gpu_gap": 16.0,            # rows+cols 8r+8w
     "gpu_adaptive_mean": 16.0,  # H+V 8r+8w
 }
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+KERNELS_SRC = os.path.join(ROOT, "jackal_navigation_amd", "csrc", "kernels.hip")
 
 
 def cpu_baseline_worker(args):
@@ -78,12 +93,12 @@ def cpu_baseline(W, H, scene, disp, budget_s=20.0):
     total = procs * per_proc
     return {
         "value": round(total / wall, 2), "unit": "pairs/s", "cores": procs, "kind": kind,
-        "sample": "%d pairs %dx%d disp_max=%d in %d processes (%.1f s wall); single core: %.2f pairs/s" %
-                  (total, W, H, disp - 1, procs, wall, 1.0 / per_pair),
+        "sample": "%d pairs %dx%d scene disparities <= %d, disp_max=%d in %d processes (%.1f s wall); single core: %.2f pairs/s" %
+                  (total, W, H, scene, disp - 1, procs, wall, 1.0 / per_pair),
     }
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -95,27 +110,89 @@ def main():
     ap.add_argument("--scene-disp", type=int, default=0, help="largest disparity in the synthetic scene (default: D)")
     ap.add_argument("--slots", type=int, default=4)
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the timed region until this many seconds have been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-config", action="store_true",
                     help="skip the informational 640x480 batch-1 leg (profiles then hold the headline workload's launches only)")
+    ap.add_argument("--no-alone-leg", action="store_true", help="skip the un-pipelined leg that times k_dense running alone")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (=RCCL, default) or gloo; gloo + --share-gpu lets two ranks dry-run the N>1 path on one GPU")
+    ap.add_argument("--merge", default="cabi", choices=["cabi", "torch"],
+                    help="cross-rig merge with the nccl backend: the library's jn_scan_allreduce (default) or torch.distributed")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses device 0")
-    a = ap.parse_args()
+    ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
+    return ap.parse_args()
 
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (this process has not touched the GPU
+    and never will), wait for them, pass rank 0's line through.  Returns the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and code == 0:
+                    code = rc
+                    for q in pending:          # one rank failed: the others would wait for it in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return code
+
+
+def kernels_sha():
+    try:
+        return hashlib.sha256(open(KERNELS_SRC, "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def golden_hash(W, H, scene, disp_max):
+    """D1 hash of the reference on the Appendix-A pair (seed 12345) for this configuration, if one was recorded."""
+    try:
+        for line in open(os.path.join(ROOT, "tests", "golden", "reference_hashes.txt")):
+            f = line.split()
+            if len(f) >= 5 and not line.startswith("#") and (int(f[0]), int(f[1]), int(f[2]), int(f[3])) == (W, H, scene, disp_max):
+                return f[4]
+    except OSError:
+        pass
+    return None
+
+
+def run_rank(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; start it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run with --nproc-per-node N" % (a.gpus, world))
     W, H, B, S = a.width, a.height, a.batch, a.slots
+    scene = a.scene_disp or a.disp
 
     # CPU baseline first: it forks worker processes, which must happen before this process touches the GPU.
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(W, H, a.disp, a.scene_disp or a.disp)
+        cpu = cpu_baseline(W, H, scene, a.disp)
 
     import torch
     import jackal_navigation_amd as jn
-    from jackal_navigation_amd import node, parallel
+    from jackal_navigation_amd import node, parallel, _lib
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -134,15 +211,20 @@ def main():
     torch.cuda.set_device(dev)
     on_gpu = a.dist_backend == "nccl"      # gloo reduces CPU tensors
 
-    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # the CPUs this process may use
+    # host cores of this rank: whole physical cores on the GPU's NUMA node, split between the ranks that share the node;
+    # set before the library starts its slot workers and Delaunay pool (threads inherit the mask)
+    pin = None
+    if not a.no_pin and hasattr(os, "sched_setaffinity"):
+        pin = parallel.pin_rank(rank, world, [0] * world if a.share_gpu else list(range(world)))
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # measured on the 2x64-core EPYC box: 16 pool threads per GPU keep the host stage hidden behind the
     # kernels of the other slots; more threads only add wake-up and cache traffic
-    host_threads = a.host_threads or max(4, min(ncpu // max(world, 1) - 2, 16))
+    host_threads = a.host_threads or max(4, min(ncpu - 2, 16))
 
     # synthetic batch of this rank, resident in HBM
     Ls = np.empty((B, H, W), np.uint8); Rs = np.empty((B, H, W), np.uint8)
     for b in range(B):
-        Ls[b], Rs[b] = node.synth_pair(W, H, a.scene_disp or a.disp, 12345 + b + 1000 * rank)
+        Ls[b], Rs[b] = node.synth_pair(W, H, scene, 12345 + b + 1000 * rank)
     dL = torch.from_numpy(Ls).to(dev); dR = torch.from_numpy(Rs).to(dev)
     D1 = [torch.zeros((B, H, W), dtype=torch.float32, device=dev) for _ in range(S)]
     D2 = [torch.zeros((B, H, W), dtype=torch.float32, device=dev) for _ in range(S)]
@@ -157,6 +239,30 @@ def main():
     lut = node.build_valid_disp_lut(sp, W, H, device=local_rank)
     torch.cuda.synchronize()
 
+    # the cross-rig merge: the library's own RCCL communicator (C-ABI), torch.distributed as the alternative
+    comm, merge_kind, comm_info = None, None, None
+    if dist is not None:
+        if on_gpu and a.merge == "cabi":
+            def exchange(raw):
+                t = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if raw is not None:
+                    t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+                dist.broadcast(t, src=0)
+                return bytes(t.cpu().numpy().tobytes())
+            try:
+                comm = parallel.ScanComm(rank, world, local_rank, exchange)
+                comm_info = comm.info()
+                merge_kind = "jn_scan_allreduce (C-ABI, RCCL ncclAllReduce MIN, one packed buffer per batch)"
+            except _lib.JnError as e:
+                print("bench.py rank %d: %s; falling back to torch.distributed for the merge" % (rank, e), file=sys.stderr)
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)                      # all ranks take the same route
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close(); comm = None
+        if comm is None:
+            merge_kind = "torch.distributed all_reduce(MIN) (%s), one packed buffer per batch" % a.dist_backend
+
     stage_acc = {}
     dense_ms = []
 
@@ -166,20 +272,27 @@ def main():
         for k, v in elas.last_times(slot).items():
             stage_acc.setdefault(k, []).append(v)
         dense_ms.append(elas.kernel_time(slot)[0])
-        if dist is not None:                      # the path's one exchange step: robot-level scan = MIN over rigs,
-            if on_gpu:                            # one all-reduce per batch
-                scans[slot].merge()
-            else:
-                host = parallel.ScanBuffer(B, 90, "cpu")
-                host.flat.copy_(scans[slot].flat)
-                host.merge()
-                scans[slot].flat.copy_(host.flat)
+        if dist is None:
+            return
+        # the path's one exchange step: robot-level scan = MIN over rigs, one all-reduce per batch; it completes
+        # before the slot is handed a new batch (the next batch's kernels write the same bins)
+        if comm is not None:
+            comm.merge(B, 90, bins[slot].data_ptr(), meta[slot].data_ptr())
+        elif on_gpu:
+            scans[slot].merge()
+            torch.cuda.current_stream().synchronize()
+        else:
+            host = parallel.ScanBuffer(B, 90, "cpu")
+            host.flat.copy_(scans[slot].flat)
+            host.merge()
+            scans[slot].flat.copy_(host.flat)
+            torch.cuda.current_stream().synchronize()
 
-    def run(steps):
+    def run(steps, depth=S):
         inflight = []
         for i in range(steps):
-            slot = i % S
-            if len(inflight) == S:
+            slot = i % depth
+            if len(inflight) == depth:
                 finish(inflight.pop(0))
             elas.submit_scan(slot, B, dL.data_ptr(), dR.data_ptr(), W, H * W, D1[slot].data_ptr(), D2[slot].data_ptr(), sp, lut.ptr,
                              U8[slot].data_ptr(), bins[slot].data_ptr(), meta[slot].data_ptr(), status[slot])
@@ -192,47 +305,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_region():
+        """EXACTLY a.steps steps between barrier + synchronize pairs; MAX over ranks."""
+        sync()
+        t0 = time.perf_counter()
+        run(a.steps)
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     run(a.warmup)
     sync()
     stage_acc.clear()
     del dense_ms[:]
-    t0 = time.perf_counter()
-    run(a.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    regions = [timed_region()]                    # identical on every rank (max-reduced), so the repeat count agrees
+    repeats = max(1, min(200, int(math.ceil(a.min_time / max(regions[0], 1e-6)))))
+    for _ in range(repeats - 1):
+        regions.append(timed_region())
+    elapsed = float(np.median(regions))
 
     failed = sum(1 for s in status for x in s if x != 0)
     pairs = world * B * a.steps
     value = pairs / elapsed
-
-    # roofline of the dominant kernel, k_dense (31 % of GPU time, profiles/): algorithmic bytes per launch
-    # (dense L+R = 16 B per pixel per pair, one launch = the whole batch, both sides) over its average
-    # duration, measured with HIP events the library records around the kernel on the stream it runs on.
     stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
-    k_ms = float(np.mean(dense_ms))
+    k_ms_pipelined = float(np.mean(dense_ms))
+
+    # k_dense running ALONE (one batch in flight, kernels back to back): what the roofline fraction is computed from
+    k_ms_alone = None
+    if not a.no_alone_leg:
+        del dense_ms[:]
+        run(6, depth=1)
+        k_ms_alone = float(np.mean(dense_ms[1:]))
+    sync()
+
+    # what was timed is what the reference computes: FNV-1a-64 of D1 (frame 0 = seed 12345 on rank 0) of every slot
+    check = None
+    if rank == 0:
+        want = golden_hash(W, H, scene, a.disp - 1)
+        L = jn.load()
+        got = []
+        for s_ in range(S):
+            host = D1[s_][0].cpu().numpy()
+            got.append("%016x" % L.jn_fnv1a64_u32(host.ctypes.data, host.size))
+        check = {"what": "FNV-1a-64 of D1, frame 0 (seed 12345), every slot, after the timed region", "got": sorted(set(got)),
+                 "expected": want, "source": "tests/golden/reference_hashes.txt (compiled reference src/elas)" if want else None,
+                 "ok": (set(got) == {want}) if want else None}
+
+    # roofline of the dominant kernel, k_dense: algorithmic bytes per launch (SURVEY §8d: dense L+R = 16 B per pixel per
+    # pair, one launch = the whole batch, both sides) over its average duration, measured with HIP events the library
+    # records around the kernel on the stream it runs on.
     alg_bytes = STAGE_BYTES_PER_PX["gpu_matching"] * W * H * B
+    k_ms = k_ms_alone if k_ms_alone else k_ms_pipelined
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None
-    extra_roof = {}
+    traffic, traffic_note, extra_roof = None, None, {}
     try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs) of the same workload
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pmc = json.load(open(PMC_FILE))
         if (W, H, B, a.disp) == (1280, 720, 32, 128):
-            traffic = pmc["k_dense"]["traffic_bytes"]
-            extra_roof = {"alone_ms_per_launch": pmc["k_dense"].get("alone_ms_per_launch"),
-                          "valu_issue_frac_alone": pmc["k_dense"].get("valu_issue_frac_alone"),
-                          "note": "k_dense is bound by vector-instruction issue, not by HBM: running alone it uses the stated fraction of "
-                                  "its VALU issue slots (PMC, profiles/r01_pmc_traffic.json); ms_per_launch above is the duration "
-                                  "stretched by the other slots' kernels sharing the GPU"}
+            if pmc.get("kernels_hip_sha256") == kernels_sha():
+                traffic = pmc["k_dense"]["traffic_bytes"]
+                extra_roof = {"valu_issue_frac_alone": pmc["k_dense"].get("valu_issue_frac_alone"),
+                              "SQ_INSTS_VALU": pmc["k_dense"].get("SQ_INSTS_VALU"), "pmc_commit": pmc.get("commit")}
+            else:
+                traffic_note = "PMC passes in %s were taken with a different kernels.hip (sha256 differs): not reported" % os.path.basename(PMC_FILE)
     except Exception:
-        pass
+        traffic_note = "no PMC file for this round yet"
     roofline = {"bound": "hbm", "kernel": "k_dense", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "ms_per_launch": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4)}
+                "ms_per_launch": round(k_ms, 4), "ms_per_launch_is": "alone (one batch in flight)" if k_ms_alone else "pipelined",
+                "ms_per_launch_pipelined": round(k_ms_pipelined, 4),
+                "frac_pipelined": round(alg_bytes / (k_ms_pipelined * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "k_dense is bound by vector-instruction issue, not by HBM; pipelined, its launches stretch because "
+                        "kernels of the other slots share the GPU"}
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
     roofline.update(extra_roof)
 
     # BASELINE config 2 beside the headline workload: 640x480, D=64, batch 1, latency mode (one synchronous
@@ -256,26 +407,56 @@ def main():
         extra = {"workload": "640x480 D=64 batch=1 latency mode (BASELINE config 2)", "ms_per_frame": round(lat * 1e3, 3),
                  "pairs_per_sec": round(1.0 / lat, 1)}
 
+    # who took part: gathered over the collective backend, so the line shows what the N ranks really ran on
+    ranks_info = None
+    if dist is not None:
+        mine = {"rank": rank, "device": local_rank, "pin": pin, "rccl_comm": comm_info, "host_threads": host_threads}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
+
     if rank == 0:
         out = {
-            "metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+            "metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s",
+            "n_gpus": (dist.get_world_size() if dist is not None else 1),
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "ms_per_frame": round(elapsed / (B * a.steps) * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32",
             "data": "synthetic",
             "config": {"workload": "%dx%d rectified pairs (scene disparities <= %d), ELAS disp_max=%d (D=%d), batch=%d per GPU -> u8 map -> 90-bin scan" %
-                                   (W, H, a.scene_disp or a.disp, a.disp - 1, a.disp, B),
+                                   (W, H, scene, a.disp - 1, a.disp, B),
                        "batch_per_gpu": B, "slots": S, "host_threads": host_threads, "pairs_failed": failed,
-                       "parallelism": "rigs sharded 1 batch/GPU, MIN all-reduce of scan bins" if world > 1 else "single GPU"},
+                       "parallelism": ("rigs sharded 1 batch/GPU over %d ranks; merge: %s" % (world, merge_kind)) if world > 1 else "single GPU"},
+            "timing": {"regions": len(regions), "region_s_median": round(elapsed, 5), "region_s_min": round(min(regions), 5),
+                       "region_s_max": round(max(regions), 5), "timed_s_total": round(sum(regions), 4),
+                       "value_from": "median region; every region is exactly `steps` steps between barrier+synchronize pairs"},
             "stage_ms_per_batch": {k: round(v, 3) for k, v in stage_ms.items()},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "check": check,
             "latency_config": extra,
         }
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+            out["distinct_devices"] = sorted({r["device"] for r in ranks_info})
+        elif pin is not None:
+            out["pin"] = pin
         print(json.dumps(out))
+        sys.stdout.flush()
     elas.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and check and check["ok"] is False:
+        raise SystemExit("bench.py: D1 of the timed path differs from the reference's golden hash: %s" % check)
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    run_rank(a)
 
 
 if __name__ == "__main__":

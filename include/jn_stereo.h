@@ -28,7 +28,8 @@ typedef enum jn_status {
   JN_ERR_UNSUPPORTED = 2,   /* parameter combination outside the HIP path (see jn_elas_create) */
   JN_ERR_INVALID = 3,       /* bad argument */
   JN_ERR_NO_DEVICE = 4,     /* no usable HIP device / HIP runtime failure */
-  JN_ERR_INTERNAL = 5
+  JN_ERR_INTERNAL = 5,
+  JN_ERR_COMM = 6           /* RCCL missing or a collective failed (jn_comm_*) */
 } jn_status;
 
 /* ---- Seam B1 ------------------------------------------------------------------------------ */
@@ -74,8 +75,9 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  *   host_threads  worker threads for the host stage (support-point filters, Delaunay, planes,
  *                 grid prior); 0 = one per online core
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
- * Unsupported (JN_ERR_UNSUPPORTED): subsampling, add_corners, filter_median, disp_max > 255,
- * disp_min != 0, ipol_gap_width > 64, candidate_stepsize < 1, plane radius > 7. */
+ * Unsupported (JN_ERR_UNSUPPORTED): subsampling, add_corners, disp_max > 255 or < 10,
+ * disp_min != 0, ipol_gap_width > 64, candidate_stepsize < 1, grid_size < 1, plane radius > 7.
+ * On any failure everything allocated so far is released and *out stays NULL. */
 jn_status jn_elas_create(const jn_elas_params* p, int32_t width, int32_t height, int32_t max_batch,
                          int32_t device, int32_t host_threads, int32_t slots, jn_elas** out);
 void jn_elas_destroy(jn_elas* h);
@@ -205,10 +207,38 @@ jn_status jn_init_undistort_rectify_map(int32_t device, const double K[9], const
 /* cv::remap(src, dst, mapx, mapy, INTER_LINEAR) with BORDER_CONSTANT 0 (point_cloud.cpp:440, :481)
  * for n grey source frames (device).  Source coordinates are quantised to 1/32 pixel
  * (round-half-even, as OpenCV does); the four taps are blended with exact 10-bit weights
- * ((32-fx)(32-fy) ...)/1024, rounded to nearest. */
+ * ((32-fx)(32-fy) ...)/1024, rounded to nearest.
+ * PARITY UNPINNED (no OpenCV in the build image).  Known difference from a real OpenCV deployment:
+ * cv::remap's 8-bit INTER_LINEAR path blends with a table of weights ROUNDED to 15 bits
+ * (INTER_REMAP_COEF_SCALE = 32768, each of the 32x32 weight quadruples rounded and then fixed up to
+ * sum to 32768) and rounds the sum once; the exact products used here differ from that table in the
+ * last bit for some (fx, fy), so individual output pixels can differ by +-1 grey level. */
 jn_status jn_remap_bilinear(int32_t device, int32_t n, const uint8_t* dSrc, int32_t src_width, int32_t src_height,
                             int32_t src_pitch, int64_t src_stride, const float* dMapX, const float* dMapY,
                             uint8_t* dDst, int32_t width, int32_t height, int32_t dst_pitch, int64_t dst_stride);
+
+/* ---- cross-rig merge (SURVEY.md 8b `jn_scan_allreduce`, 8e) ---------------------------------
+ * The path's one exchange step: per-rig obstacle scans -> robot-level scan = element-wise MIN over
+ * the bins (point_cloud.cpp:264-266 applied across rigs) and min / max / min / max of the four
+ * LaserScan extrema (:255-260), followed on every rank by the compaction of :278-282
+ * (jn_compact_ranges).  One rank (= one process) per GPU; the collective is RCCL's
+ * ncclAllReduce(ncclMin, ncclDouble) over xGMI on ONE packed buffer per batch (maxima travel
+ * negated), i.e. a single latency-bound message of n*(bins+4)*8 bytes.  librccl.so.1 is bound at
+ * run time (dlopen; the copy a host process already loaded, e.g. PyTorch's, is re-used), so the
+ * library itself has no link-time dependency on RCCL. */
+#define JN_COMM_ID_BYTES 128
+typedef struct jn_comm jn_comm;
+/* ncclGetUniqueId: rank 0 creates the id and hands it to the other ranks by any side channel. */
+jn_status jn_comm_unique_id(uint8_t id[JN_COMM_ID_BYTES]);
+/* ncclCommInitRank on `device`; collective over all `world` ranks. */
+jn_status jn_comm_create(const uint8_t id[JN_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, jn_comm** out);
+/* What RCCL itself reports for the communicator (ncclCommUserRank / ncclCommCount / ncclCommCuDevice). */
+jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* device);
+/* In place on device memory of the communicator's GPU: dBins [n][bins] doubles and dMeta [n][4] as
+ * jn_obstacle_scan writes them; afterwards every rank holds the merged scans.  The inputs must be
+ * complete (e.g. after jn_elas_wait); returns when the merged values are in place. */
+jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta);
+void jn_comm_destroy(jn_comm* c);
 
 /* ---- utilities ---------------------------------------------------------------------------- */
 
@@ -229,6 +259,9 @@ jn_status jn_device_synchronize(int32_t device);
 jn_status jn_elas_kernel_time(jn_elas* h, int32_t slot, const char* kernel, float* avg_ms, int32_t* launches);
 
 const char* jn_version(void);
+
+/* FNV-1a-64 over 32-bit words (host memory): the hash SURVEY.md 8c quotes for D1/D2 float maps. */
+uint64_t jn_fnv1a64_u32(const uint32_t* words, int64_t n);
 
 /* ---- host-stage hooks (CPU only; no device needed) ------------------------------------------
  * The serial middle of ELAS runs on host threads between the two GPU stages.  These two entry

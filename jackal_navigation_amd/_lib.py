@@ -10,8 +10,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libjn_stereo.so")
 
-JN_OK, JN_ERR_FEW_SUPPORT, JN_ERR_UNSUPPORTED, JN_ERR_INVALID, JN_ERR_NO_DEVICE, JN_ERR_INTERNAL = range(6)
-STATUS_NAMES = ["JN_OK", "JN_ERR_FEW_SUPPORT", "JN_ERR_UNSUPPORTED", "JN_ERR_INVALID", "JN_ERR_NO_DEVICE", "JN_ERR_INTERNAL"]
+JN_OK, JN_ERR_FEW_SUPPORT, JN_ERR_UNSUPPORTED, JN_ERR_INVALID, JN_ERR_NO_DEVICE, JN_ERR_INTERNAL, JN_ERR_COMM = range(7)
+STATUS_NAMES = ["JN_OK", "JN_ERR_FEW_SUPPORT", "JN_ERR_UNSUPPORTED", "JN_ERR_INVALID", "JN_ERR_NO_DEVICE", "JN_ERR_INTERNAL", "JN_ERR_COMM"]
 
 
 class JnError(RuntimeError):
@@ -88,6 +88,7 @@ EXPORTS = [
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
     "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote", "jn_device_support_filters", "jn_elas_submit_scan",
+    "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32",
 ]
 
 _lib = None
@@ -144,6 +145,14 @@ def load():
     L.jn_nav_state_reset.restype = None
     L.jn_scan_to_points.argtypes = [vp, i32, C.c_float, C.c_float, vp]
     L.jn_nav_vote.argtypes = [C.POINTER(NavParams), C.POINTER(NavState), vp, i32, C.POINTER(NavDecision)]
+    L.jn_comm_unique_id.argtypes = [vp]
+    L.jn_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.jn_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.jn_scan_allreduce.argtypes = [vp, i32, i32, vp, vp]
+    L.jn_comm_destroy.argtypes = [vp]
+    L.jn_comm_destroy.restype = None
+    L.jn_fnv1a64_u32.argtypes = [vp, i64]
+    L.jn_fnv1a64_u32.restype = C.c_uint64
     _lib = L
     return L
 

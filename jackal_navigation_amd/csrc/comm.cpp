@@ -1,0 +1,170 @@
+// comm.cpp — the path's one exchange step over RCCL (include/jn_stereo.h, "cross-rig merge").  Product code.
+//
+// Per-rig obstacle scans -> robot-level scan: element-wise MIN over the bins (point_cloud.cpp:264-266 applied
+// across rigs) and min / max / min / max of the LaserScan extrema (:255-260).  One process per GPU; the merge of a
+// whole batch is ONE ncclAllReduce(ncclMin, ncclDouble) on a packed buffer (maxima negated for the trip) — a few tens
+// of KB, latency-bound over xGMI, so the number of collectives is what matters, not the link rate.
+//
+// RCCL is bound at run time: dlopen by soname returns the copy a host process already mapped (PyTorch ships its own
+// librccl.so.1), so a Python/torch host and this library talk to one RCCL; a plain C/C++ host gets /opt/rocm/lib's.
+#include "../../include/jn_stereo.h"
+#include "kernels.h"
+
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+#include <rccl/rccl.h>
+
+using namespace jnav;
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {getenv("JN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) { fprintf(stderr, "libjn_stereo: cannot load librccl.so.1 (%s)\n", dlerror()); return; }
+#define JN_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
+    JN_SYM(GetUniqueId, "ncclGetUniqueId"); JN_SYM(CommInitRank, "ncclCommInitRank"); JN_SYM(CommDestroy, "ncclCommDestroy");
+    JN_SYM(CommCount, "ncclCommCount"); JN_SYM(CommCuDevice, "ncclCommCuDevice"); JN_SYM(CommUserRank, "ncclCommUserRank");
+    JN_SYM(AllReduce, "ncclAllReduce"); JN_SYM(GetErrorString, "ncclGetErrorString");
+#undef JN_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.CommCount && r.CommCuDevice && r.CommUserRank && r.AllReduce &&
+           r.GetErrorString;
+    if (!r.ok) fprintf(stderr, "libjn_stereo: librccl lacks an expected symbol\n");
+  });
+  return r.ok ? &r : nullptr;
+}
+
+#define RCCL_TRY(R, expr)                                                                              \
+  do {                                                                                                 \
+    ncclResult_t e__ = (expr);                                                                         \
+    if (e__ != ncclSuccess) {                                                                          \
+      fprintf(stderr, "libjn_stereo: %s failed: %s (%s:%d)\n", #expr, (R)->GetErrorString(e__), __FILE__, __LINE__); \
+      return JN_ERR_COMM;                                                                              \
+    }                                                                                                  \
+  } while (0)
+#define HIP_TRY_C(expr)                                                                                \
+  do {                                                                                                 \
+    hipError_t e__ = (expr);                                                                           \
+    if (e__ != hipSuccess) {                                                                           \
+      fprintf(stderr, "libjn_stereo: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return JN_ERR_NO_DEVICE;                                                                         \
+    }                                                                                                  \
+  } while (0)
+
+}  // namespace
+
+struct jn_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  double* flat = nullptr;          // packed [n*bins | n*4] doubles, grow-only
+  size_t cap = 0;
+  std::mutex m;
+};
+
+extern "C" {
+
+jn_status jn_comm_unique_id(uint8_t id[JN_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) == JN_COMM_ID_BYTES, "ncclUniqueId size");
+  if (!id) return JN_ERR_INVALID;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  ncclUniqueId u;
+  RCCL_TRY(R, R->GetUniqueId(&u));
+  memcpy(id, &u, sizeof(u));
+  return JN_OK;
+}
+
+jn_status jn_comm_create(const uint8_t id[JN_COMM_ID_BYTES], int32_t rank, int32_t world, int32_t device, jn_comm** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) return JN_ERR_INVALID;
+  *out = nullptr;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  HIP_TRY_C(hipSetDevice(device));
+  jn_comm* c = new jn_comm();
+  c->rank = rank; c->world = world; c->device = device;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclResult_t e = R->CommInitRank(&c->comm, world, u, rank);
+  if (e != ncclSuccess) {
+    fprintf(stderr, "libjn_stereo: ncclCommInitRank(rank %d of %d, device %d) failed: %s\n", rank, world, device, R->GetErrorString(e));
+    delete c;
+    return JN_ERR_COMM;
+  }
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { R->CommDestroy(c->comm); delete c; return JN_ERR_NO_DEVICE; }
+  *out = c;
+  return JN_OK;
+}
+
+jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* device) {
+  if (!c) return JN_ERR_INVALID;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  int r = 0, w = 0, d = 0;
+  RCCL_TRY(R, R->CommUserRank(c->comm, &r));
+  RCCL_TRY(R, R->CommCount(c->comm, &w));
+  RCCL_TRY(R, R->CommCuDevice(c->comm, &d));
+  if (rank) *rank = r;
+  if (world) *world = w;
+  if (device) *device = d;
+  return JN_OK;
+}
+
+jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta) {
+  if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  std::lock_guard<std::mutex> guard(c->m);       // collectives of one communicator are issued in one order
+  HIP_TRY_C(hipSetDevice(c->device));
+  const size_t count = (size_t)n * (bins + 4);
+  if (count > c->cap) {
+    if (c->flat) hipFree(c->flat);
+    c->flat = nullptr; c->cap = 0;
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
+    c->cap = count;
+  }
+  launch_scan_pack(c->stream, n, bins, dBins, dMeta, c->flat, true);
+  RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
+  launch_scan_pack(c->stream, n, bins, dBins, dMeta, c->flat, false);
+  HIP_TRY_C(hipStreamSynchronize(c->stream));
+  HIP_TRY_C(hipGetLastError());
+  return JN_OK;
+}
+
+void jn_comm_destroy(jn_comm* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) { hipStreamSynchronize(c->stream); }
+  if (Rccl* R = rccl()) if (c->comm) R->CommDestroy(c->comm);
+  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->flat) hipFree(c->flat);
+  delete c;
+}
+
+}  // extern "C"

@@ -1,11 +1,13 @@
 // jn_api.cpp — C-ABI of libjn_stereo.so (include/jn_stereo.h).  Product code.
 //
 // Pipeline per batch (one "slot" = one HIP stream + its buffers + one worker thread):
-//   GPU stage A : sobel -> descriptor -> support matching                    (kernels.hip)
-//   D2H         : candidate lattice D_can (int16, 2 bytes per 25 pixels)
-//   host stage  : support filters, Delaunay x2, planes, grid prior          (host_stage.cpp, thread pool)
-//   H2D         : per-frame triangle records + grid bitsets
-//   GPU stage B : raster -> dense L/R -> L/R check -> speckle -> gaps -> adaptive mean
+//   GPU stage A : sobel + descriptor -> support matching -> support filters -> support list   (kernels.hip)
+//                 the list (uc, vc, d) is written by the GPU straight into pinned host memory
+//   host stage  : Delaunay x2 per frame                                       (delaunay.cpp, thread pool)
+//                 (+ the support filters when no kernel takes the lattice or JN_HOST_FILTERS=1: host_stage.cpp)
+//   H2D         : one copy per batch: support points + triangle corner indices
+//   GPU stage B : grid prior, plane fits, raster bins -> dense L/R -> L/R check -> speckle -> gaps -> adaptive mean
+//                 [-> u8 map + obstacle scan when submitted through jn_elas_submit_scan]
 // Several slots in flight overlap one batch's host stage with another batch's GPU stages.
 #include "../../include/jn_stereo.h"
 #include "kernels.h"
@@ -233,9 +235,17 @@ hipError_t dmalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void
 
 }  // namespace
 
+extern "C" void jn_elas_destroy(jn_elas* h);
+
 extern "C" {
 
-const char* jn_version(void) { return "jn_stereo 0.1 (gfx950)"; }
+const char* jn_version(void) { return "jn_stereo 0.2 (gfx950)"; }
+
+uint64_t jn_fnv1a64_u32(const uint32_t* words, int64_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (int64_t i = 0; i < n; i++) h = (h ^ words[i]) * 1099511628211ull;
+  return h;
+}
 
 void jn_elas_params_default(jn_elas_params* p, int32_t setting) {
   // elas.h:92-145
@@ -273,6 +283,18 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   HIP_TRY(hipSetDevice(device));
 
   std::unique_ptr<jn_elas> h(new jn_elas());
+  // any failure from here on releases whatever was allocated so far (jn_elas_destroy tolerates null buffers and
+  // workers that were never started)
+#define CREATE_TRY(expr)                                                                      \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      fprintf(stderr, "libjn_stereo: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      jn_elas_destroy(h.release());                                                           \
+      return JN_ERR_NO_DEVICE;                                                                \
+    }                                                                                         \
+  } while (0)
+  CREATE_TRY(configure_device_kernels());
   h->p = *p; h->W = W; h->H = H; h->max_batch = max_batch; h->device = device;
   DevParams& dp = h->dp;
   memset(&dp, 0, sizeof(dp));
@@ -307,40 +329,42 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
   for (int i = 0; i < slots; i++) {
-    std::unique_ptr<Slot> s(new Slot());
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    h->slots.emplace_back(new Slot());         // owned by the handle from the start: a failure below frees it too
+    Slot* s = h->slots.back().get();
+    CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     // blocking-sync events: the slot worker sleeps while the GPU runs instead of spinning on a core that
     // the host stage (and, on a multi-GPU node, the other ranks) could use
-    for (int e = 0; e < EV_COUNT; e++) HIP_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
-    HIP_TRY(dmalloc(&s->desc, 2 * B * px));
-    HIP_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
-    HIP_TRY(dmalloc(&s->info, B)); HIP_TRY(dmalloc(&s->payload, B * h->payload_cap));
+    for (int e = 0; e < EV_COUNT; e++) CREATE_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
+    CREATE_TRY(dmalloc(&s->desc, 2 * B * px));
+    CREATE_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
+    CREATE_TRY(dmalloc(&s->info, B)); CREATE_TRY(dmalloc(&s->payload, B * h->payload_cap));
     const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
-    HIP_TRY(dmalloc(&s->bin_count, 2 * B * tiles)); HIP_TRY(dmalloc(&s->bin_list, 2 * B * tiles * kBinCap));
-    HIP_TRY(dmalloc(&s->raw, 2 * B * px));
-    HIP_TRY(dmalloc(&s->tmp, B * px)); HIP_TRY(dmalloc(&s->label, B * px)); HIP_TRY(dmalloc(&s->size, B * px));
-    HIP_TRY(dmalloc(&s->scan_scratch, B * 4));
+    CREATE_TRY(dmalloc(&s->bin_count, 2 * B * tiles)); CREATE_TRY(dmalloc(&s->bin_list, 2 * B * tiles * kBinCap));
+    CREATE_TRY(dmalloc(&s->raw, 2 * B * px));
+    CREATE_TRY(dmalloc(&s->tmp, B * px)); CREATE_TRY(dmalloc(&s->label, B * px)); CREATE_TRY(dmalloc(&s->size, B * px));
+    CREATE_TRY(dmalloc(&s->scan_scratch, B * 4));
     const size_t grid_words = 2 * B * dp.gw * dp.gh * kGridWords;
-    HIP_TRY(dmalloc(&s->mark, grid_words)); HIP_TRY(dmalloc(&s->gridbits, grid_words));
-    HIP_TRY(dmalloc(&s->recs, 2 * B * (size_t)h->tri_cap));
+    CREATE_TRY(dmalloc(&s->mark, grid_words)); CREATE_TRY(dmalloc(&s->gridbits, grid_words));
+    CREATE_TRY(dmalloc(&s->recs, 2 * B * (size_t)h->tri_cap));
     s->scratch.resize(B);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_can), B * dp.cw * dp.ch * sizeof(int16_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), B * sizeof(FrameInfo), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_list), B * dp.cw * dp.ch * 3 * sizeof(int16_t), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_cnt), B * sizeof(int32_t), hipHostMallocDefault));
-    h->slots.push_back(std::move(s));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_can), B * dp.cw * dp.ch * sizeof(int16_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), B * sizeof(FrameInfo), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_list), B * dp.cw * dp.ch * 3 * sizeof(int16_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_cnt), B * sizeof(int32_t), hipHostMallocDefault));
   }
   h->s_pitch = dp.pitch;
-  HIP_TRY(dmalloc(&h->s_img, 2 * (size_t)H * dp.pitch));
-  HIP_TRY(dmalloc(&h->s_D, 2 * px));
+  CREATE_TRY(dmalloc(&h->s_img, 2 * (size_t)H * dp.pitch));
+  CREATE_TRY(dmalloc(&h->s_D, 2 * px));
   for (auto& s : h->slots) s->th = std::thread(slot_loop, h.get(), s.get());
   *out = h.release();
   return JN_OK;
+#undef CREATE_TRY
 }
 
 void jn_elas_destroy(jn_elas* h) {
   if (!h) return;
+  hipSetDevice(h->device);
   for (auto& s : h->slots) {
     { std::unique_lock<std::mutex> l(s->m); s->cv.wait(l, [&] { return !s->busy; }); s->quit = true; }
     s->cv.notify_all();
@@ -584,6 +608,7 @@ jn_status jn_device_support_filters(int32_t device, const jn_elas_params* p, int
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
   HIP_TRY(hipSetDevice(device));
+  HIP_TRY(configure_device_kernels());
   DevParams dp;
   memset(&dp, 0, sizeof(dp));
   dp.W = W; dp.H = H; dp.step = p->candidate_stepsize;

@@ -7,6 +7,9 @@
 
 namespace jnav {
 
+// Sets the dynamic-LDS limits of every kernel that needs more than the default, for the current device, once.
+hipError_t configure_device_kernels();
+
 // All launchers are asynchronous on `st`.  `n` = frames in the batch; per-frame arrays are laid out
 // frame-major with the strides given.
 
@@ -59,6 +62,8 @@ void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, ui
 // lut == nullptr selects the -g flavour (points with d >= 2 minus the ground model, point_cloud.cpp:149-211).
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
                  int W, int H, double* bins, double* meta, unsigned long long* scratch);
+// Cross-rig merge: pack (bins, meta with maxima negated) into `flat` [n*bins + n*4] or unpack it back.
+void launch_scan_pack(hipStream_t st, int n, int bins, double* dBins, double* dMeta, double* flat, bool pack);
 // Rectification front end (point_cloud.cpp:440, :481, :553-554).
 void launch_undistort_map(hipStream_t st, const double iR[9], const double K[9], const double D[5], int W, int H, float* mapx, float* mapy);
 void launch_remap(hipStream_t st, int n, const uint8_t* src, int sw, int sh, int spitch, int64_t sstride, const float* mapx,

@@ -5,8 +5,8 @@
 // in the same order (built with -ffp-contract=off; products/sums that must not fuse use
 // __fmul_rn/__fadd_rn explicitly).
 #include "kernels.h"
-#include <atomic>
 #include <cstdlib>
+#include <mutex>
 
 namespace jnav {
 
@@ -1839,6 +1839,18 @@ __global__ void k_scan_finish(int total_bins, int n, unsigned long long* gbins, 
   }
 }
 
+// Cross-rig merge (comm.cpp): bins [n][bins] and extrema [n][4] of a batch <-> one packed buffer, the two maxima of
+// every frame negated (exact for doubles) so that the whole merge is a single MIN all-reduce.
+__global__ void k_scan_pack(int nb, int nm, double* __restrict__ bins, double* __restrict__ meta, double* __restrict__ flat, int pack) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nb) { if (pack) flat[i] = bins[i]; else bins[i] = flat[i]; }
+  else if (i < nb + nm) {
+    const int j = i - nb;
+    if (pack) { const double x = meta[j]; flat[i] = (j & 1) ? -x : x; }
+    else { const double x = flat[i]; meta[j] = (j & 1) ? -x : x; }
+  }
+}
+
 // initUndistortRectifyMap (point_cloud.cpp:553-554): for every rectified pixel the distorted source
 // position.  iR = inverse(P[:, :3] * R) comes from the host; the per-pixel math is OpenCV's, in
 // double, stored as float (the column walk is evaluated directly instead of by repeated addition).
@@ -1905,13 +1917,34 @@ __global__ void __launch_bounds__(256) k_pc_scatter(ScanDev s, const uint8_t* __
 // ================================================================================================
 // launchers
 static inline dim3 grid2d(int W, int H, int z) { return dim3((W + 255) / 256, H, z); }
-// kernel attributes (dynamic LDS limits) are per device: true the first time a launcher runs on the current device;
-// slot workers of several handles may get here at the same time
-static bool first_time_on_device(std::atomic<uint64_t>& seen) {
+// Kernel attributes (dynamic LDS limits) are per device.  configure_device_kernels() sets every one of them for the
+// CURRENT device, once, under a lock, and reports failures; jn_elas_create / jn_device_support_filters call it before
+// anything can launch, so the launchers themselves carry no lazy-initialisation state (four slot workers reaching a
+// launcher together during warm-up used to race on it).
+template <int PITCH> static hipError_t configure_support_pitch() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+hipError_t configure_device_kernels() {
+  static std::mutex m;
+  static uint64_t done = 0;
   int dev = 0;
-  hipGetDevice(&dev);
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> guard(m);
   const uint64_t bit = 1ull << (dev & 63);
-  return !(seen.fetch_or(bit) & bit);
+  if (done & bit) return hipSuccess;
+  constexpr int WIN = 5;
+  if ((e = configure_support_pitch<320>()) != hipSuccess) return e;
+  if ((e = configure_support_pitch<640>()) != hipSuccess) return e;
+  if ((e = configure_support_pitch<1280>()) != hipSuccess) return e;
+  if ((e = configure_support_pitch<2560>()) != hipSuccess) return e;
+  // 152 KB dynamic + 6 KB static: asking for the full 160 KB fails silently and the launch is then refused
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve_big<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  done |= bit;
+  return hipSuccess;
 }
 
 static ScanDev to_dev(const jn_scan_params& sp) {
@@ -1933,10 +1966,6 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, c
 }
 template <int PITCH>
 static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  static std::atomic<uint64_t> configured{0};
-  if (first_time_on_device(configured)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
   hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n), dim3(1024), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can);
 }
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
@@ -1968,10 +1997,6 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
   {
     const size_t need = (size_t)(dp.cw + 2 * WIN) * (dp.ch + 2 * WIN) * sizeof(int16_t) + (size_t)dp.cw * dp.ch;
     if (form == 2) {
-      static std::atomic<uint64_t> configured_fast{0};
-      if (first_time_on_device(configured_fast)) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
-      }
       uint8_t* code = reinterpret_cast<uint8_t*>(scratch);          // [n][cw*ch], column-major
       hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
       hipLaunchKernelGGL(k_filter_resolve<WIN>, dim3(n), dim3(kFilterThreads), need, st, dp, tol, min_support, d_can, code);
@@ -1994,18 +2019,9 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
   const int points = (ch + K - 1) / K;                              // points per wavefront step
   const int lanes = points <= kFilterThreads / 16 ? 16 : (points <= kFilterThreads / 8 ? 8 : 0);
   if (!lanes) return false;
-  static std::atomic<uint64_t> configured{0};
-  if (first_time_on_device(configured)) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
   const size_t lds = (size_t)cells * sizeof(int16_t);
   int sweep = 1;
   if (form == 1) {                                                  // classify + resolve from memory; the kernel below only runs the redundancy passes
-    static std::atomic<uint64_t> configured_big{0};
-    if (first_time_on_device(configured_big)) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve_big<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);   // + 6 KB static
-    }
     uint8_t* code = reinterpret_cast<uint8_t*>(scratch);
     hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
     hipLaunchKernelGGL(k_filter_resolve_big<WIN>, dim3(n), dim3(kFilterThreads), ((size_t)cw * ch + 3) & ~(size_t)3, st, dp, tol, min_support, d_can, code);
@@ -2107,6 +2123,10 @@ void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* d
   if (lut) hipLaunchKernelGGL(k_scan<false>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
   else     hipLaunchKernelGGL(k_scan<true>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
   hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta);
+}
+void launch_scan_pack(hipStream_t st, int n, int bins, double* dBins, double* dMeta, double* flat, bool pack) {
+  const int nb = n * bins, nm = n * 4;
+  hipLaunchKernelGGL(k_scan_pack, dim3((nb + nm + 255) / 256), dim3(256), 0, st, nb, nm, dBins, dMeta, flat, pack ? 1 : 0);
 }
 void launch_undistort_map(hipStream_t st, const double iR[9], const double K[9], const double D[5], int W, int H, float* mapx, float* mapy) {
   MapDev m;

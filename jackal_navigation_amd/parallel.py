@@ -76,3 +76,161 @@ class ScanBuffer:
         dist.all_reduce(self.flat, op=dist.ReduceOp.MIN)
         self.meta[:, 1::2].neg_()
         return self
+
+
+class ScanComm:
+    """The cross-rig merge through the C-ABI (`jn_comm_*`, `jn_scan_allreduce`): one RCCL communicator per rank,
+    one MIN all-reduce of a packed [batch][bins+4] buffer per batch, issued by the library on its own stream.
+
+    `exchange_id(id_bytes_or_None) -> id_bytes` is the side channel that hands rank 0's ncclUniqueId to the other
+    ranks (bench.py passes a torch.distributed broadcast; a ROS host would use a parameter or a file)."""
+
+    def __init__(self, rank, world, device, exchange_id):
+        import ctypes as C
+        from . import _lib
+        self._L = _lib.load()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(self._L.jn_comm_unique_id(ident), "jn_comm_unique_id")
+        raw = exchange_id(bytes(ident) if rank == 0 else None)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        _lib.check(self._L.jn_comm_create(ident, rank, world, device, C.byref(h)), "jn_comm_create")
+        self._h = h
+
+    def info(self):
+        """(rank, world, device) as RCCL reports them for this communicator."""
+        import ctypes as C
+        from . import _lib
+        r, w, d = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._L.jn_comm_info(self._h, C.byref(r), C.byref(w), C.byref(d)), "jn_comm_info")
+        return r.value, w.value, d.value
+
+    def merge(self, n, bins, dBins, dMeta):
+        """In place on device pointers; returns when every rank's buffers hold the merged scans."""
+        from . import _lib
+        _lib.check(self._L.jn_scan_allreduce(self._h, n, bins, dBins, dMeta), "jn_scan_allreduce")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jn_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host cores per rank ---------------------------------------------------------------------------------------------
+# What limits 1 -> 8 GPU scaling of this path is the shared host (SURVEY.md §8e): every rank runs a Delaunay pool and
+# keeps pinned buffers.  Each rank therefore gets its own whole physical cores on the NUMA node its GPU hangs off.
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def format_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 10, 11] -> '0-3,8,10-11'"""
+    cpus = sorted(cpus)
+    parts, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        parts.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(parts)
+
+
+def plan_affinity(allowed, gpu_local_cpus, siblings, rank):
+    """CPUs for `rank` of len(gpu_local_cpus) ranks on one node.
+
+    allowed         CPUs this job may use (sched_getaffinity)
+    gpu_local_cpus  per rank: the CPUs local to that rank's GPU (its NUMA node), or None if unknown
+    siblings        cpu -> tuple of hardware threads sharing its core (may be {})
+    Ranks whose GPUs share a NUMA node split that node's physical cores evenly, in rank order; a rank whose node is
+    unknown (or has no allowed CPU) shares what is left of `allowed` evenly with the other such ranks."""
+    allowed = set(allowed)
+    world = len(gpu_local_cpus)
+    keys = []
+    for cpus in gpu_local_cpus:
+        k = frozenset(cpus) & allowed if cpus else frozenset()
+        keys.append(k)
+    claimed = set().union(*[k for k in keys if k]) if any(keys) else set()
+    rest = frozenset(allowed - claimed) or frozenset(allowed)
+    keys = [k if k else rest for k in keys]
+    mine = keys[rank]
+    group = [r for r in range(world) if keys[r] == mine]
+    cores, seen = [], set()
+    for c in sorted(mine):
+        if c in seen:
+            continue
+        sib = tuple(sorted(x for x in siblings.get(c, (c,)) if x in mine)) or (c,)
+        seen.update(sib)
+        cores.append(sib)
+    lo, hi = shard(len(cores), group.index(rank), len(group))
+    share = [c for core in cores[lo:hi] for c in core]
+    return sorted(share) if share else sorted(mine)
+
+
+def gpu_local_cpulist(pci_bdf):
+    """CPUs of the NUMA node a PCI device hangs off (sysfs), or None."""
+    try:
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % pci_bdf) as f:
+            cpus = parse_cpulist(f.read())
+        return cpus or None
+    except OSError:
+        return None
+
+
+def cpu_siblings(cpus):
+    out = {}
+    for c in cpus:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                out[c] = tuple(parse_cpulist(f.read()))
+        except OSError:
+            out[c] = (c,)
+    return out
+
+
+def pin_rank(rank, world, device_of_rank):
+    """Restrict this process (and every thread it starts from now on: the library's slot workers and Delaunay pool) to
+    this rank's share of the host.  device_of_rank: HIP device ordinal per rank.  Returns a dict describing the plan."""
+    import torch
+    allowed = sorted(os.sched_getaffinity(0))
+    local = []
+    bdfs = []
+    for dev in device_of_rank:
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            bdf = None
+        bdfs.append(bdf)
+        local.append(gpu_local_cpulist(bdf) if bdf else None)
+    cpus = plan_affinity(allowed, local, cpu_siblings(allowed), rank)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        cpus = allowed
+    numa = None
+    try:
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdfs[rank]) as f:
+            numa = int(f.read())
+    except Exception:
+        pass
+    return {"rank": rank, "device": device_of_rank[rank], "pci": bdfs[rank], "numa_node": numa, "cpus": len(cpus),
+            "cpulist": format_cpulist(cpus)}

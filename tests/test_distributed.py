@@ -65,3 +65,54 @@ def test_two_rank_scan_merge(tmp_path):
     assert np.array_equal(b0, np.minimum(l0, l1))                             # element-wise MIN over rigs
     assert (b0 < 1e9 - 1).sum() >= max((l0 < 1e9 - 1).sum(), (l1 < 1e9 - 1).sum())
     assert m0[0, 0] <= m0[0, 1] and m0[0, 2] <= m0[0, 3]
+
+
+def test_cpulist_round_trip():
+    from jackal_navigation_amd.parallel import parse_cpulist, format_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert format_cpulist([0, 1, 2, 3, 8, 10, 11]) == "0-3,8,10-11"
+    assert parse_cpulist("") == [] and format_cpulist([]) == ""
+
+
+def test_plan_affinity_splits_numa_nodes_into_whole_cores():
+    """8 ranks on a 2-socket box with SMT (cpu c and c+128 share a core; GPUs 0-3 on node 0, 4-7 on node 1): every
+    rank gets its own whole physical cores of its GPU's node, nothing is shared, nothing is left over."""
+    from jackal_navigation_amd.parallel import plan_affinity
+    node0 = list(range(0, 64)) + list(range(128, 192))
+    node1 = list(range(64, 128)) + list(range(192, 256))
+    sib = {c: (c % 128, c % 128 + 128) for c in range(256)}
+    local = [node0] * 4 + [node1] * 4
+    shares = [plan_affinity(range(256), local, sib, r) for r in range(8)]
+    assert all(len(s) == 32 for s in shares)
+    assert sorted(c for s in shares for c in s) == list(range(256))
+    for r, s in enumerate(shares):
+        assert set(s) <= set(local[r])
+        assert all(sib[c][0] in s and sib[c][1] in s for c in s)           # whole cores
+    # two ranks sharing one GPU (bench.py --share-gpu) split that GPU's node
+    a, b = (plan_affinity(range(256), [node0, node0], sib, r) for r in range(2))
+    assert not set(a) & set(b) and set(a) | set(b) == set(node0)
+    # restricted affinity mask (a container with 8 CPUs), NUMA information missing
+    a, b = (plan_affinity(range(8), [None, None], {}, r) for r in range(2))
+    assert a == [0, 1, 2, 3] and b == [4, 5, 6, 7]
+    # one rank: everything local to its GPU that the mask allows
+    assert plan_affinity(range(16), [list(range(8, 64))], {}, 0) == list(range(8, 16))
+    # a GPU whose node has no allowed CPU falls back to the CPUs no other rank's node claims
+    got = plan_affinity(range(8), [[0, 1, 2, 3], [100, 101]], {}, 1)
+    assert got == [4, 5, 6, 7]
+
+
+def test_bench_refuses_a_world_size_mismatch_and_spawns_ranks_without_a_launcher():
+    """`--gpus` must agree with the launcher's WORLD_SIZE; without a launcher `--gpus 2` starts two rank processes itself.
+    No GPU here: the ranks stop at 'needs a GPU' and the parent reports the failure instead of hanging."""
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    out = subprocess.run([sys.executable, bench, "--gpus", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=2" in out.stderr
+    import torch
+    if torch.cuda.is_available():
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and out.stderr.count("needs a GPU") == 2, out.stderr[-2000:]
