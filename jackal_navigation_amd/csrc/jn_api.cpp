@@ -303,6 +303,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   dp.lr_threshold = p->lr_threshold; dp.support_threshold = p->support_threshold;
   dp.cw = (W + dp.step - 1) / dp.step; dp.ch = (H + dp.step - 1) / dp.step;            // elas.cpp:384-387
   dp.grid_size = p->grid_size;
+  dp.grid_magic = p->grid_size > 1 ? (uint32_t)((1ull << 32) / (uint64_t)p->grid_size) + 1u : 0u;   // grid_size 1: kernels divide
   dp.gw = (int)std::ceil((float)W / (float)p->grid_size); dp.gh = (int)std::ceil((float)H / (float)p->grid_size);   // elas.cpp:90-91
   dp.match_texture = p->match_texture; dp.radius = radius;
   const float two_sigma_sq = 2 * p->sigma * p->sigma;

@@ -5,6 +5,7 @@
 // in the same order (built with -ffp-contract=off; products/sums that must not fuse use
 // __fmul_rn/__fadd_rn explicitly).
 #include "kernels.h"
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 
@@ -1268,6 +1269,282 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Dense MAP matching, second form (same reference lines, strip and LDS layout as k_dense above, which stays as the
+// route for parameter sets this one does not take).  k_dense is bound by vector-instruction issue (PMC: its VALU pipes
+// are active 86 % of the kernel's duration; 395 vector instructions per wave and 64 pixels, of which only ~60 are the
+// SADs), so this form removes instructions, not bytes.  Measured attribution of k_dense's instructions (debug builds
+// that skip a phase): staging + lists + own loads 40 %, range masks 16 %, grid candidates 13 %, plane neighbourhood
+// 15 %, ownership / plane / store 16 %.
+//  * Staging: one wave per strip row, raw buffer loads whose bounds are the image row (columns outside the image
+//    read as zero without compares), addresses advanced by constants: ~5 instead of ~18 instructions per descriptor.
+//  * Lists: rank and cover words are built with v_readlane on loop-uniform indices instead of ds_bpermute shuffles; the
+//    planes are stored by rank, so the owning triangle's plane is one 16-byte LDS read.
+//  * Keys.  v_sad_hi_u8 adds the 4-byte SAD shifted left by 16 to its accumulator operand, so four of them on
+//    (bias + prior) << 16 | d give (cost << 16) | d without shift / or; the minimum of the keys is the reference's
+//    "strict <, candidates in ascending d" choice.
+//  * Grid candidates (elas.cpp:742-750) keep k_dense's per-lane bit scan — every lane evaluates a DIFFERENT disparity
+//    per round, which beats walking the wave's union of candidates with a uniform d (tried: 411 M instead of 364 M
+//    instructions, lanes want different small subsets) — but the border mask is only applied in strips that can reach
+//    the image border.
+//  * Plane neighbourhood (elas.cpp:751-756) = 2r+1 consecutive descriptors in LDS: one address, reads at immediate
+//    offsets, all in flight together; when every lane of the wave has its whole neighbourhood inside the valid range
+//    and a valid prior (the common case) no per-candidate test is left.
+enum { kDense2Slack = 16, kCellBias = 8192, kCellPriorMax = 8000, kCellInvalid = 0x60000000 };
+DEV unsigned sadhi16(const uint4& a, const uint4& b, unsigned acc) {      // acc + (SAD16(a, b) << 16)
+  acc = __builtin_amdgcn_sad_hi_u8(a.x, b.x, acc);
+  acc = __builtin_amdgcn_sad_hi_u8(a.y, b.y, acc);
+  acc = __builtin_amdgcn_sad_hi_u8(a.z, b.z, acc);
+  return __builtin_amdgcn_sad_hi_u8(a.w, b.w, acc);
+}
+typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
+template <int NW>
+__global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, const FrameInfo* __restrict__ info,
+                                               const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
+                                               const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
+                                               const uint4* __restrict__ desc, int16_t* __restrict__ raw, int nbx, int nby, int xcd_order, int dbg) {
+  static_assert(kDenseThreads / 64 == kTileH, "one wave stages one strip row");
+  __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
+  __shared__ uint4 s_plane[kStripTiles][kBinLds];                 // (pa, pb, pc, flags) of a tile's listed triangles, by rank
+  __shared__ int s_cnt[kStripTiles];
+  __shared__ uint16_t s_cover[kStripTiles][kTileH][kTileW];       // per pixel: bit k set <=> the k-th smallest listed triangle covers it
+  extern __shared__ uint4 s_Bx[];                            // kDense2Slack + [kTileH][kStripW + disp_max] + kDense2Slack
+  const int total = nbx * nby * 2 * n;
+  int item = blockIdx.x;
+  if (xcd_order) { const int per_xcd = (total + 7) / 8; item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); }   // see k_dense
+  if (item >= total) return;
+  const int side = item & 1;
+  int rest = item >> 1;
+  const int bx = rest % nbx; rest /= nbx;
+  const int by = rest % nby;
+  const int frame = rest / nby;
+  const FrameInfo& fi = info[frame];
+  if (!fi.ok) return;
+  const int W = dp.W, H = dp.H;
+  const int tid = threadIdx.x;
+  const int u0 = bx * kStripW, v0 = by * kTileH;
+  uint4* s_B = s_Bx + kDense2Slack;
+  const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
+  const uint4* B = desc + (size_t)((side ? 0 : n) + frame) * H * W;      // image searched
+  const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
+  const int tiles_x = (W + kTileW - 1) / kTileW;
+  const size_t bin_row = ((size_t)(frame * 2 + side) * nby + by) * tiles_x;
+  const int x = tid & (kTileW - 1), r = (tid / kTileW) & (kTileH - 1), grp = tid / (kTileW * kTileH);   // grp 0: tiles 0,2; grp 1: tiles 1,3
+  const int v = v0 + r;
+  const int vr = max(min(v, H - 3), 2);                                    // :701
+
+  // ---- issue every global read of this thread up front, consume afterwards ----
+  const int lw = tid >> 6, lane = tid & 63;                  // waves 4..7 (second pixel pair) have no list duty
+  const int wave = __builtin_amdgcn_readfirstlane(lw);
+  const bool list_wave = wave < kStripTiles && bx * kStripTiles + wave < tiles_x;
+  int cnt = 0, c16 = 0, myt = 0x7FFFFFFF;
+  uint32_t lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0;
+  if (list_wave) {
+    const size_t bin = bin_row + bx * kStripTiles + wave;
+    cnt = bin_count[bin];
+    c16 = min(cnt, (int)kBinLds);
+    const int words = c16 * kBinWords;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
+    if (lane < words) lw0 = src[lane];
+    if (lane + 64 < words) lw1 = src[lane + 64];
+    if (lane + 128 < words) lw2 = src[lane + 128];
+    if (lane + 192 < words) lw3 = src[lane + 192];
+    if (lane < c16) myt = (int)src[lane * kBinWords];
+  }
+  // own descriptors and grid-cell candidate sets of the thread's two pixels
+  uint4 a4[kPxPerThread];
+  uint32_t cellw[kPxPerThread][NW];
+  // x / G as one multiply-high (dense2_applies() guarantees G >= 8, so the magic constant is exact for any pixel index)
+  const uint32_t* cells = gridbits + ((size_t)(frame * 2 + side) * dp.gw * dp.gh + (size_t)__umulhi((unsigned)min(v, H - 1), dp.grid_magic) * dp.gw) * kGridWords;
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; q++) {
+    const int u = min(u0 + (grp + 2 * q) * kTileW + x, W - 1);
+    a4[q] = A[(size_t)vr * W + u];
+    const uint32_t* cell = cells + (size_t)__umulhi((unsigned)u, dp.grid_magic) * kGridWords;
+#pragma unroll
+    for (int w = 0; w < NW; w++) cellw[q][w] = cell[w];
+  }
+  // the other image's descriptors the strip can reach: wave w stages strip row w.  The buffer resource spans exactly the
+  // image row, so columns outside [0, W) come back as zeros (a negative byte offset is a huge unsigned one).  The left
+  // image's window is stored mirrored, so that on both sides the descriptor matched at disparity d sits d slots after
+  // the one matched at d = 0.
+  const int span = kStripW + dp.disp_max;
+  const int base = side ? u0 : u0 - dp.disp_max;
+  {
+    const uint4* rowp = B + (size_t)max(min(v0 + wave, H - 3), 2) * W;    // :701 row clamp
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(rowp), 0, W * 16, 0x00020000);
+    uint4* dst = s_B + wave * span;
+    int goff = (base + lane) * 16;                           // byte offset inside the row
+    int li = side ? lane : span - 1 - lane;                  // LDS slot
+    for (int c = lane; c < span; c += 64) {
+      const jn_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0);
+      dst[li] = make_uint4(t.x, t.y, t.z, t.w);
+      goff += 64 * 16; li += side ? 64 : -64;
+    }
+  }
+  if (list_wave) {
+    const int words = c16 * kBinWords;
+    if (lane < words) s_list[wave][lane] = lw0;
+    if (lane + 64 < words) s_list[wave][lane + 64] = lw1;
+    if (lane + 128 < words) s_list[wave][lane + 128] = lw2;
+    if (lane + 192 < words) s_list[wave][lane + 192] = lw3;
+    // rank among the listed triangles (indices are distinct): a pixel's owner is the covering triangle with the
+    // LARGEST index = the highest set bit of its cover word; the planes are stored by rank so that the owner's plane is
+    // one read.  v_readlane on compile-time / loop-uniform lanes instead of shuffles.
+    const int c16u = __builtin_amdgcn_readfirstlane(c16);
+    int rank = 0;
+#pragma unroll
+    for (int jj = 0; jj < kBinLds; jj++) { const int tj = __builtin_amdgcn_readlane(myt, jj); rank += (jj < c16u && tj < myt) ? 1 : 0; }
+    if (lane < c16u) {
+      const uint32_t* e = &s_list[wave][lane * kBinWords];
+      s_plane[wave][rank] = make_uint4(e[9], e[10], e[11], e[12]);
+    }
+    // lane (xx, half) accumulates rows half*4 .. half*4+3 of column xx over all listed candidates
+    const int xx = lane & (kTileW - 1), half = lane >> 5;
+    const uint32_t* mrow = &s_list[wave][1 + (xx >> 2)];
+    const int sh = (xx & 3) * 8 + half * 4;
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    for (int c = 0; c < c16u; c++) {
+      const unsigned m = mrow[c * kBinWords] >> sh;          // bits 0..3 = rows half*4 .. +3 of this column
+      const unsigned bit = 1u << __builtin_amdgcn_readlane(rank, c);
+      w0 |= (m & 1u) ? bit : 0u; w1 |= (m & 2u) ? bit : 0u; w2 |= (m & 4u) ? bit : 0u; w3 |= (m & 8u) ? bit : 0u;
+    }
+    s_cover[wave][half * 4 + 0][xx] = (uint16_t)w0; s_cover[wave][half * 4 + 1][xx] = (uint16_t)w1;
+    s_cover[wave][half * 4 + 2][xx] = (uint16_t)w2; s_cover[wave][half * 4 + 3][xx] = (uint16_t)w3;
+  }
+  if (lw < kStripTiles && lane == 0) s_cnt[lw] = cnt;
+  __syncthreads();
+  if (dbg & 4) return;
+  if (v >= H) return;
+
+  constexpr unsigned kNoKey = 0xFFFFFFFFu;
+  const int radius = dp.radius;
+  int16_t* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;   // integer disparity, -1 no match, -10 not visited (:797-798)
+  // the strip needs the image-border mask only if some pixel's disparity range can leave [2, W-2)
+  const bool border = side ? (u0 + kStripW - 1 + dp.disp_max > W - 3) : (u0 - dp.disp_max < 2);
+  const int grp_u = wave >> 2;                               // = grp, wave-uniform for the compiler
+
+#pragma unroll
+  for (int q = 0; q < kPxPerThread; q++) {
+    const int k = grp_u + 2 * q;
+    const int ut0 = u0 + k * kTileW;                                     // first column of the tile (wave-uniform)
+    if (ut0 >= W) break;
+    const int u = ut0 + x;
+    const bool inw = u < W;
+    // ---- which triangle owns this pixel: the last covering one in list order ----
+    const int cntk = s_cnt[k];
+    int t = -1; float pa = 0, pb = 0, pc = 0; bool valid = false;
+    if (inw) {
+      if (cntk <= kBinLds) {
+        const unsigned cover = s_cover[k][r][x];
+        if (cover) {
+          const uint4 pl = s_plane[k][31 - __clz(cover)];
+          t = 0;
+          pa = __uint_as_float(pl.x); pb = __uint_as_float(pl.y); pc = __uint_as_float(pl.z); valid = pl.w & 1u;
+        }
+      } else {
+        if (cntk <= kBinCap) {                               // long list: read it from global memory
+          const BinEntry* list = bin_list + (bin_row + bx * kStripTiles + k) * kBinCap;
+          for (int c = 0; c < cntk; c++) {
+            const unsigned m = reinterpret_cast<const uint8_t*>(list[c].rows)[x];
+            const int tc = list[c].t;
+            if (((m >> r) & 1u) && tc > t) t = tc;
+          }
+        } else {                                             // overflowing tile: scan every triangle of this side
+          for (int c = fi.ntri[side] - 1; c >= 0; c--) {
+            const TriRec* qq = R + c;
+            if (tri_covers(qq->Au, qq->Bu, qq->Cu, qq->ACa, qq->ACb, qq->ABa, qq->ABb, qq->BCa, qq->BCb, u, v)) { t = c; break; }
+          }
+        }
+        if (t >= 0) { const TriRec* tr = R + t; pa = tr->pa; pb = tr->pb; pc = tr->pc; valid = tr->flags & 1; }
+      }
+    }
+    const uint4 a = a4[q];
+    const bool elig = inw && t >= 0 && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture;   // :697, :715-719
+    const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
+    const int lo = max(d_plane - radius, 0), hi = min(d_plane + radius, dp.disp_max);                      // :723-724
+    // disparities whose warped column stays inside [2, W-2) (:746, :753, :764, :771)
+    const int dmax_ok = side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
+    // Bu[d] = descriptor of the column matched at disparity d (u + d in the right image's window, u - d in the mirrored left one)
+    const int uc = min(u, W - 1);
+    const uint4* Bu = s_B + r * span + (side ? (uc - base) : (span - 1 + base - uc));
+    const int dlow = d_plane - radius;
+    const int phi = min(hi, dmax_ok);
+
+    // ---- grid candidates outside the plane range (:742-750): per-lane bit scan, one (different) disparity per lane and round ----
+    unsigned best1 = kNoKey;
+    const bool no_range = hi < lo;
+    if (elig && !(dbg & 1)) {
+      // the plane range [lo, hi] (at most 15 wide) as a bit mask over the set, built 64 bits at a time: 64-bit word j
+      // holds M << (lo - 64 j), or the spill M >> (64 j - lo) of a range that starts in the word below
+      const unsigned long long M = no_range ? 0ull : ((2ull << (hi - lo)) - 1ull);
+      uint32_t excl[NW];
+#pragma unroll
+      for (int j = 0; j < NW / 2; j++) {
+        const int sft = lo - 64 * j;
+        const unsigned long long m = (sft >= 0) ? (sft < 64 ? M << sft : 0ull) : (sft > -16 ? M >> -sft : 0ull);
+        excl[2 * j] = (uint32_t)m; excl[2 * j + 1] = (uint32_t)(m >> 32);
+      }
+#pragma unroll
+      for (int w = 0; w < NW; w++) {
+        uint32_t bits = cellw[q][w] & ~excl[w];
+        if (border) bits &= range_mask(0, dmax_ok, w);
+        while (bits) {
+          const int d = (w << 5) + __builtin_ctz(bits);
+          bits &= bits - 1;
+          best1 = min(best1, sadhi16(a, Bu[d], ((unsigned)kCellBias << 16) | (unsigned)d));
+        }
+      }
+    }
+
+    // ---- plane neighbourhood with prior (:751-756): d = dlow + k, k = 0 .. 2r ----
+    unsigned best2 = kNoKey;
+    if (dbg & 2) {} else
+    if (radius == 2) {
+      // address window clamped so that it stays inside the LDS block (+- kDense2Slack); a clamped window holds no valid d
+      const uint4* Bw = Bu + max(min(dlow, dp.disp_max), -2 * radius);
+      uint4 nb[5];
+#pragma unroll
+      for (int kk = 0; kk < 5; kk++) nb[kk] = Bw[kk];
+      const bool all_in = dlow >= 0 && dlow + 4 <= phi && valid;          // whole neighbourhood valid, prior on
+      if (__ballot(elig && !all_in) == 0ull) {
+        // every lane of the wave: five valid candidates with the prior — no per-candidate tests (scalar key bases)
+        const unsigned i0 = ((unsigned)(kCellBias + dp.P[2]) << 16), i1 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 1u,
+                       i2 = ((unsigned)(kCellBias + dp.P[0]) << 16) + 2u, i3 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 3u,
+                       i4 = ((unsigned)(kCellBias + dp.P[2]) << 16) + 4u;
+        const unsigned dl = (unsigned)dlow;
+        const unsigned k0 = sadhi16(a, nb[0], i0 + dl), k1 = sadhi16(a, nb[1], i1 + dl), k2 = sadhi16(a, nb[2], i2 + dl),
+                       k3 = sadhi16(a, nb[3], i3 + dl), k4 = sadhi16(a, nb[4], i4 + dl);
+        best2 = min(min(min(k0, k1), min(k2, k3)), k4);
+      } else {
+        const unsigned prior_on = valid ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) {
+          const int d = dlow + kk;
+          const unsigned init = (d >= 0 && d <= phi) ? (((unsigned)kCellBias << 16) + (((unsigned)dp.P[kk < 2 ? 2 - kk : kk - 2] << 16) & prior_on) + (unsigned)d)
+                                                     : (unsigned)kCellInvalid;
+          best2 = min(best2, sadhi16(a, nb[kk], init));
+        }
+        if (best2 >= (unsigned)kCellInvalid) best2 = kNoKey;
+      }
+    } else if (elig) {                                                     // other radii: one read per candidate
+#pragma unroll
+      for (int off = -7; off <= 7; off++) {
+        if ((off < 0 ? -off : off) > radius) continue;                     // uniform
+        const int d = d_plane + off;
+        if (d >= lo && d <= phi) {
+          const unsigned init = (valid ? (unsigned)(kCellBias + dp.P[off < 0 ? -off : off]) << 16 : (unsigned)kCellBias << 16) + (unsigned)d;
+          best2 = min(best2, sadhi16(a, Bu[d], init));
+        }
+      }
+    }
+    const unsigned best = (best2 >> 16) < (best1 >> 16) ? best2 : best1;   // the plane phase wins only with a strictly smaller cost
+    int result = -10;                                                      // :797-798
+    if (elig) result = best == kNoKey ? -1 : (int)(best & 255u);          // :778-779
+    if (inw) out[u] = (int16_t)result;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Left/right consistency (elas.cpp:909-979), out of place: raw -> D1/D2.
 __global__ void __launch_bounds__(256) k_lr(DevParams dp, const FrameInfo* __restrict__ info, const int16_t* __restrict__ raw,
                                             float* __restrict__ D1, float* __restrict__ D2) {
@@ -2054,13 +2331,29 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
   if (max_tri <= 0) return;
   hipLaunchKernelGGL(k_bin, dim3((max_tri + kBinTris - 1) / kBinTris, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }
+bool dense2_applies(const DevParams& dp) {
+  static const int enabled = getenv("JN_DENSE2") ? atoi(getenv("JN_DENSE2")) : 1;
+  if (!enabled || dp.grid_size < 8) return false;                 // tiny grids: a wave would touch many cells
+  for (int k = 0; k <= dp.radius; k++) if (dp.P[k] < -kCellPriorMax || dp.P[k] > kCellPriorMax) return false;   // 16-bit cost field of the keys
+  return true;
+}
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
                   const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, int16_t* raw) {
+  static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
   const int nbx = (dp.W + kStripW - 1) / kStripW, nby = (dp.H + kTileH - 1) / kTileH;
   const int total = nbx * nby * 2 * n;
-  static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
   const int blocks = xcd_order ? (total + 7) / 8 * 8 : total;
   const size_t lds = (size_t)kTileH * (kStripW + dp.disp_max) * sizeof(uint4);   // 32.6 KB at disp_max 127, 49 KB at 255
+  if (dense2_applies(dp)) {
+    static const int dbg = getenv("JN_DENSE_DBG") ? atoi(getenv("JN_DENSE_DBG")) : 0;
+    if (dp.disp_max < 128)
+      hipLaunchKernelGGL(k_dense2<4>, dim3(blocks), dim3(kDenseThreads), lds + 2 * kDense2Slack * sizeof(uint4), st, dp, n, info, recs, tri_cap, bin_count,
+                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg);
+    else
+      hipLaunchKernelGGL(k_dense2<8>, dim3(blocks), dim3(kDenseThreads), lds + 2 * kDense2Slack * sizeof(uint4), st, dp, n, info, recs, tri_cap, bin_count,
+                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg);
+    return;
+  }
   hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(kDenseThreads), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
                      nbx, nby, xcd_order);
 }
