@@ -1297,6 +1297,14 @@ DEV unsigned sadhi16(const uint4& a, const uint4& b, unsigned acc) {      // acc
   return __builtin_amdgcn_sad_hi_u8(a.w, b.w, acc);
 }
 typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
+// w |= bit if bit `pos` of m is set: the sign-extended single bit as an and-mask.  Two plain VALU instructions; written as
+// asm because the compiler rewrites every C form of it into and / compare / select / or (4 instructions).
+#define or_bit_if(w, m, pos, bit)                                                                          \
+  do {                                                                                                    \
+    int sx__;                                                                                             \
+    asm("v_bfe_i32 %0, %1, " #pos ", 1" : "=v"(sx__) : "v"(m));                                             \
+    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(w) : "v"(sx__), "s"(bit));                                     \
+  } while (0)
 template <int NW>
 __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, const FrameInfo* __restrict__ info,
                                                const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
@@ -1392,8 +1400,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
     // one read.  v_readlane on compile-time / loop-uniform lanes instead of shuffles.
     const int c16u = __builtin_amdgcn_readfirstlane(c16);
     int rank = 0;
-#pragma unroll
-    for (int jj = 0; jj < kBinLds; jj++) { const int tj = __builtin_amdgcn_readlane(myt, jj); rank += (jj < c16u && tj < myt) ? 1 : 0; }
+    for (int jj = 0; jj < c16u; jj++) rank += __builtin_amdgcn_readlane(myt, jj) < myt ? 1 : 0;
     if (lane < c16u) {
       const uint32_t* e = &s_list[wave][lane * kBinWords];
       s_plane[wave][rank] = make_uint4(e[9], e[10], e[11], e[12]);
@@ -1406,7 +1413,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
     for (int c = 0; c < c16u; c++) {
       const unsigned m = mrow[c * kBinWords] >> sh;          // bits 0..3 = rows half*4 .. +3 of this column
       const unsigned bit = 1u << __builtin_amdgcn_readlane(rank, c);
-      w0 |= (m & 1u) ? bit : 0u; w1 |= (m & 2u) ? bit : 0u; w2 |= (m & 4u) ? bit : 0u; w3 |= (m & 8u) ? bit : 0u;
+      or_bit_if(w0, m, 0, bit); or_bit_if(w1, m, 1, bit); or_bit_if(w2, m, 2, bit); or_bit_if(w3, m, 3, bit);
     }
     s_cover[wave][half * 4 + 0][xx] = (uint16_t)w0; s_cover[wave][half * 4 + 1][xx] = (uint16_t)w1;
     s_cover[wave][half * 4 + 2][xx] = (uint16_t)w2; s_cover[wave][half * 4 + 3][xx] = (uint16_t)w3;
