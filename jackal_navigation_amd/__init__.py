@@ -15,3 +15,4 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # noqa: F401
 from .elas import Elas  # noqa: F401
 from . import node, device, parallel, navigate  # noqa: F401
+from .sgm import Sgm, SGM_EXPORTS  # noqa: F401

@@ -276,6 +276,52 @@ class Oracle:
         return dst
 
 
+class SgmParams(C.Structure):
+    _fields_ = [("num_disparities", C.c_int32), ("P1", C.c_int32), ("P2", C.c_int32), ("prefilter_cap", C.c_int32),
+                ("lr_max_diff", C.c_int32), ("subpixel", C.c_int32)]
+
+
+class SgmOracle:
+    """oracle/sgm_oracle.cpp — the scalar definition of the SGM mode (self-referential: the reference has no SGM)."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        self.lib = C.CDLL(ORACLE_SO)
+        self.lib.orc_sgm_process.restype = C.c_int32
+
+    @staticmethod
+    def params(num_disparities=128, P1=10, P2=60, prefilter_cap=31, lr_max_diff=1, subpixel=0):
+        return SgmParams(num_disparities, P1, P2, prefilter_cap, lr_max_diff, subpixel)
+
+    def prefilter(self, I, cap=31):
+        I = np.ascontiguousarray(I, np.uint8)
+        g = np.zeros_like(I)
+        self.lib.orc_sgm_prefilter(_p(I), I.shape[1], I.shape[0], cap, _p(g))
+        return g
+
+    def path(self, gL, gR, D, P1, P2, dx, dy):
+        H, W = gL.shape
+        out = np.zeros((H, W, D), np.uint8)
+        self.lib.orc_sgm_path(_p(np.ascontiguousarray(gL)), _p(np.ascontiguousarray(gR)), W, H, D, P1, P2, dx, dy, _p(out))
+        return out
+
+    def process(self, p, L, R):
+        L = np.ascontiguousarray(L, np.uint8); R = np.ascontiguousarray(R, np.uint8)
+        H, W = L.shape
+        disp = np.zeros((H, W), np.int16)
+        rc = self.lib.orc_sgm_process(C.byref(p), _p(L), _p(R), W, H, _p(disp))
+        if rc != 0:
+            raise ValueError("orc_sgm_process: parameters outside the definition")
+        return disp
+
+    def to_u8(self, disp, subpixel):
+        disp = np.ascontiguousarray(disp, np.int16)
+        out = np.zeros(disp.shape, np.uint8)
+        self.lib.orc_sgm_to_u8(_p(disp), int(subpixel), _p(out), C.c_int64(disp.size))
+        return out
+
+
 class Reference:
     """The compiled reference (libelas from /root/reference), per stage."""
 

@@ -1,0 +1,78 @@
+"""SGM mode on the GPU: bit-exact against its scalar definition (oracle/sgm_oracle.cpp; self-referential — the
+reference has no SGM), through the C-ABI (jn_sgm_*)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sgm():
+    from oracle.binding import SgmOracle
+    return SgmOracle()
+
+
+def run(jn, p, Ls, Rs):
+    from jackal_navigation_amd.device import DeviceArray
+    n, H, W = Ls.shape
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    dD = DeviceArray((n, H, W), np.int16)
+    with jn.Sgm(p, W, H, max_batch=n) as s:
+        s.process_batch(n, dL.ptr, dR.ptr, W, H * W, dD.ptr)
+        t = s.last_times()
+        du8 = DeviceArray((n, H, W), np.uint8)
+        s.to_u8(dD.ptr, du8.ptr, n * H * W)
+    out, u8 = dD.numpy(), du8.numpy()
+    for a in (dL, dR, dD, du8):
+        a.free()
+    return out, u8, t
+
+
+@pytest.mark.parametrize("W,H,D,scene,n,kw", [
+    (640, 480, 64, 64, 2, {}),                      # BASELINE config 2's frame and range
+    (1280, 720, 128, 128, 1, {}),                   # BASELINE config 3's frame and range
+    (320, 180, 256, 48, 2, {"subpixel": 1}),        # D = 256 (four disparities per lane), 1/16 pixel
+    (333, 101, 64, 30, 3, {"subpixel": 1, "P1": 4, "P2": 30, "prefilter_cap": 15}),   # ragged size, other penalties
+    (200, 150, 128, 90, 2, {"lr_max_diff": -1}),    # no L/R check; disparities beyond the image width near the left border
+    (96, 64, 128, 20, 1, {"lr_max_diff": 0}),       # image narrower than the disparity range
+])
+def test_sgm_bit_exact_vs_its_definition(jn, sgm, oracle, W, H, D, scene, n, kw):
+    Ls = np.stack([oracle.synth_pair(W, H, scene, 700 + b)[0] for b in range(n)])
+    Rs = np.stack([oracle.synth_pair(W, H, scene, 700 + b)[1] for b in range(n)])
+    out, u8, t = run(jn, jn.Sgm.parameters(num_disparities=D, **kw), Ls, Rs)
+    po = sgm.params(D, **{k: v for k, v in kw.items()})
+    for b in range(n):
+        exp = sgm.process(po, Ls[b], Rs[b])
+        assert np.array_equal(out[b], exp), (b, int((out[b] != exp).sum()))
+        assert np.array_equal(u8[b], sgm.to_u8(exp, kw.get("subpixel", 0)))
+    assert t["paths"] > 0 and t["total"] >= t["paths"]
+
+
+def test_sgm_on_other_scenes_and_random_images(jn, sgm):
+    from scenes import make_scene
+    W, H, D = 320, 240, 64
+    pairs = [make_scene(k, W, H, 60, 5 + i) for i, k in enumerate(["strips", "patches", "slanted", "photometric", "blobs"])]
+    rng = np.random.default_rng(9)
+    pairs.append((rng.integers(0, 256, (H, W)).astype(np.uint8), rng.integers(0, 256, (H, W)).astype(np.uint8)))   # no structure at all
+    pairs.append((np.full((H, W), 77, np.uint8), np.full((H, W), 77, np.uint8)))                                    # flat: every cost ties
+    Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+    for sub in (0, 1):
+        out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D, subpixel=sub), Ls, Rs)
+        for b in range(len(pairs)):
+            assert np.array_equal(out[b], sgm.process(sgm.params(D, subpixel=sub), Ls[b], Rs[b])), (sub, b)
+
+
+def test_sgm_feeds_the_node_tail(jn, sgm, oracle):
+    """SGM disparity -> u8 depth map -> the same LUT scan the ELAS path uses (jn_obstacle_scan), against the oracle chain."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node
+    W, H, D = 320, 180, 64
+    L, R = oracle.synth_pair(W, H, 48, 31)
+    out, u8, _ = run(jn, jn.Sgm.parameters(num_disparities=D), L[None], R[None])
+    sp, spo = node.scan_params(W, H), oracle.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    du8 = DeviceArray.from_numpy(u8)
+    bins = DeviceArray((1, sp.bins), np.float64); meta = DeviceArray((1, 4), np.float64)
+    node.obstacle_scan(sp, 1, du8.ptr, lut.ptr, W, H, bins.ptr, meta.ptr)
+    bo, mo, used = oracle.scan(spo, sgm.to_u8(sgm.process(sgm.params(D), L, R), 0), oracle.valid_lut(spo, W, H))
+    assert used > 0 and np.allclose(bins.numpy()[0], bo, rtol=0, atol=1e-4) and np.allclose(meta.numpy()[0], mo, rtol=0, atol=1e-4)
