@@ -101,6 +101,9 @@ def cpu_baseline(W, H, scene, disp, budget_s=20.0):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mode", default="elas", choices=["elas", "sgm"],
+                    help="elas (default): the reference's matcher, the headline metric; sgm: the 8-path SGM mode of include/jn_sgm.h "
+                         "(no reference counterpart), same workload shape, roofline on SURVEY 8d's B_sgm")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
@@ -121,6 +124,7 @@ def parse_args():
                     help="cross-rig merge with the nccl backend: the library's jn_scan_allreduce (default) or torch.distributed")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses device 0")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
+    ap.add_argument("--subpixel", type=int, default=0, help="sgm mode: 1/16-pixel refinement")
     return ap.parse_args()
 
 
@@ -175,7 +179,157 @@ def golden_hash(W, H, scene, disp_max):
     return None
 
 
+def sgm_cpu_worker(args):
+    W, H, scene, D, sub, seed0, count = args
+    from oracle.binding import Oracle, SgmOracle
+    o, s = Oracle(), SgmOracle()
+    sp = o.scan_params(W, H)
+    lut = o.valid_lut(sp, W, H)
+    pairs = [o.synth_pair(W, H, scene, seed0 + i) for i in range(count)]
+    t0 = time.perf_counter()
+    for L, R in pairs:
+        o.scan(sp, s.to_u8(s.process(s.params(D, subpixel=sub), L, R), sub), lut)
+    return time.perf_counter() - t0
+
+
+def sgm_cpu_baseline(W, H, scene, D, sub):
+    """The SGM mode's scalar definition (oracle/sgm_oracle.cpp, kind "port": the reference has no SGM) on a bounded sample."""
+    import multiprocessing as mp
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(ncpu // 2, 32))
+    t1 = sgm_cpu_worker((W, H, scene, D, sub, 12345, 1))
+    per_proc = max(1, min(4, int(10.0 / max(t1, 1e-3))))
+    with mp.get_context("fork").Pool(procs) as pool:
+        t0 = time.perf_counter()
+        pool.map(sgm_cpu_worker, [(W, H, scene, D, sub, 12345 + 1000 * i, per_proc) for i in range(procs)])
+        wall = time.perf_counter() - t0
+    return {"value": round(procs * per_proc / wall, 2), "unit": "pairs/s", "cores": procs, "kind": "port",
+            "sample": "%d pairs %dx%d D=%d in %d processes (%.1f s wall) of the scalar definition oracle/sgm_oracle.cpp; single core: %.2f pairs/s"
+                      % (procs * per_proc, W, H, D, procs, wall, 1.0 / t1)}
+
+
+def run_sgm(a):
+    """--mode sgm: step = one batch through prefilter -> 8 paths -> sum/WTA/check -> u8 map -> 90-bin scan."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
+    W, H, B, D = a.width, a.height, a.batch, a.disp
+    scene = a.scene_disp or a.disp
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = sgm_cpu_baseline(W, H, scene, D, a.subpixel)
+    import torch
+    import jackal_navigation_amd as jn
+    from jackal_navigation_amd import node
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    on_gpu = a.dist_backend == "nccl"
+    Ls = np.empty((B, H, W), np.uint8); Rs = np.empty((B, H, W), np.uint8)
+    for b in range(B):
+        Ls[b], Rs[b] = node.synth_pair(W, H, scene, 12345 + b + 1000 * rank)
+    dL = torch.from_numpy(Ls).to(dev); dR = torch.from_numpy(Rs).to(dev)
+    disp = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
+    u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
+    bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    sgm = jn.Sgm(jn.Sgm.parameters(num_disparities=D, subpixel=a.subpixel), W, H, max_batch=B, device=local_rank)
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H, device=local_rank)
+    torch.cuda.synchronize()
+    acc = {}
+
+    def step():
+        sgm.process_batch(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp.data_ptr())
+        for k, v in sgm.last_times().items():
+            acc.setdefault(k, []).append(v)
+        sgm.to_u8(disp.data_ptr(), u8.data_ptr(), B * H * W)
+        node.obstacle_scan(sp, B, u8.data_ptr(), lut.ptr, W, H, bins.data_ptr(), meta.data_ptr(), device=local_rank)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def region():
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if on_gpu else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    for _ in range(a.warmup):
+        step()
+    acc.clear()
+    regions = [region()]
+    for _ in range(max(1, min(200, int(math.ceil(a.min_time / max(regions[0], 1e-6))))) - 1):
+        regions.append(region())
+    elapsed = float(np.median(regions))
+    value = world * B * a.steps / elapsed
+    ms = {k: float(np.mean(v)) for k, v in acc.items()}
+    check = None
+    if rank == 0:
+        want = None
+        try:
+            for line in open(os.path.join(ROOT, "tests", "golden", "sgm_hashes.txt")):
+                f = line.split()
+                if not line.startswith("#") and len(f) >= 7 and [int(x) for x in f[:6]] == [W, H, scene, D, a.subpixel, 12345]:
+                    want = f[6]
+        except OSError:
+            pass
+        host = disp[0].cpu().numpy()
+        got = "%016x" % jn.load().jn_fnv1a64_u32(host.ctypes.data, host.size // 2)
+        check = {"what": "FNV-1a-64 of the int16 disparity map of frame 0 (seed 12345) after the timed region", "got": got, "expected": want,
+                 "source": "tests/golden/sgm_hashes.txt (scalar definition oracle/sgm_oracle.cpp; self-referential, the reference has no SGM)" if want else None,
+                 "ok": (got == want) if want else None}
+    # roofline: SURVEY 8d's algorithmic bytes of the cost-volume mode, B_sgm = 4 W H D + 5 W H per pair, over the GPU time of
+    # one batch (the three kernels, HIP events on the library's stream); the path kernel dominates.  `traffic` = the bytes
+    # this decomposition really moves: eight u8 volumes written by the path kernel and read by the WTA kernel.
+    b_sgm = (4.0 * W * H * D + 5.0 * W * H) * B
+    achieved = b_sgm / (ms["total"] * 1e-3) / 1e9
+    moved = (16.0 * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
+    roofline = {"bound": "hbm", "kernel": "k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": int(moved),
+                "traffic_note": "computed, not PMC: 8 W H D bytes written by the path kernel + 8 W H D read by the WTA kernel; "
+                                "moved bytes / time = %.0f GB/s" % (moved / (ms["total"] * 1e-3) / 1e9),
+                "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
+                "algorithmic_bytes_per_launch": int(b_sgm), "path_kernel_write_GBs": round(8.0 * W * H * D * B / (ms["paths"] * 1e-3) / 1e9, 1)}
+    if rank == 0:
+        out = {"metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": (dist.get_world_size() if dist is not None else 1),
+               "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_frame": round(elapsed / (B * a.steps) * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i16", "data": "synthetic",
+               "config": {"workload": "%dx%d rectified pairs (scene disparities <= %d), SGM 8 paths D=%d%s (include/jn_sgm.h; no reference counterpart), batch=%d per GPU -> u8 map -> 90-bin scan"
+                                      % (W, H, scene, D, " + 1/16 px" if a.subpixel else "", B), "batch_per_gpu": B, "mode": "sgm",
+                          "parallelism": "rigs sharded 1 batch/GPU over %d ranks" % world if world > 1 else "single GPU"},
+               "timing": {"regions": len(regions), "region_s_median": round(elapsed, 5), "region_s_min": round(min(regions), 5), "region_s_max": round(max(regions), 5)},
+               "stage_ms_per_batch": {k: round(v, 3) for k, v in ms.items()}, "roofline": roofline, "cpu_baseline": cpu, "check": check}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    sgm.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank == 0 and check and check["ok"] is False:
+        raise SystemExit("bench.py: the SGM disparity map differs from its golden hash: %s" % check)
+
+
 def run_rank(a):
+    if a.mode == "sgm":
+        return run_sgm(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -394,7 +548,7 @@ def run_rank(a):
         l2, r2 = node.synth_pair(w2, h2, d2, 12345)
         tl, tr = torch.from_numpy(l2).to(dev), torch.from_numpy(r2).to(dev)
         o1 = torch.zeros((h2, w2), dtype=torch.float32, device=dev); o2 = torch.zeros_like(o1)
-        e2 = jn.Elas(jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=d2 - 1), w2, h2, max_batch=1, device=local_rank, host_threads=2, slots=1)
+        e2 = jn.Elas(jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=d2 - 1), w2, h2, max_batch=1, device=local_rank, host_threads=8, slots=1)
         for _ in range(5):
             e2.process_batch(1, tl.data_ptr(), tr.data_ptr(), w2, h2 * w2, o1.data_ptr(), o2.data_ptr())
         torch.cuda.synchronize()

@@ -43,7 +43,7 @@ class Elas {
       return c.handle;
     if (c.handle) { jn_elas_destroy(c.handle); c.handle = nullptr; }
     jn_elas* out = nullptr;
-    if (jn_elas_create(&param_, w, h, /*max_batch*/ 1, /*device*/ 0, /*host_threads*/ 2, /*slots*/ 1, &out) != JN_OK) return nullptr;
+    if (jn_elas_create(&param_, w, h, /*max_batch*/ 1, /*device*/ 0, /*host_threads*/ 8, /*slots*/ 1, &out) != JN_OK) return nullptr;
     c.p = param_; c.w = w; c.h = h; c.handle = out;
     return out;
   }

@@ -271,6 +271,10 @@ uint64_t jn_fnv1a64_u32(const uint32_t* words, int64_t n);
  * elas.cpp:487-488) for n integer points: writes (org,dest,apex) per triangle into tri
  * (capacity 6*n ints); returns the triangle count or -1. */
 int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri);
+/* The same with the triangulation cut into `parts` (1, 2 or 4) independent pieces that run on their own threads and
+ * are merged afterwards — what jn_elas does when its pool has idle threads (a lone pair, a few large frames).  The
+ * output, order included, equals jn_host_triangulate's. */
+int32_t jn_host_triangulate_parts(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri, int32_t parts);
 
 /* Support filters + support list + Delaunay x2 for ONE frame (elas.cpp:416-431, :445-505).
  * d_can [ch][cw] is filtered in place.  payload receives what the GPU stage consumes:

@@ -88,7 +88,7 @@ EXPORTS = [
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
     "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote", "jn_device_support_filters", "jn_elas_submit_scan",
-    "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32",
+    "jn_host_triangulate_parts", "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def load():
     L.jn_init_undistort_rectify_map.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp]
     L.jn_remap_bilinear.argtypes = [i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, i32, i32, i32, i64]
     L.jn_host_triangulate.argtypes = [vp, vp, i32, vp]
+    L.jn_host_triangulate_parts.argtypes = [vp, vp, i32, vp, i32]
     L.jn_host_stage.argtypes = [C.POINTER(ElasParams), i32, i32, vp, vp, i64, vp]
     L.jn_host_stage.restype = i64
     L.jn_device_support_filters.argtypes = [i32, C.POINTER(ElasParams), i32, i32, i32, vp, i32]

@@ -39,8 +39,8 @@ unsigned Delaunay::draw(unsigned choices) {
   return (unsigned)(lcg_ / (714025u / choices + 1u));
 }
 
-Delaunay::H Delaunay::fresh() {
-  const int t = ntri_++;
+Delaunay::H Delaunay::fresh(Ctx& c) {
+  const int t = c.next++;
   link_[4 * t] = link_[4 * t + 1] = link_[4 * t + 2] = -1;
   vert_[4 * t] = vert_[4 * t + 1] = vert_[4 * t + 2] = -1;
   return (H)t << 2;
@@ -109,21 +109,27 @@ bool Delaunay::sort_distinct(int32_t* a, int n) {
 // unique.  We build the same array deterministically, kd-tree style: keep the vertices once in
 // (x,y) order (array a) and once in (y,x) order; a cut along one order is a prefix, the other
 // order is stably partitioned to follow.  The x-ordered array, partitioned in place, IS the result.
-void Delaunay::split(int lo, int hi, int axis) {
+// One cut of [lo, hi): the first half of the defining order goes left, the other order follows stably.
+void Delaunay::cut(int lo, int hi, int axis) {
   const int n = hi - lo;
-  if (n <= 3) return;
   const int half = n >> 1;
   int32_t* def = (axis ? by_y_.data() : order_.data()) + lo;     // order that defines the cut
   int32_t* oth = (axis ? order_.data() : by_y_.data()) + lo;     // order that must follow it
   for (int i = 0; i < half; i++) left_[def[i]] = 1;
   for (int i = half; i < n; i++) left_[def[i]] = 0;
-  int32_t* spill = tmp_.data();
+  int32_t* spill = tmp_.data() + lo;                             // ranges of concurrent parts are disjoint
   int nl = 0, nr = 0;
   for (int i = 0; i < n; i++) {
     const int32_t v = oth[i];
     if (left_[v]) oth[nl++] = v; else spill[nr++] = v;
   }
   for (int i = 0; i < nr; i++) oth[nl + i] = spill[i];
+}
+void Delaunay::split(int lo, int hi, int axis) {
+  const int n = hi - lo;
+  if (n <= 3) return;
+  cut(lo, hi, axis);
+  const int half = n >> 1;
   split(lo, lo + half, 1 - axis);
   split(lo + half, hi, 1 - axis);
 }
@@ -138,11 +144,10 @@ void Delaunay::arrange(int32_t* a, int n) {
   for (int i = 0; i < n; i++) bucket_[y_[a[i]] - ymin + 1]++;
   for (int i = 0; i < range; i++) bucket_[i + 1] += bucket_[i];
   for (int i = 0; i < n; i++) by_y_[bucket_[y_[a[i]] - ymin]++] = a[i];
-  split(0, n, 0);
 }
 
 // Merge two triangulated halves by walking up the seam between their hulls.
-void Delaunay::zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis) {
+void Delaunay::zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis, Ctx& c) {
   int il_dest = v_dest(innerleft), il_apex = v_apex(innerleft);
   int ir_org = v_org(innerright), ir_apex = v_apex(innerright);
 
@@ -184,7 +189,7 @@ void Delaunay::zip(H& farleft, H& innerleft, H& innerright, H& farright, int axi
   }
 
   H lcand = across(innerleft), rcand = across(innerright);
-  H base = fresh();
+  H base = fresh(c);
   glue(base, innerleft);  base = ccw_edge(base);
   glue(base, innerright); base = ccw_edge(base);
   v_org(base) = ir_org; v_dest(base) = il_dest;
@@ -198,7 +203,7 @@ void Delaunay::zip(H& farleft, H& innerleft, H& innerright, H& farright, int axi
     const bool l_done = orient(up_l, lo_l, lo_r) <= 0;
     const bool r_done = orient(up_r, lo_l, lo_r) <= 0;
     if (l_done && r_done) {
-      H cap = fresh();
+      H cap = fresh(c);
       v_org(cap) = lo_l; v_dest(cap) = lo_r;
       glue(cap, base);  cap = ccw_edge(cap);
       glue(cap, rcand); cap = ccw_edge(cap);
@@ -279,10 +284,10 @@ void Delaunay::zip(H& farleft, H& innerleft, H& innerright, H& farright, int axi
   }
 }
 
-void Delaunay::conquer(int32_t* a, int n, int axis, H& farleft, H& farright) {
+void Delaunay::conquer(int32_t* a, int n, int axis, H& farleft, H& farright, Ctx& c) {
   if (n == 2) {   // a lone edge: two ghosts glued on all three sides
-    farleft = fresh();  v_org(farleft) = a[0];  v_dest(farleft) = a[1];
-    farright = fresh(); v_org(farright) = a[1]; v_dest(farright) = a[0];
+    farleft = fresh(c);  v_org(farleft) = a[0];  v_dest(farleft) = a[1];
+    farright = fresh(c); v_org(farright) = a[1]; v_dest(farright) = a[0];
     glue(farleft, farright);
     farleft = cw_edge(farleft); farright = ccw_edge(farright); glue(farleft, farright);
     farleft = cw_edge(farleft); farright = ccw_edge(farright); glue(farleft, farright);
@@ -290,7 +295,7 @@ void Delaunay::conquer(int32_t* a, int n, int axis, H& farleft, H& farright) {
     return;
   }
   if (n == 3) {
-    H mid = fresh(), g1 = fresh(), g2 = fresh(), g3 = fresh();
+    H mid = fresh(c), g1 = fresh(c), g2 = fresh(c), g3 = fresh(c);
     const int turn = orient(a[0], a[1], a[2]);
     if (turn == 0) {   // collinear triple: two edges, four ghosts
       v_org(mid) = a[0]; v_dest(mid) = a[1];
@@ -321,15 +326,16 @@ void Delaunay::conquer(int32_t* a, int n, int axis, H& farleft, H& farright) {
   }
   const int half = n >> 1;
   H il, ir;
-  conquer(a, half, 1 - axis, farleft, il);
-  conquer(a + half, n - half, 1 - axis, ir, farright);
-  zip(farleft, il, ir, farright, axis);
+  conquer(a, half, 1 - axis, farleft, il, c);
+  conquer(a + half, n - half, 1 - axis, ir, farright, c);
+  zip(farleft, il, ir, farright, axis, c);
 }
 
-int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
-  if (n < 3) return -1;
-  x_ = x; y_ = y; lcg_ = 1; ntri_ = 0;
-  const size_t cap = (size_t)8 * n + 64;   // real + ghost triangles ever created (< 4n)
+int Delaunay::prepare(const int32_t* x, const int32_t* y, int n, int want_parts) {
+  nparts_ = 0; k_ = 0;
+  if (n < 3) return 0;
+  x_ = x; y_ = y; lcg_ = 1;
+  const size_t cap = (size_t)8 * n + 64;   // real + ghost triangles ever created (< 4n) + the slack of the parts' slot ranges
   if (link_.size() < 4 * cap) { link_.resize(4 * cap); vert_.resize(4 * cap); }
   if (order_.size() < (size_t)n) { order_.resize(n); by_y_.resize(n); tmp_.resize(n); left_.resize(n); }
   int32_t* a = order_.data();
@@ -343,18 +349,72 @@ int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
       if (x[a[k]] != x[a[j]] || y[a[k]] != y[a[j]]) a[++k] = a[j];
     ++k;
   }
-  if (k < 2) return -1;
+  if (k < 2) return 0;
+  k_ = k;
   arrange(a, k);
-  H hl, hr;
-  conquer(a, k, 0, hl, hr);
-  int out = 0;
-  for (int t = 0; t < ntri_; t++) {
-    const int32_t* c = &vert_[4 * t];
-    if ((c[0] | c[1] | c[2]) < 0) continue;       // ghost
-    tri[3 * out] = c[1]; tri[3 * out + 1] = c[2]; tri[3 * out + 2] = c[0];
-    out++;
+  // the top of the recursion conquer(a, k, 0): cut on axis 0, children are conquered on axis 1, grandchildren on axis 0
+  int parts = (want_parts >= 4 && k >= 256) ? 4 : ((want_parts >= 2 && k >= 128) ? 2 : 1);
+  if (parts == 1) part_[0] = Part{0, k, 0, 0, 0, 0, 0};
+  else {
+    cut(0, k, 0);
+    const int half = k >> 1;
+    if (parts == 2) { part_[0] = Part{0, half, 1, 0, 0, 0, 0}; part_[1] = Part{half, k, 1, 0, 0, 0, 0}; }
+    else {
+      cut(0, half, 1); cut(half, k, 1);
+      const int q0 = half >> 1, q2 = (k - half) >> 1;
+      part_[0] = Part{0, q0, 0, 0, 0, 0, 0}; part_[1] = Part{q0, half, 0, 0, 0, 0, 0};
+      part_[2] = Part{half, half + q2, 0, 0, 0, 0, 0}; part_[3] = Part{half + q2, k, 0, 0, 0, 0, 0};
+    }
   }
+  // slot ranges in the order the sequential recursion creates triangles: p0 p1 [merge 01] p2 p3 [merge 23] [merge top]
+  int slot = 0;
+  auto reserve_part = [&](int i) { part_[i].slot0 = slot; slot += 4 * (part_[i].hi - part_[i].lo) + 8; };
+  if (parts == 1) reserve_part(0);
+  else if (parts == 2) { reserve_part(0); reserve_part(1); zslot_[0] = slot; slot += 2; }
+  else { reserve_part(0); reserve_part(1); zslot_[0] = slot; slot += 2; reserve_part(2); reserve_part(3); zslot_[1] = slot; slot += 2; zslot_[2] = slot; slot += 2; }
+  nparts_ = parts;
+  return parts;
+}
+
+void Delaunay::subtree(int i) {
+  Part& p = part_[i];
+  split(p.lo, p.hi, p.axis);
+  Ctx c{p.slot0};
+  conquer(order_.data() + p.lo, p.hi - p.lo, p.axis, p.farleft, p.farright, c);
+  p.used = c.next - p.slot0;
+}
+
+int Delaunay::finish(int32_t* tri) {
+  if (nparts_ == 0) return -1;
+  int out = 0;
+  auto emit = [&](int slot0, int count) {
+    for (int t = slot0; t < slot0 + count; t++) {
+      const int32_t* c = &vert_[4 * t];
+      if ((c[0] | c[1] | c[2]) < 0) continue;       // ghost
+      tri[3 * out] = c[1]; tri[3 * out + 1] = c[2]; tri[3 * out + 2] = c[0];
+      out++;
+    }
+  };
+  if (nparts_ == 1) { emit(part_[0].slot0, part_[0].used); return out; }
+  if (nparts_ == 2) {
+    Ctx c{zslot_[0]};
+    zip(part_[0].farleft, part_[0].farright, part_[1].farleft, part_[1].farright, 0, c);
+    emit(part_[0].slot0, part_[0].used); emit(part_[1].slot0, part_[1].used); emit(zslot_[0], 2);
+    return out;
+  }
+  Ctx c0{zslot_[0]}, c1{zslot_[1]}, c2{zslot_[2]};
+  zip(part_[0].farleft, part_[0].farright, part_[1].farleft, part_[1].farright, 1, c0);
+  zip(part_[2].farleft, part_[2].farright, part_[3].farleft, part_[3].farright, 1, c1);
+  zip(part_[0].farleft, part_[1].farright, part_[2].farleft, part_[3].farright, 0, c2);
+  emit(part_[0].slot0, part_[0].used); emit(part_[1].slot0, part_[1].used); emit(zslot_[0], 2);
+  emit(part_[2].slot0, part_[2].used); emit(part_[3].slot0, part_[3].used); emit(zslot_[1], 2); emit(zslot_[2], 2);
   return out;
+}
+
+int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
+  if (prepare(x, y, n, 1) == 0) return -1;
+  subtree(0);
+  return finish(tri);
 }
 
 }  // namespace jnav

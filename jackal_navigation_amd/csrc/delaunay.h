@@ -21,6 +21,17 @@ class Delaunay {
   // of triangles, or -1 when fewer than 2 distinct points exist.
   int run(const int32_t* x, const int32_t* y, int n, int32_t* tri);
 
+  // The same in three phases, for a caller with idle threads (a lone pair, a small batch of large frames):
+  //   prepare()   serial: sort, duplicate removal, the first one or two alternating cuts -> 1, 2 or 4 independent parts
+  //   subtree(i)  the parts may run concurrently on different threads (they touch disjoint ranges of every array)
+  //   finish()    serial: the one or three hull merges between the parts, then the output
+  // Triangle numbers (= the reference's creation order, which decides doubly covered pixels downstream) are kept by
+  // giving every part, and every merge between parts, its own slot range in the order the sequential recursion would
+  // have reached it.  prepare returns the number of parts, 0 when there is nothing to do (finish then returns -1).
+  int prepare(const int32_t* x, const int32_t* y, int n, int want_parts);
+  void subtree(int part);
+  int finish(int32_t* tri);
+
  private:
   typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge
   const int32_t* x_ = nullptr;
@@ -29,10 +40,14 @@ class Delaunay {
   std::vector<int32_t> vert_;               // 4 per triangle (3 used): vertex or -1 (ghost corner)
   std::vector<int32_t> order_, by_y_, tmp_, bucket_;
   std::vector<uint8_t> left_;
-  int ntri_ = 0;
   uint64_t lcg_ = 1;
+  struct Ctx { int next; };                 // next free triangle slot of a slot range
+  struct Part { int lo, hi, axis, slot0, used; H farleft, farright; };
+  Part part_[4];
+  int nparts_ = 0, k_ = 0;
+  int zslot_[3] = {0, 0, 0};                // slot ranges (2 slots each) of the merges between parts, in creation order
 
-  H fresh();
+  H fresh(Ctx& c);
   inline H across(H h) const { return (H)link_[h]; }
   static inline unsigned up(unsigned e) { return e == 2 ? 0u : e + 1u; }      // edge 0->1->2->0
   static inline unsigned down(unsigned e) { return e == 0 ? 2u : e - 1u; }    // edge 0->2->1->0
@@ -51,9 +66,10 @@ class Delaunay {
   void quicksort(int32_t* a, int n);
   bool sort_distinct(int32_t* a, int n);
   void arrange(int32_t* a, int n);
+  void cut(int lo, int hi, int axis);
   void split(int lo, int hi, int axis);
-  void conquer(int32_t* a, int n, int axis, H& farleft, H& farright);
-  void zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis);
+  void conquer(int32_t* a, int n, int axis, H& farleft, H& farright, Ctx& c);
+  void zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis, Ctx& c);
 };
 
 }  // namespace jnav

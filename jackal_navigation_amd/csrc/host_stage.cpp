@@ -181,4 +181,29 @@ void HostWorker::triangulate_side_from_list(int side, const int16_t* t, uint8_t*
   info->ntri[side] = nt < 0 ? 0 : nt;
 }
 
+void HostWorker::side_prepare(int side, const int16_t* t, uint8_t* payload, const FrameInfo* info, SideState* st, int want_parts) const {
+  st->parts = 0;
+  if (!info->ok) return;
+  const int n = info->nsup, step = hp_.step;
+  st->xs.resize(n); st->ys.resize(n);
+  if (side == 0) {
+    int32_t* uvd = reinterpret_cast<int32_t*>(payload + info->sup_offset);
+    for (int i = 0; i < n; i++) {
+      const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
+      uvd[3 * i] = u; uvd[3 * i + 1] = v; uvd[3 * i + 2] = d;
+      st->xs[i] = u; st->ys[i] = v;
+    }
+  } else {
+    for (int i = 0; i < n; i++) { st->xs[i] = t[3 * i] * step - t[3 * i + 2]; st->ys[i] = t[3 * i + 1] * step; }   // (u - d, v), elas.cpp:466-467
+  }
+  st->parts = st->dt.prepare(st->xs.data(), st->ys.data(), n, want_parts);
+}
+
+void HostWorker::side_finish(int side, uint8_t* payload, FrameInfo* info, SideState* st) {
+  if (!info->ok) return;
+  int32_t* corners = reinterpret_cast<int32_t*>(payload + info->corner_offset[side]);
+  const int nt = st->parts ? st->dt.finish(corners) : -1;
+  info->ntri[side] = nt < 0 ? 0 : nt;
+}
+
 }  // namespace jnav

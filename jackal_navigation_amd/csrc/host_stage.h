@@ -46,6 +46,11 @@ class HostWorker {
   // the (uc, vc, d) triples itself, so a batch is one flat set of frame-side tasks.  `info` must hold ok / nsup and
   // its payload offsets already.
   void triangulate_side_from_list(int side, const int16_t* triples, uint8_t* payload, FrameInfo* info);
+  // The same split into phases for callers with idle threads (jn_api.cpp decides): coordinates + Delaunay::prepare into
+  // the caller's per-(frame, side) state, then Delaunay::subtree per part on any worker, then Delaunay::finish.
+  struct SideState { Delaunay dt; std::vector<int32_t> xs, ys; int parts = 0; };
+  void side_prepare(int side, const int16_t* triples, uint8_t* payload, const FrameInfo* info, SideState* st, int want_parts) const;
+  static void side_finish(int side, uint8_t* payload, FrameInfo* info, SideState* st);
   static size_t payload_capacity(const HostParams& hp);   // worst case for one frame
 
  private:

@@ -59,6 +59,7 @@ struct Slot {
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
   unsigned long long* scan_scratch = nullptr;                 // extrema of the scan tail, 4 per frame
   std::vector<FrameScratch> scratch;
+  std::vector<HostWorker::SideState> sides;                  // [2 * max_batch]: per frame side, for the phased (parallel) triangulation
   // pinned host
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
   int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
@@ -87,6 +88,7 @@ struct jn_elas {
   // batch exceeds the pool size, "1" = always host, "0" = always device.  The host also takes over when no kernel can
   // take the lattice.
   int filter_min_batch = 4;
+  bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
@@ -136,10 +138,26 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       fi.ok = fi.nsup >= 3;                              // elas.cpp:66-71
       payload_bytes += HostWorker::place(&fi, payload_bytes);
     }
-    h->pool->run(2 * n, [&](HostWorker& w, int k) {
-      const int i = k >> 1;
-      w.triangulate_side_from_list(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i]);
-    });
+    // Idle pool threads (a lone pair, a few large frames) are put to work inside the triangulations: every frame side
+    // is cut into 2 or 4 independent parts (delaunay.h), three short pool rounds instead of one long one.
+    const int threads = h->pool->size();
+    const int want_parts = h->split_delaunay ? (threads >= 8 * n ? 4 : (threads >= 4 * n ? 2 : 1)) : 1;
+    if (want_parts == 1) {
+      h->pool->run(2 * n, [&](HostWorker& w, int k) {
+        const int i = k >> 1;
+        w.triangulate_side_from_list(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i]);
+      });
+    } else {
+      h->pool->run(2 * n, [&](HostWorker& w, int k) {
+        const int i = k >> 1;
+        w.side_prepare(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i], &s.sides[k], want_parts);
+      });
+      h->pool->run(2 * n * want_parts, [&](HostWorker&, int k) {
+        HostWorker::SideState& st = s.sides[k / want_parts];
+        if (k % want_parts < st.parts) st.dt.subtree(k % want_parts);
+      });
+      h->pool->run(2 * n, [&](HostWorker&, int k) { HostWorker::side_finish(k & 1, s.h_payload, &s.h_info[k >> 1], &s.sides[k]); });
+    }
   } else {
     h->pool->run(n, [&](HostWorker& w, int i) {          // phase 1: filters + support list, per frame
       w.filter_and_list(s.h_can + (size_t)i * dp.cw * dp.ch, &s.h_info[i], &s.scratch[i], false);
@@ -322,11 +340,12 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
 
   int nthreads = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
-  nthreads = std::min(nthreads, std::max(1, max_batch * slots));
+  nthreads = std::min(nthreads, std::max(1, 8 * max_batch * slots));   // up to 2 sides x 4 parts per frame can run at once
   h->pool.reset(new Pool(nthreads, hp));
   h->filter_min_batch = nthreads + 1;
   h->filters_fast = support_filters_fast(h->dp, p->incon_window_size, p->incon_min_support);
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
+  if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
   for (int i = 0; i < slots; i++) {
@@ -348,6 +367,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     CREATE_TRY(dmalloc(&s->mark, grid_words)); CREATE_TRY(dmalloc(&s->gridbits, grid_words));
     CREATE_TRY(dmalloc(&s->recs, 2 * B * (size_t)h->tri_cap));
     s->scratch.resize(B);
+    s->sides.resize(2 * B);
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_can), B * dp.cw * dp.ch * sizeof(int16_t), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_info), B * sizeof(FrameInfo), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
@@ -601,6 +621,18 @@ int32_t jn_host_triangulate(const int32_t* x, const int32_t* y, int32_t n, int32
   if (!x || !y || !tri || n < 0) return -1;
   Delaunay dt;
   return dt.run(x, y, n, tri);
+}
+
+int32_t jn_host_triangulate_parts(const int32_t* x, const int32_t* y, int32_t n, int32_t* tri, int32_t parts) {
+  if (!x || !y || !tri || n < 0) return -1;
+  Delaunay dt;
+  const int got = dt.prepare(x, y, n, parts);
+  if (got == 0) return -1;
+  std::vector<std::thread> th;                               // the parts really run concurrently
+  for (int i = 1; i < got; i++) th.emplace_back([&dt, i] { dt.subtree(i); });
+  dt.subtree(0);
+  for (auto& t : th) t.join();
+  return dt.finish(tri);
 }
 
 jn_status jn_device_support_filters(int32_t device, const jn_elas_params* p, int32_t W, int32_t H, int32_t n, int16_t* d_can,

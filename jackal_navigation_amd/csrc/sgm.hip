@@ -1,7 +1,7 @@
 // sgm.hip — the semi-global-matching mode (include/jn_sgm.h): gfx950 kernels and their C ABI.  Product code.
 //
 // No reference counterpart (the reference's only matcher is libelas); the definition is in jn_sgm.h and its scalar
-// restatement, the checker, is oracle/sgm_oracle.cpp.  Everything is integer arithmetic, so the bar is bit-exactness.
+// restatement (the checker, test infrastructure only) lives outside the product.  Everything is integer arithmetic, so the bar is bit-exactness.
 //
 // Decomposition.  An SGM path L_r(p, .) depends only on the previous pixel of ITS line, so the lines of one direction
 // are independent 1-D recurrences: one wave64 per line, lanes = disparities (D/64 per lane), walking the line pixel by

@@ -110,3 +110,45 @@ def test_delaunay_degenerate_inputs(jn, oracle, same):
     assert same(tri, oracle.triangulate(dup.astype(np.float32)))
     same_pt = np.array([(7, 7)] * 4, np.int32)
     assert triangulate(jn, same_pt)[0] == -1
+
+
+def test_delaunay_cut_into_parts_equals_the_sequential_run(jn, oracle, same):
+    """The phased triangulation (2 or 4 parts on their own threads, merged afterwards; what jn_elas does when its pool has
+    idle threads) must reproduce the sequential output exactly, triangle ORDER included — the order decides doubly
+    covered pixels downstream.  Lattice points with and without duplicates, random points, sizes around the split
+    thresholds, collinear runs."""
+    L = jn.load()
+    rng = np.random.default_rng(5)
+    checked = 0
+    for trial in range(160):
+        kind = trial % 4
+        if kind == 0:      # ELAS-like: 5-px lattice, sparse
+            gw, gh = int(rng.integers(20, 256)), int(rng.integers(10, 144))
+            pts = np.array([(5 * x, 5 * y) for x in range(1, gw) for y in range(1, gh)], np.int32)
+            pts = pts[rng.random(len(pts)) < rng.uniform(0.03, 0.5)]
+        elif kind == 1:    # right-image coordinates: columns shifted by a disparity -> duplicates
+            gw, gh = int(rng.integers(20, 120)), int(rng.integers(10, 60))
+            pts = np.array([(5 * x - int(rng.integers(0, 14)), 5 * y) for x in range(gw) for y in range(gh)], np.int32)
+        elif kind == 2:
+            pts = rng.integers(0, 60, (int(rng.integers(100, 700)), 2)).astype(np.int32)       # many duplicates
+        else:
+            pts = rng.integers(0, 3000, (int(rng.integers(120, 4000)), 2)).astype(np.int32)
+        if len(pts) < 3:
+            continue
+        x = np.ascontiguousarray(pts[:, 0]); y = np.ascontiguousarray(pts[:, 1])
+        ref = np.zeros((2 * len(pts) + 8, 3), np.int32)
+        nref = L.jn_host_triangulate(x.ctypes.data, y.ctypes.data, len(pts), ref.ctypes.data)
+        for parts in (2, 4):
+            got = np.zeros_like(ref)
+            n = L.jn_host_triangulate_parts(x.ctypes.data, y.ctypes.data, len(pts), got.ctypes.data, parts)
+            assert n == nref and same(got[:max(n, 0)], ref[:max(nref, 0)]), (trial, kind, len(pts), parts)
+        checked += 1
+    assert checked > 150
+    # against the oracle as well (which emulates Triangle's randomised quick-select), on one large lattice set
+    pts = np.array([(5 * x, 5 * y) for x in range(1, 256) for y in range(1, 144)], np.int32)
+    pts = pts[rng.random(len(pts)) < 0.09]
+    got = np.zeros((2 * len(pts) + 8, 3), np.int32)
+    x = np.ascontiguousarray(pts[:, 0]); y = np.ascontiguousarray(pts[:, 1])
+    n = L.jn_host_triangulate_parts(x.ctypes.data, y.ctypes.data, len(pts), got.ctypes.data, 4)
+    exp = oracle.triangulate(pts.astype(np.float32))
+    assert n == len(exp) and same(got[:n], exp)
