@@ -112,11 +112,12 @@ def test_delaunay_degenerate_inputs(jn, oracle, same):
     assert triangulate(jn, same_pt)[0] == -1
 
 
-def test_delaunay_cut_into_parts_equals_the_sequential_run(jn, oracle, same):
+def test_delaunay_cut_into_parts_equals_the_sequential_run(jn, oracle, same, monkeypatch):
     """The phased triangulation (2 or 4 parts on their own threads, merged afterwards; what jn_elas does when its pool has
     idle threads) must reproduce the sequential output exactly, triangle ORDER included — the order decides doubly
     covered pixels downstream.  Lattice points with and without duplicates, random points, sizes around the split
     thresholds, collinear runs."""
+    monkeypatch.setenv("JN_DELAUNAY_MIN_POINTS", "64")       # read once per process, at the first phased call: cuts from 64 / 128 points on
     L = jn.load()
     rng = np.random.default_rng(5)
     checked = 0
