@@ -3,7 +3,7 @@
 import csv, re, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    name = re.sub(r"jnav::", "", r["Kernel_Name"]).split("(")[0]
+    name = re.sub(r"jnav::|\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0]
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 pat = sys.argv[2] if len(sys.argv) > 2 else ""
 for k, cs in acc.items():
