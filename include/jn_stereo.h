@@ -75,8 +75,10 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  *   host_threads  worker threads for the host stage (support-point filters, Delaunay, planes,
  *                 grid prior); 0 = one per online core
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
- * Unsupported (JN_ERR_UNSUPPORTED): subsampling, add_corners, disp_max > 255 or < 10,
- * disp_min != 0, ipol_gap_width > 64, candidate_stepsize < 1, grid_size < 1, plane radius > 7.
+ * Unsupported (JN_ERR_UNSUPPORTED): subsampling, disp_max > 255 or < 10, disp_min != 0,
+ * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported; with add_corners
+ * (MIDDLEBURY) the reference reads descriptor bytes it never initialises (descriptor.cpp:29) at the image border — this
+ * library defines them as 0, which is what the reference sees in freshly mapped memory.
  * On any failure everything allocated so far is released and *out stays NULL. */
 jn_status jn_elas_create(const jn_elas_params* p, int32_t width, int32_t height, int32_t max_batch,
                          int32_t device, int32_t host_threads, int32_t slots, jn_elas** out);

@@ -9,8 +9,23 @@ namespace jnav {
 
 HostWorker::HostWorker(const HostParams& hp) : hp_(hp) {}
 
+void HostWorker::corner_points(int W, int H, int n, std::vector<int32_t>& u, std::vector<int32_t>& v, std::vector<int32_t>& d) {
+  int bu[6] = {0, 0, W - 1, W - 1, 0, 0}, bv[6] = {0, H - 1, 0, H - 1, 0, 0}, bd[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    int best = 10000000;
+    for (int j = 0; j < n; j++) {
+      const int du = bu[i] - u[j], dv = bv[i] - v[j], dist = du * du + dv * dv;
+      if (dist < best) { best = dist; bd[i] = d[j]; }
+    }
+  }
+  bu[4] = bu[2] + bd[2]; bv[4] = bv[2]; bd[4] = bd[2];            // :258-259: right-image twins of the two right-hand corners
+  bu[5] = bu[3] + bd[3]; bv[5] = bv[3]; bd[5] = bd[3];
+  u.resize(n + 6); v.resize(n + 6); d.resize(n + 6);
+  for (int i = 0; i < 6; i++) { u[n + i] = bu[i]; v[n + i] = bv[i]; d[n + i] = bd[i]; }
+}
+
 size_t HostWorker::payload_capacity(const HostParams& hp) {
-  const size_t maxsup = (size_t)hp.cw * hp.ch;
+  const size_t maxsup = (size_t)hp.cw * hp.ch + kCornerPoints;
   return maxsup * 3 * sizeof(int32_t) + 2 * (2 * maxsup + 8) * 3 * sizeof(int32_t) + 256;
 }
 
@@ -135,6 +150,12 @@ void HostWorker::filter_and_list(int16_t* d_can, FrameInfo* info, FrameScratch* 
       const int u = uc * step, v = vc * step;
       fs->u.push_back(u); fs->v.push_back(v); fs->d.push_back(d); fs->x.push_back(u - d);
     }
+  if (hp_.add_corners) {                                         // elas.cpp:435
+    const int n = (int)fs->u.size();
+    corner_points(hp_.W, hp_.H, n, fs->u, fs->v, fs->d);
+    fs->x.resize(n + kCornerPoints);
+    for (int i = n; i < n + kCornerPoints; i++) fs->x[i] = fs->u[i] - fs->d[i];
+  }
   memset(info, 0, sizeof(*info));
   info->nsup = (int32_t)fs->u.size();
   info->ok = fs->u.size() >= 3;                                  // elas.cpp:66-71
@@ -162,20 +183,25 @@ void HostWorker::triangulate_side(int side, const FrameScratch& fs, uint8_t* pay
   info->ntri[side] = nt < 0 ? 0 : nt;
 }
 
+// Support points of one frame from the GPU's (uc, vc, d) lattice triples: pixel coordinates, plus the corner points when
+// the preset asks for them.  info->nsup counts both (jn_api.cpp adds kCornerPoints to the GPU's count).
+static void points_from_list(const HostParams& hp, const int16_t* t, int nsup, std::vector<int32_t>& u, std::vector<int32_t>& v, std::vector<int32_t>& d) {
+  const int nlist = hp.add_corners ? nsup - HostWorker::kCornerPoints : nsup, step = hp.step;
+  u.resize(nlist); v.resize(nlist); d.resize(nlist);
+  for (int i = 0; i < nlist; i++) { u[i] = t[3 * i] * step; v[i] = t[3 * i + 1] * step; d[i] = t[3 * i + 2]; }
+  if (hp.add_corners) HostWorker::corner_points(hp.W, hp.H, nlist, u, v, d);
+}
+static void write_support(uint8_t* payload, const FrameInfo* info, const std::vector<int32_t>& u, const std::vector<int32_t>& v, const std::vector<int32_t>& d) {
+  int32_t* uvd = reinterpret_cast<int32_t*>(payload + info->sup_offset);
+  for (int i = 0; i < info->nsup; i++) { uvd[3 * i] = u[i]; uvd[3 * i + 1] = v[i]; uvd[3 * i + 2] = d[i]; }
+}
+
 void HostWorker::triangulate_side_from_list(int side, const int16_t* t, uint8_t* payload, FrameInfo* info) {
   if (!info->ok) return;
-  const int n = info->nsup, step = hp_.step;
-  xs_.resize(n); ys_.resize(n);
-  if (side == 0) {
-    int32_t* uvd = reinterpret_cast<int32_t*>(payload + info->sup_offset);
-    for (int i = 0; i < n; i++) {
-      const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
-      uvd[3 * i] = u; uvd[3 * i + 1] = v; uvd[3 * i + 2] = d;
-      xs_[i] = u; ys_[i] = v;
-    }
-  } else {
-    for (int i = 0; i < n; i++) { xs_[i] = t[3 * i] * step - t[3 * i + 2]; ys_[i] = t[3 * i + 1] * step; }   // (u - d, v), elas.cpp:466-467
-  }
+  const int n = info->nsup;
+  points_from_list(hp_, t, n, xs_, ys_, ds_);
+  if (side == 0) write_support(payload, info, xs_, ys_, ds_);
+  else for (int i = 0; i < n; i++) xs_[i] -= ds_[i];                       // (u - d, v), elas.cpp:466-467
   int32_t* corners = reinterpret_cast<int32_t*>(payload + info->corner_offset[side]);
   const int nt = dt_.run(xs_.data(), ys_.data(), n, corners);
   info->ntri[side] = nt < 0 ? 0 : nt;
@@ -184,18 +210,11 @@ void HostWorker::triangulate_side_from_list(int side, const int16_t* t, uint8_t*
 void HostWorker::side_prepare(int side, const int16_t* t, uint8_t* payload, const FrameInfo* info, SideState* st, int want_parts) const {
   st->parts = 0;
   if (!info->ok) return;
-  const int n = info->nsup, step = hp_.step;
-  st->xs.resize(n); st->ys.resize(n);
-  if (side == 0) {
-    int32_t* uvd = reinterpret_cast<int32_t*>(payload + info->sup_offset);
-    for (int i = 0; i < n; i++) {
-      const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
-      uvd[3 * i] = u; uvd[3 * i + 1] = v; uvd[3 * i + 2] = d;
-      st->xs[i] = u; st->ys[i] = v;
-    }
-  } else {
-    for (int i = 0; i < n; i++) { st->xs[i] = t[3 * i] * step - t[3 * i + 2]; st->ys[i] = t[3 * i + 1] * step; }   // (u - d, v), elas.cpp:466-467
-  }
+  const int n = info->nsup;
+  std::vector<int32_t> d;
+  points_from_list(hp_, t, n, st->xs, st->ys, d);
+  if (side == 0) write_support(payload, info, st->xs, st->ys, d);
+  else for (int i = 0; i < n; i++) st->xs[i] -= d[i];                      // (u - d, v), elas.cpp:466-467
   st->parts = st->dt.prepare(st->xs.data(), st->ys.data(), n, want_parts);
 }
 

@@ -21,6 +21,7 @@ struct HostParams {
   int32_t disp_max, step;
   int32_t incon_window_size, incon_threshold, incon_min_support;
   int32_t grid_size, gw, gh, cw, ch;
+  int32_t add_corners = 0;     // elas.cpp:435: six border points join the support points (MIDDLEBURY preset)
 };
 
 // Support points of one frame, shared between the two phases of the host stage.
@@ -52,11 +53,16 @@ class HostWorker {
   void side_prepare(int side, const int16_t* triples, uint8_t* payload, const FrameInfo* info, SideState* st, int want_parts) const;
   static void side_finish(int side, uint8_t* payload, FrameInfo* info, SideState* st);
   static size_t payload_capacity(const HostParams& hp);   // worst case for one frame
+  // addCornerSupportPoints (elas.cpp:237-267): the four image corners with the disparity of their nearest support point
+  // (first minimum of the squared distance in list order), plus the two right-hand corners shifted by their disparity
+  // for the right image.  Appends 6 entries to u/v/d (which hold n points).
+  static void corner_points(int W, int H, int n, std::vector<int32_t>& u, std::vector<int32_t>& v, std::vector<int32_t>& d);
+  enum { kCornerPoints = 6 };
 
  private:
   HostParams hp_;
   Delaunay dt_;
-  std::vector<int32_t> xs_, ys_;                 // coordinates of one frame side (triangulate_side_from_list)
+  std::vector<int32_t> xs_, ys_, ds_;            // coordinates of one frame side (triangulate_side_from_list)
   mutable std::vector<int16_t> tr_;              // transposed lattice for the horizontal redundancy pass
   void filter_inconsistent(int16_t* D) const;
   void filter_redundant(int16_t* D, int max_dist, int thresh, bool vertical) const;

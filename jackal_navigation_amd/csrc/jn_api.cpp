@@ -134,7 +134,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     for (int i = 0; i < n; i++) {
       FrameInfo& fi = s.h_info[i];
       memset(&fi, 0, sizeof(fi));
-      fi.nsup = std::min(s.h_cnt[i], list_cap);
+      fi.nsup = std::min(s.h_cnt[i], list_cap) + (h->hp.add_corners ? HostWorker::kCornerPoints : 0);   // elas.cpp:435
       fi.ok = fi.nsup >= 3;                              // elas.cpp:66-71
       payload_bytes += HostWorker::place(&fi, payload_bytes);
     }
@@ -292,8 +292,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (!p || !out || W < 32 || H < 32 || W > 8192 || H > 8192 || max_batch < 1 || slots < 1) return JN_ERR_INVALID;
   *out = nullptr;
   const int radius = (int)std::max((float)std::ceil(p->sigma * p->sradius), 2.0f);        // elas.cpp:806
-  if (p->subsampling || p->add_corners || p->disp_max > 255 || p->disp_max < 10 ||
-      p->disp_min != 0 || p->ipol_gap_width > 64 || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
+  if (p->subsampling || p->disp_max > 255 || p->disp_max < 10 ||
+      p->disp_min != 0 || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
       p->grid_size < 1 || radius > 7 || p->incon_window_size < 0)
     return JN_ERR_UNSUPPORTED;
   int ndev = 0;
@@ -330,13 +330,15 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   for (int dd = 0; dd <= radius; dd++)            // k_dense packs cost + prior into 24 bits of a key (bias 2^20)
     if (dp.P[dd] <= -(1 << 19) || dp.P[dd] >= (1 << 19)) return JN_ERR_UNSUPPORTED;
   dp.speckle_sim = p->speckle_sim_threshold; dp.speckle_size = p->speckle_size; dp.gap_width = p->ipol_gap_width;
+  dp.add_corners = p->add_corners ? 1 : 0;
 
   HostParams& hp = h->hp;
   hp.W = W; hp.H = H; hp.disp_max = p->disp_max; hp.step = dp.step; hp.incon_window_size = p->incon_window_size;
   hp.incon_threshold = p->incon_threshold; hp.incon_min_support = p->incon_min_support;
   hp.grid_size = p->grid_size; hp.gw = dp.gw; hp.gh = dp.gh; hp.cw = dp.cw; hp.ch = dp.ch;
+  hp.add_corners = dp.add_corners;
   h->payload_cap = (HostWorker::payload_capacity(hp) + 255) / 256 * 256;
-  h->tri_cap = 2 * dp.cw * dp.ch + 8;
+  h->tri_cap = 2 * (dp.cw * dp.ch + HostWorker::kCornerPoints) + 8;
 
   int nthreads = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
   if (nthreads < 1) nthreads = 1;
@@ -676,6 +678,7 @@ int64_t jn_host_stage(const jn_elas_params* p, int32_t W, int32_t H, int16_t* d_
   hp.incon_min_support = p->incon_min_support; hp.grid_size = p->grid_size;
   hp.gw = (int)std::ceil((float)W / (float)p->grid_size); hp.gh = (int)std::ceil((float)H / (float)p->grid_size);
   hp.cw = (W + hp.step - 1) / hp.step; hp.ch = (H + hp.step - 1) / hp.step;
+  hp.add_corners = p->add_corners ? 1 : 0;
   if ((int64_t)HostWorker::payload_capacity(hp) > payload_cap) return -1;
   HostWorker w(hp);
   FrameInfo fi;

@@ -60,6 +60,7 @@ struct DevParams {
   float   speckle_sim;
   int32_t speckle_size;
   int32_t gap_width;
+  int32_t add_corners;       // elas.cpp:1169, :1253: gap interpolation also extrapolates to the image borders
   uint32_t grid_magic;       // floor(2^32 / grid_size) + 1: x / grid_size == __umulhi(x, grid_magic) for 0 <= x < 2^32 / grid_size
 };
 

@@ -1786,6 +1786,92 @@ __global__ void __launch_bounds__(64) k_gap4(DevParams dp, const FrameInfo* __re
   *reinterpret_cast<float4*>(out + frame * plane + p0) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// Gap interpolation for any gap width and with the border extrapolation of the add_corners presets
+// (elas.cpp:1137-1198, :1218-1282).  Per line: an invalid pixel with valid neighbours at L (before) and R (after) and a run
+// R - L - 1 <= gap_width takes (d1+d2)/2 if |d1-d2| < 3 else min(d1,d2); with add_corners the pixels before the line's first
+// valid pixel (at most gap_width of them) take its value and the pixels after the last valid one likewise.  Fills never
+// become bounds of other runs, so this gather form equals the reference's sequential scan.
+// Rows: one wave per image row; the row and, per pixel, the index of the nearest valid pixel at or before / at or after
+// it live in LDS (forward max-scan and backward min-scan in 64-pixel chunks with wave-uniform carries).
+__global__ void __launch_bounds__(256) k_gap_rows_any(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
+                                                      float* __restrict__ out) {
+  extern __shared__ float s_gap[];                           // per wave: [W] values | [W] prev index | [W] next index (as int)
+  const int W = dp.W, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = blockIdx.x * (blockDim.x >> 6) + wave, frame = blockIdx.y;
+  if (v >= dp.H || !info[frame].ok) return;
+  float* val = s_gap + (size_t)wave * 3 * W;
+  int* prev = reinterpret_cast<int*>(val + W);
+  int* next = prev + W;
+  const size_t row = ((size_t)frame * dp.H + v) * W;
+  int carry = -1;
+  for (int u0 = 0; u0 < W; u0 += 64) {                       // forward: index of the nearest valid pixel at or before u
+    const int u = u0 + lane;
+    const float x = u < W ? in[row + u] : -10.0f;
+    int p = (u < W && x >= 0) ? u : -1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(p, off); if (lane >= off) p = max(p, o); }
+    p = max(p, carry);
+    if (u < W) { val[u] = x; prev[u] = p; }
+    carry = __shfl(p, 63);
+  }
+  carry = 1 << 30;
+  for (int u0 = ((W - 1) / 64) * 64; u0 >= 0; u0 -= 64) {    // backward: nearest valid pixel at or after u
+    const int u = u0 + lane;
+    int q = (u < W && val[u] >= 0) ? u : (1 << 30);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_down(q, off); if (lane + off < 64) q = min(q, o); }
+    q = min(q, carry);
+    if (u < W) next[u] = q;
+    carry = __shfl(q, 0);
+  }
+  const int gw = dp.gap_width;
+  for (int u = lane; u < W; u += 64) {
+    float x = val[u];
+    if (!(x >= 0)) {
+      const int L = prev[u], R = next[u];
+      if (L >= 0 && R < W) {
+        if (R - L - 1 <= gw) { const float d1 = val[L], d2 = val[R]; x = fabsf(d1 - d2) < 3.0f ? __fadd_rn(d1, d2) / 2 : fminf(d1, d2); }   // :1149-1150
+      } else if (dp.add_corners) {
+        if (L < 0 && R < W) { if (u >= R - gw) x = val[R]; }             // :1172-1183
+        else if (L >= 0 && R >= W) { if (u <= L + gw) x = val[L]; }      // :1186-1197
+      }
+    }
+    out[row + u] = x;
+  }
+}
+// Columns: one thread per column walking down; every pixel is passed through as it is read, and when a valid pixel closes a
+// run of invalid ones (or the column ends) the run is filled behind it.  Neighbouring threads touch neighbouring addresses.
+__global__ void __launch_bounds__(256) k_gap_cols_any(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
+                                                      float* __restrict__ out) {
+  const int u = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W, H = dp.H, gw = dp.gap_width;
+  const float* I = in + (size_t)frame * H * W + u;
+  float* O = out + (size_t)frame * H * W + u;
+  int last = -1;                                             // row of the last valid pixel seen
+  float dlast = 0;
+  for (int v = 0; v < H; v++) {
+    const float x = I[(size_t)v * W];
+    O[(size_t)v * W] = x;
+    if (x >= 0) {
+      const int count = v - last - 1;
+      if (count >= 1) {
+        if (last >= 0) {
+          if (count <= gw) {
+            const float d = fabsf(dlast - x) < 3.0f ? __fadd_rn(dlast, x) / 2 : fminf(dlast, x);       // :1230-1231
+            for (int w = last + 1; w < v; w++) O[(size_t)w * W] = d;
+          }
+        } else if (dp.add_corners) {
+          for (int w = max(v - gw, 0); w < v; w++) O[(size_t)w * W] = x;                                // :1256-1267
+        }
+      }
+      last = v; dlast = x;
+    }
+  }
+  if (dp.add_corners && last >= 0)
+    for (int w = last + 1; w <= min(last + gw, H - 1); w++) O[(size_t)w * W] = dlast;                  // :1270-1281
+}
+
 // ------------------------------------------------------------------------------------------------
 // Adaptive mean (elas.cpp:1287-1492, full-resolution branch).  The reference's "abs mask" is
 // _mm_set1_ps(0x7FFFFFFF) = 2^31 as a float (0x4F000000), so the weight keeps a few exponent
@@ -2227,6 +2313,7 @@ hipError_t configure_device_kernels() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_filter_resolve_big<WIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gap_rows_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   done |= bit;
   return hipSuccess;
 }
@@ -2387,6 +2474,12 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
 }
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);
+  if (dp.add_corners || dp.gap_width > 64) {                 // any width, border extrapolation (MIDDLEBURY preset)
+    const int wpb = (size_t)4 * 3 * dp.W * sizeof(float) <= 150 * 1024 ? 4 : 1;     // rows per workgroup: three W-sized LDS arrays each
+    hipLaunchKernelGGL(k_gap_rows_any, dim3((dp.H + wpb - 1) / wpb, n), dim3(64 * wpb), (size_t)wpb * 3 * dp.W * sizeof(float), st, dp, info, D, tmp);
+    hipLaunchKernelGGL(k_gap_cols_any, dim3((dp.W + 255) / 256, n), dim3(256), 0, st, dp, info, tmp, D);
+    return;
+  }
   if ((dp.W & 3) == 0) {
     const dim3 g4((dp.W / 4 + 63) / 64, dp.H, n);
     hipLaunchKernelGGL(k_gap4<true>, g4, dim3(64), 0, st, dp, info, D, tmp);

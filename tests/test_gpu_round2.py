@@ -268,3 +268,55 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     assert all(sets)
     if len(os.sched_getaffinity(0)) >= 4:
         assert not (sets[0] & sets[1]), sets
+
+
+def _elas(jn, p, L, R):
+    H, W = L.shape
+    D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+    with jn.Elas(p, W, H, host_threads=4) as e:
+        st = e.process(np.ascontiguousarray(L), np.ascontiguousarray(R), D1, D2, (W, H, W))
+    return st, D1, D2
+
+
+def test_middlebury_preset_against_reference_hashes_and_oracle(jn, oracle, same):
+    """SURVEY row a9 and the whole MIDDLEBURY preset (elas.h:118-145): addCornerSupportPoints (six border points, two of
+    them outside the image), plane radius 3, match_texture 0, unbounded gap interpolation with border extrapolation, median
+    filter, both sides post-processed.  Against the compiled reference's hashes (uninitialised descriptor bytes zero-filled,
+    tests/golden/make_middlebury_golden.py) and bit for bit against the oracle."""
+    import os
+    from scenes import make_scene
+    rows = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "reference_middlebury_hashes.txt")) if not l.startswith("#")]
+    assert len(rows) >= 8
+    for kind, W, H, sd, dmax, seed, h1, h2 in rows:
+        W, H, sd, dmax, seed = int(W), int(H), int(sd), int(dmax), int(seed)
+        L, R = oracle.synth_pair(W, H, sd, seed) if kind == "synth" else make_scene(kind, W, H, dmax, seed)
+        st, D1, D2 = _elas(jn, jn.Elas.parameters(1, disp_max=dmax), L, R)
+        assert st == 0 and oracle.fnv(D1) == int(h1, 16) and oracle.fnv(D2) == int(h2, 16), (kind, W, H)
+        if W * H <= 640 * 480:
+            _, D1o, D2o = oracle.process(oracle.params(1, disp_max=dmax), L, R)
+            assert same(D1, D1o) and same(D2, D2o)
+        assert (D1 >= 0).mean() > 0.97                       # "full size disparity map": almost nothing stays invalid
+
+
+@pytest.mark.parametrize("kw", [
+    {"add_corners": 1}, {"ipol_gap_width": 5000}, {"ipol_gap_width": 100, "postprocess_only_left": 0},
+    {"add_corners": 1, "ipol_gap_width": 9}, {"add_corners": 1, "ipol_gap_width": 5000, "filter_adaptive_mean": 0},
+])
+def test_corner_points_and_wide_gaps_with_the_robotics_preset(jn, oracle, same, kw):
+    """add_corners and gap widths beyond 64 (the general gap kernels) switched on one at a time on top of the node's preset,
+    on a scene with occlusions (wide invalid runs) and on a ragged image size; a batch through the device-pointer API."""
+    from scenes import make_scene
+    from jackal_navigation_amd.device import DeviceArray
+    for (L, R, dmax) in (make_scene("strips", 320, 240, 79, 33) + (79,), oracle.synth_pair(333, 201, 30, 5) + (95,)):
+        st, D1, D2 = _elas(jn, jn.Elas.parameters(0, disp_max=dmax, **kw), L, R)
+        st_o, D1o, D2o = oracle.process(oracle.params(0, disp_max=dmax, **kw), L, R)
+        assert st == st_o == 0 and same(D1, D1o) and same(D2, D2o), (kw, L.shape)
+    W, H, n = 320, 180, 4
+    Ls = np.stack([oracle.synth_pair(W, H, 48, 80 + b)[0] for b in range(n)]); Rs = np.stack([oracle.synth_pair(W, H, 48, 80 + b)[1] for b in range(n)])
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    d1 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32)); d2 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32))
+    with jn.Elas(jn.Elas.parameters(0, **kw), W, H, max_batch=n, host_threads=2) as e:
+        assert e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr) == [0] * n
+    for b in range(n):
+        _, D1o, D2o = oracle.process(oracle.params(0, **kw), Ls[b], Rs[b])
+        assert same(d1.numpy()[b], D1o) and same(d2.numpy()[b], D2o), (kw, b)
