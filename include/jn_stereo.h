@@ -219,6 +219,24 @@ jn_status jn_remap_bilinear(int32_t device, int32_t n, const uint8_t* dSrc, int3
                             int32_t src_pitch, int64_t src_stride, const float* dMapX, const float* dMapY,
                             uint8_t* dDst, int32_t width, int32_t height, int32_t dst_pitch, int64_t dst_stride);
 
+/* cv::imdecode(Mat(msg->data), CV_LOAD_IMAGE_GRAYSCALE) (point_cloud.cpp:436, :478) for the node's JPEG camera frames:
+ * what OpenCV gets from libjpeg with a grey output colour space, i.e. the luminance plane reconstructed with the "slow
+ * integer" inverse DCT (third-party arithmetic outside the reference tree, restated from the JPEG standard and the IJG
+ * definition of that IDCT; pinned by Pillow / libjpeg-turbo fixtures, tests/golden/make_jpeg_golden.py).  Entropy decoding
+ * runs on the calling thread, dequantisation + IDCT on the GPU; the image lands in device memory (dOut, rows out_pitch
+ * bytes apart, at least out_rows rows) ready for jn_remap_bilinear.  Baseline / extended-sequential Huffman JPEG with 8-bit
+ * samples, 1 or 3 components in one scan, restart intervals; anything else (progressive, arithmetic, 12-bit) returns
+ * JN_ERR_UNSUPPORTED, damaged data JN_ERR_INVALID.  jn_jpeg_info reads the frame size without decoding (host only). */
+jn_status jn_jpeg_info(const uint8_t* jpeg, int64_t nbytes, int32_t* width, int32_t* height);
+jn_status jn_jpeg_decode_gray(int32_t device, const uint8_t* jpeg, int64_t nbytes, uint8_t* dOut, int32_t out_pitch, int32_t out_rows,
+                              int32_t* width, int32_t* height);
+
+/* Host-stage hook (CPU only, like jn_host_triangulate): the entropy-decoded luminance coefficients of a JPEG frame, natural
+ * (de-zigzagged) order, not dequantised, blocks_h x blocks_w blocks of 64 (padded to whole MCUs), and the luminance
+ * quantisation table.  Returns the number of coefficients, or -(jn_status) on error; coef may be NULL to query sizes. */
+int64_t jn_host_jpeg_coefficients(const uint8_t* jpeg, int64_t nbytes, int16_t* coef, int64_t coef_capacity, uint16_t quant[64],
+                                  int32_t* width, int32_t* height, int32_t* blocks_w, int32_t* blocks_h);
+
 /* ---- cross-rig merge (SURVEY.md 8b `jn_scan_allreduce`, 8e) ---------------------------------
  * The path's one exchange step: per-rig obstacle scans -> robot-level scan = element-wise MIN over
  * the bins (point_cloud.cpp:264-266 applied across rigs) and min / max / min / max of the four

@@ -1,0 +1,347 @@
+// jpeg.hip — cv::imdecode(data, CV_LOAD_IMAGE_GRAYSCALE) for the node's compressed camera frames
+// (src/obstacle_avoidance/point_cloud.cpp:436, :478), product code.
+//
+// OpenCV hands JPEG data to libjpeg(-turbo) with out_color_space = JCS_GRAYSCALE, which entropy-decodes every component
+// but reconstructs only luminance, with the default "slow integer" inverse DCT.  Neither OpenCV nor libjpeg is part of
+// the reference tree (third-party arithmetic); this file restates the published baseline-JPEG decoding
+// procedure (ITU-T T.81: marker syntax, Huffman decoding, DC prediction, zig-zag order, restart intervals) and the
+// Loeffler-Ligtenberg-Moschytz 8x8 inverse DCT in the 13-bit fixed-point form the Independent JPEG Group's "islow" method
+// defines (CONST_BITS 13, PASS1_BITS 2, range limiting modulo 1024 around +128), so that the grey image equals what
+// libjpeg produces bit for bit.  Pinned by fixtures generated with Pillow (libjpeg-turbo, the same IDCT) in
+// tests/golden/make_jpeg_golden.py.
+//
+// Split: the entropy decoder is inherently serial per scan and runs on the calling host thread; coefficients of the
+// luminance blocks go to pinned memory, dequantisation + inverse DCT + range limit run on the GPU (8 lanes per block, the
+// 8x8 workspace in LDS), the grey image stays in device memory for jn_remap_bilinear / jn_elas_*.
+// Supported: baseline sequential DCT (SOF0) and extended sequential with 8-bit samples (SOF1), Huffman coding, 1 or 3
+// components, luminance sampling factors 1 or 2, restart intervals.  Progressive, arithmetic-coded, 12-bit, lossless and
+// multi-scan files return JN_ERR_UNSUPPORTED.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+#include "../../include/jn_stereo.h"
+
+namespace {
+
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+  bool present = false;
+  uint8_t vals[256];
+  int32_t mincode[17], maxcode[18], valptr[17];     // per code length 1..16 (T.81 F.2.2.3)
+  uint8_t look_len[256], look_val[256];             // first 8 bits -> (length, value) for codes of <= 8 bits
+  void build(const uint8_t counts[16], const uint8_t* symbols, int nsym) {
+    memcpy(vals, symbols, (size_t)nsym);
+    int code = 0, k = 0;
+    memset(look_len, 0, sizeof(look_len));
+    for (int len = 1; len <= 16; len++) {
+      valptr[len] = k; mincode[len] = code;
+      for (int i = 0; i < counts[len - 1]; i++, k++, code++)
+        if (len <= 8)
+          for (int fill = 0; fill < (1 << (8 - len)); fill++) { const int idx = (code << (8 - len)) | fill; look_len[idx] = (uint8_t)len; look_val[idx] = vals[k]; }
+      maxcode[len] = counts[len - 1] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7FFFFFFF;
+    present = true;
+  }
+};
+
+struct BitReader {
+  const uint8_t* p; const uint8_t* end;
+  uint32_t acc = 0; int bits = 0;
+  bool hit_marker = false;
+  void fill() {                                       // keep >= 25 bits when possible; stuffed 0xFF00 -> 0xFF; a marker feeds zeros
+    while (bits <= 24) {
+      int b = 0;
+      if (!hit_marker && p < end) {
+        b = *p;
+        if (b == 0xFF) {
+          if (p + 1 < end && p[1] == 0x00) p += 2;
+          else { hit_marker = true; b = 0; }
+        } else p++;
+      } else hit_marker = true;
+      acc |= (uint32_t)b << (24 - bits);
+      bits += 8;
+    }
+  }
+  inline int peek(int n) { return (int)(acc >> (32 - n)); }
+  inline void drop(int n) { acc <<= n; bits -= n; }
+  inline int get(int n) { if (n == 0) return 0; fill(); const int v = peek(n); drop(n); return v; }
+  void restart() { acc = 0; bits = 0; hit_marker = false; }
+};
+
+inline int decode_symbol(BitReader& br, const Huff& h) {
+  br.fill();
+  const int top = br.peek(8);
+  if (h.look_len[top]) { br.drop(h.look_len[top]); return h.look_val[top]; }
+  int code = top, len = 8;
+  do { len++; code = br.peek(len); } while (len <= 16 && code > h.maxcode[len]);
+  if (len > 16) return -1;
+  br.drop(len);
+  return h.vals[h.valptr[len] + code - h.mincode[len]];
+}
+inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }   // T.81 F.2.2.1
+
+struct Component { int id, h, v, tq, td, ta; };
+
+struct Decoded { int width = 0, height = 0, bw = 0, bh = 0; uint16_t quant[64]; };   // bw x bh luminance blocks (MCU-padded)
+
+// Entropy-decodes the luminance coefficients (natural order, NOT dequantised) into coef [bh*bw][64].
+jn_status parse_and_decode(const uint8_t* data, size_t n, Decoded& out, std::vector<int16_t>& coef) {
+  if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return JN_ERR_INVALID;
+  uint16_t qt[4][64]; bool qt_ok[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  Component comp[3]; int ncomp = 0;
+  int restart_interval = 0;
+  bool have_frame = false;
+  size_t pos = 2;
+  while (pos + 4 <= n) {
+    if (data[pos] != 0xFF) { pos++; continue; }
+    const int m = data[pos + 1];
+    if (m == 0xFF) { pos++; continue; }
+    pos += 2;
+    if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (m == 0xD9) break;
+    if (pos + 2 > n) return JN_ERR_INVALID;
+    const size_t len = ((size_t)data[pos] << 8) | data[pos + 1];
+    if (len < 2 || pos + len > n) return JN_ERR_INVALID;
+    const uint8_t* seg = data + pos + 2; const size_t slen = len - 2;
+    if (m == 0xDB) {                                                             // DQT
+      size_t i = 0;
+      while (i < slen) {
+        const int pq = seg[i] >> 4, tq = seg[i] & 15; i++;
+        if (tq > 3 || i + (pq ? 128 : 64) > slen) return JN_ERR_INVALID;
+        for (int k = 0; k < 64; k++) { qt[tq][kZigzag[k]] = pq ? (uint16_t)((seg[i] << 8) | seg[i + 1]) : seg[i]; i += pq ? 2 : 1; }
+        qt_ok[tq] = true;
+      }
+    } else if (m == 0xC4) {                                                      // DHT
+      size_t i = 0;
+      while (i + 17 <= slen) {
+        const int tc = seg[i] >> 4, th = seg[i] & 15;
+        if (tc > 1 || th > 3) return JN_ERR_INVALID;
+        int total = 0;
+        for (int k = 0; k < 16; k++) total += seg[i + 1 + k];
+        if (total > 256 || i + 17 + total > slen) return JN_ERR_INVALID;
+        (tc ? ac[th] : dc[th]).build(seg + i + 1, seg + i + 17, total);
+        i += 17 + total;
+      }
+    } else if (m == 0xC0 || m == 0xC1) {                                         // SOF0 / SOF1 (Huffman, sequential)
+      if (slen < 6 || seg[0] != 8) return JN_ERR_UNSUPPORTED;
+      out.height = (seg[1] << 8) | seg[2]; out.width = (seg[3] << 8) | seg[4];
+      ncomp = seg[5];
+      if ((ncomp != 1 && ncomp != 3) || slen < (size_t)(6 + 3 * ncomp) || out.width < 1 || out.height < 1) return JN_ERR_UNSUPPORTED;
+      for (int c = 0; c < ncomp; c++) { comp[c].id = seg[6 + 3 * c]; comp[c].h = seg[7 + 3 * c] >> 4; comp[c].v = seg[7 + 3 * c] & 15; comp[c].tq = seg[8 + 3 * c]; }
+      have_frame = true;
+    } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8)) {
+      return JN_ERR_UNSUPPORTED;                                                 // progressive, lossless, arithmetic, hierarchical
+    } else if (m == 0xDD) {                                                      // DRI
+      if (slen < 2) return JN_ERR_INVALID;
+      restart_interval = (seg[0] << 8) | seg[1];
+    } else if (m == 0xDA) {                                                      // SOS: the one scan of a baseline file
+      if (!have_frame || slen < 1 || seg[0] != ncomp || slen < (size_t)(1 + 2 * ncomp + 3)) return JN_ERR_UNSUPPORTED;
+      for (int c = 0; c < ncomp; c++) {
+        if (seg[1 + 2 * c] != comp[c].id) return JN_ERR_UNSUPPORTED;
+        comp[c].td = seg[2 + 2 * c] >> 4; comp[c].ta = seg[2 + 2 * c] & 15;
+        if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].present || !ac[comp[c].ta].present) return JN_ERR_INVALID;
+      }
+      if (comp[0].tq > 3 || !qt_ok[comp[0].tq]) return JN_ERR_INVALID;
+      const int hmax = ncomp == 1 ? 1 : comp[0].h, vmax = ncomp == 1 ? 1 : comp[0].v;
+      if (hmax < 1 || hmax > 2 || vmax < 1 || vmax > 2) return JN_ERR_UNSUPPORTED;
+      if (ncomp == 3 && (comp[1].h > hmax || comp[1].v > vmax || comp[2].h > hmax || comp[2].v > vmax || comp[1].h < 1 || comp[2].h < 1 || comp[1].v < 1 || comp[2].v < 1))
+        return JN_ERR_UNSUPPORTED;                                               // luminance must carry the largest factors
+      const int hy = ncomp == 1 ? 1 : comp[0].h, vy = ncomp == 1 ? 1 : comp[0].v;
+      const int mcux = (out.width + 8 * hmax - 1) / (8 * hmax), mcuy = (out.height + 8 * vmax - 1) / (8 * vmax);
+      out.bw = mcux * hy; out.bh = mcuy * vy;
+      memcpy(out.quant, qt[comp[0].tq], sizeof(out.quant));
+      coef.assign((size_t)out.bw * out.bh * 64, 0);
+      BitReader br; br.p = data + pos + len; br.end = data + n;
+      int pred[3] = {0, 0, 0};
+      int until_restart = restart_interval, next_rst = 0;
+      for (int my = 0; my < mcuy; my++)
+        for (int mx = 0; mx < mcux; mx++) {
+          if (restart_interval && until_restart == 0) {                          // T.81 F.2.2.4: byte-align, RSTm, reset predictors
+            const uint8_t* q = br.p;
+            while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) q++;
+            if (q + 1 >= br.end || q[1] != 0xD0 + next_rst) return JN_ERR_INVALID;
+            br.p = q + 2; br.restart();
+            next_rst = (next_rst + 1) & 7; until_restart = restart_interval;
+            pred[0] = pred[1] = pred[2] = 0;
+          }
+          for (int c = 0; c < ncomp; c++) {
+            const int ch = ncomp == 1 ? 1 : comp[c].h, cv = ncomp == 1 ? 1 : comp[c].v;
+            const Huff& hd = dc[comp[c].td]; const Huff& ha = ac[comp[c].ta];
+            for (int by = 0; by < cv; by++)
+              for (int bx = 0; bx < ch; bx++) {
+                int16_t* blk = c == 0 ? &coef[((size_t)(my * vy + by) * out.bw + (mx * hy + bx)) * 64] : nullptr;
+                int s = decode_symbol(br, hd);
+                if (s < 0 || s > 11) return JN_ERR_INVALID;
+                if (s) pred[c] += extend(br.get(s), s);
+                if (blk) blk[0] = (int16_t)pred[c];
+                for (int k = 1; k < 64;) {
+                  const int rs = decode_symbol(br, ha);
+                  if (rs < 0) return JN_ERR_INVALID;
+                  const int r = rs >> 4; s = rs & 15;
+                  if (s) {
+                    k += r;
+                    if (k > 63) return JN_ERR_INVALID;
+                    const int v = extend(br.get(s), s);
+                    if (blk) blk[kZigzag[k]] = (int16_t)v;
+                    k++;
+                  } else if (r == 15) k += 16;                                   // ZRL
+                  else break;                                                    // EOB
+                }
+              }
+          }
+          if (restart_interval) until_restart--;
+        }
+      return JN_OK;
+    }
+    pos += len;
+  }
+  return JN_ERR_INVALID;                                                         // no scan found
+}
+
+// ---- dequantisation + 8x8 inverse DCT ("slow integer" form) + range limit: 8 lanes per block ----
+#define JDESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+__device__ __forceinline__ void idct_1d(const int in[8], int out[8], int shift) {
+  // even part
+  int z2 = in[2], z3 = in[6];
+  int z1 = (z2 + z3) * 4433;
+  int tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
+  int tmp0 = (in[0] + in[4]) * 8192, tmp1 = (in[0] - in[4]) * 8192;            // << CONST_BITS
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  // odd part
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
+  const int z5 = (z3 + z4) * 9633;
+  tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
+  z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  out[0] = JDESCALE(tmp10 + tmp3, shift); out[7] = JDESCALE(tmp10 - tmp3, shift);
+  out[1] = JDESCALE(tmp11 + tmp2, shift); out[6] = JDESCALE(tmp11 - tmp2, shift);
+  out[2] = JDESCALE(tmp12 + tmp1, shift); out[5] = JDESCALE(tmp12 - tmp1, shift);
+  out[3] = JDESCALE(tmp13 + tmp0, shift); out[4] = JDESCALE(tmp13 - tmp0, shift);
+}
+__device__ __forceinline__ uint8_t range_limit(int x) {      // IJG sample range table, indexed modulo 1024 around +128
+  const int i = x & 1023;
+  return (uint8_t)(i < 128 ? 128 + i : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+}
+struct QuantTable { uint16_t q[64]; };
+__global__ void __launch_bounds__(256) k_jpeg_idct_gray(const int16_t* __restrict__ coef, QuantTable qt, int bw, int bh, int W, int H,
+                                                        uint8_t* __restrict__ out, int pitch) {
+  __shared__ int ws[32][64 + 8];
+  const int lb = threadIdx.x >> 3, l = threadIdx.x & 7;
+  const int block = blockIdx.x * 32 + lb;
+  const bool in = block < bw * bh;
+  int col[8], tmp[8];
+  if (in) {
+    const int16_t* c = coef + (size_t)block * 64;
+#pragma unroll
+    for (int r = 0; r < 8; r++) col[r] = (int)c[8 * r + l] * (int)qt.q[8 * r + l];     // column l, dequantised
+    idct_1d(col, tmp, 13 - 2);                                                          // pass 1: CONST_BITS - PASS1_BITS
+#pragma unroll
+    for (int r = 0; r < 8; r++) ws[lb][8 * r + l] = tmp[r];
+  }
+  __syncthreads();
+  if (!in) return;
+#pragma unroll
+  for (int k = 0; k < 8; k++) col[k] = ws[lb][8 * l + k];                               // row l of the workspace
+  idct_1d(col, tmp, 13 + 2 + 3);                                                        // pass 2: CONST_BITS + PASS1_BITS + 3
+  const int bx = block % bw, by = block / bw;
+  const int y = by * 8 + l;
+  if (y >= H) return;
+#pragma unroll
+  for (int k = 0; k < 8; k++) { const int x = bx * 8 + k; if (x < W) out[(size_t)y * pitch + x] = range_limit(tmp[k]); }
+}
+
+}  // namespace
+
+#define JPG_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e__ = (expr);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      fprintf(stderr, "libjn_stereo: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return JN_ERR_NO_DEVICE;                                                              \
+    }                                                                                       \
+  } while (0)
+
+extern "C" {
+
+jn_status jn_jpeg_info(const uint8_t* jpeg, int64_t nbytes, int32_t* width, int32_t* height) {
+  if (!jpeg || nbytes < 4 || !width || !height) return JN_ERR_INVALID;
+  if (jpeg[0] != 0xFF || jpeg[1] != 0xD8) return JN_ERR_INVALID;
+  size_t pos = 2; const size_t n = (size_t)nbytes;
+  while (pos + 4 <= n) {
+    if (jpeg[pos] != 0xFF) { pos++; continue; }
+    const int m = jpeg[pos + 1];
+    if (m == 0xFF) { pos++; continue; }
+    pos += 2;
+    if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    const size_t len = ((size_t)jpeg[pos] << 8) | jpeg[pos + 1];
+    if (len < 2 || pos + len > n) return JN_ERR_INVALID;
+    if (m >= 0xC0 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      if (len < 7) return JN_ERR_INVALID;
+      *height = (jpeg[pos + 3] << 8) | jpeg[pos + 4]; *width = (jpeg[pos + 5] << 8) | jpeg[pos + 6];
+      return (m == 0xC0 || m == 0xC1) && jpeg[pos + 2] == 8 ? JN_OK : JN_ERR_UNSUPPORTED;
+    }
+    if (m == 0xDA) break;
+    pos += len;
+  }
+  return JN_ERR_INVALID;
+}
+
+int64_t jn_host_jpeg_coefficients(const uint8_t* jpeg, int64_t nbytes, int16_t* coef, int64_t coef_capacity, uint16_t quant[64],
+                                  int32_t* width, int32_t* height, int32_t* blocks_w, int32_t* blocks_h) {
+  if (!jpeg || nbytes < 4 || !quant || !width || !height || !blocks_w || !blocks_h) return -JN_ERR_INVALID;
+  Decoded d;
+  std::vector<int16_t> c;
+  const jn_status st = parse_and_decode(jpeg, (size_t)nbytes, d, c);
+  if (st != JN_OK) return -(int64_t)st;
+  *width = d.width; *height = d.height; *blocks_w = d.bw; *blocks_h = d.bh;
+  memcpy(quant, d.quant, sizeof(d.quant));
+  if (coef) {
+    if ((int64_t)c.size() > coef_capacity) return -JN_ERR_INVALID;
+    memcpy(coef, c.data(), c.size() * sizeof(int16_t));
+  }
+  return (int64_t)c.size();
+}
+
+jn_status jn_jpeg_decode_gray(int32_t device, const uint8_t* jpeg, int64_t nbytes, uint8_t* dOut, int32_t out_pitch, int32_t out_rows,
+                              int32_t* width, int32_t* height) {
+  if (!jpeg || nbytes < 4 || !dOut || !width || !height) return JN_ERR_INVALID;
+  Decoded d;
+  static thread_local std::vector<int16_t> coef;
+  const jn_status st = parse_and_decode(jpeg, (size_t)nbytes, d, coef);
+  if (st != JN_OK) return st;
+  *width = d.width; *height = d.height;
+  if (out_pitch < d.width || out_rows < d.height) return JN_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  JPG_TRY(hipSetDevice(device));
+  // grow-only device buffer per calling thread and device (no allocation per frame)
+  struct Scratch { int16_t* p = nullptr; size_t cap = 0; int dev = -1; };
+  static thread_local Scratch sc;
+  const size_t need = coef.size() * sizeof(int16_t);
+  if (sc.dev != device || sc.cap < need) {
+    if (sc.p) { hipSetDevice(sc.dev); hipFree(sc.p); hipSetDevice(device); sc.p = nullptr; sc.cap = 0; }
+    JPG_TRY(hipMalloc(reinterpret_cast<void**>(&sc.p), need));
+    sc.cap = need; sc.dev = device;
+  }
+  JPG_TRY(hipMemcpy(sc.p, coef.data(), need, hipMemcpyHostToDevice));
+  QuantTable qt;
+  memcpy(qt.q, d.quant, sizeof(qt.q));
+  const int blocks = d.bw * d.bh;
+  hipLaunchKernelGGL(k_jpeg_idct_gray, dim3((blocks + 31) / 32), dim3(256), 0, nullptr, sc.p, qt, d.bw, d.bh, d.width, d.height, dOut, out_pitch);
+  JPG_TRY(hipStreamSynchronize(nullptr));
+  JPG_TRY(hipGetLastError());
+  return JN_OK;
+}
+
+}  // extern "C"

@@ -103,6 +103,24 @@ def remap(n, dSrc, src_w, src_h, src_pitch, src_stride, dMapX, dMapY, dDst, widt
                                              dst_pitch, dst_stride), "jn_remap_bilinear")
 
 
+def jpeg_info(data):
+    """(width, height) of a JPEG frame; raises JnError(JN_ERR_UNSUPPORTED) for progressive / arithmetic / 12-bit files."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = C.c_int32(), C.c_int32()
+    _lib.check(_lib.load().jn_jpeg_info(buf.ctypes.data, buf.size, C.byref(w), C.byref(h)), "jn_jpeg_info")
+    return w.value, h.value
+
+
+def imdecode_gray(data, device=0):
+    """cv::imdecode(data, CV_LOAD_IMAGE_GRAYSCALE) — point_cloud.cpp:436, :478; returns the grey frame as a DeviceArray."""
+    buf = np.frombuffer(bytes(data), np.uint8)
+    w, h = jpeg_info(buf)
+    out = DeviceArray((h, w), np.uint8, device)
+    ww, hh = C.c_int32(), C.c_int32()
+    _lib.check(_lib.load().jn_jpeg_decode_gray(device, buf.ctypes.data, buf.size, out.ptr, w, h, C.byref(ww), C.byref(hh)), "jn_jpeg_decode_gray")
+    return out
+
+
 def synth_pair(width, height, scene_disp, seed=12345):
     L = np.zeros((height, width), np.uint8)
     R = np.zeros((height, width), np.uint8)

@@ -320,3 +320,36 @@ def test_corner_points_and_wide_gaps_with_the_robotics_preset(jn, oracle, same, 
     for b in range(n):
         _, D1o, D2o = oracle.process(oracle.params(0, **kw), Ls[b], Rs[b])
         assert same(d1.numpy()[b], D1o) and same(d2.numpy()[b], D2o), (kw, b)
+
+
+def test_imdecode_gray_on_the_gpu_equals_libjpeg(jn):
+    """cv::imdecode(GRAYSCALE) (point_cloud.cpp:436, :478): entropy decode on the host, dequantisation + IDCT on the GPU,
+    against the Pillow / libjpeg-turbo fixtures, and against Pillow itself on fresh random frames when it is importable."""
+    import hashlib
+    import io
+    import os
+    from jackal_navigation_amd import node, _lib
+    z = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+    names = sorted({k.split("__")[0] for k in z.files} - {"progressive"})
+    assert len(names) >= 10
+    for name in names:
+        img = node.imdecode_gray(z[name + "__jpeg"]).numpy()
+        assert img.shape == tuple(z[name + "__shape"]), name
+        assert hashlib.sha256(img.tobytes()).digest() == z[name + "__sha256"].tobytes(), name
+        if name + "__gray" in z.files:
+            assert np.array_equal(img, z[name + "__gray"])
+    with pytest.raises(_lib.JnError) as e:
+        node.imdecode_gray(z["progressive__jpeg"])
+    assert e.value.status == _lib.JN_ERR_UNSUPPORTED
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.default_rng(4)
+    for k in range(12):
+        W, H = int(rng.integers(9, 700)), int(rng.integers(9, 400))
+        rgb = (rng.integers(0, 256, (H // 8 + 1, W // 8 + 1, 3)).repeat(8, 0).repeat(8, 1)[:H, :W] + rng.integers(-12, 12, (H, W, 3))).clip(0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, "JPEG", quality=int(rng.integers(20, 98)), subsampling=int(rng.integers(0, 3)), optimize=bool(k & 1))
+        im = Image.open(io.BytesIO(buf.getvalue())); im.draft("L", im.size); im.load()
+        assert np.array_equal(node.imdecode_gray(buf.getvalue()).numpy(), np.asarray(im)), (k, W, H)
