@@ -190,17 +190,33 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipEventRecord(s.ev[EV_RASTER], st));
     launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
     HIP_TRY(hipEventRecord(s.ev[EV_DENSE], st));
-    launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
+    // Post-processing.  When gap interpolation and adaptive mean can run as one pass (gap_mean_fusable), the left image
+    // travels raw -> tmp (L/R check) -> tmp (speckle, run lists in the still idle output image) -> D1 (fused pass), so that
+    // every stage reads and writes the image once; otherwise the stages run in place on D1 with tmp as scratch.
+    const bool fused = gap_mean_fusable(dp) && ((dp.W * dp.H) & 3) == 0;
+    launch_lr(st, dp, n, s.info, s.raw, fused ? s.tmp : j.dD1, j.dD2);
     HIP_TRY(hipEventRecord(s.ev[EV_LR], st));
-    launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
-    if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
-    HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
-    launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
-    if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);
-    HIP_TRY(hipEventRecord(s.ev[EV_GAP], st));
-    if (h->p.filter_adaptive_mean) {
-      launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
-      if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
+    if (fused) {
+      launch_speckle(st, dp, n, s.info, s.tmp, s.label, s.size, j.dD1);
+      HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
+      launch_gap_mean_fused(st, dp, n, s.info, s.tmp, j.dD1, h->p.filter_adaptive_mean != 0);
+      if (!h->p.postprocess_only_left) {                     // right image: in place, fused pass into tmp, copied back
+        launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
+        launch_gap_mean_fused(st, dp, n, s.info, j.dD2, s.tmp, h->p.filter_adaptive_mean != 0);
+        launch_copy_ok(st, dp, n, s.info, s.tmp, j.dD2);
+      }
+      HIP_TRY(hipEventRecord(s.ev[EV_GAP], st));
+    } else {
+      launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
+      if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
+      HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
+      launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
+      if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);
+      HIP_TRY(hipEventRecord(s.ev[EV_GAP], st));
+      if (h->p.filter_adaptive_mean) {
+        launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
+        if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
+      }
     }
     if (h->p.filter_median) {                                                            // elas.cpp:133-139
       launch_median(st, dp, n, s.info, j.dD1, s.tmp);

@@ -1613,7 +1613,15 @@ DEV void uf_union(int32_t* __restrict__ lab, int a, int b) {
 // as label (no atomics: a max-scan of "run starts here" positions along the image row), and the row's runs are
 // listed compactly — run k of the row spans columns [starts[k], ends[k]] — so that the later passes that work per
 // run (sizes, removal) touch ~4 % as many items as there are pixels and never read the image.
-struct RunLists { uint16_t* starts; uint16_t* ends; int32_t* count; int pitch; };   // [n*H][pitch], [n*H]
+// The lists of frame f live inside frame f's own image-sized block of the scratch buffer ([H][pitch] starts, [H][pitch]
+// ends, [H] counts < H*W*4 bytes), so that the scratch may be a caller's output image that is idle at this point: frames
+// that fail (and whose outputs must stay untouched) see no write.
+struct RunLists {
+  uint8_t* base; size_t frame_bytes; int pitch, H;
+  __device__ uint16_t* starts(int frame) const { return reinterpret_cast<uint16_t*>(base + (size_t)frame * frame_bytes); }
+  __device__ uint16_t* ends(int frame) const { return starts(frame) + (size_t)H * pitch; }
+  __device__ int32_t* count(int frame) const { return reinterpret_cast<int32_t*>(ends(frame) + (size_t)H * pitch); }
+};
 // One wave per image row, walking it in 64-pixel chunks: the carries (latest run start, runs so far) are wave-uniform,
 // so there is no LDS and no barrier, and the next chunk's pixels are loaded before the current one is processed.
 __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
@@ -1622,7 +1630,8 @@ __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo*
   if (v >= dp.H || !info[frame].ok) return;
   const int W = dp.W, lane = threadIdx.x & 63;
   const size_t base = (size_t)frame * dp.H * W + (size_t)v * W;
-  const size_t rbase = ((size_t)frame * dp.H + v) * runs.pitch;
+  const size_t rbase = (size_t)v * runs.pitch;
+  uint16_t* r_starts = runs.starts(frame); uint16_t* r_ends = runs.ends(frame);
   const float* row = D + base;
   const float sim = dp.speckle_sim;
   int carry = -1;                                           // last run start seen in earlier chunks
@@ -1647,14 +1656,14 @@ __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo*
     const unsigned long long starts = __ballot(start);
     const int k = carry_cnt + __popcll(starts & (~0ull >> (63 - lane))) - 1;   // ordinal of the run this pixel belongs to
     if (u < W) lab[base + u] = valid ? v * W + s : -1;
-    if (start) { sz[base + u] = 0; runs.starts[rbase + k] = (uint16_t)u; }    // sizes live at roots, and roots are run starts
-    if (last) runs.ends[rbase + k] = (uint16_t)u;
+    if (start) { sz[base + u] = 0; r_starts[rbase + k] = (uint16_t)u; }    // sizes live at roots, and roots are run starts
+    if (last) r_ends[rbase + k] = (uint16_t)u;
     carry = __shfl(s, 63);
     carry_cnt += __popcll(starts);
     left = __shfl(d, 63);
     d = nxt;
   }
-  if (lane == 0) runs.count[(size_t)frame * dp.H + v] = carry_cnt;
+  if (lane == 0) runs.count(frame)[v] = carry_cnt;
 }
 // Column pass: unite vertically adjacent runs.  A pixel issues the union only if it is the first
 // column of the contact between its run and the run below (the pixel to its left belongs to the
@@ -1694,11 +1703,12 @@ __global__ void __launch_bounds__(256) k_ccl_count(DevParams dp, const FrameInfo
   const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
   if (v >= dp.H || !info[frame].ok) return;
   const int W = dp.W;
-  const size_t plane = (size_t)dp.H * W, rrow = (size_t)frame * dp.H + v;
+  const size_t plane = (size_t)dp.H * W;
   int32_t* L = lab + frame * plane;
-  const int cnt = runs.count[rrow];
+  const int cnt = runs.count(frame)[v];
+  const uint16_t* r_starts = runs.starts(frame) + (size_t)v * runs.pitch; const uint16_t* r_ends = runs.ends(frame) + (size_t)v * runs.pitch;
   for (int k = threadIdx.x & 63; k < cnt; k += 64) {
-    const int start = v * W + runs.starts[rrow * runs.pitch + k], len = runs.ends[rrow * runs.pitch + k] - runs.starts[rrow * runs.pitch + k] + 1;
+    const int start = v * W + r_starts[k], len = r_ends[k] - r_starts[k] + 1;
     const int root = uf_find(L, start);
     if (root != start) L[start] = root;                     // compress: k_ccl_apply then needs at most two hops
     // Only "at least speckle_size or not" matters (elas.cpp:1083): once a component is seen to have reached the
@@ -1715,11 +1725,12 @@ __global__ void __launch_bounds__(256) k_ccl_apply(DevParams dp, const FrameInfo
   const int v = blockIdx.x * 4 + (threadIdx.x >> 6), frame = blockIdx.y;
   if (v >= dp.H || !info[frame].ok) return;
   const int W = dp.W;
-  const size_t plane = (size_t)dp.H * W, rrow = (size_t)frame * dp.H + v;
+  const size_t plane = (size_t)dp.H * W;
   const int32_t* L = lab + frame * plane;
-  const int cnt = runs.count[rrow];
+  const int cnt = runs.count(frame)[v];
+  const uint16_t* r_starts = runs.starts(frame) + (size_t)v * runs.pitch; const uint16_t* r_ends = runs.ends(frame) + (size_t)v * runs.pitch;
   for (int k = threadIdx.x & 63; k < cnt; k += 64) {
-    const int us = runs.starts[rrow * runs.pitch + k], ue = runs.ends[rrow * runs.pitch + k];
+    const int us = r_starts[k], ue = r_ends[k];
     int x = v * W + us, q = L[x];
     while (q != x) { x = q; q = L[x]; }
     if (sz[frame * plane + x] < dp.speckle_size) {
@@ -1881,6 +1892,19 @@ DEV float am_weight(float x, float c) {
   const float m = __uint_as_float(__float_as_uint(__fsub_rn(x, c)) & 0x4F000000u);
   return fmaxf(0.0f, __fsub_rn(4.0f, m));
 }
+// Two taps at once with packed f32 (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations, two per instruction; the
+// means are bound by vector issue): pw = w(x0) + w(x1), pf = x0 w(x0) + x1 w(x1).
+typedef float jn_f2 __attribute__((ext_vector_type(2)));
+DEV void am_pair(float x0, float x1, float c, float& pw, float& pf) {
+  const jn_f2 X = {x0, x1}, C = {c, c}, four = {4.0f, 4.0f};
+  const jn_f2 d = X - C;
+  jn_f2 m;
+  m.x = __uint_as_float(__float_as_uint(d.x) & 0x4F000000u); m.y = __uint_as_float(__float_as_uint(d.y) & 0x4F000000u);
+  jn_f2 w = four - m;
+  w.x = fmaxf(0.0f, w.x); w.y = fmaxf(0.0f, w.y);
+  const jn_f2 p = X * w;
+  pw = w.x + w.y; pf = p.x + p.y;
+}
 // Horizontal pass: in = D, out = tmp; rows 3..H-4, centres 4..W-4.
 __global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const FrameInfo* __restrict__ info,
                                                          const float* __restrict__ in, float* __restrict__ out) {
@@ -1947,10 +1971,7 @@ __global__ void __launch_bounds__(64) k_adaptive_mean_h4(DevParams dp, const Fra
       float pw[4], pf[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float x0 = x[i + k], x1 = x[i + k + 4];
-        const float w0 = am_weight(x0, c), w1 = am_weight(x1, c);
-        pw[k] = __fadd_rn(w0, w1);
-        pf[k] = __fadd_rn(__fmul_rn(x0, w0), __fmul_rn(x1, w1));
+        am_pair(x[i + k], x[i + k + 4], c, pw[k], pf[k]);
       }
       // ring lane l = P[(l - u) & 3] with u & 3 == i
       const float ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[(0 - i) & 3], pw[(1 - i) & 3]), pw[(2 - i) & 3]), pw[(3 - i) & 3]);
@@ -1985,9 +2006,7 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_v(DevParams dp, const Fra
       float pw[4], pf[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const float w0 = am_weight(x[k], c), w1 = am_weight(x[k + 4], c);
-        pw[k] = __fadd_rn(w0, w1);
-        pf[k] = __fadd_rn(__fmul_rn(x[k], w0), __fmul_rn(x[k + 4], w1));
+        am_pair(x[k], x[k + 4], c, pw[k], pf[k]);
       }
       // lane l of the reference's ring holds P[(l - v) & 3]; v is the same for the whole wave, so the four possible
       // orders are four straight-line cases instead of a lane-wise rotation
@@ -2002,6 +2021,126 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_v(DevParams dp, const Fra
     }
 #pragma unroll
     for (int k = 0; k < 7; k++) x[k] = x[k + 1];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gap interpolation (rows, then columns) and adaptive mean (horizontal, then vertical) in ONE pass over the image
+// (elas.cpp:1101-1284 without the add_corners branches, :1287-1492): the four separate kernels above read and write the
+// whole float image four times (0.94 GB per 32-pair batch at ~4 TB/s = 0.24 ms); here a workgroup of 256 threads owns
+// 256 columns and walks down the rows, so every pixel is read once and written once.
+//   row y arrives -> G1(y)   = row gap fill: neighbours of the same row through an LDS copy of the row
+//                 -> G2(y-3) = column gap fill: the thread's own ring of the last 8 G1 values
+//                 -> T(y-4)  = horizontal mean of G2(y-4): neighbours through a second LDS row
+//                 -> out(y-7) = vertical mean over the thread's ring of the last 8 T values (or G2 where no mean forms)
+// One barrier per row (the two LDS rows are double-buffered by row parity).  The rings are indexed by row mod 8 with the
+// row loop unrolled by 8, so every ring access is a fixed register — and the reference's summation order, "lane l = ring
+// slot l + slot l+4", is simply "the two window rows (columns) congruent to l mod 4": no rotation is needed at all; in
+// the horizontal pass the thread reads its taps from LDS in that order (per-lane offsets fixed by u mod 4).
+// Halo: 8 columns left / 7 right of the 240 output columns are recomputed by the neighbouring workgroup; 14 rows above /
+// below a row band likewise.  Applies for gap widths <= 3 without add_corners; other settings keep the separate kernels.
+enum { kPostCols = 240, kPostHaloL = 8 };
+DEV float gap_value(float d1, float d2) { return fabsf(d1 - d2) < 3.0f ? __fadd_rn(d1, d2) / 2 : fminf(d1, d2); }   // :1149-1150
+// mean of the eight taps if it forms (sum of weights > 0, quotient >= 0), else `keep`; branch-free apart from the
+// wave-uniform shortcut: in smooth regions all eight taps carry the full weight 4 in every lane of the wave, the divisor
+// is exactly 32 and the IEEE quotient is the exact product with 1/32 (no 10-instruction division sequence)
+DEV float am_select(const float (&pw)[4], const float (&pf)[4], bool enabled, float keep) {
+  const float ws = __fadd_rn(__fadd_rn(__fadd_rn(pw[0], pw[1]), pw[2]), pw[3]);
+  const float fs = __fadd_rn(__fadd_rn(__fadd_rn(pf[0], pf[1]), pf[2]), pf[3]);
+  float d;
+  if (__ballot(ws != 32.0f) == 0ull) d = fs * 0.03125f;
+  else d = fs / (ws > 0 ? ws : 1.0f);
+  return (enabled && ws > 0 && d >= 0) ? d : keep;
+}
+__global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
+                                                        float* __restrict__ out, int rows_per_band, int do_mean) {
+  __shared__ float s_row[2][256], s_g2[2][256];
+  const int frame = blockIdx.z;
+  if (!info[frame].ok) return;
+  const int W = dp.W, H = dp.H, gw = dp.gap_width, t = threadIdx.x;
+  const int u = blockIdx.x * kPostCols - kPostHaloL + t;
+  const int r0 = blockIdx.y * rows_per_band, r1 = min(r0 + rows_per_band, H);
+  const bool col_in = u >= 0 && u < W;
+  const size_t plane = (size_t)H * W;
+  const float* I = in + frame * plane;
+  float* O = out + frame * plane;
+  const bool store_col = t >= kPostHaloL && t < kPostHaloL + kPostCols && col_in;
+  const bool mean_h_col = u >= 4 && u <= W - 4, mean_v_col = u >= 3 && u < W - 3;
+  // horizontal taps in ring order: lane l of the sum takes the window columns congruent to l mod 4
+  int tap[4];
+#pragma unroll
+  for (int l = 0; l < 4; l++) tap[l] = min(max(t - 4 + ((l - u) & 3), 0), 251);
+  float g1[8], g2[8], tw[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { g1[k] = -10.0f; g2[k] = -10.0f; tw[k] = -10.0f; }
+  const int y_begin = (r0 - 7) & ~7, y_end = r1 + 7;          // first row multiple of 8 (also for negative rows), last row needed + 1
+  float x_next = (col_in && y_begin >= 0 && y_begin < H) ? I[(size_t)y_begin * W + u] : -10.0f;
+  for (int yb = y_begin; yb < y_end; yb += 8) {
+#pragma unroll
+    for (int ph = 0; ph < 8; ph++) {
+      const int y = yb + ph;                                   // y & 7 == ph
+      const float x = x_next;
+      { const int yn = y + 1; x_next = (col_in && yn >= 0 && yn < H) ? I[(size_t)yn * W + u] : -10.0f; }
+      float* sr = s_row[ph & 1]; float* sg = s_g2[ph & 1];
+      sr[t] = x;
+      sg[t] = g2[(ph + 4) & 7];                                // G2 of row y - 4 (computed in the previous step)
+      __syncthreads();
+      // ---- G1(y): gap fill along the row (elas.cpp:1122-1166) ----
+      float v1 = x;
+      if (!(x >= 0)) {
+        int a = 0, b = 0;
+        for (int k = 1; k <= gw; k++) if (t - k >= 0 && sr[t - k] >= 0) { a = k; break; }
+        if (a) {
+          for (int k = 1; k <= gw - a + 1; k++) if (t + k < 256 && sr[t + k] >= 0) { b = k; break; }
+          if (b) v1 = gap_value(sr[t - a], sr[t + b]);
+        }
+      }
+      g1[ph] = v1;
+      // ---- G2(y - 3): gap fill along the column (:1204-1247) on the ring of G1 ----
+      {
+        const float c = g1[(ph + 5) & 7];
+        float v2 = c;
+        if (!(c >= 0)) {
+          const float up1 = g1[(ph + 4) & 7], up2 = g1[(ph + 3) & 7], up3 = g1[(ph + 2) & 7];
+          const float dn1 = g1[(ph + 6) & 7], dn2 = g1[(ph + 7) & 7], dn3 = g1[ph];
+          int a = 0; float d1 = 0;
+          if (gw >= 1 && up1 >= 0) { a = 1; d1 = up1; } else if (gw >= 2 && up2 >= 0) { a = 2; d1 = up2; } else if (gw >= 3 && up3 >= 0) { a = 3; d1 = up3; }
+          if (a) {
+            const int reach = gw - a + 1;
+            int b = 0; float d2 = 0;
+            if (dn1 >= 0) { b = 1; d2 = dn1; } else if (reach >= 2 && dn2 >= 0) { b = 2; d2 = dn2; } else if (reach >= 3 && dn3 >= 0) { b = 3; d2 = dn3; }
+            if (b) v2 = gap_value(d1, d2);
+          }
+        }
+        g2[(ph + 5) & 7] = v2;
+      }
+      // ---- T(y - 4): horizontal mean (:1394-1433) of the G2 row in LDS ----
+      {
+        const int yt = y - 4;
+        const float c = sg[t];
+        float res = c;
+        if (do_mean && yt >= 3 && yt < H - 3) {               // wave-uniform
+          float pw[4], pf[4];
+#pragma unroll
+          for (int l = 0; l < 4; l++) am_pair(sg[tap[l]], sg[tap[l] + 4], c, pw[l], pf[l]);
+          res = am_select(pw, pf, mean_h_col, c);
+        }
+        tw[(ph + 4) & 7] = res;
+      }
+      // ---- out(y - 7): vertical mean (:1436-1483) over the ring of T; where none forms the pixel keeps G2 ----
+      {
+        const int yo = y - 7;
+        float res = g2[(ph + 1) & 7];
+        if (do_mean && yo >= 4 && yo <= H - 4) {              // wave-uniform
+          const float c = tw[(ph + 1) & 7];
+          float pw[4], pf[4];
+#pragma unroll
+          for (int l = 0; l < 4; l++) am_pair(tw[l], tw[l + 4], c, pw[l], pf[l]);
+          res = am_select(pw, pf, mean_v_col, res);
+        }
+        if (store_col && yo >= r0 && yo < r1) O[(size_t)yo * W + u] = res;
+      }
+    }
   }
 }
 
@@ -2459,10 +2598,9 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
   // run lists live in the (currently idle) float scratch image: 2 x uint16 [n*H][W/2 + 2] + int32 [n*H] < n*H*W*4 bytes
   RunLists runs;
   runs.pitch = (dp.W / 2 + 2) & ~1;                          // a row of W pixels holds at most ceil(W/2) runs
-  const size_t rows = (size_t)n * dp.H;
-  runs.starts = reinterpret_cast<uint16_t*>(scratch);
-  runs.ends = runs.starts + rows * runs.pitch;
-  runs.count = reinterpret_cast<int32_t*>(runs.ends + rows * runs.pitch);
+  runs.H = dp.H;
+  runs.base = reinterpret_cast<uint8_t*>(scratch);
+  runs.frame_bytes = (size_t)dp.H * dp.W * sizeof(float);    // 2 x uint16 [H][W/2 + 2] + int32 [H] < H*W*4 bytes
   const dim3 gr((dp.H + 3) / 4, n);                          // one wave per image row
   hipLaunchKernelGGL(k_ccl_rows, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
   // enough waves to fill the GPU even for a lone small pair: split the rows of the merge pass into column segments
@@ -2494,6 +2632,29 @@ void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const Fram
   if ((dp.W & 3) == 0) hipLaunchKernelGGL(k_adaptive_mean_h4, dim3((dp.W / 4 + 63) / 64, dp.H, n), dim3(64), 0, st, dp, info, D, tmp);
   else hipLaunchKernelGGL(k_adaptive_mean_h, g, dim3(256), 0, st, dp, info, D, tmp);
   hipLaunchKernelGGL(k_adaptive_mean_v, dim3((dp.W + 255) / 256, (dp.H + kAmRows - 1) / kAmRows, n), dim3(256), 0, st, dp, info, tmp, D);
+}
+__global__ void __launch_bounds__(256) k_copy_ok(const FrameInfo* __restrict__ info, const float4* __restrict__ src, float4* __restrict__ dst, long long per_frame4) {
+  const int frame = blockIdx.y;
+  if (!info[frame].ok) return;                               // frames that failed keep the caller's values
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < per_frame4) dst[frame * per_frame4 + i] = src[frame * per_frame4 + i];
+}
+void launch_copy_ok(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* src, float* dst) {
+  const long long px = (long long)dp.W * dp.H;
+  if ((px & 3) == 0) {
+    hipLaunchKernelGGL(k_copy_ok, dim3((unsigned)((px / 4 + 255) / 256), n), dim3(256), 0, st, info, reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), px / 4);
+    return;
+  }
+  for (int f = 0; f < n; f++) hipMemcpyAsync(dst + f * px, src + f * px, px * sizeof(float), hipMemcpyDeviceToDevice, st);   // odd sizes: plain copies (all frames)
+}
+bool gap_mean_fusable(const DevParams& dp) {
+  static const int enabled = getenv("JN_POST_FUSED") ? atoi(getenv("JN_POST_FUSED")) : 1;
+  return enabled && !dp.add_corners && dp.gap_width <= 3 && dp.W >= 16 && dp.H >= 16;
+}
+void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* in, float* out, bool mean) {
+  static const int band_rows = getenv("JN_POST_BAND") ? atoi(getenv("JN_POST_BAND")) : 48;   // short bands: the pass is bound by parallelism, not by the 14 halo rows
+  const int bands = (dp.H + band_rows - 1) / band_rows, rows = (dp.H + bands - 1) / bands;
+  hipLaunchKernelGGL(k_gap_mean_fused, dim3((dp.W + kPostCols - 1) / kPostCols, bands, n), dim3(256), 0, st, dp, info, in, out, rows, mean ? 1 : 0);
 }
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);

@@ -1,0 +1,3 @@
+for b in 128 90 64 48; do
+JN_POST_BAND=$b bash scripts/prof.sh r2p_$b > gpurun_out/r2p_$b.txt 2>&1; echo band $b $(grep "k_gap_mean_fused\|total GPU" gpurun_out/r2p_$b.txt | tr '\n' ' ')
+done
