@@ -27,6 +27,14 @@ DEV unsigned sad16_acc(const uint4& a, const uint4& b, unsigned s) {   // the sa
   s = __builtin_amdgcn_sad_u8(a.z, b.z, s);
   return __builtin_amdgcn_sad_u8(a.w, b.w, s);
 }
+// v_sad_hi_u8 adds the 4-byte SAD shifted left by 16 to its accumulator: a chain of them on `d` builds the key (cost << 16) | d
+DEV unsigned sadhi16(const uint4& a, const uint4& b, unsigned acc) {      // acc + (SAD16(a, b) << 16)
+  acc = __builtin_amdgcn_sad_hi_u8(a.x, b.x, acc);
+  acc = __builtin_amdgcn_sad_hi_u8(a.y, b.y, acc);
+  acc = __builtin_amdgcn_sad_hi_u8(a.z, b.z, acc);
+  return __builtin_amdgcn_sad_hi_u8(a.w, b.w, acc);
+}
+DEV unsigned med3u(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }   // v_med3_u32
 DEV int texture16(const uint4& a) {   // sum |byte - 128| (elas.cpp:301-305, :715-719)
   const unsigned k = 0x80808080u;
   unsigned s = __builtin_amdgcn_sad_u8(a.x, k, 0u);
@@ -252,7 +260,7 @@ enum { kSupportLanes = 4 };
 // banks and costs 10-30 %.)  PMC: 21 M ds_read_b128 per launch at 8 lanes x 4 reads per disparity = 277 us of LDS
 // pipe time out of 317 us; with the tap-pair re-use below it is half that and the kernel runs in 262 us.
 // The running best / second best (reference: strict `<`, first d wins, elas.cpp:354-362) are kept as packed keys
-// energy << 8 | d: E1 = smallest key's energy with the smallest d attaining it, E2 = second smallest key's energy =
+// energy << 16 | d: E1 = smallest key's energy with the smallest d attaining it, E2 = second smallest key's energy =
 // second smallest energy of the multiset (two disparities sharing the minimum give E2 = E1, as in the reference).
 template <int LANES, int PITCH>
 DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Bt,
@@ -284,11 +292,10 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
 #define JN_STEP(LD, TR, NX)                                                                                   \
     {                                                                                                         \
       const bool more = d + 4 <= dmax;                                                                        \
-      const uint4* q = more ? nx : b;                         /* a harmless address when there is no next step */ \
-      NX##_t = q[0]; NX##_b = q[PITCH];                                                                       \
-      const unsigned s = sad16_acc(aT_t, TR##_t, sad16_acc(aL_t, LD##_t, 0u)) + sad16_acc(aT_b, TR##_b, sad16_acc(aL_b, LD##_b, 0u)); \
-      const unsigned key = (s << 8) | (unsigned)d;                                                            \
-      k2 = min(k2, max(k1, key));                                                                             \
+      NX##_t = nx[0]; NX##_b = nx[PITCH];   /* read ahead unconditionally: past the last step it stays inside the four staged rows */ \
+      /* one accumulator chain on d: 16 x v_sad_hi_u8 give (energy << 16) | d directly */                     \
+      const unsigned key = sadhi16(aT_b, TR##_b, sadhi16(aL_b, LD##_b, sadhi16(aT_t, TR##_t, sadhi16(aL_t, LD##_t, (unsigned)d)))); \
+      k2 = med3u(k1, k2, key);              /* k1 <= k2: the second smallest of the three */                  \
       k1 = min(k1, key);                                                                                      \
       if (!more) break;                                                                                       \
       d += 4; nx += 4 * dir;                                                                                  \
@@ -306,7 +313,7 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
     k2 = min(max(k1, o1), min(k2, o2));
     k1 = min(k1, o1);
   }
-  const int e1 = (int)(k1 >> 8), d1 = (int)(k1 & 255u), e2 = k2 == kNone ? 32767 : (int)(k2 >> 8);
+  const int e1 = (int)(k1 >> 16), d1 = (int)(k1 & 255u), e2 = k2 == kNone ? 32767 : (int)(k2 >> 16);
   return (ok && k1 != kNone && (float)e1 < dp.support_threshold * (float)e2) ? d1 : -1;   // :366
 }
 
@@ -1290,12 +1297,6 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
 //    offsets, all in flight together; when every lane of the wave has its whole neighbourhood inside the valid range
 //    and a valid prior (the common case) no per-candidate test is left.
 enum { kDense2Slack = 16, kCellBias = 8192, kCellPriorMax = 8000, kCellInvalid = 0x60000000 };
-DEV unsigned sadhi16(const uint4& a, const uint4& b, unsigned acc) {      // acc + (SAD16(a, b) << 16)
-  acc = __builtin_amdgcn_sad_hi_u8(a.x, b.x, acc);
-  acc = __builtin_amdgcn_sad_hi_u8(a.y, b.y, acc);
-  acc = __builtin_amdgcn_sad_hi_u8(a.z, b.z, acc);
-  return __builtin_amdgcn_sad_hi_u8(a.w, b.w, acc);
-}
 typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
 // w |= bit if bit `pos` of m is set: the sign-extended single bit as an and-mask.  Two plain VALU instructions; written as
 // asm because the compiler rewrites every C form of it into and / compare / select / or (4 instructions).
