@@ -317,37 +317,45 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
   return (ok && k1 != kNone && (float)e1 < dp.support_threshold * (float)e2) ? d1 : -1;   // :366
 }
 
+// A lattice row may be cut into `nseg` column segments, one workgroup each (images wider than the 1280-column bucket:
+// a whole 1920-column row needs all 160 KB of LDS = one workgroup of 16 waves per CU; two half rows need 80 KB each and run
+// two per CU).  A segment with candidates u in [u_lo, u_hi] stages the left rows over [u_lo - dmax - 2, u_hi + dmax + 2]
+// (the backward match of the right-image candidate u - d walks up to dmax to the right again) and the right rows over
+// [u_lo - dmax - 2, u_hi + 2]; the row pointers are shifted by the window start so that quad_match keeps indexing by column.
+// Read-aheads past a window's end stay inside the four staged rows (the right rows follow the left ones).
 template <int LANES, int PITCH>
-__global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can) {
+__global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can, int nseg) {
   extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], PITCH each
-  const int vc = blockIdx.x, frame = blockIdx.y, W = dp.W;
+  const int vc = blockIdx.x, frame = blockIdx.y, seg = blockIdx.z, W = dp.W;
   const int v = vc * dp.step;
   int16_t* out_row = d_can + ((size_t)frame * dp.ch + vc) * dp.cw;
+  const int per_seg = (dp.cw + nseg - 1) / nseg, uc_lo = seg * per_seg, uc_hi = min(uc_lo + per_seg, dp.cw);   // candidates [uc_lo, uc_hi)
   const bool row_ok = vc >= 1 && v >= 5 && v <= dp.H - 6;
   if (!row_ok) {                                        // row 0 keeps calloc's zeros, other out-of-range rows are -1
-    for (int uc = threadIdx.x; uc < dp.cw; uc += 1024) out_row[uc] = (vc == 0 || uc == 0) ? 0 : -1;
+    for (int uc = uc_lo + threadIdx.x; uc < uc_hi; uc += 1024) out_row[uc] = (vc == 0 || uc == 0) ? 0 : -1;
     return;
   }
   const uint4* L = desc + (size_t)frame * dp.H * W;
   const uint4* R = desc + (size_t)(n + frame) * dp.H * W;
-  uint4* Lt = rows; uint4* Rt = rows + 2 * PITCH;
-  for (int i = threadIdx.x; i < W; i += 1024) {
-    Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i];
-    Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i];
-  }
+  const int u_lo = uc_lo * dp.step, u_hi = (uc_hi - 1) * dp.step;
+  const int c0 = nseg == 1 ? 0 : max(u_lo - dp.disp_max - 2, 0);                        // window start, both images
+  const int c1L = nseg == 1 ? W : min(u_hi + dp.disp_max + 3, W), c1R = nseg == 1 ? W : min(u_hi + 3, W);
+  uint4* Lt = rows - c0; uint4* Rt = rows + 2 * PITCH - c0;                             // indexed by image column
+  for (int i = c0 + threadIdx.x; i < c1L; i += 1024) { Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i]; }
+  for (int i = c0 + threadIdx.x; i < c1R; i += 1024) { Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i]; }
   __syncthreads();
   const uint4* Lv = L + (size_t)v * W;                  // row v itself is only read for the texture test
   const uint4* Rv = R + (size_t)v * W;
   const int j = threadIdx.x & (LANES - 1);
-  for (int uc0 = 0; uc0 < dp.cw; uc0 += 1024 / LANES) {
+  for (int uc0 = uc_lo; uc0 < uc_hi; uc0 += 1024 / LANES) {
     const int uc = uc0 + (threadIdx.x / LANES);
-    const bool active = uc >= 1 && uc < dp.cw;
+    const bool active = uc >= 1 && uc < uc_hi;
     const int u = uc * dp.step;
     int res = -1;
     const int d = quad_match<LANES, PITCH>(dp, Lt, Rt, Lv, u, false, active, j);
     const int d2 = quad_match<LANES, PITCH>(dp, Rt, Lt, Rv, u - d, true, active && d >= 0, j);
     if (d >= 0 && d2 >= 0 && abs(d - d2) <= dp.lr_threshold) res = d;         // :404-411
-    if (j == 0 && uc < dp.cw) out_row[uc] = (int16_t)(uc == 0 ? 0 : res);
+    if (j == 0 && uc < uc_hi) out_row[uc] = (int16_t)(uc == 0 ? 0 : res);
   }
 }
 
@@ -2476,17 +2484,22 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, c
   hipLaunchKernelGGL(k_descriptor_fused, grid, dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, desc);
 }
 template <int PITCH>
-static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n), dim3(1024), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can);
+static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can, int nseg) {
+  hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n, nseg), dim3(1024), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can, nseg);
 }
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  // the LDS row pitch is a template constant (immediate tap offsets): smallest bucket that holds the image width;
+  // the LDS row pitch is a template constant (immediate tap offsets): smallest bucket that holds the staged window;
   // 1280 columns = 80 KB, two workgroups per CU; 2560 = the whole 160 KB
-  if (dp.W <= 320) launch_support_pitch<320>(st, dp, n, desc, d_can);
-  else if (dp.W <= 640) launch_support_pitch<640>(st, dp, n, desc, d_can);
-  else if (dp.W <= 1280) launch_support_pitch<1280>(st, dp, n, desc, d_can);
-  else if (dp.W <= 2560) launch_support_pitch<2560>(st, dp, n, desc, d_can);
-  else hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
+  if (dp.W <= 320) { launch_support_pitch<320>(st, dp, n, desc, d_can, 1); return; }
+  if (dp.W <= 640) { launch_support_pitch<640>(st, dp, n, desc, d_can, 1); return; }
+  if (dp.W <= 1280) { launch_support_pitch<1280>(st, dp, n, desc, d_can, 1); return; }
+  static const int max_seg = getenv("JN_SUPPORT_SEGMENTS") ? atoi(getenv("JN_SUPPORT_SEGMENTS")) : 8;
+  for (int nseg = 2; nseg <= max_seg; nseg++) {           // wider: cut the lattice rows so that a segment's window fits the 1280 bucket
+    const int per_seg = (dp.cw + nseg - 1) / nseg;
+    if (per_seg * dp.step + 2 * dp.disp_max + 8 <= 1280) { launch_support_pitch<1280>(st, dp, n, desc, d_can, nseg); return; }
+  }
+  if (dp.W <= 2560) { launch_support_pitch<2560>(st, dp, n, desc, d_can, 1); return; }
+  hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
 // classify + resolve applies when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
 // skewed-wavefront kernel (A/B and test hook), which also serves lattices that need streaming
