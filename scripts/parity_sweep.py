@@ -27,8 +27,19 @@ def oracle_job(args):
     from oracle.binding import Oracle
     o = Oracle()
     L, R = make_pair(W, H, sd, dmax, seed)
-    st, D1, D2 = o.process(o.params(0, disp_max=dmax, **kw), L, R)
+    kw = dict(kw)
+    setting = kw.pop("setting", 0)
+    kw.pop("host_threads", None)
+    st, D1, D2 = o.process(o.params(setting, disp_max=dmax, **kw), L, R)
     return st, D1, D2
+
+
+def sgm_job(args):
+    W, H, sd, D, seed, kw = args
+    from oracle.binding import SgmOracle
+    o = SgmOracle()
+    L, R = make_pair(W, H, sd, D - 1, seed)
+    return o.process(o.params(D, **kw), L, R)
 
 
 def main():
@@ -41,11 +52,26 @@ def main():
     for kind in ("strips", "patches", "slanted", "photometric", "blobs", "shallow"):
         configs += [(320, 240, kind, 79, {"postprocess_only_left": 0}), (640, 480, kind, 127, {"postprocess_only_left": 0}),
                     (1280, 720, kind, 127, {}), (448, 333, kind, 255, {"postprocess_only_left": 0, "ipol_gap_width": 7})]
-    with ProcessPoolExecutor(max_workers=min(32, os.cpu_count() or 8)) as pool:
+    # round 2: both presets, corner points, wide gaps, other grid sizes (k_dense2 / the k_dense fallback), plane radius 3,
+    # widths that cut the support kernel's lattice rows into segments, lone pairs on a large pool (Delaunay cut in parts)
+    configs += [
+        (640, 480, 64, 63, {"setting": 1}), (1280, 720, 128, 127, {"setting": 1}), (448, 333, "strips", 127, {"setting": 1}),
+        (640, 360, "blobs", 95, {"add_corners": 1, "ipol_gap_width": 12}), (800, 600, 90, 127, {"ipol_gap_width": 200, "postprocess_only_left": 0}),
+        (640, 480, 64, 63, {"grid_size": 16}), (640, 480, "slanted", 95, {"grid_size": 24, "sradius": 3.0}), (512, 384, 50, 79, {"grid_size": 6}),
+        (1280, 720, 128, 255, {}), (1600, 900, 150, 191, {}), (2048, 512, 100, 127, {"postprocess_only_left": 0}),
+        (1280, 720, 128, 127, {"host_threads": 32, "lone": 1}), (1920, 1080, 200, 255, {"host_threads": 32, "lone": 1}),
+        (640, 480, "patches", 63, {"filter_adaptive_mean": 0}), (640, 480, "photometric", 63, {"ipol_gap_width": 2}),
+    ]
+    sgm_configs = [(640, 480, 64, 64, {}), (1280, 720, 128, 128, {"subpixel": 1}), (320, 240, "strips", 64, {"subpixel": 1}),
+                   (448, 333, "blobs", 128, {"P1": 5, "P2": 40, "prefilter_cap": 20}), (500, 200, 200, 256, {"lr_max_diff": 2})]
+    with ProcessPoolExecutor(max_workers=min(48, os.cpu_count() or 8)) as pool:
         futures = []
         for ci, (W, H, sd, dmax, kw) in enumerate(configs):
             n = per if W * H <= 1280 * 720 else max(4, per // 3)
-            futures.append([pool.submit(oracle_job, (W, H, sd, dmax, 31000 + 100 * ci + b, kw)) for b in range(n)])
+            if kw.get("lone"):
+                n = 3
+            futures.append([pool.submit(oracle_job, (W, H, sd, dmax, 31000 + 100 * ci + b, {k: v for k, v in kw.items() if k != "lone"})) for b in range(n)])
+        sgm_futures = [[pool.submit(sgm_job, (W, H, sd, D, 52000 + 100 * ci + b, kw)) for b in range(max(2, per // 6))] for ci, (W, H, sd, D, kw) in enumerate(sgm_configs)]
         import jackal_navigation_amd as jn          # GPU side in the parent only (after the workers were forked)
         from jackal_navigation_amd.device import DeviceArray
         bad = 0
@@ -56,8 +82,14 @@ def main():
             dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
             d1 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32)); d2 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32))
             t0 = time.time()
-            with jn.Elas(jn.Elas.parameters(0, disp_max=dmax, **kw), W, H, max_batch=n, host_threads=8) as e:
-                status = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
+            pkw = {k: v for k, v in kw.items() if k not in ("setting", "host_threads", "lone")}
+            with jn.Elas(jn.Elas.parameters(kw.get("setting", 0), disp_max=dmax, **pkw), W, H, max_batch=n, host_threads=kw.get("host_threads", 8)) as e:
+                if kw.get("lone"):                                   # one pair per call: the pool has idle threads, Delaunay runs in parts
+                    status = []
+                    for b in range(n):
+                        status += e.process_batch(1, dL.ptr + b * H * W, dR.ptr + b * H * W, W, H * W, d1.ptr + 4 * b * H * W, d2.ptr + 4 * b * H * W)
+                else:
+                    status = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
             t_gpu = time.time() - t0
             D1, D2 = d1.numpy(), d2.numpy()
             wrong = 0
@@ -72,6 +104,20 @@ def main():
             print("%4dx%-4d scene %-11s disp_max=%-3d %-45s %3d pairs  %s  (gpu %.2f s)" %
                   (W, H, sd, dmax, kw, n, "all bit-identical" if wrong == 0 else "%d MISMATCH" % wrong, t_gpu), flush=True)
             for a in (dL, dR, d1, d2):
+                a.free()
+        for ci, (W, H, sd, D, kw) in enumerate(sgm_configs):
+            n = len(sgm_futures[ci])
+            pairs = [make_pair(W, H, sd, D - 1, 52000 + 100 * ci + b) for b in range(n)]
+            Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+            dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+            dd = DeviceArray((n, H, W), np.int16)
+            with jn.Sgm(jn.Sgm.parameters(num_disparities=D, **kw), W, H, max_batch=n) as sg:
+                sg.process_batch(n, dL.ptr, dR.ptr, W, H * W, dd.ptr)
+            out = dd.numpy()
+            wrong = sum(0 if np.array_equal(out[b], sgm_futures[ci][b].result()) else 1 for b in range(n))
+            bad += wrong
+            print("SGM %4dx%-4d scene %-8s D=%-3d %-45s %3d pairs  %s" % (W, H, sd, D, kw, n, "all bit-identical" if wrong == 0 else "%d MISMATCH" % wrong), flush=True)
+            for a in (dL, dR, dd):
                 a.free()
     print("sweep", "PASSED" if bad == 0 else "FAILED (%d)" % bad)
     return 1 if bad else 0
