@@ -106,7 +106,10 @@ jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1
 jn_status jn_elas_wait(jn_elas* h, int32_t slot);
 
 /* Per-stage timings of the last batch on a slot, milliseconds (reference stage names,
- * elas.cpp:54-144 PROFILE labels + JackalTimeLog fields msg/JackalTimeLog.msg:1-4). */
+ * elas.cpp:54-144 PROFILE labels + JackalTimeLog fields msg/JackalTimeLog.msg:1-4).  The gpu_*, d2h and h2d entries come
+ * from timing events between the stages; each costs a few microseconds of idle GPU, so a handle created with max_batch 1
+ * (latency mode) leaves them out and reports 0 there — host_stage and total are always measured.  JN_STAGE_EVENTS=1 / 0 at
+ * create time overrides either way. */
 typedef struct jn_stage_times {
   float gpu_descriptor, gpu_support, d2h, host_stage, h2d, gpu_matching, gpu_lr, gpu_speckle,
         gpu_gap, gpu_adaptive_mean, total;

@@ -88,6 +88,7 @@ struct jn_elas {
   // batch exceeds the pool size, "1" = always host, "0" = always device.  The host also takes over when no kernel can
   // take the lattice.
   int filter_min_batch = 4;
+  bool stage_events = true;         // JN_STAGE_EVENTS: default on, off for max_batch == 1 (see run_batch)
   bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
   std::unique_ptr<Pool> pool;
@@ -110,13 +111,17 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   hipStream_t st = s.stream;
   HIP_TRY(hipSetDevice(h->device));
   auto t_begin = std::chrono::steady_clock::now();
-  HIP_TRY(hipEventRecord(s.ev[EV_BEGIN], st));
+  // Stage boundaries for jn_elas_last_times.  A timing event between two kernels costs ~6 us of idle GPU: nothing when
+  // other slots fill the gap, 7 % of a lone 640x480 pair — a latency-mode handle (max_batch 1) leaves them out.
+  const bool stage_events = h->stage_events;
+  auto mark = [&](int e) { return stage_events ? hipEventRecord(s.ev[e], st) : hipSuccess; };
+  HIP_TRY(mark(EV_BEGIN));
   launch_descriptor(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
-  HIP_TRY(hipEventRecord(s.ev[EV_DESC], st));
+  HIP_TRY(mark(EV_DESC));
   launch_support(st, dp, n, s.desc, s.d_can);
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
       launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
-  HIP_TRY(hipEventRecord(s.ev[EV_SUPPORT], st));
+  HIP_TRY(mark(EV_SUPPORT));
   const int list_cap = dp.cw * dp.ch;
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
     launch_support_list(st, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
@@ -170,7 +175,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   }
   auto t_host1 = std::chrono::steady_clock::now();
 
-  HIP_TRY(hipEventRecord(s.ev[EV_H2D0], st));
+  HIP_TRY(mark(EV_H2D0));
   HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
   int max_tri = 0, max_sup = 0, any_ok = 0;
   for (int i = 0; i < n; i++) {
@@ -182,37 +187,37 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     max_sup = std::max(max_sup, fi.nsup);
   }
   if (payload_bytes) HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipEventRecord(s.ev[EV_H2D], st));
+  HIP_TRY(mark(EV_H2D));
   if (any_ok) {
     launch_grid(st, dp, n, s.info, s.payload, 0, max_sup, s.mark, s.gridbits);      // offsets in FrameInfo are batch-absolute
     launch_tri_setup(st, dp, n, s.info, s.payload, 0, max_tri, h->tri_cap, s.recs);
     launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list);
-    HIP_TRY(hipEventRecord(s.ev[EV_RASTER], st));
+    HIP_TRY(mark(EV_RASTER));
     launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
-    HIP_TRY(hipEventRecord(s.ev[EV_DENSE], st));
+    HIP_TRY(mark(EV_DENSE));
     // Post-processing.  When gap interpolation and adaptive mean can run as one pass (gap_mean_fusable), the left image
     // travels raw -> tmp (L/R check) -> tmp (speckle, run lists in the still idle output image) -> D1 (fused pass), so that
     // every stage reads and writes the image once; otherwise the stages run in place on D1 with tmp as scratch.
-    const bool fused = gap_mean_fusable(dp) && ((dp.W * dp.H) & 3) == 0;
+    const bool fused = gap_mean_fusable(dp, n) && ((dp.W * dp.H) & 3) == 0;
     launch_lr(st, dp, n, s.info, s.raw, fused ? s.tmp : j.dD1, j.dD2);
-    HIP_TRY(hipEventRecord(s.ev[EV_LR], st));
+    HIP_TRY(mark(EV_LR));
     if (fused) {
       launch_speckle(st, dp, n, s.info, s.tmp, s.label, s.size, j.dD1);
-      HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
+      HIP_TRY(mark(EV_SPECKLE));
       launch_gap_mean_fused(st, dp, n, s.info, s.tmp, j.dD1, h->p.filter_adaptive_mean != 0);
       if (!h->p.postprocess_only_left) {                     // right image: in place, fused pass into tmp, copied back
         launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
         launch_gap_mean_fused(st, dp, n, s.info, j.dD2, s.tmp, h->p.filter_adaptive_mean != 0);
         launch_copy_ok(st, dp, n, s.info, s.tmp, j.dD2);
       }
-      HIP_TRY(hipEventRecord(s.ev[EV_GAP], st));
+      HIP_TRY(mark(EV_GAP));
     } else {
       launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
       if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
-      HIP_TRY(hipEventRecord(s.ev[EV_SPECKLE], st));
+      HIP_TRY(mark(EV_SPECKLE));
       launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
       if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);
-      HIP_TRY(hipEventRecord(s.ev[EV_GAP], st));
+      HIP_TRY(mark(EV_GAP));
       if (h->p.filter_adaptive_mean) {
         launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
         if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
@@ -222,9 +227,9 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       launch_median(st, dp, n, s.info, j.dD1, s.tmp);
       if (!h->p.postprocess_only_left) launch_median(st, dp, n, s.info, j.dD2, s.tmp);
     }
-    HIP_TRY(hipEventRecord(s.ev[EV_AM], st));
+    HIP_TRY(mark(EV_AM));
   } else {
-    for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(hipEventRecord(s.ev[e], st));
+    for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(mark(e));
   }
   if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
     launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
@@ -233,7 +238,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   HIP_TRY(hipGetLastError());
   auto t_end = std::chrono::steady_clock::now();
 
-  auto ms = [&](int a, int b) { float v = 0; hipEventElapsedTime(&v, s.ev[a], s.ev[b]); return v; };
+  auto ms = [&](int a, int b) { float v = 0; if (stage_events) hipEventElapsedTime(&v, s.ev[a], s.ev[b]); return v; };
   jn_stage_times& t = s.times;
   t.gpu_descriptor = ms(EV_BEGIN, EV_DESC); t.gpu_support = ms(EV_DESC, EV_SUPPORT); t.d2h = ms(EV_SUPPORT, EV_D2H);
   t.host_stage = std::chrono::duration<float, std::milli>(t_host1 - t_host0).count();
@@ -241,7 +246,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   t.gpu_matching = ms(EV_H2D, EV_DENSE); t.gpu_lr = ms(EV_DENSE, EV_LR); t.gpu_speckle = ms(EV_LR, EV_SPECKLE);
   t.gpu_gap = ms(EV_SPECKLE, EV_GAP); t.gpu_adaptive_mean = ms(EV_GAP, EV_AM);
   t.total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
-  s.dense_ms = ms(EV_RASTER, EV_DENSE); s.dense_launches = any_ok ? 1 : 0;
+  s.dense_ms = ms(EV_RASTER, EV_DENSE); s.dense_launches = any_ok && stage_events ? 1 : 0;
   return JN_OK;
 }
 
@@ -364,6 +369,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->filters_fast = support_filters_fast(h->dp, p->incon_window_size, p->incon_min_support);
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
+  h->stage_events = max_batch > 1;
+  if (const char* e = getenv("JN_STAGE_EVENTS")) h->stage_events = atoi(e) != 0;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
   for (int i = 0; i < slots; i++) {

@@ -54,7 +54,7 @@ void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
 // Adaptive mean (elas.cpp:1287-1492): horizontal D->tmp, vertical tmp->D.
 void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
 // Gap interpolation + adaptive mean as one pass in -> out (different buffers), when gap_mean_fusable(dp).
-bool gap_mean_fusable(const DevParams& dp);
+bool gap_mean_fusable(const DevParams& dp, int n);
 void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* in, float* out, bool mean);
 void launch_copy_ok(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* src, float* dst);   // frames with info.ok only
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);

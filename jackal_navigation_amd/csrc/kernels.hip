@@ -2661,9 +2661,12 @@ void launch_copy_ok(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
   }
   for (int f = 0; f < n; f++) hipMemcpyAsync(dst + f * px, src + f * px, px * sizeof(float), hipMemcpyDeviceToDevice, st);   // odd sizes: plain copies (all frames)
 }
-bool gap_mean_fusable(const DevParams& dp) {
-  static const int enabled = getenv("JN_POST_FUSED") ? atoi(getenv("JN_POST_FUSED")) : 1;
-  return enabled && !dp.add_corners && dp.gap_width <= 3 && dp.W >= 16 && dp.H >= 16;
+bool gap_mean_fusable(const DevParams& dp, int n) {
+  const int enabled = getenv("JN_POST_FUSED") ? atoi(getenv("JN_POST_FUSED")) : 1;      // read per batch: tests and A/B runs switch it
+  // The fused pass walks a band of rows serially (~100 us whatever the batch); a lone pair or a small batch is quicker
+  // through the four short full-width kernels.  Same results either way.
+  const long long min_pixels = getenv("JN_POST_FUSED_MIN_PIXELS") ? atoll(getenv("JN_POST_FUSED_MIN_PIXELS")) : 10000000ll;
+  return enabled && !dp.add_corners && dp.gap_width <= 3 && dp.W >= 16 && dp.H >= 16 && (long long)n * dp.W * dp.H >= min_pixels;
 }
 void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* in, float* out, bool mean) {
   static const int band_rows = getenv("JN_POST_BAND") ? atoi(getenv("JN_POST_BAND")) : 48;   // short bands: the pass is bound by parallelism, not by the 14 halo rows

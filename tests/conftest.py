@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The library sends batches below ~10 M pixels through the four separate gap / adaptive-mean kernels and larger ones
+    # through the fused pass (csrc/kernels.hip gap_mean_fusable).  The GPU tests mostly use small frames: run them through the
+    # fused pass (the one the bench uses) unless a test chooses; test_both_post_processing_routes covers the other one.
+    os.environ.setdefault("JN_POST_FUSED_MIN_PIXELS", "0")
 
 
 @pytest.fixture(scope="session")

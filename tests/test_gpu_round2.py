@@ -322,6 +322,34 @@ def test_corner_points_and_wide_gaps_with_the_robotics_preset(jn, oracle, same, 
         assert same(d1.numpy()[b], D1o) and same(d2.numpy()[b], D2o), (kw, b)
 
 
+@pytest.mark.parametrize("min_pixels", ["0", "10000000", "1000000000000"])
+def test_both_post_processing_routes(jn, oracle, same, monkeypatch, min_pixels):
+    """Gap interpolation + adaptive mean run as one fused pass for large batches and as four short kernels for a lone pair
+    or a small batch (JN_POST_FUSED_MIN_PIXELS, read per batch; default 10 M pixels): both give the oracle's bits, for a
+    lone pair, a ragged size, and a batch that crosses the default threshold."""
+    from jackal_navigation_amd.device import DeviceArray
+    monkeypatch.setenv("JN_POST_FUSED_MIN_PIXELS", min_pixels)
+    for (W, H, sd, seed) in ((640, 480, 64, 3), (324, 203, 40, 4)):
+        L, R = oracle.synth_pair(W, H, sd, seed)
+        st, D1, D2 = _elas(jn, jn.Elas.parameters(0, disp_max=sd - 1), L, R)
+        _, D1o, D2o = oracle.process(oracle.params(0, disp_max=sd - 1), L, R)
+        assert st == 0 and same(D1, D1o) and same(D2, D2o), (W, H, min_pixels)
+    W, H, n = 1280, 720, 12                                   # 11 M pixels: fused by default
+    Ls = np.zeros((n, H, W), np.uint8); Rs = np.zeros((n, H, W), np.uint8)
+    for b in range(n):
+        Ls[b], Rs[b] = oracle.synth_pair(W, H, 100, 200 + b % 2)
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    d1 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32)); d2 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32))
+    with jn.Elas(jn.Elas.parameters(0, disp_max=127), W, H, max_batch=n, host_threads=8) as e:
+        assert e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr) == [0] * n
+    o1, o2 = d1.numpy(), d2.numpy()
+    for b in (0, 1):
+        _, D1o, D2o = oracle.process(oracle.params(0, disp_max=127), Ls[b], Rs[b])
+        assert same(o1[b], D1o) and same(o2[b], D2o)
+    for b in range(2, n):
+        assert same(o1[b], o1[b % 2]) and same(o2[b], o2[b % 2])
+
+
 def test_imdecode_gray_on_the_gpu_equals_libjpeg(jn):
     """cv::imdecode(GRAYSCALE) (point_cloud.cpp:436, :478): entropy decode on the host, dequantisation + IDCT on the GPU,
     against the Pillow / libjpeg-turbo fixtures, and against Pillow itself on fresh random frames when it is importable."""
