@@ -101,9 +101,10 @@ def cpu_baseline(W, H, scene, disp, budget_s=20.0):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--mode", default="elas", choices=["elas", "sgm"],
+    ap.add_argument("--mode", default="elas", choices=["elas", "sgm", "bm"],
                     help="elas (default): the reference's matcher, the headline metric; sgm: the 8-path SGM mode of include/jn_sgm.h "
-                         "(no reference counterpart), same workload shape, roofline on SURVEY 8d's B_sgm")
+                         "(no reference counterpart), same workload shape, roofline on SURVEY 8d's B_sgm; bm: the block matcher of include/jn_bm.h "
+                         "(no reference counterpart; BASELINE config 2 is --mode bm --width 640 --height 480 --disp 64 --batch 1)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32)
@@ -124,7 +125,8 @@ def parse_args():
                     help="cross-rig merge with the nccl backend: the library's jn_scan_allreduce (default) or torch.distributed")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses device 0")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
-    ap.add_argument("--subpixel", type=int, default=0, help="sgm mode: 1/16-pixel refinement")
+    ap.add_argument("--subpixel", type=int, default=0, help="sgm / bm mode: 1/16-pixel refinement")
+    ap.add_argument("--block-radius", type=int, default=4, help="bm mode: block radius r (2, 3, 4)")
     return ap.parse_args()
 
 
@@ -180,44 +182,68 @@ def golden_hash(W, H, scene, disp_max):
 
 
 def sgm_cpu_worker(args):
-    W, H, scene, D, sub, seed0, count = args
-    from oracle.binding import Oracle, SgmOracle
+    W, H, scene, D, sub, seed0, count, radius = args
+    from oracle.binding import Oracle, SgmOracle, BmOracle
     o, s = Oracle(), SgmOracle()
+    b = BmOracle() if radius else None
     sp = o.scan_params(W, H)
     lut = o.valid_lut(sp, W, H)
     pairs = [o.synth_pair(W, H, scene, seed0 + i) for i in range(count)]
     t0 = time.perf_counter()
     for L, R in pairs:
-        o.scan(sp, s.to_u8(s.process(s.params(D, subpixel=sub), L, R), sub), lut)
+        d = b.process(b.params(D, radius, subpixel=sub), L, R) if b else s.process(s.params(D, subpixel=sub), L, R)
+        o.scan(sp, s.to_u8(d, sub), lut)
     return time.perf_counter() - t0
 
 
-def sgm_cpu_baseline(W, H, scene, D, sub):
-    """The SGM mode's scalar definition (oracle/sgm_oracle.cpp, kind "port": the reference has no SGM) on a bounded sample."""
+def sgm_cpu_baseline(W, H, scene, D, sub, radius=0):
+    """The SGM (radius 0) or block-matching mode's scalar definition (oracle/sgm_oracle.cpp / bm_oracle.cpp, kind "port": the
+    reference has neither) on a bounded sample."""
     import multiprocessing as mp
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     procs = max(1, min(ncpu // 2, 32))
-    t1 = sgm_cpu_worker((W, H, scene, D, sub, 12345, 1))
+    t1 = sgm_cpu_worker((W, H, scene, D, sub, 12345, 1, radius))
     per_proc = max(1, min(4, int(10.0 / max(t1, 1e-3))))
     with mp.get_context("fork").Pool(procs) as pool:
         t0 = time.perf_counter()
-        pool.map(sgm_cpu_worker, [(W, H, scene, D, sub, 12345 + 1000 * i, per_proc) for i in range(procs)])
+        pool.map(sgm_cpu_worker, [(W, H, scene, D, sub, 12345 + 1000 * i, per_proc, radius) for i in range(procs)])
         wall = time.perf_counter() - t0
     return {"value": round(procs * per_proc / wall, 2), "unit": "pairs/s", "cores": procs, "kind": "port",
-            "sample": "%d pairs %dx%d D=%d in %d processes (%.1f s wall) of the scalar definition oracle/sgm_oracle.cpp; single core: %.2f pairs/s"
-                      % (procs * per_proc, W, H, D, procs, wall, 1.0 / t1)}
+            "sample": "%d pairs %dx%d D=%d in %d processes (%.1f s wall) of the scalar definition oracle/%s_oracle.cpp; single core: %.2f pairs/s"
+                      % (procs * per_proc, W, H, D, procs, wall, "bm" if radius else "sgm", 1.0 / t1)}
+
+
+def bm_roofline(W, H, D, B, radius, sub, ms):
+    """Block matching streams ~13 bytes per pixel (2 in, 4-8 winner records per side, 2 out, u8 map + LUT + scan) and spends
+    W H D block costs of (2r+1)^2 absolute differences on them: the bound is vector issue, not HBM.  The contract's roofline is
+    the HBM one (algorithmic bytes over the GPU time of one batch); the instruction-side figure sits next to it: the match
+    kernels' vector instructions (counted from the ISA: ~10 per (pixel, d) at 9x9, both sides) against the 256 CUs x 4 SIMDs
+    issuing one wave64 instruction per 4 cycles at 2.4 GHz."""
+    alg = (2.0 + 2.0 + 5.0) * W * H * B
+    achieved = alg / (ms["total"] * 1e-3) / 1e9
+    sides = 2
+    instr = 10.0 * (1.25 if sub else 1.0) * W * H * D * B * sides / 64.0
+    peak_issue = 256 * 4 * 2.4e9 / 4
+    return {"bound": "hbm", "kernel": "k_bm x2 (+ k_bm_prefilter, k_bm_finish: one batch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "ms_per_launch": round(ms["match"] / sides, 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
+            "algorithmic_bytes_per_launch": int(alg),
+            "note": "bound by vector issue, not HBM: ~%.0f M wave instructions per batch in the match kernels = %.0f %% of the issue peak over their %.3f ms"
+                    % (instr / 1e6, 100.0 * instr / peak_issue / (ms["match"] * 1e-3), ms["match"])}
 
 
 def run_sgm(a):
-    """--mode sgm: step = one batch through prefilter -> 8 paths -> sum/WTA/check -> u8 map -> 90-bin scan."""
+    """--mode sgm: step = one batch through prefilter -> 8 paths -> sum/WTA/check -> u8 map -> 90-bin scan.
+    --mode bm: the same with the block matcher (prefilter -> left / right block costs + WTA -> check) in place of the paths."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", str(rank)))
     W, H, B, D = a.width, a.height, a.batch, a.disp
     scene = a.scene_disp or a.disp
+    bm = a.mode == "bm"
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = sgm_cpu_baseline(W, H, scene, D, a.subpixel)
+        cpu = sgm_cpu_baseline(W, H, scene, D, a.subpixel, a.block_radius if bm else 0)
     import torch
     import jackal_navigation_amd as jn
     from jackal_navigation_amd import node
@@ -242,7 +268,10 @@ def run_sgm(a):
     disp = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
     u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
     bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
-    sgm = jn.Sgm(jn.Sgm.parameters(num_disparities=D, subpixel=a.subpixel), W, H, max_batch=B, device=local_rank)
+    if bm:
+        sgm = jn.Bm(jn.Bm.parameters(num_disparities=D, block_radius=a.block_radius, subpixel=a.subpixel), W, H, max_batch=B, device=local_rank)
+    else:
+        sgm = jn.Sgm(jn.Sgm.parameters(num_disparities=D, subpixel=a.subpixel), W, H, max_batch=B, device=local_rank)
     sp = node.scan_params(W, H)
     lut = node.build_valid_disp_lut(sp, W, H, device=local_rank)
     torch.cuda.synchronize()
@@ -286,35 +315,41 @@ def run_sgm(a):
     if rank == 0:
         want = None
         try:
-            for line in open(os.path.join(ROOT, "tests", "golden", "sgm_hashes.txt")):
+            for line in open(os.path.join(ROOT, "tests", "golden", "bm_hashes.txt" if bm else "sgm_hashes.txt")):
                 f = line.split()
-                if not line.startswith("#") and len(f) >= 7 and [int(x) for x in f[:6]] == [W, H, scene, D, a.subpixel, 12345]:
-                    want = f[6]
+                key = [W, H, scene, D, a.block_radius, a.subpixel, 12345] if bm else [W, H, scene, D, a.subpixel, 12345]
+                if not line.startswith("#") and len(f) == len(key) + 1 and [int(x) for x in f[:-1]] == key:
+                    want = f[-1]
         except OSError:
             pass
         host = disp[0].cpu().numpy()
         got = "%016x" % jn.load().jn_fnv1a64_u32(host.ctypes.data, host.size // 2)
         check = {"what": "FNV-1a-64 of the int16 disparity map of frame 0 (seed 12345) after the timed region", "got": got, "expected": want,
-                 "source": "tests/golden/sgm_hashes.txt (scalar definition oracle/sgm_oracle.cpp; self-referential, the reference has no SGM)" if want else None,
+                 "source": ("tests/golden/%s_hashes.txt (scalar definition oracle/%s_oracle.cpp; self-referential, the reference has no such matcher)"
+                            % (("bm", "bm") if bm else ("sgm", "sgm"))) if want else None,
                  "ok": (got == want) if want else None}
     # roofline: SURVEY 8d's algorithmic bytes of the cost-volume mode, B_sgm = 4 W H D + 5 W H per pair, over the GPU time of
     # one batch (the three kernels, HIP events on the library's stream); the path kernel dominates.  `traffic` = the bytes
     # this decomposition really moves: eight u8 volumes written by the path kernel and read by the WTA kernel.
     b_sgm = (4.0 * W * H * D + 5.0 * W * H) * B
-    achieved = b_sgm / (ms["total"] * 1e-3) / 1e9
-    moved = (16.0 * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
-    roofline = {"bound": "hbm", "kernel": "k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": int(moved),
-                "traffic_note": "computed, not PMC: 8 W H D bytes written by the path kernel + 8 W H D read by the WTA kernel; "
-                                "moved bytes / time = %.0f GB/s" % (moved / (ms["total"] * 1e-3) / 1e9),
-                "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
-                "algorithmic_bytes_per_launch": int(b_sgm), "path_kernel_write_GBs": round(8.0 * W * H * D * B / (ms["paths"] * 1e-3) / 1e9, 1)}
+    if bm:
+        roofline = bm_roofline(W, H, D, B, a.block_radius, a.subpixel, ms)
+    if not bm:
+        achieved = b_sgm / (ms["total"] * 1e-3) / 1e9
+        moved = (16.0 * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
+        roofline = {"bound": "hbm", "kernel": "k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": int(moved),
+                    "traffic_note": "computed, not PMC: 8 W H D bytes written by the path kernel + 8 W H D read by the WTA kernel; "
+                                    "moved bytes / time = %.0f GB/s" % (moved / (ms["total"] * 1e-3) / 1e9),
+                    "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
+                    "algorithmic_bytes_per_launch": int(b_sgm), "path_kernel_write_GBs": round(8.0 * W * H * D * B / (ms["paths"] * 1e-3) / 1e9, 1)}
     if rank == 0:
         out = {"metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": (dist.get_world_size() if dist is not None else 1),
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_frame": round(elapsed / (B * a.steps) * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i16", "data": "synthetic",
-               "config": {"workload": "%dx%d rectified pairs (scene disparities <= %d), SGM 8 paths D=%d%s (include/jn_sgm.h; no reference counterpart), batch=%d per GPU -> u8 map -> 90-bin scan"
-                                      % (W, H, scene, D, " + 1/16 px" if a.subpixel else "", B), "batch_per_gpu": B, "mode": "sgm",
+               "config": {"workload": "%dx%d rectified pairs (scene disparities <= %d), %s D=%d%s (include/jn_%s.h; no reference counterpart), batch=%d per GPU -> u8 map -> 90-bin scan"
+                                      % (W, H, scene, ("block matching %dx%d" % (2 * a.block_radius + 1, 2 * a.block_radius + 1)) if bm else "SGM 8 paths", D,
+                                         " + 1/16 px" if a.subpixel else "", "bm" if bm else "sgm", B), "batch_per_gpu": B, "mode": a.mode,
                           "parallelism": "rigs sharded 1 batch/GPU over %d ranks" % world if world > 1 else "single GPU"},
                "timing": {"regions": len(regions), "region_s_median": round(elapsed, 5), "region_s_min": round(min(regions), 5), "region_s_max": round(max(regions), 5)},
                "stage_ms_per_batch": {k: round(v, 3) for k, v in ms.items()}, "roofline": roofline, "cpu_baseline": cpu, "check": check}
@@ -324,11 +359,11 @@ def run_sgm(a):
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0 and check and check["ok"] is False:
-        raise SystemExit("bench.py: the SGM disparity map differs from its golden hash: %s" % check)
+        raise SystemExit("bench.py: the %s disparity map differs from its golden hash: %s" % (a.mode, check))
 
 
 def run_rank(a):
-    if a.mode == "sgm":
+    if a.mode in ("sgm", "bm"):
         return run_sgm(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -1,0 +1,58 @@
+/* jn_bm.h — C ABI of the block-matching mode of libjn_stereo.so.
+ *
+ * NO REFERENCE COUNTERPART (like jn_sgm.h): sourishg/jackal-navigation's only matcher is libelas; BASELINE.json's
+ * config 2 ("640x480 D=64 block-matching, batch=1, latency mode") and SURVEY.md 8f rank 4 name a block matcher, so
+ * it is defined HERE and restated scalar in oracle/bm_oracle.cpp (the checker): parity is SELF-REFERENTIAL ("parity
+ * unpinned").  It slots in where generateDisparityMap (src/obstacle_avoidance/point_cloud.cpp:406-429)
+ * calls Elas::process; the output format is jn_sgm.h's, so jn_sgm_disparity_to_u8 and the node's tail consume it.
+ *
+ * Definition (all integer arithmetic; D = number of disparities, d in [0, D); r = block_radius):
+ *   prefilter  g = clamp(Sobel_x, -cap, cap) + cap with replicated borders, exactly jn_sgm.h's
+ *   cost       CL(x,y,d) = sum_{j=-r..r} sum_{i=-r..r} | gL(cl(x+i), cr(y+j)) - gR(cl(x+i-d), cr(y+j)) |
+ *              CR(x,y,d) = sum_{j=-r..r} sum_{i=-r..r} | gR(cl(x+i), cr(y+j)) - gL(cl(x+i+d), cr(y+j)) |
+ *              cl = clamp to [0, W-1], cr = clamp to [0, H-1]        (<= (2r+1)^2 * 2 cap, fits 16 bits)
+ *   WTA        dL(x,y) = smallest d minimising CL(x,y,d);  dR(x,y) = smallest d minimising CR(x,y,d)
+ *   L/R check  dL(p) is kept iff x - dL >= 0 and |dL(p) - dR(x - dL, y)| <= lr_max_diff, else invalid (lr_max_diff < 0: all kept)
+ *   sub-pixel  (optional) for 0 < d < D-1, with C = CL(x,y,.): den = max(C(d-1) + C(d+1) - 2 C(d), 1),
+ *              d16 = 16 d + (16 (C(d-1) - C(d+1)) + den) / (2 den)  (C integer division, truncating); otherwise d16 = 16 d
+ *   output     int16 per pixel: d (subpixel = 0) or d16 (subpixel = 1); invalid = -1 (resp. -16)
+ */
+#ifndef JN_BM_H
+#define JN_BM_H
+
+#include <stdint.h>
+#include "jn_stereo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jn_bm_params {
+  int32_t num_disparities;   /* D: a multiple of 8 in [8, 256] */
+  int32_t block_radius;      /* r: 2, 3 or 4 (5x5, 7x7, 9x9 windows) */
+  int32_t prefilter_cap;     /* Sobel clip, 1..31 */
+  int32_t lr_max_diff;       /* L/R check tolerance; < 0 disables the check (and the right-referenced pass) */
+  int32_t subpixel;          /* 0: integer disparities, 1: 1/16 pixel */
+} jn_bm_params;
+
+/* D = 64, r = 4, cap = 31, lr_max_diff = 1, subpixel = 0 */
+void jn_bm_params_default(jn_bm_params* p);
+
+typedef struct jn_bm jn_bm;   /* opaque: padded prefiltered rows and one 8-byte winner record per pixel and side for max_batch pairs */
+
+jn_status jn_bm_create(const jn_bm_params* p, int32_t width, int32_t height, int32_t max_batch, int32_t device, jn_bm** out);
+void jn_bm_destroy(jn_bm* h);
+
+/* n rectified pairs (device pointers, image b at dI + b*image_stride, rows `pitch` bytes apart) -> dDisp [n][height][width]
+ * int16 (device).  Synchronous. */
+jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride,
+                              int16_t* dDisp);
+
+/* Milliseconds of the last batch: prefilter, the left- and right-referenced matching launches, check + output. */
+typedef struct jn_bm_times { float prefilter, match, finish, total; } jn_bm_times;
+jn_status jn_bm_last_times(jn_bm* h, jn_bm_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JN_BM_H */

@@ -16,3 +16,4 @@ from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # no
 from .elas import Elas  # noqa: F401
 from . import node, device, parallel, navigate  # noqa: F401
 from .sgm import Sgm, SGM_EXPORTS  # noqa: F401
+from .bm import Bm, BM_EXPORTS  # noqa: F401

@@ -322,6 +322,39 @@ class SgmOracle:
         return out
 
 
+class BmParams(C.Structure):
+    _fields_ = [("num_disparities", C.c_int32), ("block_radius", C.c_int32), ("prefilter_cap", C.c_int32),
+                ("lr_max_diff", C.c_int32), ("subpixel", C.c_int32)]
+
+
+class BmOracle:
+    """oracle/bm_oracle.cpp — the scalar definition of the block-matching mode (self-referential: the reference has none)."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build()
+        self.lib = C.CDLL(ORACLE_SO)
+        self.lib.orc_bm_process.restype = C.c_int32
+        self.lib.orc_bm_cost.restype = C.c_int32
+
+    @staticmethod
+    def params(num_disparities=64, block_radius=4, prefilter_cap=31, lr_max_diff=1, subpixel=0):
+        return BmParams(num_disparities, block_radius, prefilter_cap, lr_max_diff, subpixel)
+
+    def cost(self, gL, gR, r, side, x, y, d):
+        H, W = gL.shape
+        return int(self.lib.orc_bm_cost(_p(np.ascontiguousarray(gL)), _p(np.ascontiguousarray(gR)), W, H, r, side, x, y, d))
+
+    def process(self, p, L, R):
+        L = np.ascontiguousarray(L, np.uint8); R = np.ascontiguousarray(R, np.uint8)
+        H, W = L.shape
+        disp = np.zeros((H, W), np.int16)
+        rc = self.lib.orc_bm_process(C.byref(p), _p(L), _p(R), W, H, _p(disp))
+        if rc != 0:
+            raise ValueError("orc_bm_process: parameters outside the definition")
+        return disp
+
+
 class Reference:
     """The compiled reference (libelas from /root/reference), per stage."""
 
