@@ -42,6 +42,14 @@ def sgm_job(args):
     return o.process(o.params(D, **kw), L, R)
 
 
+def bm_job(args):
+    W, H, sd, D, seed, kw = args
+    from oracle.binding import BmOracle
+    o = BmOracle()
+    L, R = make_pair(W, H, sd, D - 1, seed)
+    return o.process(o.params(D, **kw), L, R)
+
+
 def main():
     per = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     configs = [
@@ -64,6 +72,9 @@ def main():
     ]
     sgm_configs = [(640, 480, 64, 64, {}), (1280, 720, 128, 128, {"subpixel": 1}), (320, 240, "strips", 64, {"subpixel": 1}),
                    (448, 333, "blobs", 128, {"P1": 5, "P2": 40, "prefilter_cap": 20}), (500, 200, 200, 256, {"lr_max_diff": 2})]
+    bm_configs = [(640, 480, 64, 64, {}), (1280, 720, 128, 128, {"subpixel": 1}), (320, 240, "strips", 64, {"subpixel": 1, "block_radius": 3}),
+                  (448, 333, "blobs", 120, {"block_radius": 2, "prefilter_cap": 20}), (500, 200, 200, 256, {"lr_max_diff": 2}),
+                  (1000, 37, "patches", 40, {"lr_max_diff": -1, "subpixel": 1})]
     with ProcessPoolExecutor(max_workers=min(48, os.cpu_count() or 8)) as pool:
         futures = []
         for ci, (W, H, sd, dmax, kw) in enumerate(configs):
@@ -72,6 +83,7 @@ def main():
                 n = 3
             futures.append([pool.submit(oracle_job, (W, H, sd, dmax, 31000 + 100 * ci + b, {k: v for k, v in kw.items() if k != "lone"})) for b in range(n)])
         sgm_futures = [[pool.submit(sgm_job, (W, H, sd, D, 52000 + 100 * ci + b, kw)) for b in range(max(2, per // 6))] for ci, (W, H, sd, D, kw) in enumerate(sgm_configs)]
+        bm_futures = [[pool.submit(bm_job, (W, H, sd, D, 63000 + 100 * ci + b, kw)) for b in range(max(2, per // 6))] for ci, (W, H, sd, D, kw) in enumerate(bm_configs)]
         import jackal_navigation_amd as jn          # GPU side in the parent only (after the workers were forked)
         from jackal_navigation_amd.device import DeviceArray
         bad = 0
@@ -117,6 +129,20 @@ def main():
             wrong = sum(0 if np.array_equal(out[b], sgm_futures[ci][b].result()) else 1 for b in range(n))
             bad += wrong
             print("SGM %4dx%-4d scene %-8s D=%-3d %-45s %3d pairs  %s" % (W, H, sd, D, kw, n, "all bit-identical" if wrong == 0 else "%d MISMATCH" % wrong), flush=True)
+            for a in (dL, dR, dd):
+                a.free()
+        for ci, (W, H, sd, D, kw) in enumerate(bm_configs):
+            n = len(bm_futures[ci])
+            pairs = [make_pair(W, H, sd, D - 1, 63000 + 100 * ci + b) for b in range(n)]
+            Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+            dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+            dd = DeviceArray((n, H, W), np.int16)
+            with jn.Bm(jn.Bm.parameters(num_disparities=D, **kw), W, H, max_batch=n) as bm:
+                bm.process_batch(n, dL.ptr, dR.ptr, W, H * W, dd.ptr)
+            out = dd.numpy()
+            wrong = sum(0 if np.array_equal(out[b], bm_futures[ci][b].result()) else 1 for b in range(n))
+            bad += wrong
+            print("BM  %4dx%-4d scene %-8s D=%-3d %-45s %3d pairs  %s" % (W, H, sd, D, kw, n, "all bit-identical" if wrong == 0 else "%d MISMATCH" % wrong), flush=True)
             for a in (dL, dR, dd):
                 a.free()
     print("sweep", "PASSED" if bad == 0 else "FAILED (%d)" % bad)

@@ -14,5 +14,7 @@ cat $g/${tag}_sq1.txt $g/${tag}_sq2.txt > $p/${tag}_pmc_SQ.txt
 cp $g/${tag}_bench_line.json $p/${tag}_bench_line.json
 cp $(ls $g/${tag}_sgm/*/*kernel_stats.csv | head -1) $p/${tag}_sgm_kernel_stats.csv
 cp $g/${tag}_sgm_bench_line.json $p/${tag}_sgm_bench_line.json
+cp $(ls $g/${tag}_bm/*/*kernel_stats.csv | head -1) $p/${tag}_bm_kernel_stats.csv
+cp $g/${tag}_bm_bench_line.json $g/${tag}_bm_config2_bench_line.json $p/
 python3 $root/scripts/make_pmc_json.py $tag $p/r02_pmc_traffic.json
 ls -la $p | grep ${tag}
