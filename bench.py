@@ -214,22 +214,19 @@ def sgm_cpu_baseline(W, H, scene, D, sub, radius=0):
 
 
 def bm_roofline(W, H, D, B, radius, sub, ms):
-    """Block matching streams ~13 bytes per pixel (2 in, 4-8 winner records per side, 2 out, u8 map + LUT + scan) and spends
-    W H D block costs of (2r+1)^2 absolute differences on them: the bound is vector issue, not HBM.  The contract's roofline is
-    the HBM one (algorithmic bytes over the GPU time of one batch); the instruction-side figure sits next to it: the match
-    kernels' vector instructions (counted from the ISA: ~10 per (pixel, d) at 9x9, both sides) against the 256 CUs x 4 SIMDs
-    issuing one wave64 instruction per 4 cycles at 2.4 GHz."""
+    """Block matching streams ~13 bytes per pixel (2 in, a 4-byte winner record per side, 2 out, u8 map + LUT + scan) and spends
+    W H D block costs of (2r+1)^2 absolute differences on them: the bound is vector issue, not HBM (PMC, DESIGN.md 4c: the VALU
+    pipes are busy for the whole duration of the match kernels).  The contract's roofline is the HBM one — algorithmic bytes
+    over the GPU time of one batch — and is small by construction; the rate of absolute differences sits next to it."""
     alg = (2.0 + 2.0 + 5.0) * W * H * B
     achieved = alg / (ms["total"] * 1e-3) / 1e9
     sides = 2
-    instr = 10.0 * (1.25 if sub else 1.0) * W * H * D * B * sides / 64.0
-    peak_issue = 256 * 4 * 2.4e9 / 4
+    ads = float((2 * radius + 1) ** 2) * W * H * D * B * sides
     return {"bound": "hbm", "kernel": "k_bm x2 (+ k_bm_prefilter, k_bm_finish: one batch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "ms_per_launch": round(ms["match"] / sides, 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
             "algorithmic_bytes_per_launch": int(alg),
-            "note": "bound by vector issue, not HBM: ~%.0f M wave instructions per batch in the match kernels = %.0f %% of the issue peak over their %.3f ms"
-                    % (instr / 1e6, 100.0 * instr / peak_issue / (ms["match"] * 1e-3), ms["match"])}
+            "note": "bound by vector issue, not HBM (no cost volume exists): %.1f T absolute differences/s in the match kernels" % (ads / (ms["match"] * 1e-3) / 1e12)}
 
 
 def run_sgm(a):

@@ -7,25 +7,26 @@
 //   H(x, y, d) = sum_i |a(x+i, y) - b(x+i -/+ d, y)|,     C(x, y, d) = C(x, y-1, d) + H(x, y+r, d) - H(x, y-r-1, d).
 // A workgroup owns 64 columns x a band of rows; both prefiltered images are stored with replicated borders wide enough
 // that no window ever needs a clamp in x, and the band's rows (+ r above and below, clamped in y) sit in LDS.  A wave's
-// lanes are the 64 columns; the wave takes 8 consecutive disparities at a time and walks down the band with the
-// last 2r+1 row costs of each of them in registers (the ring index is static: the row loop is unrolled by 2r+1).  Per
-// row the lane reads the 16-20 bytes of b that its 8 windows span ONCE and normalises them with v_alignbyte_b32 to start
-// at its first window; window k then starts at the compile-time byte offset k (or 7-k) of that span: two or three more
-// v_alignbyte_b32 and one v_sad_u8 per dword, the SADs chained through their accumulator operand.  ≈10 vector
-// instructions per (pixel, disparity) at 9x9 — the 81 absolute differences and the box filter included.
-// The winner per pixel is a packed key (cost << 8 | d) minimised through LDS (ds_min, 4 waves x D/32 rounds); with the
-// sub-pixel option a wave evaluates d0-1 and d0+8 too and the key carries the winner's two neighbouring costs in its low
-// half (64-bit ds_min; keys differ in the high half, so the low half never decides).  The right-referenced pass is the same
-// kernel with the roles of the images swapped and the shift direction reversed; k_bm_finish applies the L/R check and
-// the 1/16-pixel formula.
-// HBM traffic is ~4 bytes per pixel in and 8-16 out; the kernel is bound by vector issue (W H D x 10 instructions / 64 lanes).
+// lanes are the 64 columns; the wave takes 16 consecutive disparities at a time and walks down the band with the last
+// 2r+1 row costs of each of them in registers, four 16-bit costs per register pair (the ring index is static: the row
+// loop is unrolled by 2r+1).  Per row the lane reads the 24 bytes of b that its 16 windows span ONCE and normalises them
+// with v_alignbyte_b32 (per-lane shift) to start at its first window.  From there the hardware slides: v_qsad_pk_u16_u8
+// takes 8 bytes of b and 4 bytes of a and returns the SADs of the four windows at byte offsets 0..3, accumulated into
+// four packed 16-bit sums — the row costs of four consecutive disparities per instruction and dword of the window.  The
+// odd last byte(s) of the window go through v_mqsad_pk_u16_u8, which skips the bytes of a that are zero: the prefilter
+// stores g + 1, so a zero byte only ever is one this kernel put there.  Running sums and keys stay packed
+// (v_pk_sub/add_u16, v_pk_mad_u16, v_pk_min_u16): (cost << 3 | k) of eight disparities fits 16 bits.
+// Measured (scripts/probes/qsad_probe.hip): the quad SADs issue at 1/5 of v_sad_u8's rate for 4x the work and no per-window
+// alignment.  The winner per pixel is a key (cost << 8 | d) minimised through LDS (4 waves x D/64 rounds).  The
+// right-referenced pass is the same kernel with the images swapped and the shift reversed; k_bm_finish applies the L/R
+// check; with the sub-pixel option it stages the band again and evaluates the two costs next to each winner directly.
+// HBM traffic is ~13 bytes per pixel; the kernel is bound by vector issue.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <type_traits>
 #include "../../include/jn_bm.h"
 
 namespace {
@@ -34,10 +35,15 @@ struct BmDev { int W, H, D, r, cap, lr, subpixel, Wp, padx; };
 
 #define DEV static __device__ __forceinline__
 
-constexpr int kBmMaxBand = 32;        // rows of a band (the launch may choose fewer)
-constexpr int kBmPad = 96;            // LDS row of the shifted image: D + kBmPad bytes; image rows padded by D + kBmPad columns each side
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
-// ---- prefilter: g = clamp(Sobel_x, -cap, cap) + cap with replicated borders, rows padded by padx columns on both sides ----
+constexpr int kBmMaxBand = 64;        // rows of a band (the launch may choose fewer)
+constexpr int kBmPad = 112;           // LDS row of the shifted image: D + kBmPad bytes; image rows padded by D + kBmPad columns each side
+constexpr int kBmPA = 80;             // LDS row of the reference-side image: columns x0 - 4 ... x0 + 75
+
+// ---- prefilter: 4 (g + 1), g = clamp(Sobel_x, -cap, cap) + cap, with replicated borders, rows padded by padx columns.  + 1: never zero (see
+// above); x 4: every cost is then a multiple of 4 and the two low bits of a packed 16-bit sum are free to carry the position
+// of its disparity inside its quad (4 (81 x 62) + 3 < 2^16). ----
 __global__ void __launch_bounds__(256) k_bm_prefilter(BmDev s, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2, int pitch,
                                                       long long stride, int n, uint8_t* __restrict__ g) {
   const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
@@ -47,66 +53,78 @@ __global__ void __launch_bounds__(256) k_bm_prefilter(BmDev s, const uint8_t* __
   const int xm = max(x - 1, 0), xq = min(x + 1, s.W - 1), ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
   const uint8_t* r0 = I + (size_t)ym * pitch; const uint8_t* r1 = I + (size_t)y * pitch; const uint8_t* r2 = I + (size_t)yq * pitch;
   const int sx = ((int)r0[xq] - (int)r0[xm]) + 2 * ((int)r1[xq] - (int)r1[xm]) + ((int)r2[xq] - (int)r2[xm]);
-  g[((size_t)img * s.H + y) * s.Wp + xp] = (uint8_t)(min(max(sx, -s.cap), s.cap) + s.cap);
+  g[((size_t)img * s.H + y) * s.Wp + xp] = (uint8_t)(4 * (min(max(sx, -s.cap), s.cap) + s.cap + 1));
 }
 
 DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
 DEV uint32_t sad_u8(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+DEV uint64_t pack64(uint32_t hi, uint32_t lo) { return ((uint64_t)hi << 32) | lo; }
+DEV us2 as_us2(uint32_t v) { return __builtin_bit_cast(us2, v); }
+DEV uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-// ---- matching: one side.  SIDE 0: a = left, b = right at x - d;  SIDE 1: a = right, b = left at x + d. ----
-// keys: [n][H][W] of uint32 (cost << 8 | d) or, SUB, uint64 (that << 32 | cost(d-1) << 16 | cost(d+1)).
-template <int R, int SIDE, bool SUB>
-__global__ void __launch_bounds__(256) k_bm(BmDev s, int n, int band, const uint8_t* __restrict__ g, void* __restrict__ keys_out) {
-  constexpr int WB = 2 * R + 1, RING = WB, NDW = (WB + 3) / 4, LASTB = WB - 4 * (NDW - 1);
-  constexpr int NK = SUB ? 10 : 8, E = SUB ? 1 : 0, NS = (NK - 1 + WB + 3) / 4;
-  constexpr uint32_t kLastMask = LASTB == 4 ? 0xFFFFFFFFu : ((1u << (8 * LASTB)) - 1u);
-  constexpr int PA = 80;
-  extern __shared__ uint32_t s_mem[];
-  const int PB = s.D + kBmPad, rows_tot = band + 2 * R;
-  uint8_t* sA = reinterpret_cast<uint8_t*>(s_mem);                        // [rows_tot][PA]
-  uint8_t* sB = sA + (size_t)rows_tot * PA;                               // [rows_tot][PB]
-  typedef typename std::conditional<SUB, unsigned long long, uint32_t>::type Key;
-  Key* sKey = reinterpret_cast<Key*>(sB + (size_t)rows_tot * PB);         // [band][64]   (offset is a multiple of 8: PA, PB are multiples of 16... of 8)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * band, img = blockIdx.z;
+// Both images' rows of a band into LDS (aligned dwords: padx, x0, Wp are multiples of 4).  SIDE 0: b columns start at
+// x0 - D - 16 (window of disparity d at lane - d - R + D + 16); SIDE 1: at x0 - 8 (window at lane + d - R + 8).
+template <int R, int SIDE>
+DEV void bm_stage(const BmDev& s, int n, int img, int x0, int y0, int rows_tot, const uint8_t* __restrict__ g, uint8_t* sA, uint8_t* sB) {
+  const int PB = s.D + kBmPad, tid = threadIdx.x;
   const uint8_t* gA = g + (size_t)(SIDE == 0 ? img : n + img) * s.H * s.Wp;
   const uint8_t* gB = g + (size_t)(SIDE == 0 ? n + img : img) * s.H * s.Wp;
-  // stage the rows (aligned dwords: padx, x0, Wp are multiples of 4)
-  {
-    const int colA = s.padx + x0 - 4, colB = s.padx + (SIDE == 0 ? x0 - s.D - 8 : x0 - 8);
-    const int dwA = PA / 4, dwB = PB / 4;
-    for (int i = tid; i < rows_tot * dwA; i += 256) {
-      const int t = i / dwA, c = i - t * dwA, yy = min(max(y0 - R + t, 0), s.H - 1);
-      reinterpret_cast<uint32_t*>(sA)[t * dwA + c] = *reinterpret_cast<const uint32_t*>(gA + (size_t)yy * s.Wp + colA + 4 * c);
-    }
-    for (int i = tid; i < rows_tot * dwB; i += 256) {
-      const int t = i / dwB, c = i - t * dwB, yy = min(max(y0 - R + t, 0), s.H - 1);
-      reinterpret_cast<uint32_t*>(sB)[t * dwB + c] = *reinterpret_cast<const uint32_t*>(gB + (size_t)yy * s.Wp + colB + 4 * c);
-    }
-    for (int i = tid; i < band * 64; i += 256) sKey[i] = ~(Key)0;
+  const int colA = s.padx + x0 - 4, colB = s.padx + (SIDE == 0 ? x0 - s.D - 16 : x0 - 8);
+  const int dwA = kBmPA / 4, dwB = PB / 4;
+  for (int i = tid; i < rows_tot * dwA; i += 256) {
+    const int t = i / dwA, c = i - t * dwA, yy = min(max(y0 - R + t, 0), s.H - 1);
+    reinterpret_cast<uint32_t*>(sA)[t * dwA + c] = *reinterpret_cast<const uint32_t*>(gA + (size_t)yy * s.Wp + colA + 4 * c);
   }
+  for (int i = tid; i < rows_tot * dwB; i += 256) {
+    const int t = i / dwB, c = i - t * dwB, yy = min(max(y0 - R + t, 0), s.H - 1);
+    reinterpret_cast<uint32_t*>(sB)[t * dwB + c] = *reinterpret_cast<const uint32_t*>(gB + (size_t)yy * s.Wp + colB + 4 * c);
+  }
+}
+
+// ---- matching: one side.  SIDE 0: a = left, b = right at x - d;  SIDE 1: a = right, b = left at x + d. ----
+// keys: [n][H][W] uint32 (cost << 8 | d).
+template <int R, int SIDE>
+__global__ void __launch_bounds__(256) k_bm(BmDev s, int n, int band, const uint8_t* __restrict__ g, uint32_t* __restrict__ keys_out) {
+  constexpr int WB = 2 * R + 1, RING = WB, NDW = (WB + 3) / 4, LASTB = WB - 4 * (NDW - 1);
+  constexpr int CH = 16, NQ = CH / 4, NS = (CH - 1 + WB + 3) / 4;
+  constexpr uint32_t kLastMask = LASTB == 4 ? 0xFFFFFFFFu : ((1u << (8 * LASTB)) - 1u);
+  constexpr int PA = kBmPA;
+  extern __shared__ uint32_t s_mem[];
+  // rows staged: the band + 2R, rounded up to whole turns of the ring so that the unrolled row loop needs no "row exists"
+  // test (the extra rows are real image rows, clamped; what they produce is never written)
+  const int PB = s.D + kBmPad, rows_tot = (band + 2 * R + RING - 1) / RING * RING;
+  uint8_t* sA = reinterpret_cast<uint8_t*>(s_mem);                        // [rows_tot][PA]
+  uint8_t* sB = sA + (size_t)rows_tot * PA;                               // [rows_tot][PB]
+  uint32_t* sKey = reinterpret_cast<uint32_t*>(sB + (size_t)rows_tot * PB);   // [band][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * band, img = blockIdx.z;
+  bm_stage<R, SIDE>(s, n, img, x0, y0, rows_tot, g, sA, sB);
+  for (int i = tid; i < band * 64; i += 256) sKey[i] = 0xFFFFFFFFu;
   __syncthreads();
   // the reference-side window of this lane: bytes lane + 4 - R ... of the staged row
   const int cA = lane + 4 - R, offA = cA & ~3, shA = cA & 3;
-  const int chunks = s.D >> 3;
+  const int chunks = (s.D + CH - 1) / CH;
   for (int chunk = wave; chunk < chunks; chunk += 4) {
-    const int d0 = chunk * 8;
-    // first byte of the span of b this lane's NK windows cover, in the staged row
-    const int c_min = SIDE == 0 ? lane - (d0 + NK - 1 - E) - R + s.D + 8 : lane + d0 - E - R + 8;
+    const int d0 = chunk * CH;
+    const bool second = d0 + 8 < s.D;                       // D is a multiple of 8: the last chunk may hold 8 disparities only
+    // first byte of the span of b this lane's CH windows cover, in the staged row; window of d0 + k at byte 15 - k (SIDE 0) / k (SIDE 1)
+    const int c_min = SIDE == 0 ? lane - (d0 + CH - 1) - R + s.D + 16 : lane + d0 - R + 8;
     const int offB = c_min & ~3, shB = c_min & 3;
-    uint32_t ring[RING][NK];
-    uint32_t C[NK];
+    uint32_t ring[RING][NQ][2];                             // row costs: quad q = windows 4q .. 4q+3, four u16
+    uint32_t C[NQ][2];
 #pragma unroll
-    for (int k = 0; k < NK; k++) {
-      C[k] = 0;
+    for (int q = 0; q < NQ; q++) {
+      // sums start at (k & 3) of their disparity d0 + k and stay congruent to it mod 4: window 4q + i holds k = 15 - 4q - i (SIDE 0) or 4q + i (SIDE 1)
+      C[q][0] = SIDE == 0 ? (3u | 2u << 16) : (0u | 1u << 16);
+      C[q][1] = SIDE == 0 ? (1u | 0u << 16) : (2u | 3u << 16);
 #pragma unroll
-      for (int q = 0; q < RING; q++) ring[q][k] = 0;
+      for (int i = 0; i < RING; i++) ring[i][q][0] = ring[i][q][1] = 0;
     }
     for (int tb = 0; tb < rows_tot; tb += RING) {
 #pragma unroll
-      for (int q = 0; q < RING; q++) {
-        const int t = tb + q;
-        if (t < rows_tot) {
+      for (int ri = 0; ri < RING; ri++) {
+        const int t = tb + ri;
+        {
           const uint32_t* pa = reinterpret_cast<const uint32_t*>(sA + t * PA + offA);
           const uint32_t* pb = reinterpret_cast<const uint32_t*>(sB + t * PB + offB);
           uint32_t rawA[NDW + 1], rawB[NS + 1], wa[NDW], span[NS];
@@ -116,89 +134,112 @@ __global__ void __launch_bounds__(256) k_bm(BmDev s, int n, int band, const uint
           for (int j = 0; j <= NS; j++) rawB[j] = pb[j];
 #pragma unroll
           for (int j = 0; j < NDW; j++) wa[j] = alignbyte(rawA[j + 1], rawA[j], shA);
-          wa[NDW - 1] &= kLastMask;
+          wa[NDW - 1] &= kLastMask;                           // zero = "skip" for the masked quad SAD
 #pragma unroll
           for (int j = 0; j < NS; j++) span[j] = alignbyte(rawB[j + 1], rawB[j], shB);
 #pragma unroll
-          for (int k = 0; k < NK; k++) {
-            const int o = SIDE == 0 ? NK - 1 - k : k;             // byte offset of window k inside the span (compile-time after unrolling)
-            const int qd = o >> 2, sh = o & 3;
-            uint32_t acc = 0;
+          for (int q = 0; q < NQ; q++) {
+            uint64_t acc = 0;
 #pragma unroll
             for (int j = 0; j < NDW; j++) {
-              uint32_t w;
-              if (j == NDW - 1 && LASTB == 1) {
-                const int byte = o + 4 * j;                       // the one byte of the last dword that counts
-                w = (span[byte >> 2] >> (8 * (byte & 3))) & 0xFFu;
-              } else {
-                const uint32_t lo = span[qd + j], hi = qd + j + 1 < NS ? span[qd + j + 1] : 0u;
-                w = sh ? alignbyte(hi, lo, (uint32_t)sh) : lo;
-                if (j == NDW - 1) w &= kLastMask;
-              }
-              acc = sad_u8(w, wa[j], acc);
+              const uint64_t src = pack64(q + j + 1 < NS ? span[q + j + 1] : 0u, span[q + j]);
+              acc = (j == NDW - 1 && LASTB != 4) ? __builtin_amdgcn_mqsad_pk_u16_u8(src, wa[j], acc) : __builtin_amdgcn_qsad_pk_u16_u8(src, wa[j], acc);
             }
-            C[k] = C[k] - ring[q][k] + acc;
-            ring[q][k] = acc;
+            const uint32_t n0 = (uint32_t)acc, n1 = (uint32_t)(acc >> 32);
+            C[q][0] = as_u32(as_us2(C[q][0]) - as_us2(ring[ri][q][0]) + as_us2(n0));
+            C[q][1] = as_u32(as_us2(C[q][1]) - as_us2(ring[ri][q][1]) + as_us2(n1));
+            ring[ri][q][0] = n0; ring[ri][q][1] = n1;
           }
-          if (t >= 2 * R) {
-            const int ry = t - 2 * R;
-            const int dbase = d0 - E;
+          if (t >= 2 * R && t - 2 * R < band) {
+            // per quad: the smaller of its four sums (4 cost | k & 3: ties go to the smaller disparity), then the global key
             uint32_t key = 0xFFFFFFFFu;
 #pragma unroll
-            for (int k = E; k < E + 8; k++) key = min(key, (C[k] << 8) + (uint32_t)(dbase + k));
-            if constexpr (SUB) {
-              const int bk = (int)(key & 0xFFu) - dbase;          // 1..8
-              uint32_t prev = C[0], next = C[2];
-#pragma unroll
-              for (int k = 2; k <= 8; k++) { const bool m = bk == k; prev = m ? C[k - 1] : prev; next = m ? C[k + 1] : next; }
-              const unsigned long long k64 = ((unsigned long long)key << 32) | (prev << 16) | next;
-              atomicMin(&sKey[ry * 64 + lane], k64);
-            } else {
-              atomicMin(&sKey[ry * 64 + lane], key);
+            for (int q = 0; q < NQ; q++) {
+              const int k_base = SIDE == 0 ? CH - 4 - 4 * q : 4 * q;          // smallest k of the quad
+              if (k_base >= 8 && !second) continue;
+              const us2 m = __builtin_elementwise_min(as_us2(C[q][0]), as_us2(C[q][1]));
+              const uint32_t mm = min((uint32_t)m.x, (uint32_t)m.y);
+              key = min(key, ((mm & ~3u) << 6) + (mm & 3u) + (uint32_t)(d0 + k_base));
             }
+            atomicMin(&sKey[(t - 2 * R) * 64 + lane], key);
           }
         }
       }
     }
   }
   __syncthreads();
-  Key* out = reinterpret_cast<Key*>(keys_out) + (size_t)img * s.H * s.W;
+  uint32_t* out = keys_out + (size_t)img * s.H * s.W;
   for (int i = tid; i < band * 64; i += 256) {
     const int ry = i >> 6, l = i & 63, x = x0 + l, y = y0 + ry;
     if (x < s.W && y < s.H) out[(size_t)y * s.W + x] = sKey[i];
   }
 }
 
-// ---- L/R check, sub-pixel formula, output ----
-template <bool SUB>
-__global__ void __launch_bounds__(256) k_bm_finish(BmDev s, const void* __restrict__ keysL, const void* __restrict__ keysR, int16_t* __restrict__ disp) {
-  typedef typename std::conditional<SUB, unsigned long long, uint32_t>::type Key;
+// ---- L/R check and output, integer disparities ----
+__global__ void __launch_bounds__(256) k_bm_finish(BmDev s, const uint32_t* __restrict__ keysL, const uint32_t* __restrict__ keysR, int16_t* __restrict__ disp) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
   if (x >= s.W) return;
   const size_t row = ((size_t)img * s.H + y) * s.W;
-  const Key kl = reinterpret_cast<const Key*>(keysL)[row + x];
-  const uint32_t hi = SUB ? (uint32_t)((unsigned long long)kl >> 32) : (uint32_t)kl;
-  const int d = (int)(hi & 0xFFu);
+  const int d = (int)(keysL[row + x] & 0xFFu);
   bool ok = true;
-  if (s.lr >= 0) {
-    ok = x - d >= 0;
+  if (s.lr >= 0) ok = x - d >= 0 && abs(d - (int)(keysR[row + x - d] & 0xFFu)) <= s.lr;
+  disp[row + x] = (int16_t)(ok ? d : -1);
+}
+
+// ---- L/R check, the two costs next to the winner, 1/16-pixel formula ----
+// The winner's cost is in its key; C(d-1) and C(d+1) are evaluated from the staged rows: per block row one window of a
+// and two of b at per-lane byte offsets (aligned dword reads + v_alignbyte_b32), three v_sad_u8 each.
+template <int R>
+__global__ void __launch_bounds__(256) k_bm_finish_sub(BmDev s, int n, int band, const uint8_t* __restrict__ g, const uint32_t* __restrict__ keysL,
+                                                       const uint32_t* __restrict__ keysR, int16_t* __restrict__ disp) {
+  constexpr int WB = 2 * R + 1, NDW = (WB + 3) / 4, LASTB = WB - 4 * (NDW - 1);
+  constexpr uint32_t kLastMask = LASTB == 4 ? 0xFFFFFFFFu : ((1u << (8 * LASTB)) - 1u);
+  constexpr int PA = kBmPA;
+  extern __shared__ uint32_t s_mem[];
+  const int PB = s.D + kBmPad, rows_tot = band + 2 * R;
+  uint8_t* sA = reinterpret_cast<uint8_t*>(s_mem);
+  uint8_t* sB = sA + (size_t)rows_tot * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * band, img = blockIdx.z;
+  bm_stage<R, 0>(s, n, img, x0, y0, rows_tot, g, sA, sB);
+  __syncthreads();
+  const int x = x0 + lane;
+  const int cA = lane + 4 - R, offA = cA & ~3, shA = cA & 3;
+  for (int ry = wave; ry < band; ry += 4) {
+    const int y = y0 + ry;
+    if (x >= s.W || y >= s.H) continue;
+    const size_t row = ((size_t)img * s.H + y) * s.W;
+    const uint32_t kl = keysL[row + x];
+    const int d = (int)(kl & 0xFFu);
+    bool ok = true;
+    if (s.lr >= 0) ok = x - d >= 0 && abs(d - (int)(keysR[row + x - d] & 0xFFu)) <= s.lr;
+    int out = -16;
     if (ok) {
-      const Key kr = reinterpret_cast<const Key*>(keysR)[row + x - d];
-      const int dr = (int)((SUB ? (uint32_t)((unsigned long long)kr >> 32) : (uint32_t)kr) & 0xFFu);
-      ok = abs(d - dr) <= s.lr;
+      out = 16 * d;
+      if (d > 0 && d < s.D - 1) {
+        uint32_t cm = 0, cp = 0;
+        const int cM = lane - (d - 1) - R + s.D + 16, cP = cM - 2;             // windows of d - 1 and d + 1
+        const int offM = cM & ~3, shM = cM & 3, offP = cP & ~3, shP = cP & 3;
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+          const int t = ry + j;
+          const uint32_t* pa = reinterpret_cast<const uint32_t*>(sA + t * PA + offA);
+          const uint32_t* pm = reinterpret_cast<const uint32_t*>(sB + t * PB + offM);
+          const uint32_t* pp = reinterpret_cast<const uint32_t*>(sB + t * PB + offP);
+#pragma unroll
+          for (int w = 0; w < NDW; w++) {
+            uint32_t a = alignbyte(pa[w + 1], pa[w], shA), bm_ = alignbyte(pm[w + 1], pm[w], shM), bp = alignbyte(pp[w + 1], pp[w], shP);
+            if (w == NDW - 1) { a &= kLastMask; bm_ &= kLastMask; bp &= kLastMask; }
+            cm = sad_u8(a, bm_, cm); cp = sad_u8(a, bp, cp);
+          }
+        }
+        const int c0 = (int)(kl >> 8), cm1 = (int)(cm >> 2), cp1 = (int)(cp >> 2);   // the staged bytes are 4 (g + 1)
+        const int den = max(cm1 + cp1 - 2 * c0, 1);
+        out = 16 * d + (16 * (cm1 - cp1) + den) / (2 * den);
+      }
     }
+    disp[row + x] = (int16_t)out;
   }
-  int out = SUB ? -16 : -1;
-  if (ok) {
-    out = SUB ? 16 * d : d;
-    if (SUB && d > 0 && d < s.D - 1) {
-      const uint32_t lo = (uint32_t)(unsigned long long)kl;
-      const int cm = (int)(lo >> 16), cp = (int)(lo & 0xFFFFu), c0 = (int)(hi >> 8);
-      const int den = max(cm + cp - 2 * c0, 1);
-      out = 16 * d + (16 * (cm - cp) + den) / (2 * den);
-    }
-  }
-  disp[row + x] = (int16_t)out;
 }
 
 }  // namespace
@@ -208,7 +249,7 @@ struct jn_bm {
   BmDev dev;
   int W = 0, H = 0, max_batch = 0, device = 0;
   uint8_t* g = nullptr;        // prefiltered rows [2 * max_batch][H][Wp]
-  void* keys = nullptr;        // winners [2][max_batch][H][W], 4 or 8 bytes each
+  uint32_t* keys = nullptr;    // winners [2][max_batch][H][W]: cost << 8 | d
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
   jn_bm_times times = {};
@@ -225,31 +266,42 @@ struct jn_bm {
 
 namespace {
 
-size_t bm_lds_bytes(const BmDev& s, int band, bool sub) {
-  const int rows_tot = band + 2 * s.r;
-  return (size_t)rows_tot * (80 + s.D + kBmPad) + (size_t)band * 64 * (sub ? 8 : 4);
+size_t bm_lds_bytes(const BmDev& s, int band, bool keys) {
+  const int ring = 2 * s.r + 1;
+  const int rows_tot = keys ? (band + 2 * s.r + ring - 1) / ring * ring : band + 2 * s.r;     // k_bm stages whole turns of its ring
+  return (size_t)rows_tot * (kBmPA + s.D + kBmPad) + (keys ? (size_t)band * 64 * 4 : 0);
 }
 
-template <int R, int SIDE, bool SUB>
-hipError_t launch_bm_one(hipStream_t st, const BmDev& s, int n, int band, const uint8_t* g, void* keys) {
-  static bool configured[16] = {};
-  int dev = 0; hipGetDevice(&dev);
-  if (dev < 16 && !configured[dev]) {             // dynamic LDS stays below the 64 KB default; nothing to raise, kept for symmetry with kernels.hip
-    configured[dev] = true;
-  }
+template <int R, int SIDE>
+hipError_t launch_bm_one(hipStream_t st, const BmDev& s, int n, int band, const uint8_t* g, uint32_t* keys) {
   const dim3 grid((s.W + 63) / 64, (s.H + band - 1) / band, n);
-  hipLaunchKernelGGL((k_bm<R, SIDE, SUB>), grid, dim3(256), bm_lds_bytes(s, band, SUB), st, s, n, band, g, keys);
+  hipLaunchKernelGGL((k_bm<R, SIDE>), grid, dim3(256), bm_lds_bytes(s, band, true), st, s, n, band, g, keys);
   return hipGetLastError();
 }
 
 template <int SIDE>
-hipError_t launch_bm(hipStream_t st, const BmDev& s, int n, int band, const uint8_t* g, void* keys) {
-  const bool sub = s.subpixel != 0;
+hipError_t launch_bm(hipStream_t st, const BmDev& s, int n, int band, const uint8_t* g, uint32_t* keys) {
   switch (s.r) {
-    case 2: return sub ? launch_bm_one<2, SIDE, true>(st, s, n, band, g, keys) : launch_bm_one<2, SIDE, false>(st, s, n, band, g, keys);
-    case 3: return sub ? launch_bm_one<3, SIDE, true>(st, s, n, band, g, keys) : launch_bm_one<3, SIDE, false>(st, s, n, band, g, keys);
-    default: return sub ? launch_bm_one<4, SIDE, true>(st, s, n, band, g, keys) : launch_bm_one<4, SIDE, false>(st, s, n, band, g, keys);
+    case 2: return launch_bm_one<2, SIDE>(st, s, n, band, g, keys);
+    case 3: return launch_bm_one<3, SIDE>(st, s, n, band, g, keys);
+    default: return launch_bm_one<4, SIDE>(st, s, n, band, g, keys);
   }
+}
+
+hipError_t launch_bm_finish(hipStream_t st, const BmDev& s, int n, const uint8_t* g, const uint32_t* keysL, const uint32_t* keysR, int16_t* disp) {
+  if (!s.subpixel) {
+    hipLaunchKernelGGL(k_bm_finish, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, keysL, keysR, disp);
+    return hipGetLastError();
+  }
+  const int band = 16;
+  const dim3 grid((s.W + 63) / 64, (s.H + band - 1) / band, n);
+  const size_t lds = bm_lds_bytes(s, band, false);
+  switch (s.r) {
+    case 2: hipLaunchKernelGGL(k_bm_finish_sub<2>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp); break;
+    case 3: hipLaunchKernelGGL(k_bm_finish_sub<3>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp); break;
+    default: hipLaunchKernelGGL(k_bm_finish_sub<4>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp); break;
+  }
+  return hipGetLastError();
 }
 
 }  // namespace
@@ -286,7 +338,7 @@ jn_status jn_bm_create(const jn_bm_params* p, int32_t W, int32_t H, int32_t max_
   s.padx = D + kBmPad; s.Wp = (W + 2 * s.padx + 3) & ~3;
 #define BM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_bm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
   BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
-  BM_CREATE_TRY(hipMalloc(&h->keys, (size_t)2 * max_batch * H * W * (s.subpixel ? 8 : 4)));
+  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->keys), (size_t)2 * max_batch * H * W * sizeof(uint32_t)));
   BM_CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (auto& e : h->ev) BM_CREATE_TRY(hipEventCreate(&e));
 #undef BM_CREATE_TRY
@@ -302,20 +354,19 @@ jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uin
   BM_TRY(hipEventRecord(h->ev[0], st));
   hipLaunchKernelGGL(k_bm_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, h->g);
   BM_TRY(hipEventRecord(h->ev[1], st));
-  // rows per band: 32, shorter while the launch would leave most of the 256 CUs idle (a lone pair)
-  int band = kBmMaxBand;
+  // Rows per band: whole turns of the kernel's ring (band + 2r = k (2r+1)) so that no staged row is wasted, as many as
+  // fit 64 rows (halo overhead 2r / band), fewer turns while the launch would leave most of the 256 CUs idle (a lone pair).
+  const int ring = 2 * s.r + 1;
+  int turns = (kBmMaxBand + 2 * s.r) / ring;
+  while (turns > 2 && (long long)((s.W + 63) / 64) * ((s.H + turns * ring - 2 * s.r - 1) / (turns * ring - 2 * s.r)) * n < 1024) turns--;
+  int band = turns * ring - 2 * s.r;
   if (const char* e = getenv("JN_BM_BAND")) band = std::min(std::max(atoi(e), 1), kBmMaxBand);
-  else
-    while (band > 8 && (long long)((s.W + 63) / 64) * ((s.H + band - 1) / band) * n < 1024) band >>= 1;
-  const size_t key_bytes = (size_t)h->max_batch * s.H * s.W * (s.subpixel ? 8 : 4);
-  void* keysL = h->keys;
-  void* keysR = static_cast<uint8_t*>(h->keys) + key_bytes;
+  uint32_t* keysL = h->keys;
+  uint32_t* keysR = h->keys + (size_t)h->max_batch * s.H * s.W;
   BM_TRY(launch_bm<0>(st, s, n, band, h->g, keysL));
   if (s.lr >= 0) BM_TRY(launch_bm<1>(st, s, n, band, h->g, keysR));
   BM_TRY(hipEventRecord(h->ev[2], st));
-  const dim3 fg((s.W + 255) / 256, s.H, n);
-  if (s.subpixel) hipLaunchKernelGGL(k_bm_finish<true>, fg, dim3(256), 0, st, s, keysL, keysR, dDisp);
-  else hipLaunchKernelGGL(k_bm_finish<false>, fg, dim3(256), 0, st, s, keysL, keysR, dDisp);
+  BM_TRY(launch_bm_finish(st, s, n, h->g, keysL, keysR, dDisp));
   BM_TRY(hipEventRecord(h->ev[3], st));
   BM_TRY(hipStreamSynchronize(st));
   BM_TRY(hipGetLastError());
