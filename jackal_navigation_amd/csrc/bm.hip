@@ -66,18 +66,24 @@ DEV uint32_t as_u32(us2 v) { return __builtin_bit_cast(uint32_t, v); }
 // x0 - D - 16 (window of disparity d at lane - d - R + D + 16); SIDE 1: at x0 - 8 (window at lane + d - R + 8).
 template <int R, int SIDE>
 DEV void bm_stage(const BmDev& s, int n, int img, int x0, int y0, int rows_tot, const uint8_t* __restrict__ g, uint8_t* sA, uint8_t* sB) {
-  const int PB = s.D + kBmPad, tid = threadIdx.x;
+  const int PB = s.D + kBmPad, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint8_t* gA = g + (size_t)(SIDE == 0 ? img : n + img) * s.H * s.Wp;
   const uint8_t* gB = g + (size_t)(SIDE == 0 ? n + img : img) * s.H * s.Wp;
   const int colA = s.padx + x0 - 4, colB = s.padx + (SIDE == 0 ? x0 - s.D - 16 : x0 - 8);
-  const int dwA = kBmPA / 4, dwB = PB / 4;
-  for (int i = tid; i < rows_tot * dwA; i += 256) {
-    const int t = i / dwA, c = i - t * dwA, yy = min(max(y0 - R + t, 0), s.H - 1);
-    reinterpret_cast<uint32_t*>(sA)[t * dwA + c] = *reinterpret_cast<const uint32_t*>(gA + (size_t)yy * s.Wp + colA + 4 * c);
-  }
-  for (int i = tid; i < rows_tot * dwB; i += 256) {
-    const int t = i / dwB, c = i - t * dwB, yy = min(max(y0 - R + t, 0), s.H - 1);
-    reinterpret_cast<uint32_t*>(sB)[t * dwB + c] = *reinterpret_cast<const uint32_t*>(gB + (size_t)yy * s.Wp + colB + 4 * c);
+  const int dwA = kBmPA / 4, dwB = PB / 4;                 // 20 and <= 92 dwords per row
+  // one wave per row: lanes take the row's dwords of b (one or two rounds), the first 20 lanes those of a
+  for (int t = wave; t < rows_tot; t += 4) {
+    const int yy = min(max(y0 - R + t, 0), s.H - 1);
+    const uint32_t* srcB = reinterpret_cast<const uint32_t*>(gB + (size_t)yy * s.Wp + colB);
+    const uint32_t* srcA = reinterpret_cast<const uint32_t*>(gA + (size_t)yy * s.Wp + colA);
+    uint32_t* dstB = reinterpret_cast<uint32_t*>(sB + (size_t)t * PB);
+    uint32_t* dstA = reinterpret_cast<uint32_t*>(sA + (size_t)t * kBmPA);
+    const uint32_t b0 = lane < dwB ? srcB[lane] : 0u;
+    const uint32_t b1 = lane + 64 < dwB ? srcB[lane + 64] : 0u;
+    const uint32_t a0 = lane < dwA ? srcA[lane] : 0u;
+    if (lane < dwB) dstB[lane] = b0;
+    if (lane + 64 < dwB) dstB[lane + 64] = b1;
+    if (lane < dwA) dstA[lane] = a0;
   }
 }
 
@@ -120,13 +126,17 @@ __global__ void __launch_bounds__(256) k_bm(BmDev s, int n, int band, const uint
 #pragma unroll
       for (int i = 0; i < RING; i++) ring[i][q][0] = ring[i][q][1] = 0;
     }
+    const uint8_t* rowA = sA + offA;                        // walked by addition: no per-row multiplies
+    const uint8_t* rowB = sB + offB;
+    uint32_t* rowK = sKey + lane - 2 * R * 64;
     for (int tb = 0; tb < rows_tot; tb += RING) {
 #pragma unroll
       for (int ri = 0; ri < RING; ri++) {
         const int t = tb + ri;
         {
-          const uint32_t* pa = reinterpret_cast<const uint32_t*>(sA + t * PA + offA);
-          const uint32_t* pb = reinterpret_cast<const uint32_t*>(sB + t * PB + offB);
+          const uint32_t* pa = reinterpret_cast<const uint32_t*>(rowA);
+          const uint32_t* pb = reinterpret_cast<const uint32_t*>(rowB);
+          rowA += PA; rowB += PB;
           uint32_t rawA[NDW + 1], rawB[NS + 1], wa[NDW], span[NS];
 #pragma unroll
           for (int j = 0; j <= NDW; j++) rawA[j] = pa[j];
@@ -161,8 +171,9 @@ __global__ void __launch_bounds__(256) k_bm(BmDev s, int n, int band, const uint
               const uint32_t mm = min((uint32_t)m.x, (uint32_t)m.y);
               key = min(key, ((mm & ~3u) << 6) + (mm & 3u) + (uint32_t)(d0 + k_base));
             }
-            atomicMin(&sKey[(t - 2 * R) * 64 + lane], key);
+            atomicMin(rowK, key);
           }
+          rowK += 64;
         }
       }
     }
