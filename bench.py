@@ -590,8 +590,31 @@ def run_rank(a):
         torch.cuda.synchronize()
         lat = (time.perf_counter() - t1) / reps
         e2.close()
-        extra = {"workload": "640x480 D=64 batch=1 latency mode (BASELINE config 2)", "ms_per_frame": round(lat * 1e3, 3),
+        extra = {"workload": "640x480 D=64 batch=1 latency mode (BASELINE config 2), ELAS", "ms_per_frame": round(lat * 1e3, 3),
                  "pairs_per_sec": round(1.0 / lat, 1)}
+        # the same shape through the matcher config 2 names (block matching, include/jn_bm.h — no reference counterpart):
+        # one synchronous call per pair, then the u8 map and the scan
+        bm = jn.Bm(jn.Bm.parameters(num_disparities=d2), w2, h2, max_batch=1, device=local_rank)
+        d16 = torch.zeros((h2, w2), dtype=torch.int16, device=dev); u8b = torch.zeros((h2, w2), dtype=torch.uint8, device=dev)
+        sp2 = node.scan_params(w2, h2); lut2 = node.build_valid_disp_lut(sp2, w2, h2, device=local_rank)
+        bins2 = torch.zeros((1, 90), dtype=torch.float64, device=dev); meta2 = torch.zeros((1, 4), dtype=torch.float64, device=dev)
+
+        def bm_call():
+            bm.process_batch(1, tl.data_ptr(), tr.data_ptr(), w2, h2 * w2, d16.data_ptr())
+            bm.to_u8(d16.data_ptr(), u8b.data_ptr(), h2 * w2)
+            node.obstacle_scan(sp2, 1, u8b.data_ptr(), lut2.ptr, w2, h2, bins2.data_ptr(), meta2.data_ptr(), device=local_rank)
+        for _ in range(10):
+            bm_call()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(4 * reps):
+            bm_call()
+        torch.cuda.synchronize()
+        lat_bm = (time.perf_counter() - t1) / (4 * reps)
+        extra["block_matching"] = {"workload": "640x480 D=64 9x9 block matching batch=1 -> u8 map -> 90-bin scan, one synchronous call per pair",
+                                   "ms_per_frame": round(lat_bm * 1e3, 3), "pairs_per_sec": round(1.0 / lat_bm, 1),
+                                   "gpu_ms_matcher": round(bm.last_times()["total"], 4)}
+        bm.close()
 
     # who took part: gathered over the collective backend, so the line shows what the N ranks really ran on
     ranks_info = None

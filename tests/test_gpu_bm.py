@@ -60,7 +60,7 @@ def test_bm_bit_exact_vs_its_definition(jn, bm, sgm, oracle, W, H, D, scene, n, 
     assert t["match"] > 0 and t["total"] >= t["match"]
 
 
-@pytest.mark.parametrize("band", ["8", "16", "32", "5"])
+@pytest.mark.parametrize("band", ["8", "16", "37", "5", "64"])
 def test_bm_band_heights_give_the_same_map(jn, bm, oracle, monkeypatch, band):
     """The launch picks the rows per workgroup band from the batch size (JN_BM_BAND overrides): any height, the same bits."""
     monkeypatch.setenv("JN_BM_BAND", band)
