@@ -48,7 +48,14 @@ void jn_bm_destroy(jn_bm* h);
 jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride,
                               int16_t* dDisp);
 
-/* Milliseconds of the last batch: prefilter, the left- and right-referenced matching launches, check + output. */
+/* The same plus the node's tail on the same stream, one synchronisation in all (latency mode): the mono8 depth map
+ * (point_cloud.cpp:422 semantics, as jn_sgm_disparity_to_u8) and the LUT scan of it (jn_obstacle_scan's outputs:
+ * dBins [n][sp->bins], dMeta [n][4]); dLut from jn_build_valid_disp_lut.  All device pointers. */
+jn_status jn_bm_process_scan(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride,
+                             int16_t* dDisp, const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dDispU8, double* dBins, double* dMeta);
+
+/* Milliseconds of the last batch: prefilter, the left- and right-referenced matching launches, check + output (+ the scan
+ * tail after jn_bm_process_scan). */
 typedef struct jn_bm_times { float prefilter, match, finish, total; } jn_bm_times;
 jn_status jn_bm_last_times(jn_bm* h, jn_bm_times* out);
 

@@ -26,13 +26,14 @@ def _bind():
         L.jn_bm_destroy.argtypes = [vp]
         L.jn_bm_destroy.restype = None
         L.jn_bm_process_batch.argtypes = [vp, i32, vp, vp, i32, i64, vp]
+        L.jn_bm_process_scan.argtypes = [vp, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp]
         L.jn_bm_last_times.argtypes = [vp, C.POINTER(BmTimes)]
         L.jn_sgm_disparity_to_u8.argtypes = [i32, vp, i32, vp, i64]
         L._bm_bound = True
     return L
 
 
-BM_EXPORTS = ["jn_bm_params_default", "jn_bm_create", "jn_bm_destroy", "jn_bm_process_batch", "jn_bm_last_times"]
+BM_EXPORTS = ["jn_bm_params_default", "jn_bm_create", "jn_bm_destroy", "jn_bm_process_batch", "jn_bm_process_scan", "jn_bm_last_times"]
 
 
 class Bm:
@@ -55,6 +56,11 @@ class Bm:
 
     def process_batch(self, n, dI1, dI2, pitch, image_stride, dDisp):
         _lib.check(self._L.jn_bm_process_batch(self._h, n, dI1, dI2, pitch, image_stride, dDisp), "jn_bm_process_batch")
+
+    def process_scan(self, n, dI1, dI2, pitch, image_stride, dDisp, scan_params, dLut, dU8, dBins, dMeta):
+        """Matcher + u8 map + LUT scan on one stream with one synchronisation (jn_bm_process_scan)."""
+        _lib.check(self._L.jn_bm_process_scan(self._h, n, dI1, dI2, pitch, image_stride, dDisp, C.byref(scan_params), dLut, dU8, dBins, dMeta),
+                   "jn_bm_process_scan")
 
     def last_times(self):
         t = BmTimes()

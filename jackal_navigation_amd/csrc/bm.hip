@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../include/jn_bm.h"
+#include "kernels.h"          // launch_scan: the node's tail on the same stream (jn_bm_process_scan)
 
 namespace {
 
@@ -187,7 +188,14 @@ __global__ void __launch_bounds__(256) k_bm(BmDev s, int n, int band, const uint
 }
 
 // ---- L/R check and output, integer disparities ----
-__global__ void __launch_bounds__(256) k_bm_finish(BmDev s, const uint32_t* __restrict__ keysL, const uint32_t* __restrict__ keysR, int16_t* __restrict__ disp) {
+// u8 (optional): the node's mono8 depth map of the same value (point_cloud.cpp:422 semantics: invalid -> 0, saturate at 255, 1/16 pixel rounded half to even)
+DEV uint8_t bm_u8(int v, bool sub) {
+  if (v < 0) return 0;
+  if (sub) { const int q = v >> 4, r = v & 15; v = q + ((r > 8 || (r == 8 && (q & 1))) ? 1 : 0); }
+  return (uint8_t)min(v, 255);
+}
+__global__ void __launch_bounds__(256) k_bm_finish(BmDev s, const uint32_t* __restrict__ keysL, const uint32_t* __restrict__ keysR, int16_t* __restrict__ disp,
+                                                   uint8_t* __restrict__ u8) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
   if (x >= s.W) return;
   const size_t row = ((size_t)img * s.H + y) * s.W;
@@ -195,6 +203,7 @@ __global__ void __launch_bounds__(256) k_bm_finish(BmDev s, const uint32_t* __re
   bool ok = true;
   if (s.lr >= 0) ok = x - d >= 0 && abs(d - (int)(keysR[row + x - d] & 0xFFu)) <= s.lr;
   disp[row + x] = (int16_t)(ok ? d : -1);
+  if (u8) u8[row + x] = bm_u8(ok ? d : -1, false);
 }
 
 // ---- L/R check, the two costs next to the winner, 1/16-pixel formula ----
@@ -202,7 +211,7 @@ __global__ void __launch_bounds__(256) k_bm_finish(BmDev s, const uint32_t* __re
 // and two of b at per-lane byte offsets (aligned dword reads + v_alignbyte_b32), three v_sad_u8 each.
 template <int R>
 __global__ void __launch_bounds__(256) k_bm_finish_sub(BmDev s, int n, int band, const uint8_t* __restrict__ g, const uint32_t* __restrict__ keysL,
-                                                       const uint32_t* __restrict__ keysR, int16_t* __restrict__ disp) {
+                                                       const uint32_t* __restrict__ keysR, int16_t* __restrict__ disp, uint8_t* __restrict__ u8) {
   constexpr int WB = 2 * R + 1, NDW = (WB + 3) / 4, LASTB = WB - 4 * (NDW - 1);
   constexpr uint32_t kLastMask = LASTB == 4 ? 0xFFFFFFFFu : ((1u << (8 * LASTB)) - 1u);
   constexpr int PA = kBmPA;
@@ -250,6 +259,7 @@ __global__ void __launch_bounds__(256) k_bm_finish_sub(BmDev s, int n, int band,
       }
     }
     disp[row + x] = (int16_t)out;
+    if (u8) u8[row + x] = bm_u8(out, true);
   }
 }
 
@@ -261,6 +271,7 @@ struct jn_bm {
   int W = 0, H = 0, max_batch = 0, device = 0;
   uint8_t* g = nullptr;        // prefiltered rows [2 * max_batch][H][Wp]
   uint32_t* keys = nullptr;    // winners [2][max_batch][H][W]: cost << 8 | d
+  unsigned long long* scan_scratch = nullptr;   // [max_batch][4], the scan tail's extrema
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
   jn_bm_times times = {};
@@ -299,18 +310,18 @@ hipError_t launch_bm(hipStream_t st, const BmDev& s, int n, int band, const uint
   }
 }
 
-hipError_t launch_bm_finish(hipStream_t st, const BmDev& s, int n, const uint8_t* g, const uint32_t* keysL, const uint32_t* keysR, int16_t* disp) {
+hipError_t launch_bm_finish(hipStream_t st, const BmDev& s, int n, const uint8_t* g, const uint32_t* keysL, const uint32_t* keysR, int16_t* disp, uint8_t* u8) {
   if (!s.subpixel) {
-    hipLaunchKernelGGL(k_bm_finish, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, keysL, keysR, disp);
+    hipLaunchKernelGGL(k_bm_finish, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, keysL, keysR, disp, u8);
     return hipGetLastError();
   }
   const int band = 16;
   const dim3 grid((s.W + 63) / 64, (s.H + band - 1) / band, n);
   const size_t lds = bm_lds_bytes(s, band, false);
   switch (s.r) {
-    case 2: hipLaunchKernelGGL(k_bm_finish_sub<2>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp); break;
-    case 3: hipLaunchKernelGGL(k_bm_finish_sub<3>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp); break;
-    default: hipLaunchKernelGGL(k_bm_finish_sub<4>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp); break;
+    case 2: hipLaunchKernelGGL(k_bm_finish_sub<2>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp, u8); break;
+    case 3: hipLaunchKernelGGL(k_bm_finish_sub<3>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp, u8); break;
+    default: hipLaunchKernelGGL(k_bm_finish_sub<4>, grid, dim3(256), lds, st, s, n, band, g, keysL, keysR, disp, u8); break;
   }
   return hipGetLastError();
 }
@@ -327,7 +338,7 @@ void jn_bm_destroy(jn_bm* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  hipFree(h->g); hipFree(h->keys);
+  hipFree(h->g); hipFree(h->keys); hipFree(h->scan_scratch);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -350,6 +361,7 @@ jn_status jn_bm_create(const jn_bm_params* p, int32_t W, int32_t H, int32_t max_
 #define BM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_bm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
   BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
   BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->keys), (size_t)2 * max_batch * H * W * sizeof(uint32_t)));
+  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->scan_scratch), sizeof(unsigned long long) * 4 * max_batch));
   BM_CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (auto& e : h->ev) BM_CREATE_TRY(hipEventCreate(&e));
 #undef BM_CREATE_TRY
@@ -357,7 +369,8 @@ jn_status jn_bm_create(const jn_bm_params* p, int32_t W, int32_t H, int32_t max_
   return JN_OK;
 }
 
-jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp) {
+static jn_status bm_run(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
+                        const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dU8, double* dBins, double* dMeta) {
   if (!h || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dDisp || pitch < h->W) return JN_ERR_INVALID;
   BM_TRY(hipSetDevice(h->device));
   const BmDev& s = h->dev;
@@ -377,7 +390,8 @@ jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uin
   BM_TRY(launch_bm<0>(st, s, n, band, h->g, keysL));
   if (s.lr >= 0) BM_TRY(launch_bm<1>(st, s, n, band, h->g, keysR));
   BM_TRY(hipEventRecord(h->ev[2], st));
-  BM_TRY(launch_bm_finish(st, s, n, h->g, keysL, keysR, dDisp));
+  BM_TRY(launch_bm_finish(st, s, n, h->g, keysL, keysR, dDisp, dU8));
+  if (sp) jnav::launch_scan(st, *sp, n, nullptr, dU8, dLut, s.W, s.H, dBins, dMeta, h->scan_scratch);   // the node's tail, same stream
   BM_TRY(hipEventRecord(h->ev[3], st));
   BM_TRY(hipStreamSynchronize(st));
   BM_TRY(hipGetLastError());
@@ -386,6 +400,16 @@ jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uin
   hipEventElapsedTime(&h->times.finish, h->ev[2], h->ev[3]);
   hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
   return JN_OK;
+}
+
+jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp) {
+  return bm_run(h, n, dI1, dI2, pitch, image_stride, dDisp, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+jn_status jn_bm_process_scan(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
+                             const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dDispU8, double* dBins, double* dMeta) {
+  if (!sp || !dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024) return JN_ERR_INVALID;
+  return bm_run(h, n, dI1, dI2, pitch, image_stride, dDisp, sp, dLut, dDispU8, dBins, dMeta);
 }
 
 jn_status jn_bm_last_times(jn_bm* h, jn_bm_times* out) {

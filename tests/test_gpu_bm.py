@@ -92,6 +92,30 @@ def test_bm_committed_hashes(jn, oracle):
         assert "%016x" % oracle.fnv(out[0].view(np.uint32)) == h, (W, H, sub)
 
 
+@pytest.mark.parametrize("sub", [0, 1])
+def test_bm_process_scan_equals_the_separate_calls(jn, bm, sgm, oracle, sub):
+    """jn_bm_process_scan (matcher, u8 map and LUT scan on one stream, one synchronisation) against the oracle chain, batch of 3."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node
+    W, H, D, n = 320, 180, 64, 3
+    Ls = np.stack([oracle.synth_pair(W, H, 48, 40 + b)[0] for b in range(n)]); Rs = np.stack([oracle.synth_pair(W, H, 48, 40 + b)[1] for b in range(n)])
+    sp, spo = node.scan_params(W, H), oracle.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    dD = DeviceArray((n, H, W), np.int16); du8 = DeviceArray((n, H, W), np.uint8)
+    bins = DeviceArray((n, sp.bins), np.float64); meta = DeviceArray((n, 4), np.float64)
+    with jn.Bm(jn.Bm.parameters(num_disparities=D, subpixel=sub), W, H, max_batch=n) as m:
+        for _ in range(2):                                        # twice: the scan's scratch is reused
+            m.process_scan(n, dL.ptr, dR.ptr, W, H * W, dD.ptr, sp, lut.ptr, du8.ptr, bins.ptr, meta.ptr)
+    luto = oracle.valid_lut(spo, W, H)
+    for b in range(n):
+        exp = bm.process(bm.params(D, subpixel=sub), Ls[b], Rs[b])
+        u8o = sgm.to_u8(exp, sub)
+        assert np.array_equal(dD.numpy()[b], exp) and np.array_equal(du8.numpy()[b], u8o)
+        bo, mo, used = oracle.scan(spo, u8o, luto)
+        assert used > 0 and np.allclose(bins.numpy()[b], bo, rtol=0, atol=1e-4) and np.allclose(meta.numpy()[b], mo, rtol=0, atol=1e-4)
+
+
 def test_bm_feeds_the_node_tail(jn, bm, sgm, oracle):
     """Block-matching disparity -> u8 depth map -> the same LUT scan the ELAS path uses (jn_obstacle_scan), against the oracle chain."""
     from jackal_navigation_amd.device import DeviceArray
