@@ -16,5 +16,6 @@ cp $(ls $g/${tag}_sgm/*/*kernel_stats.csv | head -1) $p/${tag}_sgm_kernel_stats.
 cp $g/${tag}_sgm_bench_line.json $p/${tag}_sgm_bench_line.json
 cp $(ls $g/${tag}_bm/*/*kernel_stats.csv | head -1) $p/${tag}_bm_kernel_stats.csv
 cp $g/${tag}_bm_bench_line.json $g/${tag}_bm_config2_bench_line.json $p/
+[ -s $g/${tag}_other_configs.jsonl ] && cp $g/${tag}_other_configs.jsonl $p/
 python3 $root/scripts/make_pmc_json.py $tag $p/r02_pmc_traffic.json
 ls -la $p | grep ${tag}

@@ -18,4 +18,10 @@ cd $root
 python3 scripts/kstats.py $(ls gpurun_out/${tag}_bm/*/*kernel_stats.csv | head -1) 8 > gpurun_out/${tag}_bm_summary.txt
 python3 bench.py --mode bm --steps 20 --warmup 3 > gpurun_out/${tag}_bm_bench_line.json 2> gpurun_out/${tag}_bm_bench.err
 python3 bench.py --mode bm --width 640 --height 480 --disp 64 --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/${tag}_bm_config2_bench_line.json 2>> gpurun_out/${tag}_bm_bench.err
+# the north star's other frame sizes (pairs/s, pipelined, device-resident inputs), one JSON line each
+: > gpurun_out/${tag}_other_configs.jsonl
+for a in "--width 640 --height 480 --disp 64 --batch 32" "--width 640 --height 480 --disp 64 --batch 64" "--width 320 --height 180 --disp 256 --scene-disp 48 --batch 128" "--width 1920 --height 1080 --disp 256 --batch 8"; do
+  python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency-config $a >> gpurun_out/${tag}_other_configs.jsonl 2>> gpurun_out/${tag}_bench.err
+done
+for m in sgm bm; do python3 bench.py --mode $m --width 640 --height 480 --disp 64 --batch 32 --steps 20 --warmup 3 --no-cpu-baseline >> gpurun_out/${tag}_other_configs.jsonl 2>> gpurun_out/${tag}_bench.err; done
 tail -12 gpurun_out/${tag}_collect.log | cut -c1-400; cat gpurun_out/${tag}_sgm_summary.txt; cut -c1-300 gpurun_out/${tag}_sgm_bench_line.json; cat gpurun_out/${tag}_bm_summary.txt; cut -c1-300 gpurun_out/${tag}_bm_bench_line.json gpurun_out/${tag}_bm_config2_bench_line.json
