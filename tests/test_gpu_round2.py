@@ -381,3 +381,45 @@ def test_imdecode_gray_on_the_gpu_equals_libjpeg(jn):
         Image.fromarray(rgb).save(buf, "JPEG", quality=int(rng.integers(20, 98)), subsampling=int(rng.integers(0, 3)), optimize=bool(k & 1))
         im = Image.open(io.BytesIO(buf.getvalue())); im.draft("L", im.size); im.load()
         assert np.array_equal(node.imdecode_gray(buf.getvalue()).numpy(), np.asarray(im)), (k, W, H)
+
+
+def test_whole_frame_from_jpeg_bytes_to_laser_scan(jn, oracle, same):
+    """One frame the way the node sees it (point_cloud.cpp:431-490 -> :406-429 -> :213-296): the two compressed images of
+    tests/golden/stereo_jpeg_pair.npz -> imdecode (GPU IDCT, pinned by libjpeg's SHA-256) -> rectification maps of the
+    shipped calibration -> remap -> ELAS on device pointers -> u8 map + LUT scan -> LaserScan message and the consumer's
+    decision; every stage against the oracle chain fed with the same decoded frames."""
+    import hashlib
+    from jackal_navigation_amd import node
+    from jackal_navigation_amd.device import DeviceArray
+    z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_jpeg_pair.npz"))
+    W, H = 320, 180
+    c = node.stereo_calib()
+    r = node.stereo_rectify(c, W, H)
+    rect_dev, rect_host = [], []
+    for name, K, D, Rr, P in (("left", c.K1, c.D1, r.R1, r.P1), ("right", c.K2, c.D2, r.R2, r.P2)):
+        frame = node.imdecode_gray(z[name + "__jpeg"])                                   # device, 360 x 640
+        raw = frame.numpy()
+        assert raw.shape == (360, 640) and hashlib.sha256(raw.tobytes()).digest() == z[name + "__sha256"].tobytes(), name
+        mx, my = node.init_undistort_rectify_map(list(K), list(D), list(Rr), list(P), W, H)
+        out = DeviceArray((H, W), np.uint8)
+        node.remap(1, frame.ptr, 640, 360, 640, 640 * 360, mx.ptr, my.ptr, out.ptr, W, H, W, W * H)
+        assert same(out.numpy(), oracle.remap(raw, mx.numpy(), my.numpy())), name
+        rect_dev.append(out); rect_host.append(out.numpy())
+    sp, spo = node.scan_params(W, H), oracle.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    d1 = DeviceArray.from_numpy(np.zeros((1, H, W), np.float32)); d2 = DeviceArray.from_numpy(np.zeros((1, H, W), np.float32))
+    u8 = DeviceArray((1, H, W), np.uint8); bins = DeviceArray((1, sp.bins), np.float64); meta = DeviceArray((1, 4), np.float64)
+    st = (C.c_int32 * 1)()
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=1, host_threads=4) as e:         # the node's parameters: ROBOTICS, disp_max 255
+        e.submit_scan(0, 1, rect_dev[0].ptr, rect_dev[1].ptr, W, H * W, d1.ptr, d2.ptr, sp, lut.ptr, u8.ptr, bins.ptr, meta.ptr, st)
+        e.wait(0)
+    st_o, D1o, D2o = oracle.process(oracle.params(0), rect_host[0], rect_host[1])
+    assert list(st) == [0] and st_o == 0 and same(d1.numpy()[0], D1o)
+    assert (D1o >= 0).mean() > 0.6                                                        # a scene, not a degenerate frame
+    u8o = oracle.to_u8(D1o)
+    assert same(u8.numpy()[0], u8o)
+    bo, mo, used = oracle.scan(spo, u8o, oracle.valid_lut(spo, W, H))
+    assert used > 1000 and np.array_equal(bins.numpy()[0] < 1e9 - 1, bo < 1e9 - 1)
+    assert np.allclose(bins.numpy()[0], bo, rtol=0, atol=SCAN_TOL) and np.allclose(meta.numpy()[0], mo, rtol=0, atol=SCAN_TOL)
+    msg = node.laser_scan_message(bins.numpy()[0], meta.numpy()[0], seq=1)
+    assert msg["header"]["frame_id"] == "jackal" and len(msg["ranges"]) == int((bo < 1e9 - 1).sum()) and len(msg["ranges"]) > 30
