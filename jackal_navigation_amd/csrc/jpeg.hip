@@ -54,10 +54,22 @@ struct Huff {
 
 struct BitReader {
   const uint8_t* p; const uint8_t* end;
-  uint32_t acc = 0; int bits = 0;
+  uint64_t acc = 0; int bits = 0;                     // the next `bits` bits of the stream sit at the top of acc
   bool hit_marker = false;
-  void fill() {                                       // keep >= 25 bits when possible; stuffed 0xFF00 -> 0xFF; a marker feeds zeros
-    while (bits <= 24) {
+  // Keep >= 33 bits when possible (a symbol of <= 16 bits and its <= 16 extra bits need no second refill).  Four bytes at a
+  // time while none of them is 0xFF; byte-wise around stuffed bytes (0xFF00 -> 0xFF) and markers (a marker feeds zeros).
+  inline void fill() {
+    if (bits > 32) return;
+    if (!hit_marker && p + 4 <= end) {
+      uint32_t w; memcpy(&w, p, 4);
+      const uint32_t inv = ~w;
+      if (((inv - 0x01010101u) & ~inv & 0x80808080u) == 0) {               // no byte of w is 0xFF
+        acc |= (uint64_t)__builtin_bswap32(w) << (32 - bits);
+        bits += 32; p += 4;
+        return;
+      }
+    }
+    while (bits <= 56) {
       int b = 0;
       if (!hit_marker && p < end) {
         b = *p;
@@ -66,18 +78,17 @@ struct BitReader {
           else { hit_marker = true; b = 0; }
         } else p++;
       } else hit_marker = true;
-      acc |= (uint32_t)b << (24 - bits);
+      acc |= (uint64_t)b << (56 - bits);
       bits += 8;
     }
   }
-  inline int peek(int n) { return (int)(acc >> (32 - n)); }
+  inline int peek(int n) const { return (int)(acc >> (64 - n)); }
   inline void drop(int n) { acc <<= n; bits -= n; }
-  inline int get(int n) { if (n == 0) return 0; fill(); const int v = peek(n); drop(n); return v; }
   void restart() { acc = 0; bits = 0; hit_marker = false; }
 };
 
+// One Huffman symbol; the caller has filled the reader.
 inline int decode_symbol(BitReader& br, const Huff& h) {
-  br.fill();
   const int top = br.peek(8);
   if (h.look_len[top]) { br.drop(h.look_len[top]); return h.look_val[top]; }
   int code = top, len = 8;
@@ -179,18 +190,20 @@ jn_status parse_and_decode(const uint8_t* data, size_t n, Decoded& out, std::vec
             for (int by = 0; by < cv; by++)
               for (int bx = 0; bx < ch; bx++) {
                 int16_t* blk = c == 0 ? &coef[((size_t)(my * vy + by) * out.bw + (mx * hy + bx)) * 64] : nullptr;
+                br.fill();
                 int s = decode_symbol(br, hd);
                 if (s < 0 || s > 11) return JN_ERR_INVALID;
-                if (s) pred[c] += extend(br.get(s), s);
+                if (s) { pred[c] += extend(br.peek(s), s); br.drop(s); }
                 if (blk) blk[0] = (int16_t)pred[c];
                 for (int k = 1; k < 64;) {
+                  br.fill();                                                     // >= 33 bits: the symbol and its extra bits
                   const int rs = decode_symbol(br, ha);
                   if (rs < 0) return JN_ERR_INVALID;
                   const int r = rs >> 4; s = rs & 15;
                   if (s) {
                     k += r;
                     if (k > 63) return JN_ERR_INVALID;
-                    const int v = extend(br.get(s), s);
+                    const int v = extend(br.peek(s), s); br.drop(s);
                     if (blk) blk[kZigzag[k]] = (int16_t)v;
                     k++;
                   } else if (r == 15) k += 16;                                   // ZRL

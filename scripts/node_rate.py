@@ -20,7 +20,11 @@ from jackal_navigation_amd.device import DeviceArray  # noqa: E402
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_jpeg_pair.npz"))
-    jl, jr = bytes(z["left__jpeg"]), bytes(z["right__jpeg"])
+    jl, jr = np.ascontiguousarray(z["left__jpeg"]), np.ascontiguousarray(z["right__jpeg"])
+    from jackal_navigation_amd import _lib
+    L = _lib.load()
+    raws = [DeviceArray((360, 640), np.uint8), DeviceArray((360, 640), np.uint8)]       # persistent, as a node would keep them
+    ww, hh = C.c_int32(), C.c_int32()
     W, H = 320, 180
     c = node.stereo_calib()
     r = node.stereo_rectify(c, W, H)
@@ -37,7 +41,8 @@ def main():
         def frame():
             nonlocal t_dec, t_remap, t_match, t_msg
             t0 = time.perf_counter()
-            raws = [node.imdecode_gray(jl), node.imdecode_gray(jr)]
+            for buf, out in ((jl, raws[0]), (jr, raws[1])):                         # cv::imdecode(GRAYSCALE), point_cloud.cpp:436, :478
+                _lib.check(L.jn_jpeg_decode_gray(0, buf.ctypes.data, buf.size, out.ptr, 640, 360, C.byref(ww), C.byref(hh)), "jn_jpeg_decode_gray")
             t1 = time.perf_counter()
             for i in range(2):
                 node.remap(1, raws[i].ptr, 640, 360, 640, 640 * 360, maps[i][0].ptr, maps[i][1].ptr, rect[i].ptr, W, H, W, W * H)
@@ -46,8 +51,6 @@ def main():
             e.wait(0)
             t3 = time.perf_counter()
             msg = node.laser_scan_message(bins.numpy()[0], meta.numpy()[0], seq=0)
-            for a in raws:
-                a.free()
             t4 = time.perf_counter()
             t_dec += t1 - t0; t_remap += t2 - t1; t_match += t3 - t2; t_msg += t4 - t3
             return msg
