@@ -327,12 +327,12 @@ template <int LANES, int PITCH>
 __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can, int nseg) {
   extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], PITCH each
   const int vc = blockIdx.x, frame = blockIdx.y, seg = blockIdx.z, W = dp.W;
-  const int v = vc * dp.step;
+  const int v = vc * dp.step, nthr = blockDim.x;           // 1024 threads, fewer when a segment has fewer than 256 candidates
   int16_t* out_row = d_can + ((size_t)frame * dp.ch + vc) * dp.cw;
   const int per_seg = (dp.cw + nseg - 1) / nseg, uc_lo = seg * per_seg, uc_hi = min(uc_lo + per_seg, dp.cw);   // candidates [uc_lo, uc_hi)
   const bool row_ok = vc >= 1 && v >= 5 && v <= dp.H - 6;
   if (!row_ok) {                                        // row 0 keeps calloc's zeros, other out-of-range rows are -1
-    for (int uc = uc_lo + threadIdx.x; uc < uc_hi; uc += 1024) out_row[uc] = (vc == 0 || uc == 0) ? 0 : -1;
+    for (int uc = uc_lo + threadIdx.x; uc < uc_hi; uc += nthr) out_row[uc] = (vc == 0 || uc == 0) ? 0 : -1;
     return;
   }
   const uint4* L = desc + (size_t)frame * dp.H * W;
@@ -341,13 +341,13 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
   const int c0 = nseg == 1 ? 0 : max(u_lo - dp.disp_max - 2, 0);                        // window start, both images
   const int c1L = nseg == 1 ? W : min(u_hi + dp.disp_max + 3, W), c1R = nseg == 1 ? W : min(u_hi + 3, W);
   uint4* Lt = rows - c0; uint4* Rt = rows + 2 * PITCH - c0;                             // indexed by image column
-  for (int i = c0 + threadIdx.x; i < c1L; i += 1024) { Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i]; }
-  for (int i = c0 + threadIdx.x; i < c1R; i += 1024) { Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i]; }
+  for (int i = c0 + threadIdx.x; i < c1L; i += nthr) { Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i]; }
+  for (int i = c0 + threadIdx.x; i < c1R; i += nthr) { Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i]; }
   __syncthreads();
   const uint4* Lv = L + (size_t)v * W;                  // row v itself is only read for the texture test
   const uint4* Rv = R + (size_t)v * W;
   const int j = threadIdx.x & (LANES - 1);
-  for (int uc0 = uc_lo; uc0 < uc_hi; uc0 += 1024 / LANES) {
+  for (int uc0 = uc_lo; uc0 < uc_hi; uc0 += nthr / LANES) {
     const int uc = uc0 + (threadIdx.x / LANES);
     const bool active = uc >= 1 && uc < uc_hi;
     const int u = uc * dp.step;
@@ -2485,19 +2485,34 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, c
 }
 template <int PITCH>
 static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can, int nseg) {
-  hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n, nseg), dim3(1024), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can, nseg);
+  const int per_seg = (dp.cw + nseg - 1) / nseg;
+  const int threads = std::min(1024, (per_seg * kSupportLanes + 63) / 64 * 64);           // one pass over the segment's candidates when they fit
+  hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n, nseg), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can, nseg);
+}
+// columns of both images a workgroup stages for one of nseg segments of a lattice row
+static int support_window(const DevParams& dp, int nseg) {
+  return nseg == 1 ? dp.W : ((dp.cw + nseg - 1) / nseg) * dp.step + 2 * dp.disp_max + 8;
+}
+static bool launch_support_bucket(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can, int nseg) {
+  const int win = support_window(dp, nseg);
+  if (win <= 320) launch_support_pitch<320>(st, dp, n, desc, d_can, nseg);
+  else if (win <= 640) launch_support_pitch<640>(st, dp, n, desc, d_can, nseg);
+  else if (win <= 1280) launch_support_pitch<1280>(st, dp, n, desc, d_can, nseg);
+  else if (win <= 2560) launch_support_pitch<2560>(st, dp, n, desc, d_can, nseg);
+  else return false;
+  return true;
 }
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
-  // the LDS row pitch is a template constant (immediate tap offsets): smallest bucket that holds the staged window;
-  // 1280 columns = 80 KB, two workgroups per CU; 2560 = the whole 160 KB
-  if (dp.W <= 320) { launch_support_pitch<320>(st, dp, n, desc, d_can, 1); return; }
-  if (dp.W <= 640) { launch_support_pitch<640>(st, dp, n, desc, d_can, 1); return; }
-  if (dp.W <= 1280) { launch_support_pitch<1280>(st, dp, n, desc, d_can, 1); return; }
+  // The LDS row pitch is a template constant (immediate tap offsets): the smallest bucket that holds the staged window;
+  // 1280 columns = 80 KB, two workgroups per CU; 2560 = the whole 160 KB.  A lattice row may be cut into column segments
+  // (one workgroup each, windows overlap by 2 disp_max): rows wider than 1280 columns need it to fit the 1280 bucket, and
+  // JN_SUPPORT_SPLIT=k forces k segments (smaller workgroups that co-reside more easily with the other slots' kernels).
+  const int split = getenv("JN_SUPPORT_SPLIT") ? atoi(getenv("JN_SUPPORT_SPLIT")) : 0;
+  if (split >= 1 && launch_support_bucket(st, dp, n, desc, d_can, split)) return;
+  if (dp.W <= 1280) { launch_support_bucket(st, dp, n, desc, d_can, 1); return; }
   static const int max_seg = getenv("JN_SUPPORT_SEGMENTS") ? atoi(getenv("JN_SUPPORT_SEGMENTS")) : 8;
-  for (int nseg = 2; nseg <= max_seg; nseg++) {           // wider: cut the lattice rows so that a segment's window fits the 1280 bucket
-    const int per_seg = (dp.cw + nseg - 1) / nseg;
-    if (per_seg * dp.step + 2 * dp.disp_max + 8 <= 1280) { launch_support_pitch<1280>(st, dp, n, desc, d_can, nseg); return; }
-  }
+  for (int nseg = 2; nseg <= max_seg; nseg++)             // wider: cut the lattice rows so that a segment's window fits the 1280 bucket
+    if (support_window(dp, nseg) <= 1280) { launch_support_bucket(st, dp, n, desc, d_can, nseg); return; }
   if (dp.W <= 2560) { launch_support_pitch<2560>(st, dp, n, desc, d_can, 1); return; }
   hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
