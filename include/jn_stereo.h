@@ -105,6 +105,15 @@ jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1
                          int32_t pitch, int64_t image_stride, float* dD1, float* dD2, int32_t* status);
 jn_status jn_elas_wait(jn_elas* h, int32_t slot);
 
+/* jn_elas_submit for HOST buffers (pageable or pinned): n pairs at I + b*image_stride, rows `pitch` bytes apart; D1 / D2
+ * [n][height][width] floats.  The slot's worker copies the images in, runs the batch and copies the maps out before
+ * jn_elas_wait returns, so that with several slots the copies of one batch overlap the kernels of the others — the
+ * streaming form of Elas::process for a caller that has the next frames at hand (the synchronous one-pair drop-in is
+ * jn_elas_process below).  A pair with too few support points leaves its D1 / D2 untouched (elas.cpp:66-71) and has
+ * status JN_ERR_FEW_SUPPORT; the buffers must stay valid until the wait. */
+jn_status jn_elas_submit_host(jn_elas* h, int32_t slot, int32_t n, const uint8_t* I1, const uint8_t* I2,
+                              int32_t pitch, int64_t image_stride, float* D1, float* D2, int32_t* status);
+
 /* Per-stage timings of the last batch on a slot, milliseconds (reference stage names,
  * elas.cpp:54-144 PROFILE labels + JackalTimeLog fields msg/JackalTimeLog.msg:1-4).  The gpu_*, d2h and h2d entries come
  * from timing events between the stages; each costs a few microseconds of idle GPU, so a handle created with max_batch 1

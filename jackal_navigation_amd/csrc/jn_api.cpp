@@ -43,6 +43,8 @@ namespace {
 struct Job {
   int n = 0; const uint8_t* dI1 = nullptr; const uint8_t* dI2 = nullptr; int pitch = 0; int64_t stride = 0;
   float* dD1 = nullptr; float* dD2 = nullptr; int32_t* status = nullptr;
+  // host-pointer form (jn_elas_submit_host): the worker stages the images in and the maps out around the batch
+  bool host = false; const uint8_t* hI1 = nullptr; const uint8_t* hI2 = nullptr; float* hD1 = nullptr; float* hD2 = nullptr;
   // optional tail of the node on the same stream (jn_elas_submit_scan): u8 map + LUT scan of D1
   bool scan = false; jn_scan_params sp = {}; const uint8_t* dLut = nullptr; uint8_t* dDispU8 = nullptr; double* dBins = nullptr; double* dMeta = nullptr;
 };
@@ -58,6 +60,7 @@ struct Slot {
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
   unsigned long long* scan_scratch = nullptr;                 // extrema of the scan tail, 4 per frame
+  uint8_t* st_img = nullptr; float* st_D = nullptr;           // device staging of jn_elas_submit_host: [2][max_batch] images / maps, allocated on first use
   std::vector<FrameScratch> scratch;
   std::vector<HostWorker::SideState> sides;                  // [2 * max_batch]: per frame side, for the phased (parallel) triangulation
   // pinned host
@@ -250,6 +253,44 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   return JN_OK;
 }
 
+// Host pointers: images in (one copy per image when the caller's rows are padded or the images are apart, else one per
+// side), the batch, the maps of the pairs that matched out (elas.cpp:66-71: a pair with too few support points leaves the
+// caller's D1 / D2 untouched).  Runs on the slot's worker thread, so the copies of one slot overlap the kernels of the others.
+jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t px = (size_t)h->W * h->H, B = (size_t)h->max_batch;
+  if (!s.st_img) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.st_img), 2 * B * px));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.st_D), 2 * B * px * sizeof(float)));
+  }
+  hipStream_t st = s.stream;
+  const uint8_t* src[2] = {j.hI1, j.hI2};
+  for (int side = 0; side < 2; side++) {
+    uint8_t* dst = s.st_img + side * B * px;
+    if (j.pitch == h->W && j.stride == (int64_t)px) HIP_TRY(hipMemcpyAsync(dst, src[side], (size_t)j.n * px, hipMemcpyHostToDevice, st));
+    else
+      for (int b = 0; b < j.n; b++)
+        HIP_TRY(hipMemcpy2DAsync(dst + b * px, h->W, src[side] + (size_t)b * j.stride, j.pitch, h->W, h->H, hipMemcpyHostToDevice, st));
+  }
+  std::vector<int32_t> local(j.n, JN_OK);
+  Job d = j;
+  d.host = false; d.dI1 = s.st_img; d.dI2 = s.st_img + B * px; d.pitch = h->W; d.stride = (int64_t)px;
+  d.dD1 = s.st_D; d.dD2 = s.st_D + B * px; d.status = local.data();
+  const jn_status r = run_batch(h, s, d);                 // stream-ordered behind the copies; synchronises at its end
+  if (r != JN_OK) return r;
+  for (int b = 0; b < j.n;) {                             // runs of matched pairs go out together
+    if (local[b] != JN_OK) { b++; continue; }
+    int e = b;
+    while (e < j.n && local[e] == JN_OK) e++;
+    HIP_TRY(hipMemcpyAsync(j.hD1 + b * px, s.st_D + b * px, (size_t)(e - b) * px * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(j.hD2 + b * px, s.st_D + (B + b) * px, (size_t)(e - b) * px * sizeof(float), hipMemcpyDeviceToHost, st));
+    b = e;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (j.status) for (int b = 0; b < j.n; b++) j.status[b] = local[b];
+  return JN_OK;
+}
+
 void slot_loop(jn_elas* h, Slot* s) {
   hipSetDevice(h->device);
   for (;;) {
@@ -260,7 +301,7 @@ void slot_loop(jn_elas* h, Slot* s) {
       if (s->quit) return;
       j = s->job; s->has_job = false;
     }
-    const jn_status r = run_batch(h, *s, j);
+    const jn_status r = j.host ? run_batch_host(h, *s, j) : run_batch(h, *s, j);
     {
       std::lock_guard<std::mutex> l(s->m);
       s->result = r; s->busy = false;
@@ -419,7 +460,7 @@ void jn_elas_destroy(jn_elas* h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
     hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
-    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch);
+    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->st_img); hipFree(s->st_D);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
@@ -440,6 +481,23 @@ jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1
     std::unique_lock<std::mutex> l(s.m);
     s.cv.wait(l, [&] { return !s.busy; });
     s.job = Job{n, dI1, dI2, pitch, image_stride, dD1, dD2, status};
+    s.has_job = true; s.busy = true;
+  }
+  s.cv.notify_all();
+  return JN_OK;
+}
+
+jn_status jn_elas_submit_host(jn_elas* h, int32_t slot, int32_t n, const uint8_t* I1, const uint8_t* I2, int32_t pitch,
+                              int64_t image_stride, float* D1, float* D2, int32_t* status) {
+  if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !I1 || !I2 || !D1 || !D2 || pitch < h->W)
+    return JN_ERR_INVALID;
+  Slot& s = *h->slots[slot];
+  {
+    std::unique_lock<std::mutex> l(s.m);
+    s.cv.wait(l, [&] { return !s.busy; });
+    s.job = Job{};
+    s.job.n = n; s.job.pitch = pitch; s.job.stride = image_stride; s.job.status = status;
+    s.job.host = true; s.job.hI1 = I1; s.job.hI2 = I2; s.job.hD1 = D1; s.job.hD2 = D2;
     s.has_job = true; s.busy = true;
   }
   s.cv.notify_all();

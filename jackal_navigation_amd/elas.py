@@ -80,6 +80,15 @@ class Elas:
     def submit(self, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, status=None):
         _lib.check(self._L.jn_elas_submit(self._h, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, status), "jn_elas_submit")
 
+    def submit_host(self, slot, Ls, Rs, D1, D2, status=None):
+        """jn_elas_submit_host: numpy arrays [n][H][W] (uint8 in, float32 out, C-contiguous) staged by the slot's worker; the
+        arrays must stay alive until wait(slot)."""
+        n, H, W = Ls.shape
+        assert Ls.flags["C_CONTIGUOUS"] and Rs.flags["C_CONTIGUOUS"] and D1.flags["C_CONTIGUOUS"] and D2.flags["C_CONTIGUOUS"]
+        assert Ls.dtype.itemsize == 1 and D1.dtype.itemsize == 4 and D1.shape == Ls.shape == Rs.shape == D2.shape
+        _lib.check(self._L.jn_elas_submit_host(self._h, slot, n, Ls.ctypes.data, Rs.ctypes.data, W, H * W, D1.ctypes.data, D2.ctypes.data, status),
+                   "jn_elas_submit_host")
+
     def submit_scan(self, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, sp, dLut, dDispU8, dBins, dMeta, status=None):
         """submit() plus the node's tail (u8 depth map + LUT obstacle scan of D1) on the same stream."""
         _lib.check(self._L.jn_elas_submit_scan(self._h, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, C.byref(sp), dLut,

@@ -423,3 +423,40 @@ def test_whole_frame_from_jpeg_bytes_to_laser_scan(jn, oracle, same):
     assert np.allclose(bins.numpy()[0], bo, rtol=0, atol=SCAN_TOL) and np.allclose(meta.numpy()[0], mo, rtol=0, atol=SCAN_TOL)
     msg = node.laser_scan_message(bins.numpy()[0], meta.numpy()[0], seq=1)
     assert msg["header"]["frame_id"] == "jackal" and len(msg["ranges"]) == int((bo < 1e9 - 1).sum()) and len(msg["ranges"]) > 30
+
+
+def test_submit_host_streams_host_buffers_through_the_slots(jn, oracle, same):
+    """jn_elas_submit_host: batches of host-resident pairs through three slots at once (copies of one overlap kernels of the
+    others), a padded-pitch single pair, and a batch with a pair that has too few support points (its host maps stay untouched)."""
+    W, H, n = 320, 180, 3
+    rng = np.random.default_rng(2)
+    batches = []
+    for s in range(3):
+        Ls = np.stack([oracle.synth_pair(W, H, 48, 500 + 10 * s + b)[0] for b in range(n)]); Rs = np.stack([oracle.synth_pair(W, H, 48, 500 + 10 * s + b)[1] for b in range(n)])
+        batches.append((Ls, Rs, np.full((n, H, W), 3.0, np.float32), np.full((n, H, W), 3.0, np.float32), (C.c_int32 * n)()))
+    batches[1][0][1] = rng.integers(0, 255, (H, W)); batches[1][1][1] = rng.integers(0, 255, (H, W))        # noise: no support points
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=n, slots=3, host_threads=4) as e:
+        for rep in range(2):
+            for s, (Ls, Rs, D1, D2, st) in enumerate(batches):
+                e.submit_host(s, Ls, Rs, D1, D2, st)
+            for s in range(3):
+                e.wait(s)
+        # a single pair whose rows are padded (pitch > width), through the raw call
+        Lp = np.zeros((H, W + 24), np.uint8); Rp = np.zeros((H, W + 24), np.uint8)
+        Lp[:, :W], Rp[:, :W] = batches[0][0][0], batches[0][1][0]
+        d1 = np.zeros((H, W), np.float32); d2 = np.zeros((H, W), np.float32); st1 = (C.c_int32 * 1)()
+        from jackal_navigation_amd import _lib
+        _lib.check(jn.load().jn_elas_submit_host(e._h, 0, 1, Lp.ctypes.data, Rp.ctypes.data, W + 24, 0, d1.ctypes.data, d2.ctypes.data, st1), "jn_elas_submit_host")
+        e.wait(0)
+    po = oracle.params(0)
+    for s, (Ls, Rs, D1, D2, st) in enumerate(batches):
+        for b in range(n):
+            st_o, D1o, D2o = oracle.process(po, Ls[b], Rs[b])
+            assert st[b] == st_o, (s, b)
+            if st_o == 0:
+                assert same(D1[b], D1o) and same(D2[b], D2o), (s, b)
+            else:
+                assert (D1[b] == 3.0).all() and (D2[b] == 3.0).all()                                        # untouched (elas.cpp:66-71)
+    assert list(batches[1][4]) == [0, 1, 0]
+    _, D1o, D2o = oracle.process(po, batches[0][0][0], batches[0][1][0])
+    assert st1[0] == 0 and same(d1, D1o) and same(d2, D2o)
