@@ -21,12 +21,13 @@
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "../../include/jn_sgm.h"
 
 namespace {
 
-struct SgmDev { int W, H, D, P1, P2, cap, lr, subpixel, Wp, off; };
+struct SgmDev { int W, H, D, P1, P2, cap, lr, subpixel, Wp, off, dbg; };   // dbg: JN_SGM_DBG profiling hook (bit 0: path kernel without its stores — results are then WRONG)
 
 #define DEV static __device__ __forceinline__
 
@@ -89,9 +90,13 @@ __global__ void __launch_bounds__(256) k_sgm_path(SgmDev s, int n, const uint8_t
 
   const size_t gimg = (size_t)H * s.Wp;
   const uint8_t* gl = g + (size_t)frame * gimg + (size_t)y0 * s.Wp + s.off + x0 - 1;                      // left window x-1 .. x+1 (wave-uniform)
-  const uint8_t* gr = g + (size_t)(n + frame) * gimg + (size_t)y0 * s.Wp + s.off + x0 - DPL * lane - DPL; // right bytes of this lane's disparities
+  // right bytes of this lane's disparities: x - DPL*lane - DPL ...; kept as a wave-uniform pointer (at lane 63's bytes) plus
+  // a non-negative per-lane offset, so that the pointer walks on the scalar unit and the loads use base + offset addressing
+  const uint8_t* gr = g + (size_t)(n + frame) * gimg + (size_t)y0 * s.Wp + s.off + x0 - DPL * 63 - DPL;
+  const unsigned roff = (unsigned)(DPL * (63 - lane));
   const long long gstep = (long long)dy * s.Wp + dx;
-  uint8_t* out = Lr + (((size_t)dir * n + frame) * H * W + (size_t)y0 * W + x0) * D + DPL * lane;
+  uint8_t* out = Lr + (((size_t)dir * n + frame) * H * W + (size_t)y0 * W + x0) * D;
+  const unsigned ooff = (unsigned)(DPL * lane);
   const long long ostep = ((long long)dy * W + dx) * D;
 
   const unsigned big = 0xFFFFu;
@@ -100,26 +105,28 @@ __global__ void __launch_bounds__(256) k_sgm_path(SgmDev s, int n, const uint8_t
   for (int j = 0; j < DPL; j++) Lp[j] = 0u;                  // with L = 0 and min = 0 the recurrence yields L = C at the first pixel
   unsigned min_prev = 0u;
   const unsigned P1 = (unsigned)s.P1, P2 = (unsigned)s.P2;
+  // The neighbours across lanes arrive by DPP wave shifts into these two registers; lane 0 of `up` and lane 63 of `dn`
+  // receive nothing and keep the "does not exist" value they start with, so the registers are never re-initialised.
+  unsigned up = big, dn = big;
 
-  // loads run one pixel ahead of the arithmetic
-  uint32_t a_n = load_u32_unaligned(gl), b0_n = load_u32_unaligned(gr), b1_n = DPL == 4 ? load_u32_unaligned(gr + 4) : 0u;
-  for (int i = 0; i < len; i++) {
-    const uint32_t a = a_n & 0x00FFFFFFu, b0 = b0_n, b1 = b1_n;
-    gl += gstep; gr += gstep;
-    if (i + 1 < len) { a_n = load_u32_unaligned(gl); b0_n = load_u32_unaligned(gr); if (DPL == 4) b1_n = load_u32_unaligned(gr + 4); }
+  // One pixel of the line: costs from the loaded bytes (the SAD's accumulator operand carries -min, so C - min costs nothing),
+  // the recurrence, the minimum over d, the store.
+  auto pixel = [&](uint32_t a_raw, uint32_t b0, uint32_t b1) {
+    const uint32_t a = a_raw & 0x00FFFFFFu;
+    const unsigned nm = 0u - min_prev;
     // 1x3 SAD of the prefiltered rows: disparity DPL*lane + j matches right bytes [DPL-1-j, DPL+1-j] of the loaded run
     unsigned C[DPL];
-    if (DPL == 1) C[0] = __builtin_amdgcn_sad_u8(a, b0 & 0x00FFFFFFu, 0u);
-    if (DPL == 2) { C[0] = __builtin_amdgcn_sad_u8(a, b0 >> 8, 0u); C[1] = __builtin_amdgcn_sad_u8(a, b0 & 0x00FFFFFFu, 0u); }
+    if (DPL == 1) C[0] = __builtin_amdgcn_sad_u8(a, b0 & 0x00FFFFFFu, nm);
+    if (DPL == 2) { C[0] = __builtin_amdgcn_sad_u8(a, b0 >> 8, nm); C[1] = __builtin_amdgcn_sad_u8(a, b0 & 0x00FFFFFFu, nm); }
     if (DPL == 4) {
-      C[3] = __builtin_amdgcn_sad_u8(a, b0 & 0x00FFFFFFu, 0u);
-      C[2] = __builtin_amdgcn_sad_u8(a, b0 >> 8, 0u);
-      C[1] = __builtin_amdgcn_sad_u8(a, __builtin_amdgcn_alignbit(b1, b0, 16) & 0x00FFFFFFu, 0u);
-      C[0] = __builtin_amdgcn_sad_u8(a, __builtin_amdgcn_alignbit(b1, b0, 24) & 0x00FFFFFFu, 0u);
+      C[3] = __builtin_amdgcn_sad_u8(a, b0 & 0x00FFFFFFu, nm);
+      C[2] = __builtin_amdgcn_sad_u8(a, b0 >> 8, nm);
+      C[1] = __builtin_amdgcn_sad_u8(a, __builtin_amdgcn_alignbit(b1, b0, 16) & 0x00FFFFFFu, nm);
+      C[0] = __builtin_amdgcn_sad_u8(a, __builtin_amdgcn_alignbit(b1, b0, 24) & 0x00FFFFFFu, nm);
     }
     // neighbours in d across lanes: d-1 of this lane's first disparity, d+1 of its last
-    const unsigned up = (unsigned)__builtin_amdgcn_update_dpp((int)big, (int)Lp[DPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
-    const unsigned dn = (unsigned)__builtin_amdgcn_update_dpp((int)big, (int)Lp[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
+    up = (unsigned)__builtin_amdgcn_update_dpp((int)up, (int)Lp[DPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+    dn = (unsigned)__builtin_amdgcn_update_dpp((int)dn, (int)Lp[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
     const unsigned far = min_prev + P2;
     unsigned Ln[DPL];
     unsigned mn = 0xFFFFFFFFu;
@@ -127,17 +134,35 @@ __global__ void __launch_bounds__(256) k_sgm_path(SgmDev s, int n, const uint8_t
     for (int j = 0; j < DPL; j++) {
       const unsigned lo = j == 0 ? up : Lp[j - 1], hi = j == DPL - 1 ? dn : Lp[j + 1];
       const unsigned m = min(min(Lp[j], min(lo, hi) + P1), far);
-      Ln[j] = C[j] + m - min_prev;
+      Ln[j] = C[j] + m;                                      // C already holds cost - min_prev
       mn = min(mn, Ln[j]);
     }
     min_prev = wave_min(mn);
-    if (DPL == 1) *out = (uint8_t)Ln[0];
-    if (DPL == 2) { const uint16_t v = (uint16_t)(Ln[0] | (Ln[1] << 8)); __builtin_memcpy(out, &v, 2); }
-    if (DPL == 4) { const uint32_t v = Ln[0] | (Ln[1] << 8) | (Ln[2] << 16) | (Ln[3] << 24); __builtin_memcpy(out, &v, 4); }
+    if (s.dbg & 1) { if (Ln[0] == 0xFFFFFFF0u) out[ooff] = 1; }            // profiling: keep the arithmetic alive, never store
+    else if (DPL == 1) out[ooff] = (uint8_t)Ln[0];
+    else if (DPL == 2) { const uint16_t v = (uint16_t)(Ln[0] | (Ln[1] << 8)); __builtin_memcpy(out + ooff, &v, 2); }
+    else if (DPL == 4) { const uint32_t v = Ln[0] | (Ln[1] << 8) | (Ln[2] << 16) | (Ln[3] << 24); __builtin_memcpy(out + ooff, &v, 4); }
     out += ostep;
 #pragma unroll
     for (int j = 0; j < DPL; j++) Lp[j] = Ln[j];
+  };
+  auto load = [&](uint32_t& a, uint32_t& b0, uint32_t& b1) {
+    a = load_u32_unaligned(gl); b0 = load_u32_unaligned(gr + roff); b1 = DPL == 4 ? load_u32_unaligned(gr + roff + 4) : 0u;
+    gl += gstep; gr += gstep;
+  };
+
+  // loads run one pixel ahead of the arithmetic; two pixels per turn so that the two sets of load registers swap roles
+  // instead of being copied
+  uint32_t a0 = 0, b00 = 0, b01 = 0, a1 = 0, b10 = 0, b11 = 0;
+  load(a0, b00, b01);
+  int i = 0;
+  for (; i + 2 <= len; i += 2) {
+    load(a1, b10, b11);                                      // pixel i + 1 exists
+    pixel(a0, b00, b01);
+    if (i + 2 < len) load(a0, b00, b01);
+    pixel(a1, b10, b11);
   }
+  if (i < len) pixel(a0, b00, b01);
 }
 
 // ---- sum of the eight volumes, winner-takes-all for both images, L/R check, sub-pixel: one workgroup per image row ----
@@ -283,6 +308,7 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
   SgmDev& s = h->dev;
   s.W = W; s.H = H; s.D = D; s.P1 = p->P1; s.P2 = p->P2; s.cap = p->prefilter_cap; s.lr = p->lr_max_diff; s.subpixel = p->subpixel ? 1 : 0;
   s.off = D + 8; s.Wp = s.off + W + 8;
+  s.dbg = getenv("JN_SGM_DBG") ? atoi(getenv("JN_SGM_DBG")) : 0;
 #define SGM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_sgm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
   SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
   SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->Lr), (size_t)8 * max_batch * H * W * D));
