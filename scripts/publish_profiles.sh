@@ -17,5 +17,7 @@ cp $g/${tag}_sgm_bench_line.json $p/${tag}_sgm_bench_line.json
 cp $(ls $g/${tag}_bm/*/*kernel_stats.csv | head -1) $p/${tag}_bm_kernel_stats.csv
 cp $g/${tag}_bm_bench_line.json $g/${tag}_bm_config2_bench_line.json $p/
 [ -s $g/${tag}_other_configs.jsonl ] && cp $g/${tag}_other_configs.jsonl $p/
+for f in qsad_probe node_rate host_pointer_rate latency_check lone_timeline sgm_dbg support_split_ab; do [ -s $g/${tag}_$f.txt ] && cp $g/${tag}_$f.txt $p/; done   # scripts/extra_evidence.sh
+[ -s $g/${tag}_parity_sweep.txt ] && grep -v "Opened result" $g/${tag}_parity_sweep.txt > $p/r02_parity_sweep.txt
 python3 $root/scripts/make_pmc_json.py $tag $p/r02_pmc_traffic.json
 ls -la $p | grep ${tag}
