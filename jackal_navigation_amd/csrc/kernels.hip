@@ -2050,6 +2050,19 @@ __global__ void __launch_bounds__(256) k_adaptive_mean_v(DevParams dp, const Fra
 // below a row band likewise.  Applies for gap widths <= 3 without add_corners; other settings keep the separate kernels.
 enum { kPostCols = 240, kPostHaloL = 8 };
 DEV float gap_value(float d1, float d2) { return fabsf(d1 - d2) < 3.0f ? __fadd_rn(d1, d2) / 2 : fminf(d1, d2); }   // :1149-1150
+// One pixel of a gap pass for gap widths <= 3, without branches: c is kept when valid; otherwise the first valid neighbour
+// among b1, b2, b3 (before: left / up, at most gw away) and the first valid one among a1, a2, a3 (after) within what the gap
+// width leaves (run length = steps before + steps after - 1 <= gw, :1137-1139) interpolate it.
+DEV float gap_fill3(int gw, float c, float b1, float b2, float b3, float a1, float a2, float a3) {
+  const bool p1 = gw >= 1 && b1 >= 0, p2 = gw >= 2 && b2 >= 0, p3 = gw >= 3 && b3 >= 0;
+  const int steps = p1 ? 1 : (p2 ? 2 : 3);
+  const float d1 = p1 ? b1 : (p2 ? b2 : b3);
+  const int reach = gw - steps + 1;
+  const bool q1 = a1 >= 0, q2 = reach >= 2 && a2 >= 0, q3 = reach >= 3 && a3 >= 0;
+  const float d2 = q1 ? a1 : (q2 ? a2 : a3);
+  const bool fill = !(c >= 0) && (p1 || p2 || p3) && (q1 || q2 || q3);
+  return fill ? gap_value(d1, d2) : c;
+}
 // mean of the eight taps if it forms (sum of weights > 0, quotient >= 0), else `keep`; branch-free apart from the
 // wave-uniform shortcut: in smooth regions all eight taps carry the full weight 4 in every lane of the wave, the divisor
 // is exactly 32 and the IEEE quotient is the exact product with 1/32 (no 10-instruction division sequence)
@@ -2063,10 +2076,11 @@ DEV float am_select(const float (&pw)[4], const float (&pf)[4], bool enabled, fl
 }
 __global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
                                                         float* __restrict__ out, int rows_per_band, int do_mean) {
-  __shared__ float s_row[2][256], s_g2[2][256];
+  __shared__ float s_row[2][256 + 8], s_g2[2][256];            // s_row: 4 cells of "invalid" on either side, so the gap search reads without bounds tests
   const int frame = blockIdx.z;
   if (!info[frame].ok) return;
   const int W = dp.W, H = dp.H, gw = dp.gap_width, t = threadIdx.x;
+  if (t < 8) { s_row[0][t < 4 ? t : 256 + t] = -10.0f; s_row[1][t < 4 ? t : 256 + t] = -10.0f; }
   const int u = blockIdx.x * kPostCols - kPostHaloL + t;
   const int r0 = blockIdx.y * rows_per_band, r1 = min(r0 + rows_per_band, H);
   const bool col_in = u >= 0 && u < W;
@@ -2090,39 +2104,15 @@ __global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const Fram
       const int y = yb + ph;                                   // y & 7 == ph
       const float x = x_next;
       { const int yn = y + 1; x_next = (col_in && yn >= 0 && yn < H) ? I[(size_t)yn * W + u] : -10.0f; }
-      float* sr = s_row[ph & 1]; float* sg = s_g2[ph & 1];
+      float* sr = s_row[ph & 1] + 4; float* sg = s_g2[ph & 1];
       sr[t] = x;
       sg[t] = g2[(ph + 4) & 7];                                // G2 of row y - 4 (computed in the previous step)
       __syncthreads();
       // ---- G1(y): gap fill along the row (elas.cpp:1122-1166) ----
-      float v1 = x;
-      if (!(x >= 0)) {
-        int a = 0, b = 0;
-        for (int k = 1; k <= gw; k++) if (t - k >= 0 && sr[t - k] >= 0) { a = k; break; }
-        if (a) {
-          for (int k = 1; k <= gw - a + 1; k++) if (t + k < 256 && sr[t + k] >= 0) { b = k; break; }
-          if (b) v1 = gap_value(sr[t - a], sr[t + b]);
-        }
-      }
-      g1[ph] = v1;
+      // Branch-free (gw <= 3): nearest valid pixel within gw to the left, then within what is left of gw to the right.
+      g1[ph] = gap_fill3(gw, x, sr[t - 1], sr[t - 2], sr[t - 3], sr[t + 1], sr[t + 2], sr[t + 3]);
       // ---- G2(y - 3): gap fill along the column (:1204-1247) on the ring of G1 ----
-      {
-        const float c = g1[(ph + 5) & 7];
-        float v2 = c;
-        if (!(c >= 0)) {
-          const float up1 = g1[(ph + 4) & 7], up2 = g1[(ph + 3) & 7], up3 = g1[(ph + 2) & 7];
-          const float dn1 = g1[(ph + 6) & 7], dn2 = g1[(ph + 7) & 7], dn3 = g1[ph];
-          int a = 0; float d1 = 0;
-          if (gw >= 1 && up1 >= 0) { a = 1; d1 = up1; } else if (gw >= 2 && up2 >= 0) { a = 2; d1 = up2; } else if (gw >= 3 && up3 >= 0) { a = 3; d1 = up3; }
-          if (a) {
-            const int reach = gw - a + 1;
-            int b = 0; float d2 = 0;
-            if (dn1 >= 0) { b = 1; d2 = dn1; } else if (reach >= 2 && dn2 >= 0) { b = 2; d2 = dn2; } else if (reach >= 3 && dn3 >= 0) { b = 3; d2 = dn3; }
-            if (b) v2 = gap_value(d1, d2);
-          }
-        }
-        g2[(ph + 5) & 7] = v2;
-      }
+      g2[(ph + 5) & 7] = gap_fill3(gw, g1[(ph + 5) & 7], g1[(ph + 4) & 7], g1[(ph + 3) & 7], g1[(ph + 2) & 7], g1[(ph + 6) & 7], g1[(ph + 7) & 7], g1[ph]);
       // ---- T(y - 4): horizontal mean (:1394-1433) of the G2 row in LDS ----
       {
         const int yt = y - 4;
