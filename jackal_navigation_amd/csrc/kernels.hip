@@ -975,18 +975,17 @@ DEV bool bin_entry(const DevParams& dp, const TriRec& q, int t, int u0, int v0, 
     if (u0 + wd * 4 + 3 >= c0 && u0 + wd * 4 <= c1)        // most of a tile's columns lie outside a ~10 px wide triangle
 #pragma unroll
     for (int b = 0; b < 4; b++) {
+      // straight-line per column: which edge bounds it (part 1 [Au,Bu): AB, :875-876; part 2 [Bu,Cu): BC, :890-891), the two
+      // truncated line values (:878-879 / :893-894), their rows inside the tile as a mask (empty when the column is outside)
       const int uc = u0 + wd * 4 + b;
-      float ea = 0, eb = 0; bool in = false;
-      if (uc < Bu) { if (Au != Bu && uc >= Au) { in = true; ea = q.ABa; eb = q.ABb; } }       // :875-876
-      else         { if (Bu != Cu && uc < Cu)  { in = true; ea = q.BCa; eb = q.BCb; } }       // :890-891
-      uint32_t m = 0;
-      if (in && uc < dp.W) {
-        const float fu = (float)uc;
-        const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(q.ACa, fu), q.ACb);                 // :878 / :893
-        const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);                       // :879 / :894
-        const int lo = max(min(v1, v2) - v0, 0), hi = min(max(v1, v2) - v0, kTileH);         // rows [lo,hi) of this tile
-        if (hi > lo) m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-      }
+      const bool first = uc < Bu;
+      const bool in = (first ? (Au != Bu && uc >= Au) : (Bu != Cu && uc < Cu)) && uc < dp.W;
+      const float ea = first ? q.ABa : q.BCa, eb = first ? q.ABb : q.BCb;
+      const float fu = (float)uc;
+      const int v1 = (int)(unsigned)__fadd_rn(__fmul_rn(q.ACa, fu), q.ACb);
+      const int v2 = (int)(unsigned)__fadd_rn(__fmul_rn(ea, fu), eb);
+      const int lo = min(max(min(v1, v2) - v0, 0), kTileH), hi = max(min(max(v1, v2) - v0, kTileH), lo);   // rows [lo,hi) of this tile
+      const uint32_t m = in ? (((1u << hi) - 1u) & ~((1u << lo) - 1u)) : 0u;
       packed |= m << (8 * b);
     }
     e.rows[wd] = packed; any |= packed;
