@@ -364,6 +364,55 @@ def run_sgm(a):
         raise SystemExit("bench.py: the %s disparity map differs from its golden hash: %s" % (a.mode, check))
 
 
+def thread_cpu_seconds():
+    """user + system seconds of every thread of this process, keyed by the thread's name (/proc/self/task/*/comm; the library names
+    its threads jn-pool and jn-slot)."""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                name = open("/proc/self/task/%s/comm" % tid).read().strip()
+                f = open("/proc/self/task/%s/stat" % tid).read().rsplit(")", 1)[1].split()
+                out.setdefault(name, [0.0, 0])
+                out[name][0] += (int(f[11]) + int(f[12])) / tick
+                out[name][1] += 1
+            except OSError:
+                pass
+    except OSError:
+        pass
+    return out
+
+
+def cgroup_cpu_stat():
+    try:
+        d = {l.split()[0]: int(l.split()[1]) for l in open("/sys/fs/cgroup/cpu.stat")}
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        d["quota_cpus"] = None if q[0] == "max" else int(q[0]) / int(q[1])
+        return d
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def host_cpu_report(cpu0, cg0, wall):
+    """Host cores the timed regions used, by thread role, next to the container's CPU quota (cgroup v2 cpu.max) and how often the
+    kernel throttled the container meanwhile — the host stage (Delaunay) is the path's CPU consumer."""
+    cpu1, cg1 = thread_cpu_seconds(), cgroup_cpu_stat()
+    roles = {}
+    for name, (sec, cnt) in cpu1.items():
+        d = sec - cpu0.get(name, [0.0, 0])[0]
+        if d > 0.005 * wall:
+            roles[name] = {"threads": cnt, "cores": round(d / wall, 2)}
+    rep = {"wall_s": round(wall, 3), "cores_by_thread_name": dict(sorted(roles.items(), key=lambda kv: -kv[1]["cores"])),
+           "cores_total": round(sum(v["cores"] for v in roles.values()), 2)}
+    if cg0 and cg1:
+        rep["cgroup"] = {"quota_cpus": cg1.get("quota_cpus"), "cores_used": round((cg1["usage_usec"] - cg0["usage_usec"]) / 1e6 / wall, 2),
+                         "periods": cg1.get("nr_periods", 0) - cg0.get("nr_periods", 0),
+                         "periods_throttled": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
+                         "throttled_thread_seconds": round((cg1.get("throttled_usec", 0) - cg0.get("throttled_usec", 0)) / 1e6, 3)}
+    return rep
+
+
 def run_rank(a):
     if a.mode in ("sgm", "bm"):
         return run_sgm(a)
@@ -513,10 +562,12 @@ def run_rank(a):
     sync()
     stage_acc.clear()
     del dense_ms[:]
+    cpu0, cg0, t_cpu0 = thread_cpu_seconds(), cgroup_cpu_stat(), time.perf_counter()
     regions = [timed_region()]                    # identical on every rank (max-reduced), so the repeat count agrees
     repeats = max(1, min(200, int(math.ceil(a.min_time / max(regions[0], 1e-6)))))
     for _ in range(repeats - 1):
         regions.append(timed_region())
+    host_cpu = host_cpu_report(cpu0, cg0, time.perf_counter() - t_cpu0)
     elapsed = float(np.median(regions))
 
     failed = sum(1 for s in status for x in s if x != 0)
@@ -650,6 +701,7 @@ def run_rank(a):
             "cpu_baseline": cpu,
             "check": check,
             "latency_config": extra,
+            "host_cpu": host_cpu,
         }
         if ranks_info is not None:
             out["ranks"] = ranks_info

@@ -27,6 +27,9 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sys/prctl.h>
+
 using namespace jnav;
 
 #define HIP_TRY(expr)                                                                       \
@@ -108,6 +111,24 @@ namespace {
 // value; it only takes effect if the HIP runtime has not initialised yet (load this library first, or export it).
 __attribute__((constructor)) void prefer_one_queue_per_slot() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
+// Waiting for the GPU without burning the host's cores.  hipEventSynchronize spins on this runtime even for events created
+// with hipEventBlockingSync: the four slot workers then cost 2.5 cores of pure waiting (measured: 4.2 ms of CPU per 32-pair
+// batch), and on the GPU boxes the container's CPU quota (16 CPUs) is what the Delaunay pool needs.  So: poll the event —
+// tightly for the first ~60 us (a lone pair's stages end within that; latency mode keeps its latency), then between short
+// sleeps (a batch's stage lasts milliseconds; the other slots keep the GPU busy meanwhile).
+hipError_t wait_event(hipEvent_t ev) {
+  static const int spin_us = getenv("JN_WAIT_SPIN_US") ? atoi(getenv("JN_WAIT_SPIN_US")) : 60;     // < 0: plain hipEventSynchronize
+  if (spin_us < 0) return hipEventSynchronize(ev);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (waited < std::chrono::microseconds(spin_us)) { __builtin_ia32_pause(); continue; }
+    std::this_thread::sleep_for(std::chrono::microseconds(waited < std::chrono::microseconds(500) ? 20 : 50));
+  }
+}
+
 jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const DevParams& dp = h->dp;
   const int n = j.n;
@@ -133,7 +154,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipEventRecord(s.ev[EV_D2H], st));
-  HIP_TRY(hipEventSynchronize(s.ev[EV_D2H]));
+  HIP_TRY(wait_event(s.ev[EV_D2H]));
 
   auto t_host0 = std::chrono::steady_clock::now();
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
@@ -237,7 +258,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
     launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
-  HIP_TRY(hipEventSynchronize(s.ev[EV_END]));
+  HIP_TRY(wait_event(s.ev[EV_END]));
   HIP_TRY(hipGetLastError());
   auto t_end = std::chrono::steady_clock::now();
 
@@ -286,12 +307,15 @@ jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipMemcpyAsync(j.hD2 + b * px, s.st_D + (B + b) * px, (size_t)(e - b) * px * sizeof(float), hipMemcpyDeviceToHost, st));
     b = e;
   }
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(s.ev[EV_END], st));
+  HIP_TRY(wait_event(s.ev[EV_END]));
   if (j.status) for (int b = 0; b < j.n; b++) j.status[b] = local[b];
   return JN_OK;
 }
 
 void slot_loop(jn_elas* h, Slot* s) {
+  pthread_setname_np(pthread_self(), "jn-slot");
+  prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);                 // the short sleeps of wait_event mean what they say (default slack: 50 us)
   hipSetDevice(h->device);
   for (;;) {
     Job j;

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <pthread.h>
 #include "host_stage.h"
 
 namespace jnav {
@@ -43,6 +44,7 @@ class Pool {
   struct Group { const std::function<void(HostWorker&, int)>* fn; int left; std::mutex m; std::condition_variable cv; };
   struct Item { Group* g; int i; };
   void loop(int id) {
+    pthread_setname_np(pthread_self(), "jn-pool");          // visible in /proc/<pid>/task/*/comm: CPU accounting per role
     for (;;) {
       Item it;
       {
