@@ -73,7 +73,8 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  * buffers for up to `max_batch` WxH pairs per pipeline slot are allocated once.
  *   device        HIP device ordinal
  *   host_threads  worker threads for the host stage (support-point filters, Delaunay, planes,
- *                 grid prior); 0 = one per online core
+ *                 grid prior); 0 = one per CPU the process may use (affinity mask, cut down to the container's
+ *                 cgroup CPU quota)
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
  * Unsupported (JN_ERR_UNSUPPORTED): subsampling, disp_max > 255 or < 10, disp_min != 0,
  * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported; with add_corners

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include <pthread.h>
+#include <sched.h>
 #include <sys/prctl.h>
 
 using namespace jnav;
@@ -94,6 +95,7 @@ struct jn_elas {
   // batch exceeds the pool size, "1" = always host, "0" = always device.  The host also takes over when no kernel can
   // take the lattice.
   int filter_min_batch = 4;
+  int wait_spin_us = 60;            // JN_WAIT_SPIN_US; 1000 for max_batch == 1 (see wait_event)
   bool stage_events = true;         // JN_STAGE_EVENTS: default on, off for max_batch == 1 (see run_batch)
   bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
@@ -114,10 +116,10 @@ __attribute__((constructor)) void prefer_one_queue_per_slot() { setenv("GPU_MAX_
 // Waiting for the GPU without burning the host's cores.  hipEventSynchronize spins on this runtime even for events created
 // with hipEventBlockingSync: the four slot workers then cost 2.5 cores of pure waiting (measured: 4.2 ms of CPU per 32-pair
 // batch), and on the GPU boxes the container's CPU quota (16 CPUs) is what the Delaunay pool needs.  So: poll the event —
-// tightly for the first ~60 us (a lone pair's stages end within that; latency mode keeps its latency), then between short
-// sleeps (a batch's stage lasts milliseconds; the other slots keep the GPU busy meanwhile).
-hipError_t wait_event(hipEvent_t ev) {
-  static const int spin_us = getenv("JN_WAIT_SPIN_US") ? atoi(getenv("JN_WAIT_SPIN_US")) : 60;     // < 0: plain hipEventSynchronize
+// tightly for the first 60 us, then between short sleeps (a batch's stage lasts milliseconds; the other slots keep the GPU
+// busy meanwhile).  A latency-mode handle (max_batch 1) polls tightly for 1 ms: its stages are short and a sleep's wake-up
+// would show in every call.  JN_WAIT_SPIN_US overrides (-1: plain hipEventSynchronize).
+hipError_t wait_event(hipEvent_t ev, int spin_us) {
   if (spin_us < 0) return hipEventSynchronize(ev);
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
@@ -127,6 +129,20 @@ hipError_t wait_event(hipEvent_t ev) {
     if (waited < std::chrono::microseconds(spin_us)) { __builtin_ia32_pause(); continue; }
     std::this_thread::sleep_for(std::chrono::microseconds(waited < std::chrono::microseconds(500) ? 20 : 50));
   }
+}
+
+// CPUs this process may really use: its affinity mask, cut down to the container's CPU quota (cgroup v2 cpu.max) — a pool
+// sized by the machine's core count inside a container with a smaller quota gets the whole container throttled.
+int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0;
+    if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) n = std::min<long long>(n, std::max<long long>(1, quota / period));
+    fclose(f);
+  }
+  return n;
 }
 
 jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
@@ -154,7 +170,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipEventRecord(s.ev[EV_D2H], st));
-  HIP_TRY(wait_event(s.ev[EV_D2H]));
+  HIP_TRY(wait_event(s.ev[EV_D2H], h->wait_spin_us));
 
   auto t_host0 = std::chrono::steady_clock::now();
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
@@ -258,7 +274,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
     launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
-  HIP_TRY(wait_event(s.ev[EV_END]));
+  HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   HIP_TRY(hipGetLastError());
   auto t_end = std::chrono::steady_clock::now();
 
@@ -308,7 +324,7 @@ jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
     b = e;
   }
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
-  HIP_TRY(wait_event(s.ev[EV_END]));
+  HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   if (j.status) for (int b = 0; b < j.n; b++) j.status[b] = local[b];
   return JN_OK;
 }
@@ -426,7 +442,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->payload_cap = (HostWorker::payload_capacity(hp) + 255) / 256 * 256;
   h->tri_cap = 2 * (dp.cw * dp.ch + HostWorker::kCornerPoints) + 8;
 
-  int nthreads = host_threads > 0 ? host_threads : (int)std::thread::hardware_concurrency();
+  int nthreads = host_threads > 0 ? host_threads : usable_cpus();
   if (nthreads < 1) nthreads = 1;
   nthreads = std::min(nthreads, std::max(1, 8 * max_batch * slots));   // up to 2 sides x 4 parts per frame can run at once
   h->pool.reset(new Pool(nthreads, hp));
@@ -435,6 +451,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
   h->stage_events = max_batch > 1;
+  h->wait_spin_us = max_batch > 1 ? 60 : 1000;
+  if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
   if (const char* e = getenv("JN_STAGE_EVENTS")) h->stage_events = atoi(e) != 0;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
