@@ -2493,16 +2493,18 @@ static bool launch_support_bucket(hipStream_t st, const DevParams& dp, int n, co
 }
 void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
   // The LDS row pitch is a template constant (immediate tap offsets): the smallest bucket that holds the staged window;
-  // 1280 columns = 80 KB, two workgroups per CU; 2560 = the whole 160 KB.  A lattice row may be cut into column segments
-  // (one workgroup each, windows overlap by 2 disp_max): rows wider than 1280 columns need it to fit the 1280 bucket, and
-  // JN_SUPPORT_SPLIT=k forces k segments (smaller workgroups that co-reside more easily with the other slots' kernels).
+  // 1280 columns = 80 KB, 2560 = the whole 160 KB.  A lattice row is cut into column segments, one workgroup each (windows
+  // overlap by 2 disp_max): segments of 64 candidates (256 threads, a 320 / 640-column bucket) while the overlap stays below
+  // the segment itself, else of 128.  Alone, one workgroup per row is a little quicker (it stages every descriptor once);
+  // among the other slots' kernels the small workgroups find room at once instead of queueing for 80 KB of LDS, and the
+  // pipelined rate gains 1.5 % (profiles/r02_d_support_split_ab.txt).  JN_SUPPORT_SPLIT=k forces k segments (1 = one per row).
   const int split = getenv("JN_SUPPORT_SPLIT") ? atoi(getenv("JN_SUPPORT_SPLIT")) : 0;
   if (split >= 1 && launch_support_bucket(st, dp, n, desc, d_can, split)) return;
-  if (dp.W <= 1280) { launch_support_bucket(st, dp, n, desc, d_can, 1); return; }
+  const int per = 2 * dp.disp_max + 8 <= 64 * dp.step ? 64 : 128;
   static const int max_seg = getenv("JN_SUPPORT_SEGMENTS") ? atoi(getenv("JN_SUPPORT_SEGMENTS")) : 8;
-  for (int nseg = 2; nseg <= max_seg; nseg++)             // wider: cut the lattice rows so that a segment's window fits the 1280 bucket
-    if (support_window(dp, nseg) <= 1280) { launch_support_bucket(st, dp, n, desc, d_can, nseg); return; }
-  if (dp.W <= 2560) { launch_support_pitch<2560>(st, dp, n, desc, d_can, 1); return; }
+  for (int nseg = std::min(std::max(1, (dp.cw + per - 1) / per), std::max(1, max_seg)); nseg <= std::max(1, max_seg); nseg++)
+    if (launch_support_bucket(st, dp, n, desc, d_can, nseg)) return;       // more segments until the window fits a bucket
+  if (launch_support_bucket(st, dp, n, desc, d_can, 1)) return;
   hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
 }
 // classify + resolve applies when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
