@@ -323,6 +323,14 @@ typedef struct jn_host_frame_info {
 int64_t jn_host_stage(const jn_elas_params* p, int32_t width, int32_t height, int16_t* d_can, uint8_t* payload,
                       int64_t payload_cap, jn_host_frame_info* info);
 
+/* The alternating-cut arrangement the triangulation starts from (triangle.cpp:5514-5606, :6197-6206): on the host (what
+ * jn_host_triangulate uses; returns 1, or 0 when vertices coincide and Triangle's own sort has to be replayed) and on the GPU
+ * from a support list of (uc, vc, d) triples with coordinates x = uc*step (left) / uc*step - d (right), y = vc*step
+ * (kernels.hip k_arrange; ok[side] = 0 when the side is left to the host).  Exposed so that the two can be compared. */
+int32_t jn_host_arrangement(const int32_t* x, const int32_t* y, int32_t n, uint16_t* out);
+jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t n, int32_t step, uint16_t* left, uint16_t* right,
+                                int32_t ok[2]);
+
 /* The GPU's support filters on their own (elas.cpp:416-422 on n candidate lattices [n][ch][cw], host memory, filtered in
  * place), exposed so that the kernels can be verified on arbitrary lattices.  form: 0 = whatever jn_elas would use,
  * 1 = skewed wavefront, 2 = classification + resolution.  Returns JN_ERR_UNSUPPORTED when no kernel takes the lattice

@@ -416,6 +416,42 @@ int Delaunay::finish(int32_t* tri) {
   return out;
 }
 
+int Delaunay::run_arranged(const int32_t* x, const int32_t* y, int n, const uint16_t* arrangement, int32_t* tri) {
+  nparts_ = 0; k_ = 0;
+  if (n < 3) return -1;
+  x_ = x; y_ = y; lcg_ = 1;
+  const size_t cap = (size_t)8 * n + 64;
+  if (link_.size() < 4 * cap) { link_.resize(4 * cap); vert_.resize(4 * cap); }
+  if (order_.size() < (size_t)n) { order_.resize(n); by_y_.resize(n); tmp_.resize(n); left_.resize(n); }
+  for (int i = 0; i < n; i++) order_[i] = arrangement[i];
+  k_ = n;
+  part_[0] = Part{0, n, 0, 0, 0, 0, 0};
+  nparts_ = 1;
+  Ctx c{0};
+  conquer(order_.data(), n, 0, part_[0].farleft, part_[0].farright, c);
+  part_[0].used = c.next;
+  return finish(tri);
+}
+
+bool Delaunay::arrangement(const int32_t* x, const int32_t* y, int n, uint16_t* out) {
+  if (n < 3 || n > 65535) return false;
+  x_ = x; y_ = y; lcg_ = 1;
+  if (order_.size() < (size_t)n) { order_.resize(n); by_y_.resize(n); tmp_.resize(n); left_.resize(n); }
+  int32_t* a = order_.data();
+  if (!sort_distinct(a, n)) {                       // sparse keys or coinciding vertices: the reference's sort, then its duplicate removal
+    for (int i = 0; i < n; i++) a[i] = i;
+    quicksort(a, n);
+    int k = 0;
+    for (int j = 1; j < n; j++)
+      if (x[a[k]] != x[a[j]] || y[a[k]] != y[a[j]]) a[++k] = a[j];
+    if (k + 1 != n) return false;
+  }
+  arrange(a, n);
+  split(0, n, 0);
+  for (int i = 0; i < n; i++) out[i] = (uint16_t)order_[i];
+  return true;
+}
+
 int Delaunay::run(const int32_t* x, const int32_t* y, int n, int32_t* tri) {
   if (prepare(x, y, n, 1) == 0) return -1;
   subtree(0);

@@ -20,6 +20,12 @@ class Delaunay {
   // every triangle, in Triangle's output order, to tri (capacity 3*2*n ints).  Returns the number
   // of triangles, or -1 when fewer than 2 distinct points exist.
   int run(const int32_t* x, const int32_t* y, int n, int32_t* tri);
+  // The same when the alternating-cut arrangement of the n DISTINCT vertices is already known (the GPU computes it from the
+  // support list, kernels.hip k_arrange): arrangement[i] = vertex at position i of what arrange() + split() would leave in
+  // order_.  Only the hull recursion runs.
+  int run_arranged(const int32_t* x, const int32_t* y, int n, const uint16_t* arrangement, int32_t* tri);
+  // The arrangement run() would use (test hook): returns false when vertices coincide (run() then replays Triangle's sort).
+  bool arrangement(const int32_t* x, const int32_t* y, int n, uint16_t* out);
 
   // The same in three phases, for a caller with idle threads (a lone pair, a small batch of large frames):
   //   prepare()   serial: sort, duplicate removal, the first one or two alternating cuts -> 1, 2 or 4 independent parts

@@ -196,14 +196,14 @@ static void write_support(uint8_t* payload, const FrameInfo* info, const std::ve
   for (int i = 0; i < info->nsup; i++) { uvd[3 * i] = u[i]; uvd[3 * i + 1] = v[i]; uvd[3 * i + 2] = d[i]; }
 }
 
-void HostWorker::triangulate_side_from_list(int side, const int16_t* t, uint8_t* payload, FrameInfo* info) {
+void HostWorker::triangulate_side_from_list(int side, const int16_t* t, uint8_t* payload, FrameInfo* info, const uint16_t* arrangement) {
   if (!info->ok) return;
   const int n = info->nsup;
   points_from_list(hp_, t, n, xs_, ys_, ds_);
   if (side == 0) write_support(payload, info, xs_, ys_, ds_);
   else for (int i = 0; i < n; i++) xs_[i] -= ds_[i];                       // (u - d, v), elas.cpp:466-467
   int32_t* corners = reinterpret_cast<int32_t*>(payload + info->corner_offset[side]);
-  const int nt = dt_.run(xs_.data(), ys_.data(), n, corners);
+  const int nt = arrangement ? dt_.run_arranged(xs_.data(), ys_.data(), n, arrangement, corners) : dt_.run(xs_.data(), ys_.data(), n, corners);
   info->ntri[side] = nt < 0 ? 0 : nt;
 }
 

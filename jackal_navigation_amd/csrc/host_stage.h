@@ -46,7 +46,9 @@ class HostWorker {
   // The same from the GPU's list (k_support_list), with no shared scratch: the task builds the coordinates it needs from
   // the (uc, vc, d) triples itself, so a batch is one flat set of frame-side tasks.  `info` must hold ok / nsup and
   // its payload offsets already.
-  void triangulate_side_from_list(int side, const int16_t* triples, uint8_t* payload, FrameInfo* info);
+  // `arrangement` (optional): the alternating-cut arrangement of this side's vertices computed on the GPU (k_arrange); with it
+  // only the hull recursion of the triangulation runs here.
+  void triangulate_side_from_list(int side, const int16_t* triples, uint8_t* payload, FrameInfo* info, const uint16_t* arrangement = nullptr);
   // The same split into phases for callers with idle threads (jn_api.cpp decides): coordinates + Delaunay::prepare into
   // the caller's per-(frame, side) state, then Delaunay::subtree per part on any worker, then Delaunay::finish.
   struct SideState { Delaunay dt; std::vector<int32_t> xs, ys; int parts = 0; };

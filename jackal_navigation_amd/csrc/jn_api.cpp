@@ -70,6 +70,7 @@ struct Slot {
   // pinned host
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
   int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
+  uint16_t* h_arr = nullptr; int32_t* h_arr_ok = nullptr;    // alternating-cut arrangements per frame side (k_arrange), same route
   // worker
   std::thread th; std::mutex m; std::condition_variable cv;
   bool has_job = false, busy = false, quit = false;
@@ -97,6 +98,8 @@ struct jn_elas {
   int filter_min_batch = 4;
   int wait_spin_us = 60;            // JN_WAIT_SPIN_US; 1000 for max_batch == 1 (see wait_event)
   bool stage_events = true;         // JN_STAGE_EVENTS: default on, off for max_batch == 1 (see run_batch)
+  bool gpu_arrange = true;          // JN_GPU_ARRANGE=0: the host computes the alternating-cut arrangement itself (A/B, tests)
+  int arr_cap = 0;                  // vertices per frame side k_arrange takes (more: host)
   bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
   std::unique_ptr<Pool> pool;
@@ -145,6 +148,12 @@ int usable_cpus() {
   return n;
 }
 
+// Parts a triangulation is cut into on the host: idle pool threads (a lone pair, a few large frames) are put to work inside it.
+int delaunay_parts(const jn_elas* h, int n) {
+  const int threads = h->pool->size();
+  return h->split_delaunay ? (threads >= 8 * n ? 4 : (threads >= 4 * n ? 2 : 1)) : 1;
+}
+
 jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const DevParams& dp = h->dp;
   const int n = j.n;
@@ -163,8 +172,12 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
   HIP_TRY(mark(EV_SUPPORT));
   const int list_cap = dp.cw * dp.ch;
+  bool arranged = false;
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
     launch_support_list(st, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
+    // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
+    arranged = h->gpu_arrange && delaunay_parts(h, n) == 1;
+    if (arranged) launch_arrange(st, n, s.h_list, s.h_cnt, list_cap, dp.step, h->arr_cap, s.h_arr, s.h_arr_ok);
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
     HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
@@ -185,12 +198,12 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     }
     // Idle pool threads (a lone pair, a few large frames) are put to work inside the triangulations: every frame side
     // is cut into 2 or 4 independent parts (delaunay.h), three short pool rounds instead of one long one.
-    const int threads = h->pool->size();
-    const int want_parts = h->split_delaunay ? (threads >= 8 * n ? 4 : (threads >= 4 * n ? 2 : 1)) : 1;
+    const int want_parts = delaunay_parts(h, n);
     if (want_parts == 1) {
       h->pool->run(2 * n, [&](HostWorker& w, int k) {
         const int i = k >> 1;
-        w.triangulate_side_from_list(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i]);
+        const uint16_t* arr = (arranged && s.h_arr_ok[k]) ? s.h_arr + (size_t)k * h->arr_cap : nullptr;
+        w.triangulate_side_from_list(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i], arr);
       });
     } else {
       h->pool->run(2 * n, [&](HostWorker& w, int k) {
@@ -450,6 +463,9 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->filters_fast = support_filters_fast(h->dp, p->incon_window_size, p->incon_min_support);
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
+  h->arr_cap = std::min(dp.cw * dp.ch, 8192);
+  h->gpu_arrange = !h->hp.add_corners;                     // the six corner points join the list on the host
+  if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
   h->stage_events = max_batch > 1;
   h->wait_spin_us = max_batch > 1 ? 60 : 1000;
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
@@ -481,6 +497,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_list), B * dp.cw * dp.ch * 3 * sizeof(int16_t), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_cnt), B * sizeof(int32_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr), B * 2 * (size_t)h->arr_cap * sizeof(uint16_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr_ok), B * 2 * sizeof(int32_t), hipHostMallocDefault));
   }
   h->s_pitch = dp.pitch;
   CREATE_TRY(dmalloc(&h->s_img, 2 * (size_t)H * dp.pitch));
@@ -504,7 +522,7 @@ void jn_elas_destroy(jn_elas* h) {
     hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
     hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->st_img); hipFree(s->st_D);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
-    hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt);
+    hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt); hipHostFree(s->h_arr); hipHostFree(s->h_arr_ok);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
     if (s->stream) hipStreamDestroy(s->stream);
   }
@@ -758,6 +776,37 @@ int32_t jn_host_triangulate_parts(const int32_t* x, const int32_t* y, int32_t n,
   dt.subtree(0);
   for (auto& t : th) t.join();
   return dt.finish(tri);
+}
+
+int32_t jn_host_arrangement(const int32_t* x, const int32_t* y, int32_t n, uint16_t* out) {
+  if (!x || !y || !out || n < 0) return -1;
+  Delaunay dt;
+  return dt.arrangement(x, y, n, out) ? 1 : 0;
+}
+
+jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t n, int32_t step, uint16_t* left, uint16_t* right,
+                                int32_t ok[2]) {
+  if (!triples || !left || !right || !ok || n < 0 || step < 1) return JN_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(configure_device_kernels());
+  const int cap = std::max(n, 1), arr_cap = std::min(cap, 8192);
+  int16_t* d_list = nullptr; int32_t* d_cnt = nullptr; uint16_t* d_arr = nullptr; int32_t* d_ok = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_list), (size_t)cap * 3 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_arr), (size_t)2 * arr_cap * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), 2 * sizeof(int32_t));
+  if (e == hipSuccess && n) e = hipMemcpy(d_list, triples, (size_t)n * 3 * sizeof(int16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_cnt, &n, sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, d_arr, d_ok); e = hipStreamSynchronize(nullptr); }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(ok, d_ok, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && ok[0]) e = hipMemcpy(left, d_arr, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && ok[1]) e = hipMemcpy(right, d_arr + arr_cap, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);
+  hipFree(d_list); hipFree(d_cnt); hipFree(d_arr); hipFree(d_ok);
+  HIP_TRY(e);
+  return JN_OK;
 }
 
 jn_status jn_device_support_filters(int32_t device, const jn_elas_params* p, int32_t W, int32_t H, int32_t n, int16_t* d_can,

@@ -26,6 +26,10 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
 // (uc, vc, d) int16 triples of the support points of each frame in the reference's order + their counts; `list` and
 // `count` may be pinned host memory
 void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap);
+// Alternating-cut arrangement of the support points of every frame side (what Delaunay::arrange + split compute on the host):
+// arr [n][2][arr_cap] vertex numbers, arr_ok [n][2] (0: leave the side to the host: too many points or coinciding vertices).
+size_t arrange_lds_bytes(int arr_cap);
+void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, uint16_t* arr, int32_t* arr_ok);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,

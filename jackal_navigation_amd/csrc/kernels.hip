@@ -2431,6 +2431,8 @@ static inline dim3 grid2d(int W, int H, int z) { return dim3((W + 255) / 256, H,
 template <int PITCH> static hipError_t configure_support_pitch() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+__global__ void k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step, int arr_cap,
+                          uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok);
 hipError_t configure_device_kernels() {
   static std::mutex m;
   static uint64_t done = 0;
@@ -2451,6 +2453,7 @@ hipError_t configure_device_kernels() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gap_rows_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
   done |= bit;
   return hipSuccess;
 }
@@ -2560,6 +2563,148 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
   if (lanes == 16) hipLaunchKernelGGL((k_support_filters<WIN, 16>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r, sweep);
   else             hipLaunchKernelGGL((k_support_filters<WIN, 8>), dim3(n), dim3(kFilterThreads), lds, st, dp, tol, min_support, d_can, seg_c, seg_r, sweep);
   return true;
+}
+// ------------------------------------------------------------------------------------------------
+// The alternating-cut arrangement of a frame side's support points, on the GPU.
+// Triangle's divide-and-conquer first re-partitions the (x, y)-sorted vertices by alternating median cuts
+// (triangle.cpp:5514-5606, :6197-6206); csrc/delaunay.cpp computes the same array kd-style (Delaunay::arrange / split): a
+// quarter of the triangulation's time on the host, whose cores are the scarce resource of the path.  The result
+// depends on the coordinates alone, so it is computed here, one workgroup per frame side, and only the recursion over hulls
+// stays on the host.  Level by level instead of recursively: all ranges of one depth are cut along the same axis; a cut
+// keeps the first half of the defining order (x-sorted array for axis 0, y-sorted for axis 1) and stably partitions the
+// other array to follow — one flag pass, one workgroup-wide prefix sum, one scatter per level.  Ranges of <= 3 vertices are
+// final (Delaunay::split).  Sides whose vertices are not all distinct (two support points can share (u - d, v) in the right
+// image) are left to the host, which must replay Triangle's randomised sort for them (delaunay.cpp): ok = 0.
+constexpr int kArrThreads = 1024;
+DEV void arr_sort(unsigned long long* keys, int N, int tid) {      // bitonic, N a power of two, ascending
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < N; i += kArrThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
+                                                         int arr_cap, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok) {
+  extern __shared__ unsigned long long s_arr[];
+  const int side = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+  const int n = count[frame];
+  int32_t* ok = arr_ok + frame * 2 + side;
+  if (n < 3 || n > arr_cap || n > list_cap) { if (tid == 0) *ok = 0; return; }
+  int N = 1; while (N < n) N <<= 1;
+  // LDS: [sort keys, N u64; afterwards tmp, rlo, rn, sx, arr_cap u16 each] | ord, byy [arr_cap] u16 | isleft [arr_cap] u8
+  int Ncap = 1; while (Ncap < arr_cap) Ncap <<= 1;
+  unsigned long long* keys = s_arr;
+  uint16_t* tmp = reinterpret_cast<uint16_t*>(s_arr); uint16_t* rlo = tmp + arr_cap; uint16_t* rn = rlo + arr_cap; uint16_t* sx = rn + arr_cap;
+  uint16_t* ord = reinterpret_cast<uint16_t*>(s_arr + Ncap);
+  uint16_t* byy = ord + arr_cap;
+  uint8_t* isleft = reinterpret_cast<uint8_t*>(byy + arr_cap);
+  __shared__ int s_wave[kArrThreads / 64 + 1];
+  __shared__ int s_flag;
+  const int16_t* t = list + (size_t)frame * list_cap * 3;
+  if (tid == 0) s_flag = 0;
+  // (x, y) order.  Left image: the list is written u-major, v ascending = already sorted.  Right image: x = u - d.
+  if (side == 0) {
+    for (int i = tid; i < n; i += kArrThreads) ord[i] = (uint16_t)i;
+    __syncthreads();
+  } else {
+    for (int i = tid; i < N; i += kArrThreads) {
+      unsigned long long k = ~0ull;
+      if (i < n) { const int x = t[3 * i] * step - t[3 * i + 2], vc = t[3 * i + 1]; k = ((unsigned long long)(unsigned)(x + 32768) << 32) | ((unsigned)vc << 16) | (unsigned)i; }
+      keys[i] = k;
+    }
+    __syncthreads();
+    arr_sort(keys, N, tid);
+    for (int i = tid; i < n; i += kArrThreads) {
+      ord[i] = (uint16_t)(keys[i] & 0xFFFFu);
+      if (i > 0 && (keys[i] >> 16) == (keys[i - 1] >> 16)) s_flag = 1;          // two vertices coincide
+    }
+    __syncthreads();
+    if (s_flag) { if (tid == 0) *ok = 0; return; }
+  }
+  // (y, x) order: stable sort of the x-sorted array by y
+  for (int i = tid; i < N; i += kArrThreads) {
+    unsigned long long k = ~0ull;
+    if (i < n) { const int v = ord[i]; k = ((unsigned long long)(unsigned)t[3 * v + 1] << 32) | ((unsigned)i << 16) | (unsigned)v; }
+    keys[i] = k;
+  }
+  __syncthreads();
+  arr_sort(keys, N, tid);
+  for (int i = tid; i < n; i += kArrThreads) byy[i] = (uint16_t)(keys[i] & 0xFFFFu);
+  __syncthreads();                                             // the key space is free now: it holds tmp, rlo, rn, sx from here on
+  for (int i = tid; i < n; i += kArrThreads) { rlo[i] = 0; rn[i] = (uint16_t)n; }
+  __syncthreads();
+  const int per = (n + kArrThreads - 1) / kArrThreads, p_lo = min(tid * per, n), p_hi = min(p_lo + per, n);
+  for (int level = 0; level < 32; level++) {
+    uint16_t* def = (level & 1) ? byy : ord;
+    uint16_t* oth = (level & 1) ? ord : byy;
+    // flags: the first half of every active range in the defining order goes left
+    int active = 0;
+    for (int i = p_lo; i < p_hi; i++) {
+      const int len = rn[i];
+      if (len > 3) { isleft[def[i]] = (uint8_t)((i - rlo[i]) < (len >> 1)); active = 1; }
+    }
+    if (tid == 0) s_flag = 0;
+    __syncthreads();
+    if (active) s_flag = 1;
+    __syncthreads();
+    if (!s_flag) break;
+    // exclusive prefix sum of the flags over the other order (sx), workgroup-wide
+    int mine = 0;
+    for (int i = p_lo; i < p_hi; i++) { const int f = rn[i] > 3 ? isleft[oth[i]] : 0; sx[i] = (uint16_t)mine; mine += f; }
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if ((tid & 63) >= off) incl += o; }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+      const int w = tid < kArrThreads / 64 ? s_wave[tid] : 0;
+      int acc = w;
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) { const int o = __shfl_up(acc, off); if (tid >= off) acc += o; }
+      if (tid < kArrThreads / 64) s_wave[tid] = acc - w;      // exclusive over waves
+    }
+    __syncthreads();
+    const int base = s_wave[tid >> 6] + incl - mine;
+    for (int i = p_lo; i < p_hi; i++) sx[i] = (uint16_t)(sx[i] + base);
+    __syncthreads();
+    // scatter: left vertices keep their order at the front of the range, the others follow
+    for (int i = p_lo; i < p_hi; i++) {
+      const int len = rn[i], lo = rlo[i];
+      int to = i;
+      if (len > 3) {
+        const int before = sx[i] - sx[lo];                    // left vertices of this range ahead of position i
+        to = isleft[oth[i]] ? lo + before : lo + (len >> 1) + (i - lo - before);
+      }
+      tmp[to] = oth[i];
+    }
+    __syncthreads();
+    for (int i = p_lo; i < p_hi; i++) {
+      oth[i] = tmp[i];
+      const int len = rn[i], lo = rlo[i];
+      if (len > 3) {                                           // children of the cut
+        const int half = len >> 1;
+        if (i - lo < half) rn[i] = (uint16_t)half; else { rlo[i] = (uint16_t)(lo + half); rn[i] = (uint16_t)(len - half); }
+      }
+    }
+    __syncthreads();
+  }
+  uint16_t* out = arr + ((size_t)frame * 2 + side) * arr_cap;
+  for (int i = tid; i < n; i += kArrThreads) out[i] = ord[i];
+  if (tid == 0) *ok = 1;
+}
+size_t arrange_lds_bytes(int arr_cap) {
+  int N = 1; while (N < arr_cap) N <<= 1;
+  return (size_t)N * 8 + (size_t)arr_cap * (2 * 2 + 1) + 16;
+}
+void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, uint16_t* arr, int32_t* arr_ok) {
+  hipLaunchKernelGGL(k_arrange, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr, arr_ok);
 }
 void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap) {
   hipLaunchKernelGGL(k_support_list, dim3(n), dim3(kFilterThreads), 0, st, dp, d_can, list, count, cap);

@@ -460,3 +460,50 @@ def test_submit_host_streams_host_buffers_through_the_slots(jn, oracle, same):
     assert list(batches[1][4]) == [0, 1, 0]
     _, D1o, D2o = oracle.process(po, batches[0][0][0], batches[0][1][0])
     assert st1[0] == 0 and same(d1, D1o) and same(d2, D2o)
+
+
+def test_gpu_arrangement_equals_the_hosts(jn):
+    """k_arrange (the alternating-cut arrangement of a frame side's support points, computed on the GPU so that the host only
+    runs the hull recursion) against Delaunay::arrange + split on the host: lattice points as the support list holds them
+    (u-major, v ascending), right image x = u - d; sizes from 3 to the kernel's limit; sides with coinciding vertices and
+    sides beyond the limit are handed back (ok = 0)."""
+    L = jn.load()
+    rng = np.random.default_rng(12)
+
+    def case(n, cw, ch, dmax, step=5, force_dup=False):
+        cells = rng.choice(cw * ch, size=n, replace=False)
+        cells.sort()                                            # uc-major, vc ascending = the list's order
+        uc, vc = cells // ch, cells % ch
+        d = rng.integers(0, dmax + 1, n)
+        if force_dup and n >= 2:                                # two right-image vertices coincide: (u - d, v) equal, (u, v) distinct
+            taken = set(zip(uc.tolist(), vc.tolist()))
+            for j in range(1, n):
+                if uc[j] > uc[j - 1] and (int(uc[j]), int(vc[j - 1])) not in taken:
+                    vc[j] = vc[j - 1]; d[j] = d[j - 1] + step * (uc[j] - uc[j - 1])
+                    break
+            order = np.lexsort((vc, uc)); uc, vc, d = uc[order], vc[order], d[order]      # keep the list's order
+        tri = np.stack([uc, vc, d], axis=1).astype(np.int16).copy()
+        left = np.zeros(max(n, 1), np.uint16); right = np.zeros(max(n, 1), np.uint16); ok = (C.c_int32 * 2)()
+        assert L.jn_device_arrangement(0, tri.ctypes.data, n, step, left.ctypes.data, right.ctypes.data, ok) == 0
+        for side, got in ((0, left), (1, right)):
+            x = (uc * step - (d if side else 0)).astype(np.int32).copy(); y = (vc * step).astype(np.int32).copy()
+            exp = np.zeros(max(n, 1), np.uint16)
+            host_ok = L.jn_host_arrangement(x.ctypes.data, y.ctypes.data, n, exp.ctypes.data)
+            distinct = len(set(zip(x.tolist(), y.tolist()))) == n
+            if n < 3 or n > 8192 or not distinct:
+                assert ok[side] == 0, (n, side)
+            else:
+                assert ok[side] == 1 and host_ok == 1, (n, side)
+                assert np.array_equal(got[:n], exp[:n]), (n, side, int((got[:n] != exp[:n]).sum()))
+        return ok[0], ok[1]
+
+    for n in (0, 2, 3, 4, 5, 7, 8, 13, 64, 100, 1023, 1024, 1025, 3232, 5000, 8192):
+        case(n, 256, 144, 127)
+    assert case(8193, 256, 144, 127) == (0, 0)                  # beyond the kernel's limit: host
+    for n in (50, 700, 4000):
+        case(n, 384, 216, 255)                                  # 1080p lattice, D = 256: negative right-image columns
+    dup = 0
+    for n in (10, 300, 3000):
+        a, b = case(n, 256, 144, 127, force_dup=True)
+        dup += (b == 0)
+    assert dup >= 1                                             # the coinciding pair was seen and handed back
