@@ -71,6 +71,7 @@ struct Slot {
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
   int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
   uint16_t* h_arr = nullptr; int32_t* h_arr_ok = nullptr;    // alternating-cut arrangements per frame side (k_arrange), same route
+  int arr_hint = 0;                                           // most support points a frame of this slot's previous batch had
   // worker
   std::thread th; std::mutex m; std::condition_variable cv;
   bool has_job = false, busy = false, quit = false;
@@ -176,8 +177,15 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
     launch_support_list(st, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
     // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
-    arranged = h->gpu_arrange && delaunay_parts(h, n) == 1;
-    if (arranged) launch_arrange(st, n, s.h_list, s.h_cnt, list_cap, dp.step, h->arr_cap, s.h_arr, s.h_arr_ok);
+    // Sized by what this slot's previous batch held (+25 %): a 720p frame has 3.2 k support points and needs 52 KB of LDS, not
+    // the 104 KB of the 8192-vertex maximum — a workgroup that asks for less finds room among the other slots' kernels sooner.
+    // Frames beyond the maximum (1920x1080: 11 k points) skip the launch: it could only hand every side back.
+    arranged = h->gpu_arrange && delaunay_parts(h, n) == 1 && s.arr_hint <= h->arr_cap;
+    if (arranged) {
+      const int want = s.arr_hint ? s.arr_hint + s.arr_hint / 4 + 64 : h->arr_cap;
+      const int cap = std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
+      launch_arrange(st, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_cap, s.h_arr, s.h_arr_ok);
+    }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
     HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
@@ -189,7 +197,9 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
   if (filtered) {
     // the counts are known, so the frames can be placed at once and the batch is one flat set of frame-side tasks
+    s.arr_hint = 0;
     for (int i = 0; i < n; i++) {
+      s.arr_hint = std::max(s.arr_hint, (int)s.h_cnt[i]);
       FrameInfo& fi = s.h_info[i];
       memset(&fi, 0, sizeof(fi));
       fi.nsup = std::min(s.h_cnt[i], list_cap) + (h->hp.add_corners ? HostWorker::kCornerPoints : 0);   // elas.cpp:435
@@ -799,7 +809,7 @@ jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t 
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), 2 * sizeof(int32_t));
   if (e == hipSuccess && n) e = hipMemcpy(d_list, triples, (size_t)n * 3 * sizeof(int16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_cnt, &n, sizeof(int32_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, d_arr, d_ok); e = hipStreamSynchronize(nullptr); }
+  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, arr_cap, d_arr, d_ok); e = hipStreamSynchronize(nullptr); }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(ok, d_ok, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e == hipSuccess && ok[0]) e = hipMemcpy(left, d_arr, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);

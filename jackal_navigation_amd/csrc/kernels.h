@@ -29,7 +29,9 @@ void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16
 // Alternating-cut arrangement of the support points of every frame side (what Delaunay::arrange + split compute on the host):
 // arr [n][2][arr_cap] vertex numbers, arr_ok [n][2] (0: leave the side to the host: too many points or coinciding vertices).
 size_t arrange_lds_bytes(int arr_cap);
-void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, uint16_t* arr, int32_t* arr_ok);
+// arr_cap: vertices per side this launch takes (sizes its LDS; sides with more are left to the host), arr_stride: layout of arr.
+void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
+                    int32_t* arr_ok);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,

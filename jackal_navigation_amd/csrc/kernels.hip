@@ -2432,7 +2432,7 @@ template <int PITCH> static hipError_t configure_support_pitch() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 __global__ void k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step, int arr_cap,
-                          uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok);
+                          int arr_stride, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok);
 hipError_t configure_device_kernels() {
   static std::mutex m;
   static uint64_t done = 0;
@@ -2591,7 +2591,7 @@ DEV void arr_sort(unsigned long long* keys, int N, int tid) {      // bitonic, N
     }
 }
 __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
-                                                         int arr_cap, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok) {
+                                                         int arr_cap, int arr_stride, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok) {
   extern __shared__ unsigned long long s_arr[];
   const int side = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
   const int n = count[frame];
@@ -2695,7 +2695,7 @@ __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restri
     }
     __syncthreads();
   }
-  uint16_t* out = arr + ((size_t)frame * 2 + side) * arr_cap;
+  uint16_t* out = arr + ((size_t)frame * 2 + side) * arr_stride;
   for (int i = tid; i < n; i += kArrThreads) out[i] = ord[i];
   if (tid == 0) *ok = 1;
 }
@@ -2703,8 +2703,9 @@ size_t arrange_lds_bytes(int arr_cap) {
   int N = 1; while (N < arr_cap) N <<= 1;
   return (size_t)N * 8 + (size_t)arr_cap * (2 * 2 + 1) + 16;
 }
-void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, uint16_t* arr, int32_t* arr_ok) {
-  hipLaunchKernelGGL(k_arrange, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr, arr_ok);
+void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
+                    int32_t* arr_ok) {
+  hipLaunchKernelGGL(k_arrange, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr_stride, arr, arr_ok);
 }
 void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap) {
   hipLaunchKernelGGL(k_support_list, dim3(n), dim3(kFilterThreads), 0, st, dp, d_can, list, count, cap);
