@@ -13,8 +13,8 @@ python3 scripts/lone_timeline.py $(ls $out/${tag}_lone/*/*kernel_trace.csv | hea
 for d in 0 1; do JN_SGM_DBG=$d python3 bench.py --mode sgm --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys
 j=json.loads(sys.stdin.read()); print('JN_SGM_DBG=$d', j['stage_ms_per_batch'])"; done > $out/${tag}_sgm_dbg.txt 2>&1
-for rep in 1 2; do for v in 0 4; do JN_SUPPORT_SPLIT=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | python3 -c "
+for rep in 1 2; do for v in 0 1; do JN_SUPPORT_SPLIT=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | python3 -c "
 import json,sys
-j=json.loads(sys.stdin.read()); print('JN_SUPPORT_SPLIT=$v', j['value'], 'pairs/s', j['ms_per_step'], 'ms/step, gpu_support', j['stage_ms_per_batch']['gpu_support'], 'ms')"; done; done > $out/${tag}_support_split_ab.txt 2>&1
+j=json.loads(sys.stdin.read()); print('JN_SUPPORT_SPLIT=$v (0 = default segments, 1 = one workgroup per lattice row)', j['value'], 'pairs/s', j['ms_per_step'], 'ms/step, gpu_support', j['stage_ms_per_batch']['gpu_support'], 'ms')"; done; done > $out/${tag}_support_split_ab.txt 2>&1
 timeout 900 python3 scripts/parity_sweep.py 12 > $out/${tag}_parity_sweep.txt 2>&1
 tail -3 $out/${tag}_parity_sweep.txt; cat $out/${tag}_qsad_probe.txt $out/${tag}_node_rate.txt $out/${tag}_sgm_dbg.txt $out/${tag}_support_split_ab.txt; tail -4 $out/${tag}_lone_timeline.txt
