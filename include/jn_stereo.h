@@ -72,9 +72,9 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
 /* Replaces `Elas elas(param)` (point_cloud.cpp:416-418), but long-lived: all device and pinned
  * buffers for up to `max_batch` WxH pairs per pipeline slot are allocated once.
  *   device        HIP device ordinal
- *   host_threads  worker threads for the host stage (support-point filters, Delaunay, planes,
- *                 grid prior); 0 = one per CPU the process may use (affinity mask, cut down to the container's
- *                 cgroup CPU quota)
+ *   host_threads  worker threads for the host stage (the hull recursion of the Delaunay triangulations; the support
+ *                 filters only where no kernel takes the lattice); 0 = one per CPU the process may use (affinity
+ *                 mask, cut down to the container's cgroup CPU quota); 16 feed one MI355X at 20 k 720p pairs/s
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
  * Unsupported (JN_ERR_UNSUPPORTED): subsampling, disp_max > 255 or < 10, disp_min != 0,
  * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported; with add_corners
