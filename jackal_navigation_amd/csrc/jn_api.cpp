@@ -72,6 +72,7 @@ struct Slot {
   int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
   uint16_t* h_arr = nullptr; int32_t* h_arr_ok = nullptr;    // alternating-cut arrangements per frame side (k_arrange), same route
   int arr_hint = 0;                                           // most support points a frame of this slot's previous batch had
+  void* arr_scratch = nullptr;                                // device: working arrays of k_arrange for sides beyond its LDS capacity
   // worker
   std::thread th; std::mutex m; std::condition_variable cv;
   bool has_job = false, busy = false, quit = false;
@@ -100,7 +101,7 @@ struct jn_elas {
   int wait_spin_us = 60;            // JN_WAIT_SPIN_US; 1000 for max_batch == 1 (see wait_event)
   bool stage_events = true;         // JN_STAGE_EVENTS: default on, off for max_batch == 1 (see run_batch)
   bool gpu_arrange = true;          // JN_GPU_ARRANGE=0: the host computes the alternating-cut arrangement itself (A/B, tests)
-  int arr_cap = 0;                  // vertices per frame side k_arrange takes (more: host)
+  int arr_cap = 0, arr_stride = 0;  // vertices per frame side k_arrange orders in LDS / at all (more: in global scratch / on the host)
   bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
   std::unique_ptr<Pool> pool;
@@ -180,11 +181,12 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     // Sized by what this slot's previous batch held (+25 %): a 720p frame has 3.2 k support points and needs 52 KB of LDS, not
     // the 104 KB of the 8192-vertex maximum — a workgroup that asks for less finds room among the other slots' kernels sooner.
     // Frames beyond the maximum (1920x1080: 11 k points) skip the launch: it could only hand every side back.
-    arranged = h->gpu_arrange && delaunay_parts(h, n) == 1 && s.arr_hint <= h->arr_cap;
+    arranged = h->gpu_arrange && delaunay_parts(h, n) == 1 && s.arr_hint <= h->arr_stride;
     if (arranged) {
       const int want = s.arr_hint ? s.arr_hint + s.arr_hint / 4 + 64 : h->arr_cap;
-      const int cap = std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
-      launch_arrange(st, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_cap, s.h_arr, s.h_arr_ok);
+      // more points than the LDS can order (1920x1080: 11 k): every side works in its slice of the global scratch, the launch asks for the minimum of LDS
+      const int cap = s.arr_hint > h->arr_cap ? 1024 : std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
+      launch_arrange(st, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_stride, s.h_arr, s.h_arr_ok, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -212,7 +214,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     if (want_parts == 1) {
       h->pool->run(2 * n, [&](HostWorker& w, int k) {
         const int i = k >> 1;
-        const uint16_t* arr = (arranged && s.h_arr_ok[k]) ? s.h_arr + (size_t)k * h->arr_cap : nullptr;
+        const uint16_t* arr = (arranged && s.h_arr_ok[k]) ? s.h_arr + (size_t)k * h->arr_stride : nullptr;
         w.triangulate_side_from_list(k & 1, s.h_list + (size_t)i * list_cap * 3, s.h_payload, &s.h_info[i], arr);
       });
     } else {
@@ -474,6 +476,10 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
   h->arr_cap = std::min(dp.cw * dp.ch, 8192);
+  // Sides with more vertices than the LDS can order (8192; a 1920x1080 frame has 11 k) could run k_arrange in global scratch
+  // (up to 16384, JN_ARRANGE_GLOBAL=1), but through L2 the kernel takes milliseconds, which a batch of 8 such frames on 4
+  // slots cannot hide: 4.6 k against 5.4 k pairs/s with the host doing it — off by default, those sides stay on the host.
+  h->arr_stride = (getenv("JN_ARRANGE_GLOBAL") && atoi(getenv("JN_ARRANGE_GLOBAL"))) ? std::min(dp.cw * dp.ch, 16384) : h->arr_cap;
   h->gpu_arrange = !h->hp.add_corners;                     // the six corner points join the list on the host
   if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
   h->stage_events = max_batch > 1;
@@ -507,7 +513,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_payload), B * h->payload_cap, hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_list), B * dp.cw * dp.ch * 3 * sizeof(int16_t), hipHostMallocDefault));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_cnt), B * sizeof(int32_t), hipHostMallocDefault));
-    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr), B * 2 * (size_t)h->arr_cap * sizeof(uint16_t), hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr), B * 2 * (size_t)h->arr_stride * sizeof(uint16_t), hipHostMallocDefault));
+    if (h->arr_stride > h->arr_cap) CREATE_TRY(hipMalloc(&s->arr_scratch, arrange_scratch_bytes((int)B, h->arr_stride)));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr_ok), B * 2 * sizeof(int32_t), hipHostMallocDefault));
   }
   h->s_pitch = dp.pitch;
@@ -530,7 +537,7 @@ void jn_elas_destroy(jn_elas* h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
     hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
-    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->st_img); hipFree(s->st_D);
+    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->st_img); hipFree(s->st_D); hipFree(s->arr_scratch);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt); hipHostFree(s->h_arr); hipHostFree(s->h_arr_ok);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
@@ -801,20 +808,22 @@ jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t 
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(configure_device_kernels());
-  const int cap = std::max(n, 1), arr_cap = std::min(cap, 8192);
+  const int cap = std::max(n, 1), arr_cap = std::min(cap, 8192), g_cap = std::min(cap, 16384);
   int16_t* d_list = nullptr; int32_t* d_cnt = nullptr; uint16_t* d_arr = nullptr; int32_t* d_ok = nullptr;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_list), (size_t)cap * 3 * sizeof(int16_t));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_arr), (size_t)2 * arr_cap * sizeof(uint16_t));
+  void* d_scratch = nullptr;
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_arr), (size_t)2 * g_cap * sizeof(uint16_t));
+  if (e == hipSuccess && g_cap > arr_cap) e = hipMalloc(&d_scratch, arrange_scratch_bytes(1, g_cap));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), 2 * sizeof(int32_t));
   if (e == hipSuccess && n) e = hipMemcpy(d_list, triples, (size_t)n * 3 * sizeof(int16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_cnt, &n, sizeof(int32_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, arr_cap, d_arr, d_ok); e = hipStreamSynchronize(nullptr); }
+  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, g_cap, d_arr, d_ok, d_scratch, d_scratch ? g_cap : 0); e = hipStreamSynchronize(nullptr); }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(ok, d_ok, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e == hipSuccess && ok[0]) e = hipMemcpy(left, d_arr, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);
-  if (e == hipSuccess && ok[1]) e = hipMemcpy(right, d_arr + arr_cap, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);
-  hipFree(d_list); hipFree(d_cnt); hipFree(d_arr); hipFree(d_ok);
+  if (e == hipSuccess && ok[1]) e = hipMemcpy(right, d_arr + g_cap, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);
+  hipFree(d_list); hipFree(d_cnt); hipFree(d_arr); hipFree(d_ok); hipFree(d_scratch);
   HIP_TRY(e);
   return JN_OK;
 }

@@ -29,9 +29,11 @@ void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16
 // Alternating-cut arrangement of the support points of every frame side (what Delaunay::arrange + split compute on the host):
 // arr [n][2][arr_cap] vertex numbers, arr_ok [n][2] (0: leave the side to the host: too many points or coinciding vertices).
 size_t arrange_lds_bytes(int arr_cap);
-// arr_cap: vertices per side this launch takes (sizes its LDS; sides with more are left to the host), arr_stride: layout of arr.
+// arr_cap: vertices per side this launch orders in LDS (sizes it); sides with more use their slice of gbuf (capacity g_cap per
+// side, arrange_scratch_bytes(n, g_cap) bytes in all; may be null) or are left to the host.  arr_stride: layout of arr.
+size_t arrange_scratch_bytes(int n, int g_cap);
 void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
-                    int32_t* arr_ok);
+                    int32_t* arr_ok, void* gbuf, int g_cap);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,

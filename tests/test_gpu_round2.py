@@ -465,16 +465,18 @@ def test_submit_host_streams_host_buffers_through_the_slots(jn, oracle, same):
 def test_gpu_arrangement_equals_the_hosts(jn):
     """k_arrange (the alternating-cut arrangement of a frame side's support points, computed on the GPU so that the host only
     runs the hull recursion) against Delaunay::arrange + split on the host: lattice points as the support list holds them
-    (u-major, v ascending), right image x = u - d; sizes from 3 to the kernel's limit; sides with coinciding vertices and
+    (u-major, v ascending), right image x = u - d; sizes from 3 to the kernel's limit (8192 vertices in LDS, 16384 through global scratch); sides with coinciding vertices and
     sides beyond the limit are handed back (ok = 0)."""
     L = jn.load()
     rng = np.random.default_rng(12)
 
-    def case(n, cw, ch, dmax, step=5, force_dup=False):
+    def case(n, cw, ch, dmax, step=5, force_dup=False, row_d=False):
         cells = rng.choice(cw * ch, size=n, replace=False)
         cells.sort()                                            # uc-major, vc ascending = the list's order
         uc, vc = cells // ch, cells % ch
         d = rng.integers(0, dmax + 1, n)
+        if row_d:
+            d = (vc * 7) % (dmax + 1)                           # one disparity per lattice row: (u - d, v) stays distinct, the order changes
         if force_dup and n >= 2:                                # two right-image vertices coincide: (u - d, v) equal, (u, v) distinct
             taken = set(zip(uc.tolist(), vc.tolist()))
             for j in range(1, n):
@@ -490,7 +492,7 @@ def test_gpu_arrangement_equals_the_hosts(jn):
             exp = np.zeros(max(n, 1), np.uint16)
             host_ok = L.jn_host_arrangement(x.ctypes.data, y.ctypes.data, n, exp.ctypes.data)
             distinct = len(set(zip(x.tolist(), y.tolist()))) == n
-            if n < 3 or n > 8192 or not distinct:
+            if n < 3 or n > 16384 or not distinct:
                 assert ok[side] == 0, (n, side)
             else:
                 assert ok[side] == 1 and host_ok == 1, (n, side)
@@ -499,7 +501,10 @@ def test_gpu_arrangement_equals_the_hosts(jn):
 
     for n in (0, 2, 3, 4, 5, 7, 8, 13, 64, 100, 1023, 1024, 1025, 3232, 5000, 8192):
         case(n, 256, 144, 127)
-    assert case(8193, 256, 144, 127) == (0, 0)                  # beyond the kernel's limit: host
+    for n in (8193, 11200, 16384):
+        assert case(n, 384, 216, 255, row_d=True) == (1, 1)     # beyond the LDS: the working arrays live in global scratch
+        assert case(n, 384, 216, 255)[0] == 1                   # random disparities this dense: right-image vertices coincide
+    assert case(16385, 384, 216, 255) == (0, 0)                 # beyond the kernel's limit: host
     for n in (50, 700, 4000):
         case(n, 384, 216, 255)                                  # 1080p lattice, D = 256: negative right-image columns
     dup = 0
