@@ -2431,6 +2431,7 @@ static inline dim3 grid2d(int W, int H, int z) { return dim3((W + 255) / 256, H,
 template <int PITCH> static hipError_t configure_support_pitch() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
+template <bool IN_LDS>
 __global__ void k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step, int arr_cap,
                           int arr_stride, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok, unsigned long long* gbuf, int g_cap);
 hipError_t configure_device_kernels() {
@@ -2453,7 +2454,7 @@ hipError_t configure_device_kernels() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gap_rows_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
   done |= bit;
   return hipSuccess;
 }
@@ -2590,6 +2591,7 @@ DEV void arr_sort(unsigned long long* keys, int N, int tid) {      // bitonic, N
       __syncthreads();
     }
 }
+template <bool IN_LDS>
 __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
                                                          int arr_cap, int arr_stride, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok,
                                                          unsigned long long* gbuf, int g_cap) {
@@ -2597,16 +2599,20 @@ __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restri
   const int side = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
   const int n = count[frame];
   int32_t* ok = arr_ok + frame * 2 + side;
-  // Working arrays: in LDS when the side's vertices fit this launch's LDS (arr_cap), else — frames with more support points
-  // than 160 KB of LDS can order (1920x1080: 11 k) — in this side's slice of a global scratch buffer: the same code, every
-  // pass then goes through L2 (a few times slower per level, still off the host's cores).
-  const bool in_lds = n <= arr_cap;
-  if (n < 3 || n > list_cap || (!in_lds && (!gbuf || n > g_cap))) { if (tid == 0) *ok = 0; return; }
-  if (!in_lds) arr_cap = g_cap;
+  // Working arrays: in LDS (IN_LDS: sides whose vertices fit this launch's LDS, arr_cap; the others are marked for the host)
+  // or — second instantiation, launched only on request for frames with more support points than 160 KB of LDS can order
+  // (1920x1080: 11 k) — in this side's slice of a global scratch buffer: the same code, every pass then goes through L2.
+  // Two instantiations rather than a run-time choice: a pointer that may be either makes every access a flat one.
+  if (IN_LDS) {
+    if (n < 3 || n > list_cap || n > arr_cap) { if (tid == 0) *ok = 0; return; }
+  } else {
+    if (n <= arr_cap || n > list_cap || n > g_cap) return;             // the LDS launch has dealt with this side (or handed it back)
+    arr_cap = g_cap;
+  }
   int N = 1; while (N < n) N <<= 1;
   // layout: [sort keys, N u64; afterwards tmp, rlo, rn, sx, arr_cap u16 each] | ord, byy [arr_cap] u16 | isleft [arr_cap] u8
   int Ncap = 1; while (Ncap < arr_cap) Ncap <<= 1;
-  unsigned long long* s_arr = in_lds ? s_lds : gbuf + ((size_t)frame * 2 + side) * (((size_t)Ncap * 8 + (size_t)arr_cap * 5 + 15) / 8);
+  unsigned long long* s_arr = IN_LDS ? s_lds : gbuf + ((size_t)frame * 2 + side) * (((size_t)Ncap * 8 + (size_t)arr_cap * 5 + 15) / 8);
   unsigned long long* keys = s_arr;
   uint16_t* tmp = reinterpret_cast<uint16_t*>(s_arr); uint16_t* rlo = tmp + arr_cap; uint16_t* rn = rlo + arr_cap; uint16_t* sx = rn + arr_cap;
   uint16_t* ord = reinterpret_cast<uint16_t*>(s_arr + Ncap);
@@ -2713,8 +2719,11 @@ size_t arrange_lds_bytes(int arr_cap) {
 size_t arrange_scratch_bytes(int n, int g_cap) { return (size_t)n * 2 * ((arrange_lds_bytes(g_cap) + 7) / 8 * 8); }
 void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
                     int32_t* arr_ok, void* gbuf, int g_cap) {
-  hipLaunchKernelGGL(k_arrange, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr_stride, arr, arr_ok,
-                     static_cast<unsigned long long*>(gbuf), g_cap);
+  hipLaunchKernelGGL(k_arrange<true>, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr_stride, arr,
+                     arr_ok, static_cast<unsigned long long*>(nullptr), 0);
+  if (gbuf && g_cap > arr_cap)     // sides beyond the LDS capacity: same kernel on global scratch (it overwrites their "handed back" mark)
+    hipLaunchKernelGGL(k_arrange<false>, dim3(2, n), dim3(kArrThreads), 0, st, list, count, list_cap, step, arr_cap, arr_stride, arr, arr_ok,
+                       static_cast<unsigned long long*>(gbuf), g_cap);
 }
 void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap) {
   hipLaunchKernelGGL(k_support_list, dim3(n), dim3(kFilterThreads), 0, st, dp, d_can, list, count, cap);
