@@ -58,7 +58,7 @@ KERNELS_SRC = os.path.join(ROOT, "jackal_navigation_amd", "csrc", "kernels.hip")
 def cpu_baseline_worker(args):
     """Times the CPU path on `count` pairs in this process (reference build if present, else the port)."""
     W, H, scene, disp, seed0, count = args
-    from oracle.binding import Oracle, Reference
+    from oracle.binding import Oracle, LocalReference as Reference   # timing only: heap state is irrelevant
     o = Oracle()
     ref = Reference() if Reference.available() else None
     p = o.params(disp_max=disp - 1)

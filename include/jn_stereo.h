@@ -77,9 +77,13 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  *                 mask, cut down to the container's cgroup CPU quota); 16 feed one MI355X at 20 k 720p pairs/s
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
  * Unsupported (JN_ERR_UNSUPPORTED): subsampling, disp_max > 255 or < 10, disp_min != 0,
- * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported; with add_corners
- * (MIDDLEBURY) the reference reads descriptor bytes it never initialises (descriptor.cpp:29) at the image border — this
- * library defines them as 0, which is what the reference sees in freshly mapped memory.
+ * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported.
+ * UNINITIALISED BYTES, both presets: the reference never writes descriptor columns 0..2 and W-3..W-1 (descriptor.cpp:29,
+ * :84-88) but reads column W-3 in the right-image support match (elas.cpp:326, :340-349) and columns 2 and W-3 in
+ * findMatch (elas.cpp:744-746, :752-754, :763-765, :770-772), so its D1/D2 depend on what malloc returned — with the node's
+ * ROBOTICS parameters too (tens to hundreds of pixels per frame), and far more with add_corners (MIDDLEBURY).  This
+ * library defines those bytes as 0, which is what the reference sees in freshly mapped memory; all parity statements are
+ * against the reference run with zero-filled allocations.
  * On any failure everything allocated so far is released and *out stays NULL. */
 jn_status jn_elas_create(const jn_elas_params* p, int32_t width, int32_t height, int32_t max_batch,
                          int32_t device, int32_t host_threads, int32_t slots, jn_elas** out);

@@ -85,6 +85,10 @@ class Oracle:
         self.lib.orc_synth_pair(W, H, sceneD, C.c_uint32(seed), _p(L_), _p(R_))
         return L_, R_
 
+    def set_uninit_fill(self, byte):
+        """Byte the descriptor border holds (default 0 = the definition); see Reference for what reads it."""
+        self.lib.orc_set_uninit_fill(int(byte))
+
     def fnv(self, a):
         a = np.ascontiguousarray(a)
         assert a.dtype.itemsize == 4
@@ -355,8 +359,12 @@ class BmOracle:
         return disp
 
 
-class Reference:
-    """The compiled reference (libelas from /root/reference), per stage."""
+class LocalReference:
+    """The compiled reference (libelas from /root/reference), per stage, loaded INTO THIS PROCESS.
+
+    libelas reads descriptor bytes it never wrote (see ``Reference`` below), so results obtained through this class depend
+    on what the calling process's heap happens to hold.  Use it only where that does not matter (bench.py's cpu_baseline
+    timing) or inside the isolated worker; parity checks and golden generators go through ``Reference``."""
 
     @staticmethod
     def available():
@@ -478,3 +486,98 @@ class RefSession:
     def gap(self, D): return self._ip(self.lib.ref_gap, D)
     def adaptive_mean(self, D): return self._ip(self.lib.ref_adaptive_mean, D)
     def median(self, D): return self._ip(self.lib.ref_median, D)
+
+
+class _Remote:
+    """Handle of an object living in the reference worker; method calls are forwarded."""
+
+    def __init__(self, owner, oid):
+        self._owner, self._oid = owner, oid
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return lambda *a, **kw: self._owner._call(self._oid, name, a, kw)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self._owner._call(self._oid, "close", (), {})
+        self._owner._call(None, "_drop", (self._oid,), {})
+
+
+class Reference:
+    """The compiled reference run in a WORKER PROCESS whose heap hands out memory filled with one known byte.
+
+    Why: libelas allocates its 16-byte-per-pixel descriptor image with _mm_malloc and never initialises it
+    (descriptor.cpp:29); createDescriptor writes only u in [3,W-4], v in [3,H-4] (descriptor.cpp:84-88), yet
+      * the right-image support match reads the tap at u+d+2 = W-3 when u+d = W-5 (elas.cpp:323-326 bound, :340-349 loads),
+      * findMatch admits warp columns 2 and W-3 (`u_warp<window_size || u_warp>=width-window_size`, elas.cpp:744-746,
+        :752-754, :763-765, :770-772).
+    So D1/D2 depend on what malloc returned.  Freshly mapped pages are zero, which is what the product and the oracle
+    define those bytes to be (include/jn_stereo.h); glibc's MALLOC_PERTURB_=255 fills every allocation
+    with 0x00 (byte = 255 ^ 0xff) and pins the reference to exactly that state, whatever the calling process's heap or
+    environment looks like.  ``Reference(fill=b)`` (b != 0xff) pins it to another byte, for the tests that show the
+    dependence.  The worker is oracle/ref_worker.py; arguments and results travel pickled over its stdin/stdout."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self, fill=0):
+        import pickle
+        import sys
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO + " (build with `make -C oracle ref` where /root/reference exists)")
+        if not 0 <= fill < 255:
+            raise ValueError("fill must be in [0, 254] (MALLOC_PERTURB_=0 switches the fill off)")
+        self.fill = fill
+        self._pickle = pickle
+        env = dict(os.environ, MALLOC_PERTURB_=str(255 - fill), PYTHONPATH=os.path.dirname(HERE))
+        self._proc = subprocess.Popen([sys.executable, os.path.join(HERE, "ref_worker.py")], stdin=subprocess.PIPE,
+                                      stdout=subprocess.PIPE, env=env)
+
+    def _call(self, oid, name, args, kw):
+        self._pickle.dump((oid, name, args, kw), self._proc.stdin, protocol=4)
+        self._proc.stdin.flush()
+        kind, val = self._pickle.load(self._proc.stdout)
+        if kind == "err":
+            raise RuntimeError("reference worker: " + val)
+        if kind == "obj":
+            return _Remote(self, val)
+        return val
+
+    def params(self, setting=0, **kw):
+        p = self._call(0, "params_bytes", (setting,), {})
+        q = Params.from_buffer_copy(p)
+        for k, v in kw.items():
+            setattr(q, k, v)
+        return q
+
+    def process(self, p, I1, I2, fill=0.0):
+        return self._call(0, "process", (bytes(p), I1, I2, fill), {})
+
+    def sobel(self, I):
+        return self._call(0, "sobel", (I,), {})
+
+    def triangulate(self, xy):
+        return self._call(0, "triangulate", (xy,), {})
+
+    def open(self, p, I1, I2):
+        return self._call(0, "open", (bytes(p), I1, I2), {})
+
+    def close(self):
+        if self._proc and self._proc.poll() is None:
+            try:
+                self._proc.stdin.close()
+                self._proc.wait(timeout=10)
+            except Exception:
+                self._proc.kill()
+        self._proc = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

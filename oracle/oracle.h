@@ -34,7 +34,9 @@ uint64_t orc_fnv1a64_u32(const uint32_t* words, int64_t n);
 // ---- ELAS stages (each cites the reference lines it restates, see elas_oracle.cpp) ----------
 // Sobel: I [H][bpl] -> du,dv [H][bpl]; rows 0 and H-1 are left untouched.
 void orc_sobel3x3(const uint8_t* I, int32_t bpl, int32_t H, uint8_t* du, uint8_t* dv);
-// Descriptor: [H][W][16]; bytes outside u in [3,W-4], v in [3,H-4] are set to 0.
+// Descriptor: [H][W][16]; bytes outside u in [3,W-4], v in [3,H-4] are set to 0 — the reference leaves them
+// uninitialised and reads columns 2 and W-3 (see elas_oracle.cpp).  orc_set_uninit_fill picks another byte (tests only).
+void orc_set_uninit_fill(int32_t byte);
 void orc_descriptor(const uint8_t* I, int32_t W, int32_t H, int32_t pitch, uint8_t* desc);
 // One support candidate (returns d or -1).
 int32_t orc_match_candidate(const orc_params* p, const uint8_t* desc1, const uint8_t* desc2, int32_t W,

@@ -32,7 +32,7 @@ def reference():
     from oracle.binding import Reference
     if not Reference.available():
         pytest.skip("oracle/_ref/libelas_ref.so not built (needs /root/reference)")
-    return Reference()
+    return Reference()        # zero-filled worker process, see oracle.binding.Reference
 
 
 @pytest.fixture(scope="session")

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Generates tests/golden/*.npz from the REAL reference (oracle/_ref/libelas_ref.so, i.e. the
-reference's own src/elas compiled from /root/reference by oracle/Makefile).  Run in the dev
+reference's own src/elas compiled from /root/reference by oracle/Makefile), run through
+oracle.binding.Reference: a worker process whose allocations are zero-filled, because libelas reads
+descriptor bytes it never wrote (readers listed in that class's docstring).  Run in the dev
 container only; the fixtures are data (inputs + the reference's outputs per stage), no source.
 
     python tests/golden/make_golden.py
@@ -63,7 +65,7 @@ def main():
         lines.append("%d %d %d %d %016x %016x" % (W, H, sd, dmax, o.fnv(D1), o.fnv(D2)))
         print(lines[-1])
     with open(os.path.join(here, "reference_hashes.txt"), "w") as f:
-        f.write("# W H scene_disp disp_max fnv1a64(D1) fnv1a64(D2) -- reference src/elas, ROBOTICS params, seed 12345, D pre-filled 0\n")
+        f.write("# W H scene_disp disp_max fnv1a64(D1) fnv1a64(D2) -- reference src/elas, ROBOTICS params, seed 12345, D pre-filled 0, uninitialised allocations zero-filled\n")
         f.write("\n".join(lines) + "\n")
     # the other scene kinds (tests/scenes.py), both sides post-processed
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -77,7 +79,7 @@ def main():
             print(lines[-1])
     with open(os.path.join(here, "reference_scene_hashes.txt"), "w") as f:
         f.write("# kind W H disp_max seed fnv1a64(D1) fnv1a64(D2) -- reference src/elas, ROBOTICS params with postprocess_only_left=0,\n"
-                "# tests/scenes.py make_scene(kind, W, H, disp_max, seed), D pre-filled 0\n")
+                "# tests/scenes.py make_scene(kind, W, H, disp_max, seed), D pre-filled 0, uninitialised allocations zero-filled\n")
         f.write("\n".join(lines) + "\n")
 
 

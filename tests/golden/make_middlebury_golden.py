@@ -2,21 +2,16 @@
 """Generates tests/golden/reference_middlebury_hashes.txt from the REAL reference (oracle/_ref/libelas_ref.so) with the
 MIDDLEBURY preset (elas.h:118-145: add_corners, ipol_gap_width 5000, median filter, both sides post-processed).
 
-With add_corners the reference reads descriptor bytes it never initialises (descriptor.cpp:29: `_mm_malloc`, borders
-untouched); its output then depends on what that memory held.  This script re-runs ITSELF with MALLOC_PERTURB_=255, which
-makes glibc hand out zero-filled blocks (the complement of the low byte), i.e. what a freshly mapped buffer holds anyway
-— the definition the product and the oracle use (border descriptor bytes = 0).  Run in the dev container only:
+The reference reads descriptor bytes it never initialises (descriptor.cpp:29; readers listed in the docstring of
+oracle.binding.Reference); `Reference()` runs it in a worker whose allocations are zero-filled — what a freshly mapped buffer
+holds anyway, and the definition the product and the oracle use.  Run in the dev container only:
 
     python tests/golden/make_middlebury_golden.py
 """
 import os
-import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if os.environ.get("MALLOC_PERTURB_") != "255":
-    sys.exit(subprocess.call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, MALLOC_PERTURB_="255")))
-
 import numpy as np  # noqa: E402
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -38,5 +33,5 @@ for kind in ("strips", "patches", "slanted", "blobs"):
     print(lines[-1])
 with open(os.path.join(ROOT, "tests", "golden", "reference_middlebury_hashes.txt"), "w") as f:
     f.write("# kind W H scene_disp disp_max seed fnv1a64(D1) fnv1a64(D2) -- reference src/elas, MIDDLEBURY preset, D pre-filled 0,\n"
-            "# uninitialised allocations zero-filled (MALLOC_PERTURB_=255); kind synth = Appendix-A generator, else tests/scenes.py\n")
+            "# uninitialised allocations zero-filled (oracle.binding.Reference worker); kind synth = Appendix-A generator, else tests/scenes.py\n")
     f.write("\n".join(lines) + "\n")

@@ -115,4 +115,5 @@ def test_bench_refuses_a_world_size_mismatch_and_spawns_ranks_without_a_launcher
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=env)
-    assert out.returncode != 0 and out.stderr.count("needs a GPU") == 2, out.stderr[-2000:]
+    # the parent terminates the surviving rank as soon as one fails, so the second message may not get out
+    assert out.returncode != 0 and 1 <= out.stderr.count("needs a GPU") <= 2, out.stderr[-2000:]

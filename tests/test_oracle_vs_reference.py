@@ -1,6 +1,11 @@
 """Pins the CPU oracle against the REAL reference library compiled from /root/reference
 (oracle/_ref).  Skipped where that library was not built; the committed golden vectors
-(test_oracle_golden.py) carry the same evidence everywhere else."""
+(test_oracle_golden.py) carry the same evidence everywhere else.
+
+Every reference call here goes through oracle.binding.Reference: a worker process whose heap hands out zero-filled
+memory, because libelas reads descriptor bytes it never wrote (test_reference_reads_the_uninitialised_descriptor_border
+below names the lines).  The suite therefore gives the same answers whatever MALLOC_PERTURB_ / heap history the pytest
+process itself has."""
 import os
 
 import numpy as np
@@ -115,35 +120,86 @@ def test_sobel_rows(oracle, reference, same):
     assert same(du[1:-1, 1:-1], dur[1:-1, 1:-1]) and same(dv[1:-2, 1:-1], dvr[1:-2, 1:-1])
 
 
-def test_oracle_equals_reference_on_the_middlebury_preset_with_zero_filled_memory():
+def test_oracle_equals_reference_on_the_middlebury_preset_with_zero_filled_memory(oracle, reference, same):
     """MIDDLEBURY (elas.h:118-145): add_corners, unbounded gap interpolation with border extrapolation, median filter, both
-    sides post-processed.  The reference reads descriptor bytes it never initialises there (descriptor.cpp:29); with those
-    bytes zero — glibc's MALLOC_PERTURB_=255, or simply freshly mapped memory — its output is deterministic and the oracle
-    (which defines them as zero) must equal it bit for bit.  Runs in a subprocess so that the allocator setting applies.
+    sides post-processed.  With the uninitialised descriptor bytes zero (the `reference` fixture's worker) the reference is
+    deterministic and the oracle (which defines them as zero) must equal it bit for bit.
     (add_corners together with the ADAPTIVE MEAN — no preset does that — is left out: the reference's vertical pass then also
     reads rows of its scratch image that nothing wrote, elas.cpp:1298 / :1436-1446, and the oracle defines those as a copy.)"""
-    import subprocess
-    import sys
+    from scenes import make_scene
+    pairs = [oracle.synth_pair(320, 180, 48, 12345), oracle.synth_pair(400, 300, 60, 7), make_scene("strips", 320, 240, 79, 21),
+             make_scene("blobs", 320, 240, 79, 21)]
+    for (L, R), d in zip(pairs, [255, 127, 79, 79]):
+        for kw in ({}, {"ipol_gap_width": 7}, {"filter_median": 0}, {"sradius": 2.0, "gamma": 3.0, "match_texture": 1}):
+            D1r, D2r = reference.process(reference.params(1, disp_max=d, **kw), L, R)
+            st, D1o, D2o = oracle.process(oracle.params(1, disp_max=d, **kw), L, R)
+            assert st == 0 and same(D1r, D1o) and same(D2r, D2o), (d, kw)
+
+
+NODE_SCENES = (("strips", 320, 240, 79, 5), ("slanted", 400, 304, 127, 6), ("photometric", 400, 304, 127, 6))
+
+
+def test_reference_reads_the_uninitialised_descriptor_border(oracle, reference, same):
+    """What the reference is pinned TO.  libelas' descriptor image comes from _mm_malloc and is never initialised
+    (descriptor.cpp:29); createDescriptor writes u in [3,W-4], v in [3,H-4] only (descriptor.cpp:84-88).  Two places read
+    outside that, also with the node's own configuration (ROBOTICS, postprocess_only_left=1, point_cloud.cpp:416-418):
+      * the right-image support match: disp_max_valid = W-u-5 (elas.cpp:326) allows u+d = W-5, whose +2 tap is column W-3
+        (loads at elas.cpp:340-349);
+      * findMatch: `u_warp<window_size || u_warp>=width-window_size` with window_size 2 (elas.cpp:744-746, :752-754,
+        :763-765, :770-772) admits warp columns 2 and W-3.
+    Shown here: (1) the reference's D1 moves when its heap is filled with another byte; (2) an oracle whose descriptor
+    border holds that same byte reproduces the reference bit for bit under BOTH fills — so this border is the only
+    uninitialised memory the result depends on; (3) zero fill — freshly mapped pages, the product's and the oracle's
+    definition (include/jn_stereo.h) — is what the goldens and every other test are pinned to."""
     from oracle.binding import Reference
+    from scenes import make_scene
+    other = Reference(fill=0x7f)
+    try:
+        moved = 0
+        for kind, W, H, dmax, seed in NODE_SCENES:
+            L, R = make_scene(kind, W, H, dmax, seed)
+            p = oracle.params(0, disp_max=dmax)                                 # the node's parameters
+            assert p.postprocess_only_left == 1 and p.add_corners == 0
+            D1z, D2z = reference.process(p, L, R)
+            D1f, D2f = other.process(p, L, R)
+            moved += int((D1z.view(np.uint32) != D1f.view(np.uint32)).sum())
+            st, D1o, D2o = oracle.process(p, L, R)
+            assert st == 0 and same(D1o, D1z) and same(D2o, D2z), ("zero fill", kind)
+            oracle.set_uninit_fill(0x7f)
+            try:
+                st, D1o, D2o = oracle.process(p, L, R)
+            finally:
+                oracle.set_uninit_fill(0)
+            assert st == 0 and same(D1o, D1f) and same(D2o, D2f), ("0x7f fill", kind)
+        assert moved > 100, "the reference's D1 no longer depends on the fill byte?"
+    finally:
+        other.close()
+
+
+def test_reference_worker_ignores_the_callers_allocator_settings(oracle, same):
+    """The pin must not depend on the pytest process: a Reference() created under MALLOC_PERTURB_=128 still zero-fills."""
+    from oracle.binding import Reference
+    from scenes import make_scene
     if not Reference.available():
         pytest.skip("oracle/_ref/libelas_ref.so not built (needs /root/reference)")
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from oracle.binding import Oracle, Reference
-from scenes import make_scene
-o, r = Oracle(), Reference()
-pairs = [o.synth_pair(320, 180, 48, 12345), o.synth_pair(400, 300, 60, 7), make_scene("strips", 320, 240, 79, 21), make_scene("blobs", 320, 240, 79, 21)]
-dm = [255, 127, 79, 79]
-for (L, R), d in zip(pairs, dm):
-    for kw in ({}, {"ipol_gap_width": 7}, {"filter_median": 0}, {"sradius": 2.0, "gamma": 3.0, "match_texture": 1}):
-        D1r, D2r = r.process(r.params(1, disp_max=d, **kw), L, R)
-        st, D1o, D2o = o.process(o.params(1, disp_max=d, **kw), L, R)
-        assert st == 0 and np.array_equal(D1r.view(np.uint32), D1o.view(np.uint32)) and np.array_equal(D2r.view(np.uint32), D2o.view(np.uint32)), (d, kw)
-print("middlebury ok")
-''' % (ROOT, os.path.join(ROOT, "tests"))
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, MALLOC_PERTURB_="255"))
-    assert out.returncode == 0 and "middlebury ok" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    old = os.environ.get("MALLOC_PERTURB_")
+    os.environ["MALLOC_PERTURB_"] = "128"
+    try:
+        r = Reference()
+    finally:
+        if old is None:
+            del os.environ["MALLOC_PERTURB_"]
+        else:
+            os.environ["MALLOC_PERTURB_"] = old
+    try:
+        kind, W, H, dmax, seed = NODE_SCENES[0]
+        L, R = make_scene(kind, W, H, dmax, seed)
+        p = oracle.params(0, disp_max=dmax)
+        D1r, D2r = r.process(p, L, R)
+        st, D1o, D2o = oracle.process(p, L, R)
+        assert st == 0 and same(D1o, D1r) and same(D2o, D2r)
+    finally:
+        r.close()
 
 
 def test_oracle_reproduces_the_committed_middlebury_hashes(oracle):
