@@ -14,6 +14,7 @@
 #include "host_stage.h"
 #include "pool.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -71,7 +72,9 @@ struct Slot {
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
   int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
   uint16_t* h_arr = nullptr; int32_t* h_arr_ok = nullptr;    // alternating-cut arrangements per frame side (k_arrange), same route
-  int arr_hint = 0;                                           // most support points a frame of this slot's previous batch had
+  int arr_hint = 0;                                           // most support points a frame of this slot's last kArrHist batches had
+  static constexpr int kArrHist = 4;
+  int arr_hist[kArrHist] = {0, 0, 0, 0}; int arr_pos = 0;
   void* arr_scratch = nullptr;                                // device: working arrays of k_arrange for sides beyond its LDS capacity
   // worker
   std::thread th; std::mutex m; std::condition_variable cv;
@@ -199,9 +202,11 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
   if (filtered) {
     // the counts are known, so the frames can be placed at once and the batch is one flat set of frame-side tasks
-    s.arr_hint = 0;
+    int batch_most = 0;
+    for (int i = 0; i < n; i++) batch_most = std::max(batch_most, (int)s.h_cnt[i]);
+    s.arr_hist[s.arr_pos] = batch_most; s.arr_pos = (s.arr_pos + 1) % Slot::kArrHist;   // a lone sparse frame no longer shrinks
+    s.arr_hint = *std::max_element(s.arr_hist, s.arr_hist + Slot::kArrHist);            // the next batch's arrangement space
     for (int i = 0; i < n; i++) {
-      s.arr_hint = std::max(s.arr_hint, (int)s.h_cnt[i]);
       FrameInfo& fi = s.h_info[i];
       memset(&fi, 0, sizeof(fi));
       fi.nsup = std::min(s.h_cnt[i], list_cap) + (h->hp.add_corners ? HostWorker::kCornerPoints : 0);   // elas.cpp:435
@@ -321,9 +326,13 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
 jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
   HIP_TRY(hipSetDevice(h->device));
   const size_t px = (size_t)h->W * h->H, B = (size_t)h->max_batch;
-  if (!s.st_img) {
+  if (!s.st_img || !s.st_D) {                            // both or neither: a failed second allocation must not leave a half-made pair
+    if (s.st_img) { hipFree(s.st_img); s.st_img = nullptr; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.st_img), 2 * B * px));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.st_D), 2 * B * px * sizeof(float)));
+    if (hipMalloc(reinterpret_cast<void**>(&s.st_D), 2 * B * px * sizeof(float)) != hipSuccess) {
+      hipFree(s.st_img); s.st_img = nullptr; s.st_D = nullptr;
+      return JN_ERR_NO_DEVICE;
+    }
   }
   hipStream_t st = s.stream;
   const uint8_t* src[2] = {j.hI1, j.hI2};
@@ -548,10 +557,14 @@ void jn_elas_destroy(jn_elas* h) {
   delete h;
 }
 
+static bool stride_ok(const jn_elas* h, int32_t n, int32_t pitch, int64_t image_stride) {
+  return n == 1 || image_stride >= (int64_t)pitch * h->H;      // image b starts at base + b*image_stride: images must not overlap
+}
+
 jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch,
                          int64_t image_stride, float* dD1, float* dD2, int32_t* status) {
   if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dD1 || !dD2 ||
-      pitch < h->W)
+      pitch < h->W || !stride_ok(h, n, pitch, image_stride))
     return JN_ERR_INVALID;
   Slot& s = *h->slots[slot];
   {
@@ -566,7 +579,8 @@ jn_status jn_elas_submit(jn_elas* h, int32_t slot, int32_t n, const uint8_t* dI1
 
 jn_status jn_elas_submit_host(jn_elas* h, int32_t slot, int32_t n, const uint8_t* I1, const uint8_t* I2, int32_t pitch,
                               int64_t image_stride, float* D1, float* D2, int32_t* status) {
-  if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !I1 || !I2 || !D1 || !D2 || pitch < h->W)
+  if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !I1 || !I2 || !D1 || !D2 || pitch < h->W ||
+      !stride_ok(h, n, pitch, image_stride))
     return JN_ERR_INVALID;
   Slot& s = *h->slots[slot];
   {
@@ -585,7 +599,7 @@ jn_status jn_elas_submit_scan(jn_elas* h, int32_t slot, int32_t n, const uint8_t
                               int64_t image_stride, float* dD1, float* dD2, const jn_scan_params* sp, const uint8_t* dLut,
                               uint8_t* dDispU8, double* dBins, double* dMeta, int32_t* status) {
   if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dD1 || !dD2 ||
-      pitch < h->W || !sp || !dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024)
+      pitch < h->W || !stride_ok(h, n, pitch, image_stride) || !sp || !dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024)
     return JN_ERR_INVALID;
   Slot& s = *h->slots[slot];
   {

@@ -100,3 +100,63 @@ def test_jpeg_info_and_refusals(jn):
     cut = good[: len(good) // 2].copy()                    # truncated scan: still decodes (zeros are fed past the end), like libjpeg's warning path
     st, img = host_decode(jn, cut)
     assert st in (0, _lib.JN_ERR_INVALID)
+
+
+def _dht(counts, nsym=None, tc_th=0x00):
+    counts = list(counts) + [0] * (16 - len(counts))
+    n = sum(counts) if nsym is None else nsym
+    body = bytes([tc_th]) + bytes(counts) + bytes(range(n % 257))[:n]
+    return b"\xff\xc4" + (len(body) + 2).to_bytes(2, "big") + body
+
+
+def test_damaged_huffman_tables_and_oversized_frames_are_refused(jn):
+    """a DHT that is not a prefix code (255 codes of length 1) made the 8-bit look-up index run past the
+    table — an out-of-bounds stack write from a 40-byte file.  libjpeg rejects such tables (JERR_BAD_HUFF_TABLE); so must we.
+    (medium): SOF dimensions drive the coefficient buffer; frames beyond 8192x8192 are refused before any allocation."""
+    from jackal_navigation_amd import _lib
+    soi = b"\xff\xd8"
+    for counts in ([255], [3], [2, 3], [1, 1, 1, 1, 1, 1, 1, 1, 2], [0] * 15 + [255, ]):
+        st, _ = host_decode(jn, np.frombuffer(soi + _dht(counts) + b"\xff\xd9", np.uint8))
+        assert st == _lib.JN_ERR_INVALID, counts
+    # the all-ones code of a length is reserved (T.81 C.2): 2 codes of length 1 use it
+    st, _ = host_decode(jn, np.frombuffer(soi + _dht([2]) + b"\xff\xd9", np.uint8))
+    assert st == _lib.JN_ERR_INVALID
+    z, _ = cases()
+    good = bytes(z["q90_422__jpeg"])
+    i = good.index(b"\xff\xc0")
+    huge = bytearray(good); huge[i + 5:i + 9] = b"\xff\xff\xff\xff"          # 65535 x 65535
+    st, _ = host_decode(jn, np.frombuffer(bytes(huge), np.uint8))
+    assert st == _lib.JN_ERR_UNSUPPORTED
+    big = bytearray(good); big[i + 5:i + 9] = (8200).to_bytes(2, "big") + (16).to_bytes(2, "big")
+    st, _ = host_decode(jn, np.frombuffer(bytes(big), np.uint8))
+    assert st == _lib.JN_ERR_UNSUPPORTED
+
+
+def test_fuzzed_files_never_crash_the_host_decoder(jn):
+    """Small fuzz corpus: byte flips, truncations, spliced segments and random DHT/DQT/SOF/SOS bodies over three valid files.
+    Every outcome must be a status (or a decoded image), never a crash; test_sanitizers.py repeats this under ASan/UBSan."""
+    z, names = cases()
+    rng = np.random.default_rng(2026)
+    seeds = [bytes(z[n + "__jpeg"]) for n in ("ragged_35x21_q95_422", "q90_422", "restart_blocks_q80_444")]
+    outcomes = {}
+    for it in range(600):
+        b = bytearray(seeds[it % len(seeds)])
+        kind = it % 5
+        if kind == 0:                                                       # flips in the headers
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(2, min(len(b), 700)))] = int(rng.integers(0, 256))
+        elif kind == 1:                                                     # flips anywhere
+            for _ in range(int(rng.integers(1, 30))):
+                b[int(rng.integers(2, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 2:
+            b = b[:int(rng.integers(2, len(b)))]
+        elif kind == 3:                                                     # a random table segment right after SOI
+            m = [0xC4, 0xDB, 0xC0, 0xDA, 0xDD][int(rng.integers(0, 5))]
+            body = bytes(rng.integers(0, 256, int(rng.integers(0, 300))).astype(np.uint8))
+            b = bytearray(b[:2] + bytes([0xFF, m]) + (len(body) + 2).to_bytes(2, "big") + body + bytes(b[2:]))
+        else:                                                               # a random prefix-violating DHT
+            b = bytearray(b[:2] + _dht(list(rng.integers(0, 256, 16)), nsym=int(rng.integers(0, 257))) + bytes(b[2:]))
+        st, img = host_decode(jn, np.frombuffer(bytes(b), np.uint8))
+        outcomes[st] = outcomes.get(st, 0) + 1
+    assert set(outcomes) <= {0, 2, 3, 5}, outcomes
+    assert outcomes.get(3, 0) > 50, outcomes

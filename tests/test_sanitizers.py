@@ -71,3 +71,70 @@ def test_host_and_oracle_under_asan_ubsan(tmp_path):
         out = subprocess.run([str(exe), *args], capture_output=True, text=True, env=env, timeout=300)
         assert out.returncode == 0, (args, out.returncode, out.stdout[-2000:], out.stderr[-4000:])
         assert "sanitized run ok" in out.stdout
+
+
+JPEG_FUZZ = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "jpeg_host.h"
+static uint32_t rng = 2463534242u;
+static inline uint32_t xr() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return rng; }
+int main(int argc, char** argv) {
+  int counts[8] = {0};
+  for (int f = 1; f < argc; f++) {
+    FILE* fp = fopen(argv[f], "rb"); if (!fp) return 2;
+    std::vector<uint8_t> good(1 << 20); good.resize(fread(good.data(), 1, good.size(), fp)); fclose(fp);
+    for (int it = 0; it < 1500; it++) {
+      // exactly-sized heap copy: any read past the end is an ASan report
+      std::vector<uint8_t> b = good;
+      switch (it % 6) {
+        case 0: for (uint32_t k = 0, n = 1 + xr() % 8; k < n; k++) b[2 + xr() % (b.size() < 700 ? b.size() - 2 : 698)] = (uint8_t)xr(); break;
+        case 1: for (uint32_t k = 0, n = 1 + xr() % 30; k < n; k++) b[2 + xr() % (b.size() - 2)] = (uint8_t)xr(); break;
+        case 2: b.resize(2 + xr() % (b.size() - 2)); break;
+        case 3: case 4: {                                                     // a random DHT / DQT / SOF / SOS / DRI body after SOI
+          static const uint8_t ms[5] = {0xC4, 0xDB, 0xC0, 0xDA, 0xDD};
+          std::vector<uint8_t> seg; const uint32_t len = xr() % 300;
+          seg.push_back(0xFF); seg.push_back(it % 6 == 4 ? 0xC4 : ms[xr() % 5]); seg.push_back((uint8_t)((len + 2) >> 8)); seg.push_back((uint8_t)(len + 2));
+          for (uint32_t k = 0; k < len; k++) seg.push_back((uint8_t)(it % 6 == 4 && k == 0 ? xr() % 2 * 16 + xr() % 4 : xr()));
+          b.insert(b.begin() + 2, seg.begin(), seg.end());
+        } break;
+        default: {                                                           // SOF dimensions
+          for (size_t i = 2; i + 9 < b.size(); i++) if (b[i] == 0xFF && (b[i + 1] == 0xC0)) { b[i + 5] = (uint8_t)xr(); b[i + 6] = (uint8_t)xr(); b[i + 7] = (uint8_t)xr(); b[i + 8] = (uint8_t)xr(); break; }
+        }
+      }
+      uint8_t* exact = (uint8_t*)malloc(b.size()); memcpy(exact, b.data(), b.size());
+      jnav::JpegFrame fr; std::vector<int16_t> coef;
+      const jn_status st = jnav::jpeg_parse_and_decode(exact, b.size(), fr, coef);
+      int w, h; jn_jpeg_info(exact, (int64_t)b.size(), &w, &h);
+      free(exact);
+      if (st == JN_OK && (coef.size() != (size_t)fr.bw * fr.bh * 64 || fr.width > jnav::kJpegMaxDim || fr.height > jnav::kJpegMaxDim)) return 3;
+      counts[st & 7]++;
+    }
+  }
+  printf("jpeg fuzz ok: ok %d unsupported %d invalid %d\n", counts[JN_OK], counts[JN_ERR_UNSUPPORTED], counts[JN_ERR_INVALID]);
+  return 0;
+}
+'''
+
+
+@pytest.mark.timeout(900)
+def test_jpeg_host_decoder_fuzzed_under_asan_ubsan(tmp_path):
+    """ADVICE r02: the entropy decoder takes compressed camera frames from the network.  4500 mutated files (header and
+    scan byte flips, truncations, random DHT/DQT/SOF/SOS/DRI bodies, random frame sizes) through jpeg_host.cpp built with
+    ASan + UBSan, each from an exactly-sized heap block."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+    files = []
+    for name in ("ragged_35x21_q95_422", "q90_422", "restart_blocks_q80_444"):
+        f = tmp_path / (name + ".jpg")
+        f.write_bytes(bytes(z[name + "__jpeg"]))
+        files.append(str(f))
+    src = tmp_path / "jpeg_fuzz.cpp"
+    src.write_text(JPEG_FUZZ)
+    exe = tmp_path / "jpeg_fuzz"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", CSRC,
+                    str(src), os.path.join(CSRC, "jpeg_host.cpp"), "-o", str(exe)], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([str(exe), *files], capture_output=True, text=True, env=env, timeout=800)
+    assert out.returncode == 0 and "jpeg fuzz ok" in out.stdout, (out.returncode, out.stdout[-500:], out.stderr[-4000:])
