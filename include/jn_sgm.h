@@ -58,6 +58,13 @@ jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const u
 typedef struct jn_sgm_times { float prefilter, paths, wta, total; } jn_sgm_times;
 jn_status jn_sgm_last_times(jn_sgm* h, jn_sgm_times* out);
 
+/* Test hook: device pointers of the intermediate buffers of the last batch (valid until the next call on `h`).
+ * which: 0 = sum of (L - C) over the three downward paths [n][H][W][D] (bytes; 16-bit when info[0] != 0), 1 / 2 = the same for
+ * the horizontal path towards -x / +x (bytes), 3 = right-image winners [n][H][W] u32 (S << 16 | d), 4 = left winners
+ * [n][H][W] u32 (d | d16 << 16), 5 = prefiltered rows.  All volumes are indexed by the MIRRORED column W-1-x.
+ * info = {wide, row pitch of the prefiltered rows, left padding, blocks per frame, implementation (0 = round-2 kernels: no buffers)}. */
+const void* jn_sgm_debug_ptr(jn_sgm* h, int32_t which, int32_t info[5]);
+
 /* int16 SGM disparities -> the u8 depth map the node publishes (point_cloud.cpp:422 semantics: invalid -> 0, values
  * saturate at 255; 1/16-pixel input is rounded half-to-even like convertTo does for floats). */
 jn_status jn_sgm_disparity_to_u8(int32_t device, const int16_t* dDisp, int32_t subpixel, uint8_t* dOut, int64_t n);

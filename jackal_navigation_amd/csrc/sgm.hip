@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../include/jn_sgm.h"
+#include "sgm_sweep.h"
 
 namespace {
 
@@ -261,8 +262,11 @@ struct jn_sgm {
   jn_sgm_params p;
   SgmDev dev;
   int W = 0, H = 0, max_batch = 0, device = 0;
-  uint8_t* g = nullptr;        // prefiltered rows [2 * max_batch][H][Wp]
-  uint8_t* Lr = nullptr;       // path volumes [8][max_batch][H][W][D]
+  int impl = 1;                // 1: the sweep kernels of sgm_sweep.hip (default); 0: the round-2 one-wave-per-line kernels below (JN_SGM_IMPL=0, kept for A/B)
+  uint8_t* g = nullptr;        // impl 0: prefiltered rows [2 * max_batch][H][Wp]
+  uint8_t* Lr = nullptr;       // impl 0: path volumes [8][max_batch][H][W][D]
+  jnav_sgm::SwDev sw = {};     // impl 1
+  jnav_sgm::SweepBuffers sb = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
   jn_sgm_times times = {};
@@ -288,6 +292,7 @@ void jn_sgm_destroy(jn_sgm* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->g); hipFree(h->Lr);
+  hipFree(h->sb.gm); hipFree(h->sb.volF); hipFree(h->sb.volH0); hipFree(h->sb.volH1); hipFree(h->sb.gx); hipFree(h->sb.flags); hipFree(h->sb.minr); hipFree(h->sb.dl);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -310,8 +315,22 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
   s.off = D + 8; s.Wp = s.off + W + 8;
   s.dbg = getenv("JN_SGM_DBG") ? atoi(getenv("JN_SGM_DBG")) : 0;
 #define SGM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_sgm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
-  SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
-  SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->Lr), (size_t)8 * max_batch * H * W * D));
+  h->impl = getenv("JN_SGM_IMPL") ? atoi(getenv("JN_SGM_IMPL")) : 1;
+  if (h->impl == 0) {
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->Lr), (size_t)8 * max_batch * H * W * D));
+  } else {
+    jnav_sgm::SweepSizes z;
+    jnav_sgm::sweep_geometry(W, H, D, p->P1, p->P2, p->prefilter_cap, p->lr_max_diff, p->subpixel, &h->sw, &z, max_batch);
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.gm), z.gm));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.volF), z.vol * (h->sw.wide ? 2 : 1)));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.volH0), z.vol));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.volH1), z.vol));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.gx), z.gx));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.flags), z.flags));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.minr), z.minr));
+    SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.dl), z.dl));
+  }
   SGM_CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   for (auto& e : h->ev) SGM_CREATE_TRY(hipEventCreate(&e));
 #undef SGM_CREATE_TRY
@@ -324,6 +343,16 @@ jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const u
   SGM_TRY(hipSetDevice(h->device));
   const SgmDev& s = h->dev;
   hipStream_t st = h->stream;
+  if (h->impl != 0) {
+    SGM_TRY(jnav_sgm::sweep_run(h->sw, n, dI1, dI2, pitch, (long long)image_stride, dDisp, st, h->sb, h->ev));
+    SGM_TRY(hipStreamSynchronize(st));
+    SGM_TRY(hipGetLastError());
+    hipEventElapsedTime(&h->times.prefilter, h->ev[0], h->ev[1]);
+    hipEventElapsedTime(&h->times.paths, h->ev[1], h->ev[2]);
+    hipEventElapsedTime(&h->times.wta, h->ev[2], h->ev[3]);
+    hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
+    return JN_OK;
+  }
   SGM_TRY(hipEventRecord(h->ev[0], st));
   hipLaunchKernelGGL(k_sgm_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, h->g);
   SGM_TRY(hipEventRecord(h->ev[1], st));
@@ -347,6 +376,17 @@ jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const u
   hipEventElapsedTime(&h->times.wta, h->ev[2], h->ev[3]);
   hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
   return JN_OK;
+}
+
+const void* jn_sgm_debug_ptr(jn_sgm* h, int32_t which, int32_t info[5]) {
+  if (!h) return nullptr;
+  if (info) { info[0] = h->sw.wide; info[1] = h->sw.Wp; info[2] = h->sw.padl; info[3] = h->sw.NB; info[4] = h->impl; }
+  if (h->impl == 0) return nullptr;
+  switch (which) {
+    case 0: return h->sb.volF; case 1: return h->sb.volH0; case 2: return h->sb.volH1;
+    case 3: return h->sb.minr; case 4: return h->sb.dl; case 5: return h->sb.gm;
+  }
+  return nullptr;
 }
 
 jn_status jn_sgm_last_times(jn_sgm* h, jn_sgm_times* out) {

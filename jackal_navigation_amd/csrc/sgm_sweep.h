@@ -1,0 +1,36 @@
+// sgm_sweep.h — host interface of the sweep kernels (sgm_sweep.hip) used by the SGM mode's C ABI (sgm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace jnav_sgm {
+
+struct SwDev {
+  int W, H, D, P1, P2, lr, subpixel, cap;
+  int Wp, padl;      // prefiltered rows, x-mirrored and padded: Wp bytes per row, image column x_k = W-1-x at byte padl + x_k
+  int NB, xmin;      // sheared blocks of the row sweeps: x' = x_k - (row in sweep order) in [xmin, W-1], NB blocks
+  int wide;          // 3 P2 > 255: the three-path volume is u16, the horizontal volumes are unpacked one by one
+};
+
+struct SweepSizes { size_t gm, vol, gx, flags, minr, dl; };     // bytes; the F volume takes 2 * vol when SwDev::wide
+
+struct SweepBuffers {
+  uint8_t* gm;            // prefiltered rows [2 n][H][Wp]
+  uint8_t* volF;          // m of the three downward paths [n][H][W][D] (u8, or u16 when wide)
+  uint8_t* volH0;         // m of the horizontal path walking x_k upwards
+  uint8_t* volH1;         // ... downwards
+  uint32_t* gx;           // boundary columns handed from block to block [n][NB][H][3][4][D/8]
+  uint32_t* flags;        // rows done per (frame, block), then the ticket counter
+  uint32_t* minr;         // right-image winners [n][H][W] (S << 16 | d)
+  uint32_t* dl;           // left winners [n][H][W] (d | d16 << 16), mirrored columns
+};
+
+void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch);
+
+// Queues prefilter, the two horizontal paths, the downward sweep, the upward sweep + winners, the L/R check on `st`.
+// ev[0..3] are recorded before the prefilter, before the paths, before the final sweep and at the end.
+hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
+                     const SweepBuffers& b, hipEvent_t* ev);
+
+}  // namespace jnav_sgm

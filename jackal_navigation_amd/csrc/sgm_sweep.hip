@@ -1,0 +1,472 @@
+// sgm_sweep.hip — the semi-global-matching mode (include/jn_sgm.h) as four sweeps with lanes = pixels.  Product code.
+//
+// No reference counterpart (the reference's only matcher is libelas); the definition is in jn_sgm.h, everything is integer
+// arithmetic and the bar is bit-exactness against its scalar restatement (the checker, outside the product).
+//
+// Why this decomposition (round 3; sgm.hip keeps the round-2 one-wave-per-line kernels for A/B).  With lanes = disparities
+// a path pixel costs ~27 wave-instructions (a 6-step DPP prefix-min and two wave shifts per pixel) and every direction
+// writes and re-reads its own W*H*D volume (16 W H D bytes of traffic).  Here a lane owns a PIXEL and DPL = D/4
+// consecutive disparities of it (four lanes per pixel), the path values live in registers as packed u16 pairs and all the
+// arithmetic is v_pk_min_u16 / v_pk_add_u16, two cells per lane-instruction:
+//   * the minimum over d is in-lane (plus two cross-lane steps over the four lanes of the pixel), L(p-r, d+-1) are register
+//     neighbours (one v_alignbit per register), the 1x3 SAD costs of four consecutive disparities come from ONE
+//     v_mqsad_pk_u16_u8 on the prefiltered right row (the prefilter stores g+1, so a zero byte in the left reference
+//     masks the fourth tap), already packed as the recurrence wants them;
+//   * the recurrence is carried NORMALISED: Lq = L(p-r, .) - min L(p-r, .), so L(p, d) = C + min(Lq[d], Lq[d+-1] + P1, P2)
+//     and what a path contributes beyond the cost, m = L - C, lies in [0, P2]: S = sum_r L_r = 8 C + sum_r m_r.  The
+//     sweeps store sums of m (bytes), and the last sweep adds 8 C, which it computes anyway;
+//   * k_sw_h: the two horizontal paths, lanes = 16 image rows x 4 disparity quarters, walking along x (one volume each);
+//   * k_sw_v<.., FINAL=false>: the three downward paths (0,1), (1,1), (-1,1) in ONE top-to-bottom sweep, summed in
+//     registers, one byte volume out;  k_sw_v<.., FINAL=true>: the three upward paths in one bottom-to-top sweep which
+//     also reads the three stored volumes, forms S, takes the left winner (packed 16-bit keys S*32 + j), the right
+//     image's winners (LDS atomic minima, flushed per row with global atomic minima) and the sub-pixel offset;
+//     k_sw_lr applies the L/R check.
+// HBM traffic: 3 volumes written + 3 read = 6 W H D (+ images), against 16 W H D before; SURVEY 8d's bound is 4 W H D.
+//
+// The row sweeps and their one-directional pipeline.  A pixel's three downward paths need the previous row at x, x-1 and
+// x+1, so 16-pixel strips of a row sweep cannot be independent.  In the SHEARED coordinate x' = x - y (a lane keeps x' and
+// so walks along the (1,1) diagonal) the three predecessors sit at x'+0, x'+1 and x'+2: all on ONE side.  A strip then
+// depends only on its right neighbour's first two columns of the previous row — a pipeline, not a lock-step: inside a
+// workgroup (NS strips, one barrier per row) the columns go through LDS; between workgroups through a global buffer with
+// a progress flag per block (write-through stores, drain, flag; polled and fetched by a COMMUNICATION wave that does no
+// arithmetic, so no computing wave ever waits on memory latency).  Workgroups take a ticket when they start, and tickets
+// are numbered so that a block's producer always holds a smaller one: whatever the dispatch order, a waiting block's
+// producer is running or done (placement-independent, no co-residency assumption).
+// The kernels work in x-mirrored image space (x_k = W-1-x), where the right-image tap x - d becomes x_k + d and the bytes a
+// lane needs ascend with d; the upward sweep is the downward one on the row-flipped image.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+#include <cstdio>
+#include "sgm_sweep.h"
+
+namespace jnav_sgm {
+
+#define DEV static __device__ __forceinline__
+
+constexpr int PX = 16;           // pixels per strip = lanes per disparity quarter (one DPP row)
+constexpr int NQ = 4;            // lanes per pixel
+constexpr uint32_t INF2 = 0x40004000u;   // "does not exist" for both halves; + P1 cannot wrap
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+DEV uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
+DEV uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
+DEV uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b))); }
+DEV uint32_t pk_mad(uint32_t a, uint32_t m, uint32_t c) {
+  return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, m) + __builtin_bit_cast(u16x2, c)));
+}
+DEV uint32_t bperm(int src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
+DEV uint32_t load_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// 1x3 SAD of the prefiltered rows for this lane's 2*NR disparities: run = right-row bytes from column x_k - 1 + d0 on,
+// ref = left-row bytes x_k-1, x_k, x_k+1 (top byte 0 = masked).  C[r] = (cost(d0 + 2r), cost(d0 + 2r + 1)) as u16 halves.
+template <int NR>
+DEV void costs(const uint8_t* __restrict__ run, uint32_t ref, uint32_t (&C)[NR]) {
+  constexpr int NW = NR / 2 + 1;
+  uint32_t w[NW];
+#pragma unroll
+  for (int k = 0; k < NW; k++) w[k] = load_u32_unaligned(run + 4 * k);
+#pragma unroll
+  for (int k = 0; k < NR / 2; k++) {
+    const uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, 0ull);
+    C[2 * k] = (uint32_t)r; C[2 * k + 1] = (uint32_t)(r >> 32);
+  }
+}
+
+// One pixel of one path.  L: normalised values of the predecessor pixel (in) -> of this pixel (out); acc += m = L - C.
+template <int NR>
+DEV void path_step(uint32_t (&L)[NR], const uint32_t (&C)[NR], uint32_t (&acc)[NR], uint32_t P1pk, uint32_t P2pk, int lane, int q) {
+  uint32_t up = bperm((lane - PX) & 63, L[NR - 1]);            // the quarter below: its last pair holds d0 - 1 in the high half
+  uint32_t dn = bperm((lane + PX) & 63, L[0]);                 // the quarter above: its first pair holds d0 + 2 NR in the low half
+  if (q == 0) up = INF2;
+  if (q == NQ - 1) dn = INF2;
+  uint32_t Ln[NR];
+  uint32_t sprev = __builtin_amdgcn_alignbit(L[0], up, 16);    // (d-1, d) of the first pair
+  uint32_t mn = 0xFFFFFFFFu;
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const uint32_t snext = r == NR - 1 ? __builtin_amdgcn_alignbit(dn, L[NR - 1], 16) : __builtin_amdgcn_alignbit(L[r + 1], L[r], 16);
+    uint32_t t = pk_min(sprev, snext);                         // min(Lq[d-1], Lq[d+1]) for both cells of the pair
+    t = pk_add(t, P1pk);
+    t = pk_min(t, L[r]);
+    t = pk_min(t, P2pk);
+    acc[r] = pk_add(acc[r], t);
+    Ln[r] = pk_add(C[r], t);
+    mn = pk_min(mn, Ln[r]);
+    sprev = snext;
+  }
+  uint32_t m = min(mn & 0xFFFFu, mn >> 16);
+  m = min(m, bperm(lane ^ 16, m));
+  m = min(m, bperm(lane ^ 32, m));
+  const uint32_t mpk = m | (m << 16);
+#pragma unroll
+  for (int r = 0; r < NR; r++) L[r] = pk_sub(Ln[r], mpk);
+}
+
+// pairs (d0,d1), (d2,d3) with values <= 255 -> bytes d0 d1 d2 d3; and back
+DEV uint32_t pack4(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x06040200u); }
+DEV uint32_t unpack_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); }
+DEV uint32_t unpack_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }
+
+// ---- prefilter: mirrored, padded, +1 ----
+// gm[img][y][padl + x_k] = clamp(Sobel_x(I, W-1-cl(x_k), y), -cap, cap) + cap + 1, cl = clamp to [0, W-1] (replicated borders:
+// the cost's coordinate clamps become plain reads).  +1 keeps every byte non-zero for v_mqsad's mask.
+__global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2, int pitch,
+                                                      long long stride, int n, uint8_t* __restrict__ gm) {
+  const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+  if (xp >= s.Wp) return;
+  const uint8_t* I = img < n ? I1 + (long long)img * stride : I2 + (long long)(img - n) * stride;
+  const int xk = min(max(xp - s.padl, 0), s.W - 1);
+  const int x = s.W - 1 - xk;
+  const int xm = max(x - 1, 0), xq = min(x + 1, s.W - 1), ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
+  const uint8_t* r0 = I + (size_t)ym * pitch; const uint8_t* r1 = I + (size_t)y * pitch; const uint8_t* r2 = I + (size_t)yq * pitch;
+  const int sx = ((int)r0[xq] - (int)r0[xm]) + 2 * ((int)r1[xq] - (int)r1[xm]) + ((int)r2[xq] - (int)r2[xm]);
+  gm[((size_t)img * s.H + y) * s.Wp + xp] = (uint8_t)(min(max(sx, -s.cap), s.cap) + s.cap + 1);
+}
+
+// ---- horizontal paths: lanes = 16 rows x 4 disparity quarters; blockIdx.z = 0 walks x_k upwards, 1 downwards ----
+template <int NR>
+__global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __restrict__ gm, uint8_t* __restrict__ vol0, uint8_t* __restrict__ vol1) {
+  constexpr int DPL = 2 * NR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, p = lane & 15;
+  const int y = (blockIdx.x * 4 + wave) * PX + p, frame = blockIdx.y, dir = blockIdx.z;
+  const bool valid = y < s.H;
+  const int yc = min(y, s.H - 1);
+  const uint8_t* rowL = gm + ((size_t)frame * s.H + yc) * s.Wp + s.padl - 1;
+  const uint8_t* rowR = gm + ((size_t)(n + frame) * s.H + yc) * s.Wp + s.padl - 1 + DPL * q;
+  uint8_t* vol = (dir ? vol1 : vol0) + (((size_t)frame * s.H + yc) * s.W) * s.D + DPL * q;
+  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
+  uint32_t L[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) L[r] = 0u;                      // Lq = 0 makes the first pixel of a line L = C
+  for (int t = 0; t < s.W; t++) {
+    const int xk = dir ? s.W - 1 - t : t;
+    uint32_t C[NR], acc[NR];
+    costs<NR>(rowR + xk, load_u32_unaligned(rowL + xk) & 0x00FFFFFFu, C);
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0u;
+    path_step<NR>(L, C, acc, P1pk, P2pk, lane, q);
+    if (valid) {
+      uint32_t* o = reinterpret_cast<uint32_t*>(vol + (size_t)xk * s.D);
+#pragma unroll
+      for (int k = 0; k < NR / 2; k += 4) {
+        uint4 v;
+        v.x = pack4(acc[2 * k], acc[2 * k + 1]); v.y = pack4(acc[2 * k + 2], acc[2 * k + 3]);
+        v.z = pack4(acc[2 * k + 4], acc[2 * k + 5]); v.w = pack4(acc[2 * k + 6], acc[2 * k + 7]);
+        *reinterpret_cast<uint4*>(o + k) = v;
+      }
+    }
+  }
+}
+
+// ---- the three paths of one vertical direction, sheared strips ----
+DEV uint32_t ld_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV uint64_t ld_sc1_64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEV void st_sc1_64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NR, int NS, bool FINAL, bool WIDE>
+__global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
+                                                        const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1,
+                                                        uint32_t* __restrict__ gx, uint32_t* __restrict__ gflag, uint32_t* __restrict__ ctr,
+                                                        uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
+  constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = BLK + DPL + 8;
+  __shared__ uint32_t exch[2][NS + 1][SLOT];                   // boundary columns: [row parity][strip; NS = from the next block][V0 | M0 | M1][quarter][NR]
+  __shared__ uint32_t minR[FINAL ? 2 : 1][FINAL ? NQ : 1][FINAL ? MR : 1];   // right-image winners of one row of this block, per disparity quarter
+  __shared__ int s_ticket;
+  extern __shared__ uint16_t sS[];                             // FINAL + sub-pixel: S of the block's pixels [BLK][D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = s.W, H = s.H, D = s.D, NB = s.NB;
+  if (tid == 0) s_ticket = (int)atomicAdd(ctr, 1u);
+  for (int k = tid; k < 2 * (NS + 1) * SLOT; k += (NS + 1) * 64) (&exch[0][0][0])[k] = 0u;
+  if (FINAL) for (int k = tid; k < 2 * NQ * MR; k += (NS + 1) * 64) (&minR[0][0][0])[k] = 0xFFFFFFFFu;
+  __syncthreads();
+  const int ticket = s_ticket;
+  const int j = NB - 1 - ticket / n, frame = ticket % n;       // producers (larger j) hold the smaller tickets
+  const int x0 = s.xmin + BLK * j;                             // sheared origin of this block: x' in [x0, x0 + BLK)
+  const int ybs = max(0, -(x0 + BLK - 1)), ybe = min(H - 1, W - 1 - x0);
+  if (ybs > ybe) return;
+  const size_t slot_stride = (size_t)SLOT;
+  uint32_t* my_gx = gx + ((size_t)frame * NB + j) * H * slot_stride;
+  uint32_t* my_flag = gflag + (size_t)frame * NB + j;
+
+  if (wave == NS) {
+    // ---- communication wave: fetches the producer's boundary columns one row ahead, publishes this block's, flushes the
+    // right-image minima.  It has a whole row's time for each of these, so their latencies never reach a computing wave.
+    const bool has_prod = j + 1 < NB;
+    const int x0p = x0 + BLK;
+    const int ybsp = max(0, -(x0p + BLK - 1)), ybep = min(H - 1, W - 1 - x0p);
+    const uint32_t* p_gx = gx + ((size_t)frame * NB + j + 1) * H * slot_stride;
+    const uint32_t* p_flag = gflag + (size_t)frame * NB + j + 1;
+    int known = 0;
+    auto fetch = [&](int yb) {                                 // producer's columns after ITS row yb -> exch[yb & 1][NS]
+      uint32_t* dst = &exch[yb & 1][NS][0];
+      if (has_prod && yb >= ybsp && yb <= ybep) {
+        if (known < yb + 1) {
+          int v = (int)ld_sc1(p_flag);
+          while (v < yb + 1) { __builtin_amdgcn_s_sleep(8); v = (int)ld_sc1(p_flag); }
+          known = v;
+        }
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(p_gx + (size_t)yb * slot_stride);
+        for (int o = lane; o < SLOT / 2; o += 64) { const uint64_t v = ld_sc1_64(src + o); dst[2 * o] = (uint32_t)v; dst[2 * o + 1] = (uint32_t)(v >> 32); }
+      } else {
+        for (int o = lane; o < SLOT; o += 64) dst[o] = 0u;
+      }
+    };
+    fetch(ybs - 1);
+    __syncthreads();
+    for (int yb = ybs; yb <= ybe; yb++) {
+      if (yb < ybe) fetch(yb);
+      __syncthreads();                                         // the computing waves have finished row yb
+      if (j > 0) {
+        const uint32_t* src = &exch[yb & 1][0][0];
+        uint64_t* dst = reinterpret_cast<uint64_t*>(my_gx + (size_t)yb * slot_stride);
+        for (int o = lane; o < SLOT / 2; o += 64) st_sc1_64(dst + o, (uint64_t)src[2 * o] | ((uint64_t)src[2 * o + 1] << 32));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every write-through store of this wave has left before the flag does
+        if (lane == 0) st_sc1(my_flag, (uint32_t)(yb + 1));
+      }
+      if (FINAL) {
+        const int y = flip ? H - 1 - yb : yb;
+        uint32_t* grow = gminR + ((size_t)frame * H + y) * W;
+        for (int e = lane; e < BLK + DPL; e += 64) {
+#pragma unroll
+          for (int qq = 0; qq < NQ; qq++) {
+            const uint32_t k = minR[yb & 1][qq][e];
+            if (k != 0xFFFFFFFFu) {
+              minR[yb & 1][qq][e] = 0xFFFFFFFFu;
+              const int xr = x0 + yb + e + DPL * qq;
+              if (xr >= 0 && xr < W) atomicMin(grow + xr, k + (uint32_t)(DPL * qq));
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- computing waves: strip `wave` of the block ----
+  const int q = lane >> 4, p = lane & 15;
+  const int xl = x0 + PX * wave + p;                           // this lane's sheared column
+  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
+  uint32_t V[NR], G[NR], M[NR];                                // normalised path values of the pixel this lane computed last: vertical, own diagonal, other diagonal
+#pragma unroll
+  for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = 0u;
+  const size_t img_rows = (size_t)H * s.Wp;
+  __syncthreads();
+  for (int yb = ybs; yb <= ybe; yb++) {
+    const int y = flip ? H - 1 - yb : yb;
+    const int xk = xl + yb;
+    const bool in = xk >= 0 && xk < W;
+    const int xc = min(max(xk, -PX), W + PX - 1);
+    const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc;
+    const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc + DPL * q;
+    uint32_t C[NR], acc[NR];
+    costs<NR>(rowR, load_u32_unaligned(rowL) & 0x00FFFFFFu, C);
+    // volumes of the earlier sweeps for this pixel (FINAL): issue the loads before the arithmetic
+    uint32_t fF[WIDE ? NR : NR / 2], fH0[NR / 2], fH1[NR / 2];
+    const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
+    if (FINAL) {
+      const uint32_t* pf = reinterpret_cast<const uint32_t*>(volF + (pix * D + DPL * q) * (WIDE ? 2 : 1));
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(volH0 + pix * D + DPL * q);
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>(volH1 + pix * D + DPL * q);
+#pragma unroll
+      for (int k = 0; k < (WIDE ? NR : NR / 2); k += 4) { const uint4 v = *reinterpret_cast<const uint4*>(pf + k); fF[k] = v.x; fF[k + 1] = v.y; fF[k + 2] = v.z; fF[k + 3] = v.w; }
+#pragma unroll
+      for (int k = 0; k < NR / 2; k += 4) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p0 + k); fH0[k] = a.x; fH0[k + 1] = a.y; fH0[k + 2] = a.z; fH0[k + 3] = a.w;
+        const uint4 b = *reinterpret_cast<const uint4*>(p1 + k); fH1[k] = b.x; fH1[k + 1] = b.y; fH1[k + 2] = b.z; fH1[k + 3] = b.w;
+      }
+    }
+    // predecessors: vertical from x'+1, other diagonal from x'+2 (one / two shifts along the strip; the last lane takes the
+    // right neighbour's columns, which DPP leaves in place as the `old` operand), own diagonal in place
+    {
+      const uint32_t* e = &exch[(yb + 1) & 1][wave + 1][0];
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const uint32_t v0 = e[(0 * NQ + q) * NR + r], m0 = e[(1 * NQ + q) * NR + r], m1 = e[(2 * NQ + q) * NR + r];
+        V[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)v0, (int)V[r], 0x101, 0xf, 0xf, false);           // row_shl:1
+        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)m0, (int)M[r], 0x101, 0xf, 0xf, false);
+        M[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)m1, (int)t, 0x101, 0xf, 0xf, false);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0u;
+    path_step<NR>(V, C, acc, P1pk, P2pk, lane, q);
+    path_step<NR>(G, C, acc, P1pk, P2pk, lane, q);
+    path_step<NR>(M, C, acc, P1pk, P2pk, lane, q);
+    if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
+#pragma unroll
+      for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : 0u; G[r] = in ? G[r] : 0u; M[r] = in ? M[r] : 0u; }
+    }
+    {
+      uint32_t* o = &exch[yb & 1][wave][0];
+      if (p == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) { o[(0 * NQ + q) * NR + r] = V[r]; o[(1 * NQ + q) * NR + r] = M[r]; }
+      }
+      if (p == 1) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) o[(2 * NQ + q) * NR + r] = M[r];
+      }
+    }
+    if (!FINAL) {
+      if (in) {
+        if (WIDE) {
+          uint32_t* o = reinterpret_cast<uint32_t*>(volF + (pix * D + DPL * q) * 2);
+#pragma unroll
+          for (int k = 0; k < NR; k += 4) *reinterpret_cast<uint4*>(o + k) = make_uint4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
+        } else {
+          uint32_t* o = reinterpret_cast<uint32_t*>(volF + pix * D + DPL * q);
+#pragma unroll
+          for (int k = 0; k < NR / 2; k += 4)
+            *reinterpret_cast<uint4*>(o + k) = make_uint4(pack4(acc[2 * k], acc[2 * k + 1]), pack4(acc[2 * k + 2], acc[2 * k + 3]),
+                                                          pack4(acc[2 * k + 4], acc[2 * k + 5]), pack4(acc[2 * k + 6], acc[2 * k + 7]));
+        }
+      }
+    } else {
+      // S = 8 C + the three upward m + the stored five
+      uint32_t S[NR];
+#pragma unroll
+      for (int k = 0; k < NR / 2; k++) {
+        uint32_t a, b;
+        if (WIDE) { a = pk_add(pk_add(fF[2 * k], unpack_lo(fH0[k])), unpack_lo(fH1[k])); b = pk_add(pk_add(fF[2 * k + 1], unpack_hi(fH0[k])), unpack_hi(fH1[k])); }
+        else { const uint32_t hb = fH0[k] + fH1[k];            // bytes <= 2 P2 <= 170: no carry between bytes
+               a = pk_add(unpack_lo(fF[k]), unpack_lo(hb)); b = pk_add(unpack_hi(fF[k]), unpack_hi(hb)); }
+        S[2 * k] = pk_add(pk_mad(C[2 * k], 0x00080008u, acc[2 * k]), a);
+        S[2 * k + 1] = pk_add(pk_mad(C[2 * k + 1], 0x00080008u, acc[2 * k + 1]), b);
+      }
+      // left winner: S <= 2040, so S*32 + (index within a run of 32 disparities) is a 16-bit key; smallest d wins ties
+      uint32_t key = 0xFFFFFFFFu;
+#pragma unroll
+      for (int c = 0; c < NR; c += 16) {
+        uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = c; r < c + 16 && r < NR; r++) {
+          const uint32_t jc = (uint32_t)((2 * r) & 31) | ((uint32_t)((2 * r + 1) & 31) << 16);
+          best = pk_min(best, pk_mad(S[r], 0x00200020u, jc));
+        }
+        const uint32_t b16 = min(best & 0xFFFFu, best >> 16);
+        key = min(key, ((b16 >> 5) << 16) | (uint32_t)(DPL * q + 2 * c + (int)(b16 & 31u)));
+      }
+      key = in ? key : 0xFFFFFFFFu;
+      key = min(key, bperm(lane ^ 16, key));
+      key = min(key, bperm(lane ^ 32, key));
+      // right image: cell (x_k, d) belongs to right pixel x_k + d; keys S << 16 | (d within the quarter)
+      if (in) {
+        uint32_t* mr = &minR[yb & 1][q][PX * wave + p];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          atomicMin(mr + 2 * r, (S[r] << 16) | (uint32_t)(2 * r));
+          atomicMin(mr + 2 * r + 1, (S[r] & 0xFFFF0000u) | (uint32_t)(2 * r + 1));
+        }
+      }
+      const int d = (int)(key & 0xFFFFu);
+      int d16 = 16 * d;
+      if (s.subpixel) {
+        uint32_t* my = reinterpret_cast<uint32_t*>(sS + ((size_t)(PX * wave + p) * D + DPL * q));
+#pragma unroll
+        for (int r = 0; r < NR; r++) my[r] = S[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (in && q == 0 && d > 0 && d < D - 1) {
+          const uint16_t* ps = sS + (size_t)(PX * wave + p) * D;
+          const int sm = ps[d - 1], sc = ps[d], sp = ps[d + 1];
+          const int den = max(sm + sp - 2 * sc, 1);
+          d16 = 16 * d + (16 * (sm - sp) + den) / (2 * den);
+        }
+      }
+      if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- L/R check: the left winner survives if the right image's winner at x - d agrees ----
+__global__ void __launch_bounds__(256) k_sw_lr(SwDev s, int n, const uint32_t* __restrict__ dLp, const uint32_t* __restrict__ gminR, int16_t* __restrict__ disp) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
+  if (x >= s.W) return;
+  const int xk = s.W - 1 - x;
+  const size_t row = ((size_t)frame * s.H + y) * s.W;
+  const uint32_t e = dLp[row + xk];
+  const int d = (int)(e & 0xFFFFu);
+  bool ok = true;
+  if (s.lr >= 0) {
+    const int xr = xk + d;                                     // x - d >= 0  <=>  x_k + d <= W - 1
+    ok = xr < s.W && abs(d - (int)(gminR[row + min(xr, s.W - 1)] & 0xFFFFu)) <= s.lr;
+  }
+  const int scale = s.subpixel ? 16 : 1;
+  disp[row + x] = (int16_t)(ok ? (s.subpixel ? (int)(int16_t)(e >> 16) : d) : -scale);
+}
+
+}  // namespace jnav_sgm
+
+// ---------------------------------------------------------------- host side ----------------------------------------------------------------
+namespace jnav_sgm {
+
+static int strips_for(int D) { return D == 256 ? 4 : 7; }      // computing waves per workgroup (+ 1 communication wave)
+
+void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch) {
+  s->W = W; s->H = H; s->D = D; s->P1 = P1; s->P2 = P2; s->cap = cap; s->lr = lr; s->subpixel = subpixel ? 1 : 0;
+  s->padl = 32; s->Wp = ((s->padl + W + D + 64) + 15) / 16 * 16;
+  const int BLK = strips_for(D) * PX;
+  s->xmin = -(H - 1);
+  s->NB = (W + H - 1 + BLK - 1) / BLK;
+  s->wide = 3 * P2 > 255 ? 1 : 0;
+  const size_t px = (size_t)W * H;
+  z->gm = (size_t)2 * max_batch * H * s->Wp + 256;
+  z->vol = (size_t)max_batch * px * D;                          // one byte volume; the F volume is twice that when wide
+  z->gx = (size_t)max_batch * s->NB * H * (3 * NQ * (D / 8)) * sizeof(uint32_t);
+  z->flags = ((size_t)max_batch * s->NB + 16) * sizeof(uint32_t);
+  z->minr = (size_t)max_batch * px * sizeof(uint32_t);
+  z->dl = (size_t)max_batch * px * sizeof(uint32_t);
+}
+
+template <int NR, int NS>
+static hipError_t launch_v(const SwDev& s, int n, bool final, hipStream_t st, const SweepBuffers& b) {
+  const dim3 grid((unsigned)(n * s.NB)), block((NS + 1) * 64);
+  const size_t dyn = final && s.subpixel ? (size_t)NS * PX * s.D * sizeof(uint16_t) : 0;
+  uint32_t* ctr = b.flags + (size_t)n * s.NB;                   // the ticket counter sits behind the flags (one memset clears both)
+#define JN_SW_V(FINAL, WIDE)                                                                                                            \
+  do {                                                                                                                                  \
+    if (dyn > 48 * 1024) {                                                                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw_v<NR, NS, FINAL, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+      if (e != hipSuccess) return e;                                                                                                    \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((k_sw_v<NR, NS, FINAL, WIDE>), grid, block, dyn, st, s, n, FINAL ? 1 : 0, b.gm, b.volF, b.volH0, b.volH1, b.gx, b.flags, ctr, b.minr, b.dl); \
+  } while (0)
+  if (final) { if (s.wide) JN_SW_V(true, true); else JN_SW_V(true, false); }
+  else { if (s.wide) JN_SW_V(false, true); else JN_SW_V(false, false); }
+#undef JN_SW_V
+  return hipGetLastError();
+}
+
+template <int NR, int NS>
+static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
+                          const SweepBuffers& b, hipEvent_t* ev) {
+  hipError_t e;
+  const size_t px = (size_t)s.W * s.H;
+  if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
+  if ((e = hipMemsetAsync(b.minr, 0xFF, (size_t)n * px * sizeof(uint32_t), st)) != hipSuccess) return e;
+  if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
+  hipLaunchKernelGGL((k_sw_h<NR>), dim3((s.H + 4 * PX - 1) / (4 * PX), n, 2), dim3(256), 0, st, s, n, b.gm, b.volH0, b.volH1);
+  const size_t flag_bytes = ((size_t)n * s.NB + 1) * sizeof(uint32_t);
+  if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
+  if ((e = launch_v<NR, NS>(s, n, false, st, b)) != hipSuccess) return e;
+  if ((e = hipEventRecord(ev[2], st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
+  if ((e = launch_v<NR, NS>(s, n, true, st, b)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_sw_lr, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, n, b.dl, b.minr, dDisp);
+  if ((e = hipEventRecord(ev[3], st)) != hipSuccess) return e;
+  return hipGetLastError();
+}
+
+hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
+                     const SweepBuffers& b, hipEvent_t* ev) {
+  if (s.D == 64) return run_all<8, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+  if (s.D == 128) return run_all<16, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+  return run_all<32, 4>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+}
+
+}  // namespace jnav_sgm

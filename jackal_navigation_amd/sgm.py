@@ -28,12 +28,14 @@ def _bind():
         L.jn_sgm_process_batch.argtypes = [vp, i32, vp, vp, i32, i64, vp]
         L.jn_sgm_last_times.argtypes = [vp, C.POINTER(SgmTimes)]
         L.jn_sgm_disparity_to_u8.argtypes = [i32, vp, i32, vp, i64]
+        L.jn_sgm_debug_ptr.argtypes = [vp, i32, C.POINTER(i32 * 5)]
+        L.jn_sgm_debug_ptr.restype = vp
         L._sgm_bound = True
     return L
 
 
 SGM_EXPORTS = ["jn_sgm_params_default", "jn_sgm_create", "jn_sgm_destroy", "jn_sgm_process_batch", "jn_sgm_last_times",
-               "jn_sgm_disparity_to_u8"]
+               "jn_sgm_disparity_to_u8", "jn_sgm_debug_ptr"]
 
 
 class Sgm:
@@ -64,6 +66,12 @@ class Sgm:
 
     def to_u8(self, dDisp, dOut, n):
         _lib.check(self._L.jn_sgm_disparity_to_u8(self.device, dDisp, self.param.subpixel, dOut, n), "jn_sgm_disparity_to_u8")
+
+    def debug_ptr(self, which):
+        """(device pointer, info) of an intermediate buffer of the last batch (include/jn_sgm.h jn_sgm_debug_ptr)."""
+        info = (C.c_int32 * 5)()
+        ptr = self._L.jn_sgm_debug_ptr(self._h, which, C.byref(info))
+        return ptr, list(info)
 
     def close(self):
         if getattr(self, "_h", None):
