@@ -38,6 +38,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include "sgm_sweep.h"
 
 namespace jnav_sgm {
@@ -60,12 +61,14 @@ DEV uint32_t load_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy
 
 // 1x3 SAD of the prefiltered rows for this lane's 2*NR disparities: run = right-row bytes from column x_k - 1 + d0 on,
 // ref = left-row bytes x_k-1, x_k, x_k+1 (top byte 0 = masked).  C[r] = (cost(d0 + 2r), cost(d0 + 2r + 1)) as u16 halves.
+// Loading and arithmetic are separate so that a sweep can fetch the next pixel's bytes before it works on this one.
 template <int NR>
-DEV void costs(const uint8_t* __restrict__ run, uint32_t ref, uint32_t (&C)[NR]) {
-  constexpr int NW = NR / 2 + 1;
-  uint32_t w[NW];
+DEV void load_run(const uint8_t* __restrict__ run, uint32_t (&w)[NR / 2 + 1]) {
 #pragma unroll
-  for (int k = 0; k < NW; k++) w[k] = load_u32_unaligned(run + 4 * k);
+  for (int k = 0; k < NR / 2 + 1; k++) w[k] = load_u32_unaligned(run + 4 * k);
+}
+template <int NR>
+DEV void costs(const uint32_t (&w)[NR / 2 + 1], uint32_t ref, uint32_t (&C)[NR]) {
 #pragma unroll
   for (int k = 0; k < NR / 2; k++) {
     const uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, 0ull);
@@ -73,34 +76,55 @@ DEV void costs(const uint8_t* __restrict__ run, uint32_t ref, uint32_t (&C)[NR])
   }
 }
 
-// One pixel of one path.  L: normalised values of the predecessor pixel (in) -> of this pixel (out); acc += m = L - C.
+// One pixel of one path, in three parts so that the three paths of a row sweep can overlap their cross-lane steps.
+// L: normalised values of the predecessor pixel; up / dn: the neighbouring quarters' adjoining pairs (path_neighbours);
+// acc += m = L_new - C; Ln = C + m (not yet normalised), mn = packed running minimum of Ln.
 template <int NR>
-DEV void path_step(uint32_t (&L)[NR], const uint32_t (&C)[NR], uint32_t (&acc)[NR], uint32_t P1pk, uint32_t P2pk, int lane, int q) {
-  uint32_t up = bperm((lane - PX) & 63, L[NR - 1]);            // the quarter below: its last pair holds d0 - 1 in the high half
-  uint32_t dn = bperm((lane + PX) & 63, L[0]);                 // the quarter above: its first pair holds d0 + 2 NR in the low half
-  if (q == 0) up = INF2;
-  if (q == NQ - 1) dn = INF2;
-  uint32_t Ln[NR];
-  uint32_t sprev = __builtin_amdgcn_alignbit(L[0], up, 16);    // (d-1, d) of the first pair
-  uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-  for (int r = 0; r < NR; r++) {
-    const uint32_t snext = r == NR - 1 ? __builtin_amdgcn_alignbit(dn, L[NR - 1], 16) : __builtin_amdgcn_alignbit(L[r + 1], L[r], 16);
-    uint32_t t = pk_min(sprev, snext);                         // min(Lq[d-1], Lq[d+1]) for both cells of the pair
+DEV void path_neighbours(const uint32_t (&L)[NR], int lane, int q, uint32_t& up, uint32_t& dn) {
+  const uint32_t a = bperm((lane - PX) & 63, L[NR - 1]);       // the quarter below: its last pair holds d0 - 1 in the high half
+  const uint32_t b = bperm((lane + PX) & 63, L[0]);            // the quarter above: its first pair holds d0 + 2 NR in the low half
+  up = q == 0 ? INF2 : a;
+  dn = q == NQ - 1 ? INF2 : b;
+}
+template <int NR>
+DEV void path_cells(const uint32_t (&L)[NR], uint32_t up, uint32_t dn, const uint32_t (&C)[NR], uint32_t (&acc)[NR], uint32_t (&Ln)[NR], uint32_t& mn,
+                    uint32_t P1pk, uint32_t P2pk) {
+  mn = 0xFFFFFFFFu;
+  auto cell = [&](int r, uint32_t sl, uint32_t sr) {           // sl = (Lq[d-1], Lq[d]) of the pair, sr = (Lq[d+1], Lq[d+2])
+    uint32_t t = pk_min(sl, sr);
     t = pk_add(t, P1pk);
     t = pk_min(t, L[r]);
     t = pk_min(t, P2pk);
     acc[r] = pk_add(acc[r], t);
     Ln[r] = pk_add(C[r], t);
     mn = pk_min(mn, Ln[r]);
-    sprev = snext;
-  }
+  };
+  // the inner pairs first: they do not need the other quarters' values, whose permutes are still in flight
+#pragma unroll
+  for (int r = 1; r < NR - 1; r++) cell(r, __builtin_amdgcn_alignbit(L[r], L[r - 1], 16), __builtin_amdgcn_alignbit(L[r + 1], L[r], 16));
+  cell(0, __builtin_amdgcn_alignbit(L[0], up, 16), __builtin_amdgcn_alignbit(L[1], L[0], 16));
+  cell(NR - 1, __builtin_amdgcn_alignbit(L[NR - 1], L[NR - 2], 16), __builtin_amdgcn_alignbit(dn, L[NR - 1], 16));
+}
+// minimum over the pixel's four lanes (and both halves) with the gfx950 row / half swaps: pure VALU, no LDS round trip
+DEV uint32_t pixel_min(uint32_t mn) {
   uint32_t m = min(mn & 0xFFFFu, mn >> 16);
-  m = min(m, bperm(lane ^ 16, m));
-  m = min(m, bperm(lane ^ 32, m));
+  const auto a = __builtin_amdgcn_permlane16_swap(m, m, false, false);
+  m = min(a[0], a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
+  return min(b[0], b[1]);
+}
+template <int NR>
+DEV void path_normalise(uint32_t (&L)[NR], const uint32_t (&Ln)[NR], uint32_t m) {
   const uint32_t mpk = m | (m << 16);
 #pragma unroll
   for (int r = 0; r < NR; r++) L[r] = pk_sub(Ln[r], mpk);
+}
+template <int NR>
+DEV void path_step(uint32_t (&L)[NR], const uint32_t (&C)[NR], uint32_t (&acc)[NR], uint32_t P1pk, uint32_t P2pk, int lane, int q) {
+  uint32_t up, dn, mn, Ln[NR];
+  path_neighbours<NR>(L, lane, q, up, dn);
+  path_cells<NR>(L, up, dn, C, acc, Ln, mn, P1pk, P2pk);
+  path_normalise<NR>(L, Ln, pixel_min(mn));
 }
 
 // pairs (d0,d1), (d2,d3) with values <= 255 -> bytes d0 d1 d2 d3; and back
@@ -139,14 +163,25 @@ __global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __r
   uint32_t L[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++) L[r] = 0u;                      // Lq = 0 makes the first pixel of a line L = C
-  for (int t = 0; t < s.W; t++) {
-    const int xk = dir ? s.W - 1 - t : t;
+  const int step = dir ? -1 : 1;
+  int xk = dir ? s.W - 1 : 0;
+  uint32_t w[NR / 2 + 1], ref;                                 // bytes of the pixel being worked on; the next pixel's are fetched meanwhile
+  load_run<NR>(rowR + xk, w); ref = load_u32_unaligned(rowL + xk);
+  for (int t = 0; t < s.W; t++, xk += step) {
+    uint32_t wn[NR / 2 + 1], refn;
+    const int xn = t + 1 < s.W ? xk + step : xk;
+    if (!(s.dbg & 2)) { load_run<NR>(rowR + xn, wn); refn = load_u32_unaligned(rowL + xn); }
+    else {
+#pragma unroll
+      for (int k = 0; k < NR / 2 + 1; k++) wn[k] = w[k] + 0x01010101u * (uint32_t)t;
+      refn = ref;
+    }
     uint32_t C[NR], acc[NR];
-    costs<NR>(rowR + xk, load_u32_unaligned(rowL + xk) & 0x00FFFFFFu, C);
+    costs<NR>(w, ref & 0x00FFFFFFu, C);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
     path_step<NR>(L, C, acc, P1pk, P2pk, lane, q);
-    if (valid) {
+    if (valid && (!(s.dbg & 1) || L[0] == 0x12345678u)) {
       uint32_t* o = reinterpret_cast<uint32_t*>(vol + (size_t)xk * s.D);
 #pragma unroll
       for (int k = 0; k < NR / 2; k += 4) {
@@ -156,6 +191,9 @@ __global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __r
         *reinterpret_cast<uint4*>(o + k) = v;
       }
     }
+#pragma unroll
+    for (int k = 0; k < NR / 2 + 1; k++) w[k] = wn[k];
+    ref = refn;
   }
 }
 
@@ -166,7 +204,7 @@ DEV uint64_t ld_sc1_64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC
 DEV void st_sc1_64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int NR, int NS, bool FINAL, bool WIDE>
-__global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
+__global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k_sw_v(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
                                                         const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1,
                                                         uint32_t* __restrict__ gx, uint32_t* __restrict__ gflag, uint32_t* __restrict__ ctr,
                                                         uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
@@ -252,31 +290,46 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
 #pragma unroll
   for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = 0u;
   const size_t img_rows = (size_t)H * s.Wp;
+  // a row's inputs: the prefiltered bytes for the costs and, in the final sweep, this pixel's bytes of the three stored volumes.
+  // They are fetched one row ahead (the next row's loads are in flight while this row's arithmetic runs).
+  struct RowIn { uint32_t w[NR / 2 + 1], ref, fF[FINAL ? (WIDE ? NR : NR / 2) : 1], fH0[FINAL ? NR / 2 : 1], fH1[FINAL ? NR / 2 : 1]; };
+  auto fetch_row = [&](int yb, RowIn& in_) {
+    const int y = flip ? H - 1 - yb : yb;
+    const int xk = xl + yb;
+    const int xc = min(max(xk, -PX), W + PX - 1);
+    const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc;
+    const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc + DPL * q;
+    load_run<NR>(rowR, in_.w);
+    in_.ref = load_u32_unaligned(rowL);
+    if (FINAL) {
+      const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
+      const uint32_t* pf = reinterpret_cast<const uint32_t*>(volF + (pix * D + DPL * q) * (WIDE ? 2 : 1));
+      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(volH0 + pix * D + DPL * q);
+      const uint32_t* p1 = reinterpret_cast<const uint32_t*>(volH1 + pix * D + DPL * q);
+#pragma unroll
+      for (int k = 0; k < (WIDE ? NR : NR / 2); k += 4) { const uint4 v = *reinterpret_cast<const uint4*>(pf + k); in_.fF[k] = v.x; in_.fF[k + 1] = v.y; in_.fF[k + 2] = v.z; in_.fF[k + 3] = v.w; }
+#pragma unroll
+      for (int k = 0; k < NR / 2; k += 4) {
+        const uint4 a = *reinterpret_cast<const uint4*>(p0 + k); in_.fH0[k] = a.x; in_.fH0[k + 1] = a.y; in_.fH0[k + 2] = a.z; in_.fH0[k + 3] = a.w;
+        const uint4 b = *reinterpret_cast<const uint4*>(p1 + k); in_.fH1[k] = b.x; in_.fH1[k + 1] = b.y; in_.fH1[k + 2] = b.z; in_.fH1[k + 3] = b.w;
+      }
+    }
+  };
+  RowIn cur;
+  fetch_row(ybs, cur);
   __syncthreads();
   for (int yb = ybs; yb <= ybe; yb++) {
     const int y = flip ? H - 1 - yb : yb;
     const int xk = xl + yb;
     const bool in = xk >= 0 && xk < W;
-    const int xc = min(max(xk, -PX), W + PX - 1);
-    const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc;
-    const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc + DPL * q;
-    uint32_t C[NR], acc[NR];
-    costs<NR>(rowR, load_u32_unaligned(rowL) & 0x00FFFFFFu, C);
-    // volumes of the earlier sweeps for this pixel (FINAL): issue the loads before the arithmetic
-    uint32_t fF[WIDE ? NR : NR / 2], fH0[NR / 2], fH1[NR / 2];
     const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
-    if (FINAL) {
-      const uint32_t* pf = reinterpret_cast<const uint32_t*>(volF + (pix * D + DPL * q) * (WIDE ? 2 : 1));
-      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(volH0 + pix * D + DPL * q);
-      const uint32_t* p1 = reinterpret_cast<const uint32_t*>(volH1 + pix * D + DPL * q);
-#pragma unroll
-      for (int k = 0; k < (WIDE ? NR : NR / 2); k += 4) { const uint4 v = *reinterpret_cast<const uint4*>(pf + k); fF[k] = v.x; fF[k + 1] = v.y; fF[k + 2] = v.z; fF[k + 3] = v.w; }
-#pragma unroll
-      for (int k = 0; k < NR / 2; k += 4) {
-        const uint4 a = *reinterpret_cast<const uint4*>(p0 + k); fH0[k] = a.x; fH0[k + 1] = a.y; fH0[k + 2] = a.z; fH0[k + 3] = a.w;
-        const uint4 b = *reinterpret_cast<const uint4*>(p1 + k); fH1[k] = b.x; fH1[k + 1] = b.y; fH1[k + 2] = b.z; fH1[k + 3] = b.w;
-      }
-    }
+    RowIn nxt;
+    fetch_row(min(yb + 1, ybe), nxt);
+    uint32_t C[NR], acc[NR];
+    costs<NR>(cur.w, cur.ref & 0x00FFFFFFu, C);
+    const uint32_t (&fF)[FINAL ? (WIDE ? NR : NR / 2) : 1] = cur.fF;
+    const uint32_t (&fH0)[FINAL ? NR / 2 : 1] = cur.fH0;
+    const uint32_t (&fH1)[FINAL ? NR / 2 : 1] = cur.fH1;
     // predecessors: vertical from x'+1, other diagonal from x'+2 (one / two shifts along the strip; the last lane takes the
     // right neighbour's columns, which DPP leaves in place as the `old` operand), own diagonal in place
     {
@@ -291,9 +344,20 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
     }
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
-    path_step<NR>(V, C, acc, P1pk, P2pk, lane, q);
-    path_step<NR>(G, C, acc, P1pk, P2pk, lane, q);
-    path_step<NR>(M, C, acc, P1pk, P2pk, lane, q);
+    {
+      // the three paths side by side: all quarter-boundary permutes first, then the cells, then the three minima together
+      uint32_t upV, dnV, upG, dnG, upM, dnM, mnV, mnG, mnM, LnV[NR], LnG[NR], LnM[NR];
+      path_neighbours<NR>(V, lane, q, upV, dnV);
+      path_neighbours<NR>(G, lane, q, upG, dnG);
+      path_neighbours<NR>(M, lane, q, upM, dnM);
+      path_cells<NR>(V, upV, dnV, C, acc, LnV, mnV, P1pk, P2pk);
+      path_cells<NR>(G, upG, dnG, C, acc, LnG, mnG, P1pk, P2pk);
+      path_cells<NR>(M, upM, dnM, C, acc, LnM, mnM, P1pk, P2pk);
+      const uint32_t a = pixel_min(mnV), b = pixel_min(mnG), c = pixel_min(mnM);
+      path_normalise<NR>(V, LnV, a);
+      path_normalise<NR>(G, LnG, b);
+      path_normalise<NR>(M, LnM, c);
+    }
     if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
 #pragma unroll
       for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : 0u; G[r] = in ? G[r] : 0u; M[r] = in ? M[r] : 0u; }
@@ -349,8 +413,12 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
         key = min(key, ((b16 >> 5) << 16) | (uint32_t)(DPL * q + 2 * c + (int)(b16 & 31u)));
       }
       key = in ? key : 0xFFFFFFFFu;
-      key = min(key, bperm(lane ^ 16, key));
-      key = min(key, bperm(lane ^ 32, key));
+      {
+        const auto a = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+        key = min(a[0], a[1]);
+        const auto b = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+        key = min(b[0], b[1]);
+      }
       // right image: cell (x_k, d) belongs to right pixel x_k + d; keys S << 16 | (d within the quarter)
       if (in) {
         uint32_t* mr = &minR[yb & 1][q][PX * wave + p];
@@ -378,6 +446,7 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
       }
       if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
     }
+    cur = nxt;
     __syncthreads();
   }
 }
@@ -404,7 +473,8 @@ __global__ void __launch_bounds__(256) k_sw_lr(SwDev s, int n, const uint32_t* _
 // ---------------------------------------------------------------- host side ----------------------------------------------------------------
 namespace jnav_sgm {
 
-static int strips_for(int D) { return D == 256 ? 4 : 7; }      // computing waves per workgroup (+ 1 communication wave)
+// computing waves per workgroup (+ 1 communication wave).  D = 256: four waves, one per SIMD, so that 96 pairs of path state plus a row of inputs fit the registers
+static int strips_for(int D) { return D == 256 ? 3 : 7; }
 
 void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch) {
   s->W = W; s->H = H; s->D = D; s->P1 = P1; s->P2 = P2; s->cap = cap; s->lr = lr; s->subpixel = subpixel ? 1 : 0;
@@ -413,6 +483,7 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
   s->xmin = -(H - 1);
   s->NB = (W + H - 1 + BLK - 1) / BLK;
   s->wide = 3 * P2 > 255 ? 1 : 0;
+  s->dbg = getenv("JN_SGM_DBG") ? atoi(getenv("JN_SGM_DBG")) : 0;
   const size_t px = (size_t)W * H;
   z->gm = (size_t)2 * max_batch * H * s->Wp + 256;
   z->vol = (size_t)max_batch * px * D;                          // one byte volume; the F volume is twice that when wide
@@ -466,7 +537,7 @@ hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* d
                      const SweepBuffers& b, hipEvent_t* ev) {
   if (s.D == 64) return run_all<8, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
   if (s.D == 128) return run_all<16, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
-  return run_all<32, 4>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+  return run_all<32, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
 }
 
 }  // namespace jnav_sgm
