@@ -229,6 +229,19 @@ def bm_roofline(W, H, D, B, radius, sub, ms):
             "note": "bound by vector issue, not HBM (no cost volume exists): %.1f T absolute differences/s in the match kernels" % (ads / (ms["match"] * 1e-3) / 1e12)}
 
 
+def sgm_pmc_traffic(W, H, D, B):
+    """HBM bytes per batch of the sweep kernels from the committed PMC passes (profiles/r03_sgm_pmc_traffic.json), if they were
+    taken on this source (sha256 of sgm_sweep.hip) and this workload."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r03_sgm_pmc_traffic.json")))
+        src = os.path.join(ROOT, "jackal_navigation_amd", "csrc", "sgm_sweep.hip")
+        if j.get("sgm_sweep_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest() or j.get("workload") != [W, H, D, B]:
+            return None
+        return {"bytes": int(j["bytes_per_batch"]), "note": "PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, profiles/r03_sgm_pmc_traffic.json);"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def run_sgm(a):
     """--mode sgm: step = one batch through prefilter -> 8 paths -> sum/WTA/check -> u8 map -> 90-bin scan.
     --mode bm: the same with the block matcher (prefilter -> left / right block costs + WTA -> check) in place of the paths."""
@@ -338,13 +351,20 @@ def run_sgm(a):
         roofline = bm_roofline(W, H, D, B, a.block_radius, a.subpixel, ms)
     if not bm:
         achieved = b_sgm / (ms["total"] * 1e-3) / 1e9
-        moved = (16.0 * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
-        roofline = {"bound": "hbm", "kernel": "k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": int(moved),
-                    "traffic_note": "computed, not PMC: 8 W H D bytes written by the path kernel + 8 W H D read by the WTA kernel; "
-                                    "moved bytes / time = %.0f GB/s" % (moved / (ms["total"] * 1e-3) / 1e9),
+        old = os.environ.get("JN_SGM_IMPL") == "0"
+        moved = ((16.0 if old else 6.0) * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
+        pmc = sgm_pmc_traffic(W, H, D, B) if not old else None
+        roofline = {"bound": "hbm", "kernel": ("k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)" if old else
+                                                "k_sw_h + k_sw_v<down> + k_sw_v<up, winners> (+ k_sw_prefilter, k_sw_lr: one batch)"),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": pmc["bytes"] if pmc else int(moved),
+                    "traffic_note": (pmc["note"] if pmc else "computed, not PMC: %s; " % ("8 W H D written by the path kernel + 8 W H D read by the WTA kernel" if old else
+                                     "3 byte volumes of W H D written (two horizontal sweeps, the downward sweep) and read once by the upward sweep")) +
+                                    " moved bytes / time = %.0f GB/s" % ((pmc["bytes"] if pmc else moved) / (ms["total"] * 1e-3) / 1e9),
                     "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
-                    "algorithmic_bytes_per_launch": int(b_sgm), "path_kernel_write_GBs": round(8.0 * W * H * D * B / (ms["paths"] * 1e-3) / 1e9, 1)}
+                    "algorithmic_bytes_per_launch": int(b_sgm),
+                    "bound_note": "the sweeps are integer-VALU bound, not HBM bound: ~100 packed 16-bit wave-instructions per pixel against the chip's "
+                                  "~540 G wave-instructions/s (scripts/probes/valu_rate_probe.hip); frac is still quoted on SURVEY 8d's byte count"}
     if rank == 0:
         out = {"metric": "stereo_pairs_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": (dist.get_world_size() if dist is not None else 1),
                "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "ms_per_frame": round(elapsed / (B * a.steps) * 1e3, 4),

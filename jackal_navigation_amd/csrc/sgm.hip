@@ -316,6 +316,7 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
   s.dbg = getenv("JN_SGM_DBG") ? atoi(getenv("JN_SGM_DBG")) : 0;
 #define SGM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_sgm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
   h->impl = getenv("JN_SGM_IMPL") ? atoi(getenv("JN_SGM_IMPL")) : 1;
+  if (h->impl == 0 && W > 7168) { jn_sgm_destroy(h); return JN_ERR_UNSUPPORTED; }   // k_sgm_wta's 2 W dwords + 8 KB of LDS would pass the 64 KB a launch gets by default
   if (h->impl == 0) {
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->Lr), (size_t)8 * max_batch * H * W * D));

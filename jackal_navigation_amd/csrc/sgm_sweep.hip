@@ -47,63 +47,72 @@ namespace jnav_sgm {
 
 constexpr int PX = 16;           // pixels per strip = lanes per disparity quarter (one DPP row)
 constexpr int NQ = 4;            // lanes per pixel
-constexpr uint32_t INF2 = 0x40004000u;   // "does not exist" for both halves; + P1 cannot wrap
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-DEV uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b))); }
-DEV uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b))); }
-DEV uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b))); }
-DEV uint32_t pk_mad(uint32_t a, uint32_t m, uint32_t c) {
-  return __builtin_bit_cast(uint32_t, (u16x2)(__builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, m) + __builtin_bit_cast(u16x2, c)));
-}
+DEV u16x2 v2(uint32_t a) { return __builtin_bit_cast(u16x2, a); }
+DEV uint32_t u1(u16x2 a) { return __builtin_bit_cast(uint32_t, a); }
+DEV uint32_t pk_min(uint32_t a, uint32_t b) { return u1(__builtin_elementwise_min(v2(a), v2(b))); }
+DEV uint32_t pk_max(uint32_t a, uint32_t b) { return u1(__builtin_elementwise_max(v2(a), v2(b))); }
+DEV uint32_t pk_add(uint32_t a, uint32_t b) { return u1((u16x2)(v2(a) + v2(b))); }
+DEV uint32_t pk_sub(uint32_t a, uint32_t b) { return u1((u16x2)(v2(a) - v2(b))); }
+DEV uint32_t pk_subsat(uint32_t a, uint32_t b) { return u1(__builtin_elementwise_sub_sat(v2(a), v2(b))); }   // max(a - b, 0) per half
+DEV uint32_t pk_shl3(uint32_t a) { return u1((u16x2)(v2(a) << (u16x2)(3))); }
 DEV uint32_t bperm(int src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 DEV uint32_t load_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-// 1x3 SAD of the prefiltered rows for this lane's 2*NR disparities: run = right-row bytes from column x_k - 1 + d0 on,
-// ref = left-row bytes x_k-1, x_k, x_k+1 (top byte 0 = masked).  C[r] = (cost(d0 + 2r), cost(d0 + 2r + 1)) as u16 halves.
-// Loading and arithmetic are separate so that a sweep can fetch the next pixel's bytes before it works on this one.
+// REGISTER LAYOUT.  A lane owns DPL = 2 NR disparities j = 0 .. DPL-1 of its quarter (d = DPL q + j); register r holds the
+// pair (j = r, j = r + NR) in its low / high half.  With this "stride-NR" pairing both halves of register r have their
+// disparity neighbours in registers r-1 and r+1, in the same halves: max(X[r-1], X[r+1]) needs no shuffling; only r = 0 and
+// r = NR-1 wrap (the low half of register 0 continues the quarter below, the high half of register NR-1 the quarter above).
+//
+// ARITHMETIC.  The recurrence is carried normalised, clamped and negated: X = P2 - min(L(p-r, .) - min L(p-r, .), P2), so
+//   Y = max(X[d], max(X[d-1], X[d+1]) (-) P1)      ((-) saturates at 0; a neighbour that does not exist is X = 0)
+//   L(p, d) - C = P2 - Y,   Ln = (C + P2) - Y,   X_new = (P2 + min Ln) (-) Ln
+// is exactly include/jn_sgm.h's L = C + min(Lq[d], Lq[d+-1] + P1, P2) with Lq = L(p-r, .) - min: seven packed
+// instructions per register and path (max, sub, max, add into the sum of Y, sub, min, sub).  A path entering the image has
+// Lq = 0, i.e. X = P2.  The sweeps store sums of Y (bytes; Y <= P2); S = sum_r L_r = 8 (C + P2) - sum_r Y_r.
+
+// 1x3 SAD costs + P2.  run: right-row bytes from column x_k - 1 + DPL q on (NR/2 + 1 dwords), ref: left-row bytes x_k-1, x_k,
+// x_k+1 (top byte 0 = masked by v_mqsad).  One v_mqsad gives 4 consecutive disparities; a v_perm per register re-pairs them.
 template <int NR>
-DEV void load_run(const uint8_t* __restrict__ run, uint32_t (&w)[NR / 2 + 1]) {
-#pragma unroll
-  for (int k = 0; k < NR / 2 + 1; k++) w[k] = load_u32_unaligned(run + 4 * k);
-}
-template <int NR>
-DEV void costs(const uint32_t (&w)[NR / 2 + 1], uint32_t ref, uint32_t (&C)[NR]) {
+DEV void costs(const uint32_t (&w)[NR / 2 + 1], uint32_t ref, uint32_t P2pk, uint32_t (&Cp)[NR]) {
+  uint32_t a[NR];                                              // a[2k] = (c[4k], c[4k+1]), a[2k+1] = (c[4k+2], c[4k+3])
+  const uint64_t p2 = (uint64_t)P2pk | ((uint64_t)P2pk << 32);
 #pragma unroll
   for (int k = 0; k < NR / 2; k++) {
-    const uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, 0ull);
-    C[2 * k] = (uint32_t)r; C[2 * k + 1] = (uint32_t)(r >> 32);
+    const uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)w[k] | ((uint64_t)w[k + 1] << 32), ref, p2);
+    a[2 * k] = (uint32_t)r; a[2 * k + 1] = (uint32_t)(r >> 32);
   }
+#pragma unroll
+  for (int r = 0; r < NR; r++)                                 // (c[r], c[r + NR]): c[j] is half (j & 1) of a[j >> 1]
+    Cp[r] = __builtin_amdgcn_perm(a[(r + NR) >> 1], a[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
 }
 
-// One pixel of one path, in three parts so that the three paths of a row sweep can overlap their cross-lane steps.
-// L: normalised values of the predecessor pixel; up / dn: the neighbouring quarters' adjoining pairs (path_neighbours);
-// acc += m = L_new - C; Ln = C + m (not yet normalised), mn = packed running minimum of Ln.
+// The adjoining pairs of the neighbouring quarters: up = the quarter below's j = DPL-1 (high half of its register NR-1) for
+// this lane's j = 0; dn = the quarter above's j = 0 for this lane's j = DPL-1.  Issued ahead of the cells that use them.
 template <int NR>
-DEV void path_neighbours(const uint32_t (&L)[NR], int lane, int q, uint32_t& up, uint32_t& dn) {
-  const uint32_t a = bperm((lane - PX) & 63, L[NR - 1]);       // the quarter below: its last pair holds d0 - 1 in the high half
-  const uint32_t b = bperm((lane + PX) & 63, L[0]);            // the quarter above: its first pair holds d0 + 2 NR in the low half
-  up = q == 0 ? INF2 : a;
-  dn = q == NQ - 1 ? INF2 : b;
+DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t& up, uint32_t& dn) {
+  const uint32_t a = bperm((lane - PX) & 63, X[NR - 1]);
+  const uint32_t b = bperm((lane + PX) & 63, X[0]);
+  up = q == 0 ? 0u : a;
+  dn = q == NQ - 1 ? 0u : b;
 }
 template <int NR>
-DEV void path_cells(const uint32_t (&L)[NR], uint32_t up, uint32_t dn, const uint32_t (&C)[NR], uint32_t (&acc)[NR], uint32_t (&Ln)[NR], uint32_t& mn,
-                    uint32_t P1pk, uint32_t P2pk) {
+DEV void path_cells(const uint32_t (&X)[NR], uint32_t up, uint32_t dn, const uint32_t (&Cp)[NR], uint32_t (&acc)[NR], uint32_t (&Ln)[NR], uint32_t& mn,
+                    uint32_t P1pk) {
   mn = 0xFFFFFFFFu;
-  auto cell = [&](int r, uint32_t sl, uint32_t sr) {           // sl = (Lq[d-1], Lq[d]) of the pair, sr = (Lq[d+1], Lq[d+2])
-    uint32_t t = pk_min(sl, sr);
-    t = pk_add(t, P1pk);
-    t = pk_min(t, L[r]);
-    t = pk_min(t, P2pk);
-    acc[r] = pk_add(acc[r], t);
-    Ln[r] = pk_add(C[r], t);
+  auto cell = [&](int r, uint32_t nb) __attribute__((always_inline)) {
+    const uint32_t y = pk_max(X[r], pk_subsat(nb, P1pk));
+    acc[r] = pk_add(acc[r], y);
+    Ln[r] = pk_sub(Cp[r], y);
     mn = pk_min(mn, Ln[r]);
   };
-  // the inner pairs first: they do not need the other quarters' values, whose permutes are still in flight
 #pragma unroll
-  for (int r = 1; r < NR - 1; r++) cell(r, __builtin_amdgcn_alignbit(L[r], L[r - 1], 16), __builtin_amdgcn_alignbit(L[r + 1], L[r], 16));
-  cell(0, __builtin_amdgcn_alignbit(L[0], up, 16), __builtin_amdgcn_alignbit(L[1], L[0], 16));
-  cell(NR - 1, __builtin_amdgcn_alignbit(L[NR - 1], L[NR - 2], 16), __builtin_amdgcn_alignbit(dn, L[NR - 1], 16));
+  for (int r = 1; r < NR - 1; r++) cell(r, pk_max(X[r - 1], X[r + 1]));
+  // register 0: j = 0 has j-1 in the quarter below, j = NR has j-1 = NR-1 in the low half of register NR-1
+  cell(0, pk_max(__builtin_amdgcn_perm(X[NR - 1], up, 0x05040302u), X[1]));
+  // register NR-1: j = NR-1 has j+1 = NR in the high half of register 0, j = DPL-1 has j+1 in the quarter above
+  cell(NR - 1, pk_max(X[NR - 2], __builtin_amdgcn_perm(dn, X[0], 0x05040302u)));
 }
 // minimum over the pixel's four lanes (and both halves) with the gfx950 row / half swaps: pure VALU, no LDS round trip
 DEV uint32_t pixel_min(uint32_t mn) {
@@ -114,23 +123,48 @@ DEV uint32_t pixel_min(uint32_t mn) {
   return min(b[0], b[1]);
 }
 template <int NR>
-DEV void path_normalise(uint32_t (&L)[NR], const uint32_t (&Ln)[NR], uint32_t m) {
-  const uint32_t mpk = m | (m << 16);
+DEV void path_normalise(uint32_t (&X)[NR], const uint32_t (&Ln)[NR], uint32_t m, uint32_t P2) {
+  const uint32_t t = (m + P2) * 0x10001u;
 #pragma unroll
-  for (int r = 0; r < NR; r++) L[r] = pk_sub(Ln[r], mpk);
-}
-template <int NR>
-DEV void path_step(uint32_t (&L)[NR], const uint32_t (&C)[NR], uint32_t (&acc)[NR], uint32_t P1pk, uint32_t P2pk, int lane, int q) {
-  uint32_t up, dn, mn, Ln[NR];
-  path_neighbours<NR>(L, lane, q, up, dn);
-  path_cells<NR>(L, up, dn, C, acc, Ln, mn, P1pk, P2pk);
-  path_normalise<NR>(L, Ln, pixel_min(mn));
+  for (int r = 0; r < NR; r++) X[r] = pk_subsat(t, Ln[r]);
 }
 
-// pairs (d0,d1), (d2,d3) with values <= 255 -> bytes d0 d1 d2 d3; and back
+// register pairs with values <= 255 -> 4 bytes (lo a, hi a, lo b, hi b); and back
 DEV uint32_t pack4(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x06040200u); }
 DEV uint32_t unpack_lo(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); }
 DEV uint32_t unpack_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030c02u); }
+// VOLUME LAYOUT.  A pixel's D bytes are stored as 16-byte pieces: piece c of quarter q at byte 64 c + 16 q, so that the four
+// lanes of a pixel write (and read) 64 contiguous bytes per instruction.  Within a lane, piece c holds registers 8c .. 8c+7
+// as pack4 pairs.  Only these kernels read the volumes, so the order of the disparities inside a pixel is theirs to choose.
+template <int NR>
+DEV void store_bytes(uint8_t* pixel_base, int q, const uint32_t (&acc)[NR]) {
+#pragma unroll
+  for (int c = 0; c < NR / 8; c++)
+    *reinterpret_cast<uint4*>(pixel_base + 64 * c + 16 * q) = make_uint4(pack4(acc[8 * c], acc[8 * c + 1]), pack4(acc[8 * c + 2], acc[8 * c + 3]),
+                                                                          pack4(acc[8 * c + 4], acc[8 * c + 5]), pack4(acc[8 * c + 6], acc[8 * c + 7]));
+}
+template <int NR>
+DEV void load_bytes(const uint8_t* pixel_base, int q, uint32_t (&f)[NR / 2]) {
+#pragma unroll
+  for (int c = 0; c < NR / 8; c++) {
+    const uint4 v = *reinterpret_cast<const uint4*>(pixel_base + 64 * c + 16 * q);
+    f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
+  }
+}
+// 16-bit form (three-path sums beyond 255): piece c of quarter q holds registers 4c .. 4c+3 as they are
+template <int NR>
+DEV void store_words(uint8_t* pixel_base, int q, const uint32_t (&acc)[NR]) {
+#pragma unroll
+  for (int c = 0; c < NR / 4; c++) *reinterpret_cast<uint4*>(pixel_base + 64 * c + 16 * q) = make_uint4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+}
+template <int NR>
+DEV void load_words(const uint8_t* pixel_base, int q, uint32_t (&f)[NR]) {
+#pragma unroll
+  for (int c = 0; c < NR / 4; c++) {
+    const uint4 v = *reinterpret_cast<const uint4*>(pixel_base + 64 * c + 16 * q);
+    f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
+  }
+}
 
 // ---- prefilter: mirrored, padded, +1 ----
 // gm[img][y][padl + x_k] = clamp(Sobel_x(I, W-1-cl(x_k), y), -cap, cap) + cap + 1, cl = clamp to [0, W-1] (replicated borders:
@@ -149,6 +183,62 @@ __global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __
 }
 
 // ---- horizontal paths: lanes = 16 rows x 4 disparity quarters; blockIdx.z = 0 walks x_k upwards, 1 downwards ----
+// The bytes a lane needs at x_k + 1 are those of x_k shifted by one: the lane keeps an ALIGNED window of its row in registers
+// (rows start 16-byte aligned and every lane of the wave is at the same x_k, so the byte phase is wave-uniform), forms each
+// pixel's dwords with v_alignbyte, and loads one new dword every fourth pixel — four pixels ahead of its use.
+template <int NR, int DIR>
+DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t* __restrict__ rowR, uint8_t* __restrict__ vol, bool valid, int lane, int q) {
+  constexpr int NW = NR / 2 + 1;                               // dwords of one pixel's run
+  const int W = s.W;
+  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
+  uint32_t X[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) X[r] = P2pk;
+  // rowL / rowR point at column x_k = 0 of this lane's row (rowR at its quarter's first disparity); the run of pixel x_k starts
+  // at byte x_k - 1.  Window: aligned dwords Rw[0 .. NW+1] from aligned byte address `al`; Lw[0 .. 2] likewise for the left row.
+  int xk = DIR ? W - 1 : 0;
+  int al = (xk - 1) & ~3;                                      // relative to the row pointers (may be -4)
+  uint32_t Rw[NW + 2], Lw[3];
+#pragma unroll
+  for (int k = 0; k < NW + 2; k++) Rw[k] = *reinterpret_cast<const uint32_t*>(rowR + al + 4 * (DIR ? k - 1 : k));
+#pragma unroll
+  for (int k = 0; k < 3; k++) Lw[k] = *reinterpret_cast<const uint32_t*>(rowL + al + 4 * (DIR ? k - 1 : k));
+  // upwards: Rw[k] = dword at al + 4k (k = NW+1 is the one fetched ahead); downwards: Rw[k] = dword at al + 4(k-1) (k = 0 fetched ahead)
+  for (int t = 0; t < W; t++) {
+    const int sh = (xk - 1) & 3;
+    uint32_t w[NW], Cp[NR], acc[NR], Ln[NR], up, dn, mn;
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = __builtin_amdgcn_alignbyte(Rw[k + 1 + DIR], Rw[k + DIR], sh);
+    const uint32_t ref = __builtin_amdgcn_alignbyte(Lw[1 + DIR], Lw[DIR], sh) & 0x00FFFFFFu;
+    costs<NR>(w, ref, P2pk, Cp);
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0u;
+    path_neighbours<NR>(X, lane, q, up, dn);
+    path_cells<NR>(X, up, dn, Cp, acc, Ln, mn, P1pk);
+    path_normalise<NR>(X, Ln, pixel_min(mn), (uint32_t)s.P2);
+    if (valid && (!(s.dbg & 1) || X[0] == 0x12345678u)) store_bytes<NR>(vol + (size_t)xk * s.D, q, acc);
+    // next pixel: slide the window when the byte phase wraps
+    if (!DIR) {
+      xk++;
+      if (sh == 3) {
+        al += 4;
+#pragma unroll
+        for (int k = 0; k < NW + 1; k++) Rw[k] = Rw[k + 1];
+        Lw[0] = Lw[1]; Lw[1] = Lw[2];
+        if (!(s.dbg & 2)) { Rw[NW + 1] = *reinterpret_cast<const uint32_t*>(rowR + al + 4 * (NW + 1)); Lw[2] = *reinterpret_cast<const uint32_t*>(rowL + al + 8); }
+      }
+    } else {
+      xk--;
+      if (sh == 0) {
+        al -= 4;
+#pragma unroll
+        for (int k = NW + 1; k > 0; k--) Rw[k] = Rw[k - 1];
+        Lw[2] = Lw[1]; Lw[1] = Lw[0];
+        if (!(s.dbg & 2)) { Rw[0] = *reinterpret_cast<const uint32_t*>(rowR + al - 4); Lw[0] = *reinterpret_cast<const uint32_t*>(rowL + al - 4); }
+      }
+    }
+  }
+}
 template <int NR>
 __global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __restrict__ gm, uint8_t* __restrict__ vol0, uint8_t* __restrict__ vol1) {
   constexpr int DPL = 2 * NR;
@@ -156,45 +246,11 @@ __global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __r
   const int y = (blockIdx.x * 4 + wave) * PX + p, frame = blockIdx.y, dir = blockIdx.z;
   const bool valid = y < s.H;
   const int yc = min(y, s.H - 1);
-  const uint8_t* rowL = gm + ((size_t)frame * s.H + yc) * s.Wp + s.padl - 1;
-  const uint8_t* rowR = gm + ((size_t)(n + frame) * s.H + yc) * s.Wp + s.padl - 1 + DPL * q;
-  uint8_t* vol = (dir ? vol1 : vol0) + (((size_t)frame * s.H + yc) * s.W) * s.D + DPL * q;
-  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
-  uint32_t L[NR];
-#pragma unroll
-  for (int r = 0; r < NR; r++) L[r] = 0u;                      // Lq = 0 makes the first pixel of a line L = C
-  const int step = dir ? -1 : 1;
-  int xk = dir ? s.W - 1 : 0;
-  uint32_t w[NR / 2 + 1], ref;                                 // bytes of the pixel being worked on; the next pixel's are fetched meanwhile
-  load_run<NR>(rowR + xk, w); ref = load_u32_unaligned(rowL + xk);
-  for (int t = 0; t < s.W; t++, xk += step) {
-    uint32_t wn[NR / 2 + 1], refn;
-    const int xn = t + 1 < s.W ? xk + step : xk;
-    if (!(s.dbg & 2)) { load_run<NR>(rowR + xn, wn); refn = load_u32_unaligned(rowL + xn); }
-    else {
-#pragma unroll
-      for (int k = 0; k < NR / 2 + 1; k++) wn[k] = w[k] + 0x01010101u * (uint32_t)t;
-      refn = ref;
-    }
-    uint32_t C[NR], acc[NR];
-    costs<NR>(w, ref & 0x00FFFFFFu, C);
-#pragma unroll
-    for (int r = 0; r < NR; r++) acc[r] = 0u;
-    path_step<NR>(L, C, acc, P1pk, P2pk, lane, q);
-    if (valid && (!(s.dbg & 1) || L[0] == 0x12345678u)) {
-      uint32_t* o = reinterpret_cast<uint32_t*>(vol + (size_t)xk * s.D);
-#pragma unroll
-      for (int k = 0; k < NR / 2; k += 4) {
-        uint4 v;
-        v.x = pack4(acc[2 * k], acc[2 * k + 1]); v.y = pack4(acc[2 * k + 2], acc[2 * k + 3]);
-        v.z = pack4(acc[2 * k + 4], acc[2 * k + 5]); v.w = pack4(acc[2 * k + 6], acc[2 * k + 7]);
-        *reinterpret_cast<uint4*>(o + k) = v;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < NR / 2 + 1; k++) w[k] = wn[k];
-    ref = refn;
-  }
+  const uint8_t* rowL = gm + ((size_t)frame * s.H + yc) * s.Wp + s.padl;
+  const uint8_t* rowR = gm + ((size_t)(n + frame) * s.H + yc) * s.Wp + s.padl + DPL * q;
+  const size_t row_px = ((size_t)frame * s.H + yc) * s.W;
+  if (dir == 0) h_sweep<NR, 0>(s, rowL, rowR, vol0 + row_px * s.D, valid, lane, q);
+  else h_sweep<NR, 1>(s, rowL, rowR, vol1 + row_px * s.D, valid, lane, q);
 }
 
 // ---- the three paths of one vertical direction, sheared strips ----
@@ -204,7 +260,7 @@ DEV uint64_t ld_sc1_64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC
 DEV void st_sc1_64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int NR, int NS, bool FINAL, bool WIDE>
-__global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k_sw_v(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
+__global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
                                                         const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1,
                                                         uint32_t* __restrict__ gx, uint32_t* __restrict__ gflag, uint32_t* __restrict__ ctr,
                                                         uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
@@ -215,8 +271,9 @@ __global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k
   extern __shared__ uint16_t sS[];                             // FINAL + sub-pixel: S of the block's pixels [BLK][D]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = s.W, H = s.H, D = s.D, NB = s.NB;
+  const uint32_t P2pk = (uint32_t)s.P2 * 0x10001u;
   if (tid == 0) s_ticket = (int)atomicAdd(ctr, 1u);
-  for (int k = tid; k < 2 * (NS + 1) * SLOT; k += (NS + 1) * 64) (&exch[0][0][0])[k] = 0u;
+  for (int k = tid; k < 2 * (NS + 1) * SLOT; k += (NS + 1) * 64) (&exch[0][0][0])[k] = P2pk;     // X = P2: a path that starts here
   if (FINAL) for (int k = tid; k < 2 * NQ * MR; k += (NS + 1) * 64) (&minR[0][0][0])[k] = 0xFFFFFFFFu;
   __syncthreads();
   const int ticket = s_ticket;
@@ -237,7 +294,7 @@ __global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k
     const uint32_t* p_gx = gx + ((size_t)frame * NB + j + 1) * H * slot_stride;
     const uint32_t* p_flag = gflag + (size_t)frame * NB + j + 1;
     int known = 0;
-    auto fetch = [&](int yb) {                                 // producer's columns after ITS row yb -> exch[yb & 1][NS]
+    auto fetch = [&](int yb) __attribute__((always_inline)) {                                 // producer's columns after ITS row yb -> exch[yb & 1][NS]
       uint32_t* dst = &exch[yb & 1][NS][0];
       if (has_prod && yb >= ybsp && yb <= ybep) {
         if (known < yb + 1) {
@@ -248,7 +305,7 @@ __global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k
         const uint64_t* src = reinterpret_cast<const uint64_t*>(p_gx + (size_t)yb * slot_stride);
         for (int o = lane; o < SLOT / 2; o += 64) { const uint64_t v = ld_sc1_64(src + o); dst[2 * o] = (uint32_t)v; dst[2 * o + 1] = (uint32_t)(v >> 32); }
       } else {
-        for (int o = lane; o < SLOT; o += 64) dst[o] = 0u;
+        for (int o = lane; o < SLOT; o += 64) dst[o] = P2pk;
       }
     };
     fetch(ybs - 1);
@@ -285,82 +342,90 @@ __global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k
   // ---- computing waves: strip `wave` of the block ----
   const int q = lane >> 4, p = lane & 15;
   const int xl = x0 + PX * wave + p;                           // this lane's sheared column
-  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
-  uint32_t V[NR], G[NR], M[NR];                                // normalised path values of the pixel this lane computed last: vertical, own diagonal, other diagonal
+  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u;
+  uint32_t V[NR], G[NR], M[NR];                                // X of the pixel this lane computed last, per path: vertical, own diagonal, other diagonal
 #pragma unroll
-  for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = 0u;
+  for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = P2pk;
   const size_t img_rows = (size_t)H * s.Wp;
   // a row's inputs: the prefiltered bytes for the costs and, in the final sweep, this pixel's bytes of the three stored volumes.
-  // They are fetched one row ahead (the next row's loads are in flight while this row's arithmetic runs).
-  struct RowIn { uint32_t w[NR / 2 + 1], ref, fF[FINAL ? (WIDE ? NR : NR / 2) : 1], fH0[FINAL ? NR / 2 : 1], fH1[FINAL ? NR / 2 : 1]; };
-  auto fetch_row = [&](int yb, RowIn& in_) {
-    const int y = flip ? H - 1 - yb : yb;
-    const int xk = xl + yb;
-    const int xc = min(max(xk, -PX), W + PX - 1);
-    const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc;
-    const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y * s.Wp + s.padl - 1 + xc + DPL * q;
-    load_run<NR>(rowR, in_.w);
+  // They are fetched one row ahead (the next row's loads are in flight while this row's arithmetic runs).  From one row to
+  // the next a lane moves one column to the right and one image row down (up, in the flipped sweep): plain pointer steps —
+  // the rows are padded by a block's width on both sides, so columns outside the image need no clamping.
+  struct RowIn { uint32_t w[NR / 2 + 1], ref; };
+  const int y0 = flip ? H - 1 - ybs : ybs;
+  const long long row_step = (flip ? -(long long)s.Wp : (long long)s.Wp) + 1;
+  const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs);
+  const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs) + DPL * q;
+  auto fetch_row = [&](RowIn& in_) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NR / 2 + 1; k++) in_.w[k] = load_u32_unaligned(rowR + 4 * k);
     in_.ref = load_u32_unaligned(rowL);
-    if (FINAL) {
-      const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
-      const uint32_t* pf = reinterpret_cast<const uint32_t*>(volF + (pix * D + DPL * q) * (WIDE ? 2 : 1));
-      const uint32_t* p0 = reinterpret_cast<const uint32_t*>(volH0 + pix * D + DPL * q);
-      const uint32_t* p1 = reinterpret_cast<const uint32_t*>(volH1 + pix * D + DPL * q);
-#pragma unroll
-      for (int k = 0; k < (WIDE ? NR : NR / 2); k += 4) { const uint4 v = *reinterpret_cast<const uint4*>(pf + k); in_.fF[k] = v.x; in_.fF[k + 1] = v.y; in_.fF[k + 2] = v.z; in_.fF[k + 3] = v.w; }
-#pragma unroll
-      for (int k = 0; k < NR / 2; k += 4) {
-        const uint4 a = *reinterpret_cast<const uint4*>(p0 + k); in_.fH0[k] = a.x; in_.fH0[k + 1] = a.y; in_.fH0[k + 2] = a.z; in_.fH0[k + 3] = a.w;
-        const uint4 b = *reinterpret_cast<const uint4*>(p1 + k); in_.fH1[k] = b.x; in_.fH1[k + 1] = b.y; in_.fH1[k + 2] = b.z; in_.fH1[k + 3] = b.w;
-      }
-    }
+    rowL += row_step; rowR += row_step;
   };
   RowIn cur;
-  fetch_row(ybs, cur);
+  fetch_row(cur);
   __syncthreads();
   for (int yb = ybs; yb <= ybe; yb++) {
     const int y = flip ? H - 1 - yb : yb;
     const int xk = xl + yb;
     const bool in = xk >= 0 && xk < W;
     const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
+    // NR <= 16 runs three or four waves per SIMD, which hide this row's loads; holding the next row's bytes as well would
+    // cost the registers that occupancy needs.  NR = 32 (one wave per SIMD) fetches a row ahead instead.
+    constexpr bool AHEAD = true;
     RowIn nxt;
-    fetch_row(min(yb + 1, ybe), nxt);
-    uint32_t C[NR], acc[NR];
-    costs<NR>(cur.w, cur.ref & 0x00FFFFFFu, C);
-    const uint32_t (&fF)[FINAL ? (WIDE ? NR : NR / 2) : 1] = cur.fF;
-    const uint32_t (&fH0)[FINAL ? NR / 2 : 1] = cur.fH0;
-    const uint32_t (&fH1)[FINAL ? NR / 2 : 1] = cur.fH1;
+    if constexpr (AHEAD) { if (yb < ybe) fetch_row(nxt); else nxt = cur; }
+    else { if (yb > ybs) fetch_row(cur); }
+    // the final sweep's three stored volumes for this pixel: loaded now, used after the three paths (the arithmetic hides them)
+    uint32_t fF[FINAL ? (WIDE ? NR : NR / 2) : 1], fH0[FINAL ? NR / 2 : 1], fH1[FINAL ? NR / 2 : 1];
+    if constexpr (FINAL) {
+      if (in && !(s.dbg & 4)) {
+        if constexpr (WIDE) load_words<NR>(volF + pix * D * 2, q, fF); else load_bytes<NR>(volF + pix * D, q, fF);
+        load_bytes<NR>(volH0 + pix * D, q, fH0);
+        load_bytes<NR>(volH1 + pix * D, q, fH1);
+      }
+    }
     // predecessors: vertical from x'+1, other diagonal from x'+2 (one / two shifts along the strip; the last lane takes the
     // right neighbour's columns, which DPP leaves in place as the `old` operand), own diagonal in place
     {
       const uint32_t* e = &exch[(yb + 1) & 1][wave + 1][0];
 #pragma unroll
-      for (int r = 0; r < NR; r++) {
-        const uint32_t v0 = e[(0 * NQ + q) * NR + r], m0 = e[(1 * NQ + q) * NR + r], m1 = e[(2 * NQ + q) * NR + r];
-        V[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)v0, (int)V[r], 0x101, 0xf, 0xf, false);           // row_shl:1
-        const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)m0, (int)M[r], 0x101, 0xf, 0xf, false);
-        M[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)m1, (int)t, 0x101, 0xf, 0xf, false);
+      for (int r4 = 0; r4 < NR; r4 += 4) {                     // four registers at a time: the scheduler would otherwise hoist all 3 NR LDS reads and hold them
+        const uint4 v0 = *reinterpret_cast<const uint4*>(e + (0 * NQ + q) * NR + r4);
+        const uint4 m0 = *reinterpret_cast<const uint4*>(e + (1 * NQ + q) * NR + r4);
+        const uint4 m1 = *reinterpret_cast<const uint4*>(e + (2 * NQ + q) * NR + r4);
+        const uint32_t a0[4] = {v0.x, v0.y, v0.z, v0.w}, b0[4] = {m0.x, m0.y, m0.z, m0.w}, b1[4] = {m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int r = r4 + k;
+          V[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)a0[k], (int)V[r], 0x101, 0xf, 0xf, false);           // row_shl:1
+          const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)b0[k], (int)M[r], 0x101, 0xf, 0xf, false);
+          M[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)b1[k], (int)t, 0x101, 0xf, 0xf, false);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    uint32_t Cp[NR], acc[NR];
+    costs<NR>(cur.w, cur.ref & 0x00FFFFFFu, P2pk, Cp);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
     {
-      // the three paths side by side: all quarter-boundary permutes first, then the cells, then the three minima together
-      uint32_t upV, dnV, upG, dnG, upM, dnM, mnV, mnG, mnM, LnV[NR], LnG[NR], LnM[NR];
+      // all quarter-boundary permutes first (their LDS round trip overlaps the first path's cells), then one path at a time:
+      // side by side the three paths would keep 3 NR unnormalised registers alive and cost a wave per SIMD in occupancy
+      uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];
       path_neighbours<NR>(V, lane, q, upV, dnV);
       path_neighbours<NR>(G, lane, q, upG, dnG);
       path_neighbours<NR>(M, lane, q, upM, dnM);
-      path_cells<NR>(V, upV, dnV, C, acc, LnV, mnV, P1pk, P2pk);
-      path_cells<NR>(G, upG, dnG, C, acc, LnG, mnG, P1pk, P2pk);
-      path_cells<NR>(M, upM, dnM, C, acc, LnM, mnM, P1pk, P2pk);
-      const uint32_t a = pixel_min(mnV), b = pixel_min(mnG), c = pixel_min(mnM);
-      path_normalise<NR>(V, LnV, a);
-      path_normalise<NR>(G, LnG, b);
-      path_normalise<NR>(M, LnM, c);
+      path_cells<NR>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
+      path_normalise<NR>(V, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_cells<NR>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
+      path_normalise<NR>(G, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_cells<NR>(M, upM, dnM, Cp, acc, Ln, mn, P1pk);
+      path_normalise<NR>(M, Ln, pixel_min(mn), (uint32_t)s.P2);
     }
     if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
 #pragma unroll
-      for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : 0u; G[r] = in ? G[r] : 0u; M[r] = in ? M[r] : 0u; }
+      for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : P2pk; G[r] = in ? G[r] : P2pk; M[r] = in ? M[r] : P2pk; }
     }
     {
       uint32_t* o = &exch[yb & 1][wave][0];
@@ -373,67 +438,55 @@ __global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k
         for (int r = 0; r < NR; r++) o[(2 * NQ + q) * NR + r] = M[r];
       }
     }
-    if (!FINAL) {
-      if (in) {
-        if (WIDE) {
-          uint32_t* o = reinterpret_cast<uint32_t*>(volF + (pix * D + DPL * q) * 2);
-#pragma unroll
-          for (int k = 0; k < NR; k += 4) *reinterpret_cast<uint4*>(o + k) = make_uint4(acc[k], acc[k + 1], acc[k + 2], acc[k + 3]);
-        } else {
-          uint32_t* o = reinterpret_cast<uint32_t*>(volF + pix * D + DPL * q);
-#pragma unroll
-          for (int k = 0; k < NR / 2; k += 4)
-            *reinterpret_cast<uint4*>(o + k) = make_uint4(pack4(acc[2 * k], acc[2 * k + 1]), pack4(acc[2 * k + 2], acc[2 * k + 3]),
-                                                          pack4(acc[2 * k + 4], acc[2 * k + 5]), pack4(acc[2 * k + 6], acc[2 * k + 7]));
-        }
+    if constexpr (!FINAL) {
+      if (in && !(s.dbg & 4)) {
+        if constexpr (WIDE) store_words<NR>(volF + pix * D * 2, q, acc); else store_bytes<NR>(volF + pix * D, q, acc);
       }
     } else {
-      // S = 8 C + the three upward m + the stored five
+      // S = 8 (C + P2) - (the three upward Y + the stored five)
       uint32_t S[NR];
 #pragma unroll
       for (int k = 0; k < NR / 2; k++) {
         uint32_t a, b;
-        if (WIDE) { a = pk_add(pk_add(fF[2 * k], unpack_lo(fH0[k])), unpack_lo(fH1[k])); b = pk_add(pk_add(fF[2 * k + 1], unpack_hi(fH0[k])), unpack_hi(fH1[k])); }
-        else { const uint32_t hb = fH0[k] + fH1[k];            // bytes <= 2 P2 <= 170: no carry between bytes
+        if constexpr (WIDE) { a = pk_add(pk_add(fF[2 * k], unpack_lo(fH0[k])), unpack_lo(fH1[k])); b = pk_add(pk_add(fF[2 * k + 1], unpack_hi(fH0[k])), unpack_hi(fH1[k])); }
+        else { const uint32_t hb = fH0[k] + fH1[k];    // bytes <= 2 P2 <= 170: no carry between bytes
                a = pk_add(unpack_lo(fF[k]), unpack_lo(hb)); b = pk_add(unpack_hi(fF[k]), unpack_hi(hb)); }
-        S[2 * k] = pk_add(pk_mad(C[2 * k], 0x00080008u, acc[2 * k]), a);
-        S[2 * k + 1] = pk_add(pk_mad(C[2 * k + 1], 0x00080008u, acc[2 * k + 1]), b);
+        S[2 * k] = pk_sub(pk_shl3(Cp[2 * k]), pk_add(acc[2 * k], a));
+        S[2 * k + 1] = pk_sub(pk_shl3(Cp[2 * k + 1]), pk_add(acc[2 * k + 1], b));
       }
-      // left winner: S <= 2040, so S*32 + (index within a run of 32 disparities) is a 16-bit key; smallest d wins ties
+      // winners.  Keys S << 16 | j (j = disparity within the quarter): the smallest key is the smallest S, ties to the smallest j.
+      // Left image: minimum over this lane's cells, then over the pixel's four lanes (+ DPL q: larger quarters lose ties).
+      // Right image: cell (x_k, d) belongs to right pixel x_k + d: LDS atomic minima per quarter, merged when the row is flushed.
       uint32_t key = 0xFFFFFFFFu;
+      uint32_t* mr = &minR[yb & 1][q][PX * wave + p];
 #pragma unroll
-      for (int c = 0; c < NR; c += 16) {
-        uint32_t best = 0xFFFFFFFFu;
-#pragma unroll
-        for (int r = c; r < c + 16 && r < NR; r++) {
-          const uint32_t jc = (uint32_t)((2 * r) & 31) | ((uint32_t)((2 * r + 1) & 31) << 16);
-          best = pk_min(best, pk_mad(S[r], 0x00200020u, jc));
-        }
-        const uint32_t b16 = min(best & 0xFFFFu, best >> 16);
-        key = min(key, ((b16 >> 5) << 16) | (uint32_t)(DPL * q + 2 * c + (int)(b16 & 31u)));
+      for (int r = 0; r < NR; r++) {
+        const uint32_t klo = (S[r] << 16) | (uint32_t)r, khi = (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR);
+        key = min(key, min(klo, khi));
       }
-      key = in ? key : 0xFFFFFFFFu;
+      if (in) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          atomicMin(mr + r, (S[r] << 16) | (uint32_t)r);
+          atomicMin(mr + r + NR, (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR));
+        }
+      }
+      key = in ? key + (uint32_t)(DPL * q) : 0xFFFFFFFFu;
       {
         const auto a = __builtin_amdgcn_permlane16_swap(key, key, false, false);
         key = min(a[0], a[1]);
         const auto b = __builtin_amdgcn_permlane32_swap(key, key, false, false);
         key = min(b[0], b[1]);
       }
-      // right image: cell (x_k, d) belongs to right pixel x_k + d; keys S << 16 | (d within the quarter)
-      if (in) {
-        uint32_t* mr = &minR[yb & 1][q][PX * wave + p];
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-          atomicMin(mr + 2 * r, (S[r] << 16) | (uint32_t)(2 * r));
-          atomicMin(mr + 2 * r + 1, (S[r] & 0xFFFF0000u) | (uint32_t)(2 * r + 1));
-        }
-      }
       const int d = (int)(key & 0xFFFFu);
       int d16 = 16 * d;
       if (s.subpixel) {
         uint32_t* my = reinterpret_cast<uint32_t*>(sS + ((size_t)(PX * wave + p) * D + DPL * q));
 #pragma unroll
-        for (int r = 0; r < NR; r++) my[r] = S[r];
+        for (int r = 0; r < NR; r += 2) {                      // S in disparity order: low halves are j = r, high halves j = r + NR
+          my[r / 2] = __builtin_amdgcn_perm(S[r + 1], S[r], 0x05040100u);
+          my[(r + NR) / 2] = __builtin_amdgcn_perm(S[r + 1], S[r], 0x07060302u);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -446,7 +499,7 @@ __global__ void __launch_bounds__((NS + 1) * 64, (!FINAL && NR <= 16) ? 4 : 1) k
       }
       if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
     }
-    cur = nxt;
+    if constexpr (AHEAD) cur = nxt;
     __syncthreads();
   }
 }
@@ -474,12 +527,17 @@ __global__ void __launch_bounds__(256) k_sw_lr(SwDev s, int n, const uint32_t* _
 namespace jnav_sgm {
 
 // computing waves per workgroup (+ 1 communication wave).  D = 256: four waves, one per SIMD, so that 96 pairs of path state plus a row of inputs fit the registers
-static int strips_for(int D) { return D == 256 ? 3 : 7; }
+static int strips_for(int D) {
+  if (D == 256) return 3;
+  const char* e = getenv("JN_SGM_NS");                         // A/B switch: 3 (default), 5 or 7 strips per workgroup
+  const int v = e ? atoi(e) : 3;                               // measured at 1280x720 D=128 batch 32: 11.3 / 13.8 / 12.6 ms per batch (profiles/r03_sgm_strips_ab.txt)
+  return v == 5 || v == 7 ? v : 3;
+}
 
 void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch) {
   s->W = W; s->H = H; s->D = D; s->P1 = P1; s->P2 = P2; s->cap = cap; s->lr = lr; s->subpixel = subpixel ? 1 : 0;
-  s->padl = 32; s->Wp = ((s->padl + W + D + 64) + 15) / 16 * 16;
   const int BLK = strips_for(D) * PX;
+  s->padl = BLK + 32; s->Wp = ((s->padl + W + D + BLK + 64) + 15) / 16 * 16;   // a block's width of padding: lanes outside the image read plain bytes
   s->xmin = -(H - 1);
   s->NB = (W + H - 1 + BLK - 1) / BLK;
   s->wide = 3 * P2 > 255 ? 1 : 0;
@@ -535,8 +593,11 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
 
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
                      const SweepBuffers& b, hipEvent_t* ev) {
-  if (s.D == 64) return run_all<8, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
-  if (s.D == 128) return run_all<16, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+  const int ns = strips_for(s.D);
+  if (s.D == 64) return ns == 3 ? run_all<8, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev) : ns == 5 ? run_all<8, 5>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
+                                                                                                                : run_all<8, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+  if (s.D == 128) return ns == 3 ? run_all<16, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev) : ns == 5 ? run_all<16, 5>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
+                                                                                                                  : run_all<16, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
   return run_all<32, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
 }
 

@@ -32,6 +32,21 @@ def cost_volume(gL, gR, D):
     return Cv
 
 
+def volume_order(D, wide):
+    """d of every stored element of a pixel (sgm_sweep.hip VOLUME LAYOUT / REGISTER LAYOUT)."""
+    NR, DPL = D // 8, D // 4
+    out = np.zeros(D, np.int64)
+    for e in range(D):
+        if wide:
+            c, q, w = e // 32, (e % 32) // 8, e % 8
+            r, half = 4 * c + w // 2, w % 2
+        else:
+            c, q, b = e // 64, (e % 64) // 16, e % 16
+            r, half = 8 * c + 2 * (b // 4) + ((b % 4) >> 1), b & 1
+        out[e] = DPL * q + r + half * NR
+    return out
+
+
 def report(name, got, exp):
     bad = got != exp
     if not bad.any():
@@ -69,9 +84,10 @@ def one(W, H, D, n, kw, scene=None):
                 Cv = cost_volume(gL, gR, D)
                 m = {dxy: so.path(gL, gR, D, po.P1, po.P2, *dxy).astype(np.int32) - Cv for dxy in ((1, 0), (-1, 0), (0, 1), (1, 1), (-1, 1), (0, -1), (-1, -1), (1, -1))}
                 print(" frame", b)
-                ok &= report("H0 (-1,0)", vH0[b], m[(-1, 0)][:, ::-1])
-                ok &= report("H1 (+1,0)", vH1[b], m[(1, 0)][:, ::-1])
-                ok &= report("F down", vF[b], (m[(0, 1)] + m[(1, 1)] + m[(-1, 1)])[:, ::-1])
+                ob, of = volume_order(D, 0), volume_order(D, wide)           # the volumes hold sums of Y = P2 - (L - C), in the kernels' own order
+                ok &= report("H0 (-1,0)", vH0[b], (po.P2 - m[(-1, 0)])[:, ::-1][:, :, ob])
+                ok &= report("H1 (+1,0)", vH1[b], (po.P2 - m[(1, 0)])[:, ::-1][:, :, ob])
+                ok &= report("F down", vF[b], (3 * po.P2 - (m[(0, 1)] + m[(1, 1)] + m[(-1, 1)]))[:, ::-1][:, :, of])
                 S = 8 * Cv + sum(m.values())
                 dLexp = S.argmin(axis=2)
                 ok &= report("dL", (dl[b] & 0xFFFF).astype(np.int64), dLexp[:, ::-1])

@@ -76,3 +76,57 @@ def test_sgm_feeds_the_node_tail(jn, sgm, oracle):
     node.obstacle_scan(sp, 1, du8.ptr, lut.ptr, W, H, bins.ptr, meta.ptr)
     bo, mo, used = oracle.scan(spo, sgm.to_u8(sgm.process(sgm.params(D), L, R), 0), oracle.valid_lut(spo, W, H))
     assert used > 0 and np.allclose(bins.numpy()[0], bo, rtol=0, atol=1e-4) and np.allclose(meta.numpy()[0], mo, rtol=0, atol=1e-4)
+
+
+def test_sgm_config3_batch32_720p(jn, sgm, oracle):
+    """BASELINE config 3 as it is named: 1280x720, D = 128, SGM 8 paths, batch 32 in one call.  Frames 0 and 17 against the scalar
+    definition, frame 0 also against the committed hash, every frame against a second run (the block pipeline must not depend on
+    which workgroup started first)."""
+    import os
+    W, H, D, n = 1280, 720, 128, 32
+    pairs = [oracle.synth_pair(W, H, 128, 12345 + b) for b in range(n)]
+    Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+    out, u8, t = run(jn, jn.Sgm.parameters(num_disparities=D), Ls, Rs)
+    for b in (0, 17):
+        exp = sgm.process(sgm.params(D), Ls[b], Rs[b])
+        assert np.array_equal(out[b], exp), (b, int((out[b] != exp).sum()))
+    rows = [l.split() for l in open(os.path.join(os.path.dirname(__file__), "golden", "sgm_hashes.txt")) if not l.startswith("#")]
+    want = [r[6] for r in rows if r[:6] == ["1280", "720", "128", "128", "0", "12345"]][0]
+    assert "%016x" % oracle.fnv(np.ascontiguousarray(out[0]).view(np.uint32)) == want
+    again, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D), Ls, Rs)
+    assert np.array_equal(out, again)
+    assert len({out[b].tobytes() for b in range(n)}) == n          # 32 different frames in, 32 different maps out
+
+
+def test_sgm_config5_share_1080p_d256_subpixel(jn, sgm, oracle):
+    """BASELINE config 5's per-GPU share: 1920x1080, D = 256, SGM + 1/16-pixel refinement, 8 pairs per GPU.  Frame 3 against the
+    scalar definition; all 8 frames twice (determinism)."""
+    W, H, D, n = 1920, 1080, 256, 8
+    pairs = [oracle.synth_pair(W, H, 256, 500 + b) for b in range(n)]
+    Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+    p = jn.Sgm.parameters(num_disparities=D, subpixel=1)
+    out, u8, t = run(jn, p, Ls, Rs)
+    exp = sgm.process(sgm.params(D, subpixel=1), Ls[3], Rs[3])
+    assert np.array_equal(out[3], exp), int((out[3] != exp).sum())
+    assert np.array_equal(u8[3], sgm.to_u8(exp, 1))
+    again, _, _ = run(jn, p, Ls, Rs)
+    assert np.array_equal(out, again)
+
+
+def test_sgm_round2_kernels_still_agree(jn, sgm, oracle):
+    """JN_SGM_IMPL=0 keeps the one-wave-per-line kernels of round 2 for A/B runs; both implementations give the definition."""
+    import os
+    W, H, D = 320, 180, 128
+    L, R = oracle.synth_pair(W, H, 60, 77)
+    exp = sgm.process(sgm.params(D), L, R)
+    old = os.environ.get("JN_SGM_IMPL")
+    try:
+        for impl in ("0", "1"):
+            os.environ["JN_SGM_IMPL"] = impl
+            out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D), L[None], R[None])
+            assert np.array_equal(out[0], exp), impl
+    finally:
+        if old is None:
+            del os.environ["JN_SGM_IMPL"]
+        else:
+            os.environ["JN_SGM_IMPL"] = old
