@@ -124,6 +124,9 @@ def parse_args():
     ap.add_argument("--merge", default="cabi", choices=["cabi", "torch"],
                     help="cross-rig merge with the nccl backend: the library's jn_scan_allreduce (default) or torch.distributed")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses device 0")
+    ap.add_argument("--force-merge", action="store_true",
+                    help="N=1 only: attach a ONE-rank RCCL communicator, so that every batch ends with the cross-rig merge it has on a multi-GPU node "
+                         "(pack -> ncclAllReduce(MIN) -> unpack in the slot worker); the line then carries merge_ms_per_step and the rate without it")
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
     ap.add_argument("--subpixel", type=int, default=0, help="sgm / bm mode: 1/16-pixel refinement")
     ap.add_argument("--block-radius", type=int, default=4, help="bm mode: block radius r (2, 3, 4)")
@@ -527,9 +530,20 @@ def run_rank(a):
                 comm.close(); comm = None
         if comm is None:
             merge_kind = "torch.distributed all_reduce(MIN) (%s), one packed buffer per batch" % a.dist_backend
+    elif a.force_merge and on_gpu:
+        comm = parallel.ScanComm(0, 1, local_rank, lambda raw: raw)
+        comm_info = comm.info()
+        merge_kind = "jn_elas_set_comm with a ONE-rank communicator (--force-merge): the merge's own cost, no peer"
+    if comm is not None:
+        # the merge is the batch's tail, queued by the slot's worker (jn_elas_set_comm): jn_elas_wait returns with robot-level bins
+        elas.set_comm(comm)
+        if dist is not None:
+            merge_kind = "jn_elas_set_comm (C-ABI): pack -> RCCL ncclAllReduce(MIN) -> unpack queued by the slot worker behind the scan, one packed buffer per batch"
 
     stage_acc = {}
     dense_ms = []
+    merge_ms = []
+    merge_state = {"attached": comm is not None}
 
     def finish(slot):
         """Tail of a batch: wait for ELAS + u8 map + scan, then the cross-rig MIN reduce."""
@@ -537,13 +551,14 @@ def run_rank(a):
         for k, v in elas.last_times(slot).items():
             stage_acc.setdefault(k, []).append(v)
         dense_ms.append(elas.kernel_time(slot)[0])
+        if merge_state["attached"]:               # merged already: the batch ended with the all-reduce (jn_elas_set_comm)
+            merge_ms.append(elas.merge_time(slot))
+            return
         if dist is None:
             return
         # the path's one exchange step: robot-level scan = MIN over rigs, one all-reduce per batch; it completes
         # before the slot is handed a new batch (the next batch's kernels write the same bins)
-        if comm is not None:
-            comm.merge(B, 90, bins[slot].data_ptr(), meta[slot].data_ptr())
-        elif on_gpu:
+        if on_gpu:
             scans[slot].merge()
             torch.cuda.current_stream().synchronize()
         else:
@@ -600,6 +615,22 @@ def run_rank(a):
     value = pairs / elapsed
     stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
     k_ms_pipelined = float(np.mean(dense_ms))
+
+    # --force-merge: the same timed region once more with the communicator detached = what the merge costs the pipeline
+    merge_report = None
+    if merge_state["attached"]:
+        merge_report = {"kind": merge_kind, "merge_ms_per_step": round(float(np.mean(merge_ms)), 4) if merge_ms else None,
+                        "what": "HIP events on the slot's / the communicator's stream: scan finished -> merged bins in place (pack, ncclAllReduce MIN, unpack; "
+                                "queueing behind the previous batch's merge included); runs as the batch's tail in the slot worker, overlapped with the other slots"}
+        if a.force_merge and dist is None:
+            elas.set_comm(None); merge_state["attached"] = False
+            run(a.warmup)
+            without = [timed_region() for _ in range(min(5, len(regions)))]
+            merge_report["pairs_per_sec_without_merge"] = round(pairs / float(np.median(without)), 1)
+            merge_report["pairs_per_sec_with_merge"] = round(value, 1)
+            merge_report["cost_frac"] = round(1.0 - value / (pairs / float(np.median(without))), 4)
+            stage_acc.clear(); run(a.warmup)           # stage times of the un-merged pipeline again, as in a plain run
+            stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
 
     # k_dense running ALONE (one batch in flight, kernels back to back): what the roofline fraction is computed from
     k_ms_alone = None
@@ -733,6 +764,8 @@ def run_rank(a):
             "latency_config": extra,
             "host_cpu": host_cpu,
         }
+        if merge_report is not None:
+            out["merge"] = merge_report
         if ranks_info is not None:
             out["ranks"] = ranks_info
             out["distinct_devices"] = sorted({r["device"] for r in ranks_info})

@@ -275,6 +275,15 @@ jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* devic
  * jn_obstacle_scan writes them; afterwards every rank holds the merged scans.  The inputs must be
  * complete (e.g. after jn_elas_wait); returns when the merged values are in place. */
 jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta);
+/* The merge as the TAIL OF EVERY SCAN BATCH: with a communicator attached, jn_elas_submit_scan's batches finish with
+ * pack -> ncclAllReduce(MIN) -> unpack, queued by the slot's worker behind the scan (no host thread waits for it, the
+ * submitting thread is not involved), so jn_elas_wait returns with the ROBOT-level bins in dBins / dMeta.  RCCL needs every
+ * rank to issue a communicator's collectives in one order: batches queue their merges in submission order, so every rank
+ * must submit the same sequence of scan batches (same n, same bins).  Call with no batch in flight; c = NULL detaches.
+ * The communicator must live on the handle's device and outlive its use here.  jn_elas_merge_time: milliseconds from the
+ * end of the slot's last scan to its merged bins being in place (queueing behind earlier batches' merges included). */
+jn_status jn_elas_set_comm(jn_elas* h, jn_comm* c);
+jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms);
 void jn_comm_destroy(jn_comm* c);
 
 /* ---- utilities ---------------------------------------------------------------------------- */

@@ -20,6 +20,12 @@
 
 using namespace jnav;
 
+struct jn_comm;
+namespace jnav {
+jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done);
+int comm_device(const jn_comm* c);
+}
+
 namespace {
 
 struct Rccl {
@@ -136,26 +142,52 @@ jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* devic
   return JN_OK;
 }
 
-jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta) {
-  if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
-  Rccl* R = rccl();
-  if (!R) return JN_ERR_COMM;
-  std::lock_guard<std::mutex> guard(c->m);       // collectives of one communicator are issued in one order
+// pack -> all-reduce -> unpack queued on the communicator's stream.  `ready` (may be null) is an event the inputs are
+// complete behind; `done` (may be null) is recorded behind the unpack.  Every collective of a communicator goes through
+// here under its mutex and onto its ONE stream, so all ranks execute them in the order they were queued.
+static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done) {
+  std::lock_guard<std::mutex> guard(c->m);
   HIP_TRY_C(hipSetDevice(c->device));
   const size_t count = (size_t)n * (bins + 4);
   if (count > c->cap) {
+    HIP_TRY_C(hipStreamSynchronize(c->stream));            // a merge queued earlier may still use the old buffer
     if (c->flat) hipFree(c->flat);
     c->flat = nullptr; c->cap = 0;
     HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
     c->cap = count;
   }
+  if (ready) HIP_TRY_C(hipStreamWaitEvent(c->stream, ready, 0));
   launch_scan_pack(c->stream, n, bins, dBins, dMeta, c->flat, true);
   RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
   launch_scan_pack(c->stream, n, bins, dBins, dMeta, c->flat, false);
+  if (done) HIP_TRY_C(hipEventRecord(done, c->stream));
+  return JN_OK;
+}
+
+jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta) {
+  if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  const jn_status st = queue_merge(c, R, n, bins, dBins, dMeta, nullptr, nullptr);
+  if (st != JN_OK) return st;
   HIP_TRY_C(hipStreamSynchronize(c->stream));
   HIP_TRY_C(hipGetLastError());
   return JN_OK;
 }
+
+extern "C++" {
+namespace jnav {
+// The batch pipeline's form (jn_elas_set_comm): nothing waits on the host; the slot's stream continues behind `done`.
+// The flat buffer is shared by consecutive merges: they run one after the other on the communicator's stream.
+jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done) {
+  if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  return queue_merge(c, R, n, bins, dBins, dMeta, ready, done);
+}
+int comm_device(const jn_comm* c) { return c ? c->device : -1; }
+}  // namespace jnav
+}  // extern "C++"
 
 void jn_comm_destroy(jn_comm* c) {
   if (!c) return;

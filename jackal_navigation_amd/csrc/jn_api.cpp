@@ -49,6 +49,8 @@ struct Job {
   int n = 0; const uint8_t* dI1 = nullptr; const uint8_t* dI2 = nullptr; int pitch = 0; int64_t stride = 0;
   float* dD1 = nullptr; float* dD2 = nullptr; int32_t* status = nullptr;
   // host-pointer form (jn_elas_submit_host): the worker stages the images in and the maps out around the batch
+  uint64_t seq = 0; bool merge = false;                       // scan batch whose bins are MIN-reduced across ranks before it completes
+  bool staged = false;                                        // the images were written on the slot's ordinary stream (run_batch_host): stage A stays there
   bool host = false; const uint8_t* hI1 = nullptr; const uint8_t* hI2 = nullptr; float* hD1 = nullptr; float* hD2 = nullptr;
   // optional tail of the node on the same stream (jn_elas_submit_scan): u8 map + LUT scan of D1
   bool scan = false; jn_scan_params sp = {}; const uint8_t* dLut = nullptr; uint8_t* dDispU8 = nullptr; double* dBins = nullptr; double* dMeta = nullptr;
@@ -58,6 +60,9 @@ enum { EV_BEGIN, EV_DESC, EV_SUPPORT, EV_D2H, EV_H2D0, EV_H2D, EV_RASTER, EV_DEN
 
 struct Slot {
   hipStream_t stream = nullptr;
+  hipEvent_t ev_scan = nullptr, ev_merged = nullptr;          // around the cross-rig merge (created with the slot)
+  float merge_ms = 0.f;
+  hipStream_t stream_a = nullptr;                             // highest-priority stream for stage A (see run_batch); only with JN_STAGE_A_PRIORITY=1
   hipEvent_t ev[EV_COUNT] = {};
   // device
   uint4* desc = nullptr; int16_t* d_can = nullptr;
@@ -107,12 +112,21 @@ struct jn_elas {
   int arr_cap = 0, arr_stride = 0;  // vertices per frame side k_arrange orders in LDS / at all (more: in global scratch / on the host)
   bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
+  // cross-rig merge as the tail of a scan batch (jn_elas_set_comm): merges are queued in submission order on every rank
+  jn_comm* comm = nullptr;
+  std::mutex merge_m; std::condition_variable merge_cv;
+  uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
   // staging for the host-pointer drop-in call
   uint8_t* s_img = nullptr; float* s_D = nullptr; int s_pitch = 0;
   std::mutex api_m;
 };
+
+namespace jnav {
+jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done);
+int comm_device(const jn_comm* c);
+}
 
 namespace {
 
@@ -169,17 +183,24 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   // other slots fill the gap, 7 % of a lone 640x480 pair — a latency-mode handle (max_batch 1) leaves them out.
   const bool stage_events = h->stage_events;
   auto mark = [&](int e) { return stage_events ? hipEventRecord(s.ev[e], st) : hipSuccess; };
-  HIP_TRY(mark(EV_BEGIN));
-  launch_descriptor(st, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
-  HIP_TRY(mark(EV_DESC));
-  launch_support(st, dp, n, s.desc, s.d_can);
+  // Stage A (descriptors -> support matches -> filters -> list -> arrangement) ends in the host stage, which the whole batch
+  // waits for; its small kernels (one workgroup per frame or side) would otherwise queue behind the dense kernels of the
+  // other slots.  It runs on a stream of the highest priority; stage B stays on the slot's ordinary stream.  The two never
+  // overlap within a slot (the worker waits for stage A, and for the batch's end before the next stage A), so no events tie
+  // them together.  Host-pointer jobs stage their images on the ordinary stream and keep everything there.
+  hipStream_t sa = (s.stream_a && !j.staged) ? s.stream_a : st;
+  auto mark_a = [&](int e) { return stage_events ? hipEventRecord(s.ev[e], sa) : hipSuccess; };
+  HIP_TRY(mark_a(EV_BEGIN));
+  launch_descriptor(sa, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
+  HIP_TRY(mark_a(EV_DESC));
+  launch_support(sa, dp, n, s.desc, s.d_can);
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
-      launch_support_filters(st, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
-  HIP_TRY(mark(EV_SUPPORT));
+      launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
+  HIP_TRY(mark_a(EV_SUPPORT));
   const int list_cap = dp.cw * dp.ch;
   bool arranged = false;
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
-    launch_support_list(st, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
+    launch_support_list(sa, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
     // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
     // Sized by what this slot's previous batch held (+25 %): a 720p frame has 3.2 k support points and needs 52 KB of LDS, not
     // the 104 KB of the 8192-vertex maximum — a workgroup that asks for less finds room among the other slots' kernels sooner.
@@ -189,13 +210,13 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       const int want = s.arr_hint ? s.arr_hint + s.arr_hint / 4 + 64 : h->arr_cap;
       // more points than the LDS can order (1920x1080: 11 k): every side works in its slice of the global scratch, the launch asks for the minimum of LDS
       const int cap = s.arr_hint > h->arr_cap ? 1024 : std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
-      launch_arrange(st, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_stride, s.h_arr, s.h_arr_ok, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
+      launch_arrange(sa, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_stride, s.h_arr, s.h_arr_ok, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
-    HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, sa));
   }
-  HIP_TRY(hipEventRecord(s.ev[EV_D2H], st));
+  HIP_TRY(hipEventRecord(s.ev[EV_D2H], sa));
   HIP_TRY(wait_event(s.ev[EV_D2H], h->wait_spin_us));
 
   auto t_host0 = std::chrono::steady_clock::now();
@@ -303,6 +324,24 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   }
   if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
     launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
+  bool merged = false;
+  if (j.merge) {
+    // The path's one exchange step (point_cloud.cpp:264-266 across rigs): the bins of this batch MIN-reduced over the ranks,
+    // as the batch's tail — queued by this worker, behind the scan, on the communicator's stream; the slot's stream picks
+    // up behind the unpack.  RCCL wants every rank to issue a communicator's collectives in one order: batches queue their
+    // merges in submission order (every rank submits the same sequence), whatever order their host stages finished in.
+    std::unique_lock<std::mutex> l(h->merge_m);
+    h->merge_cv.wait(l, [&] { return h->merge_seq == j.seq; });
+    jn_status ms_ = JN_OK;
+    if (hipEventRecord(s.ev_scan, st) != hipSuccess) ms_ = JN_ERR_NO_DEVICE;
+    if (ms_ == JN_OK) ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, s.ev_scan, s.ev_merged);
+    h->merge_seq++;                                        // even on failure: the batches behind must not wait for ever
+    l.unlock();
+    h->merge_cv.notify_all();
+    if (ms_ != JN_OK) return ms_;
+    HIP_TRY(hipStreamWaitEvent(st, s.ev_merged, 0));
+    merged = true;
+  }
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
   HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   HIP_TRY(hipGetLastError());
@@ -317,6 +356,8 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   t.gpu_gap = ms(EV_SPECKLE, EV_GAP); t.gpu_adaptive_mean = ms(EV_GAP, EV_AM);
   t.total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   s.dense_ms = ms(EV_RASTER, EV_DENSE); s.dense_launches = any_ok && stage_events ? 1 : 0;
+  s.merge_ms = 0.f;
+  if (merged) hipEventElapsedTime(&s.merge_ms, s.ev_scan, s.ev_merged);   // scan done -> merged bins in place (queueing behind earlier merges included)
   return JN_OK;
 }
 
@@ -345,7 +386,7 @@ jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
   }
   std::vector<int32_t> local(j.n, JN_OK);
   Job d = j;
-  d.host = false; d.dI1 = s.st_img; d.dI2 = s.st_img + B * px; d.pitch = h->W; d.stride = (int64_t)px;
+  d.host = false; d.staged = true; d.dI1 = s.st_img; d.dI2 = s.st_img + B * px; d.pitch = h->W; d.stride = (int64_t)px;
   d.dD1 = s.st_D; d.dD2 = s.st_D + B * px; d.status = local.data();
   const jn_status r = run_batch(h, s, d);                 // stream-ordered behind the copies; synchronises at its end
   if (r != JN_OK) return r;
@@ -501,9 +542,18 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     h->slots.emplace_back(new Slot());         // owned by the handle from the start: a failure below frees it too
     Slot* s = h->slots.back().get();
     CREATE_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    // Measured (profiles/r03_stage_a_priority_ab.txt): with stage A prioritised the pipelined 720p bench LOSES 12 % (17.5 k
+    // against 20.2 k pairs/s) — the descriptor and support kernels of one slot then push the other slots' dense kernels
+    // aside, and the GPU, not the host stage, is what the pipeline waits for.  Opt-in only: JN_STAGE_A_PRIORITY=1.
+    if (getenv("JN_STAGE_A_PRIORITY") && atoi(getenv("JN_STAGE_A_PRIORITY")) != 0) {
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        CREATE_TRY(hipStreamCreateWithPriority(&s->stream_a, hipStreamNonBlocking, greatest));
+    }
     // blocking-sync events: the slot worker sleeps while the GPU runs instead of spinning on a core that
     // the host stage (and, on a multi-GPU node, the other ranks) could use
     for (int e = 0; e < EV_COUNT; e++) CREATE_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
+    CREATE_TRY(hipEventCreate(&s->ev_scan)); CREATE_TRY(hipEventCreate(&s->ev_merged));
     CREATE_TRY(dmalloc(&s->desc, 2 * B * px));
     CREATE_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     CREATE_TRY(dmalloc(&s->info, B)); CREATE_TRY(dmalloc(&s->payload, B * h->payload_cap));
@@ -550,6 +600,9 @@ void jn_elas_destroy(jn_elas* h) {
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt); hipHostFree(s->h_arr); hipHostFree(s->h_arr_ok);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
+    if (s->ev_scan) hipEventDestroy(s->ev_scan);
+    if (s->ev_merged) hipEventDestroy(s->ev_merged);
+    if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);
   }
   hipFree(h->s_img); hipFree(h->s_D);
@@ -607,9 +660,31 @@ jn_status jn_elas_submit_scan(jn_elas* h, int32_t slot, int32_t n, const uint8_t
     s.cv.wait(l, [&] { return !s.busy; });
     s.job = Job{n, dI1, dI2, pitch, image_stride, dD1, dD2, status};
     s.job.scan = true; s.job.sp = *sp; s.job.dLut = dLut; s.job.dDispU8 = dDispU8; s.job.dBins = dBins; s.job.dMeta = dMeta;
+    {
+      std::lock_guard<std::mutex> g(h->merge_m);             // the submitting thread numbers the batches: same order on every rank
+      if (h->comm) { s.job.merge = true; s.job.seq = h->submit_seq++; }
+    }
     s.has_job = true; s.busy = true;
   }
   s.cv.notify_all();
+  return JN_OK;
+}
+
+jn_status jn_elas_set_comm(jn_elas* h, jn_comm* c) {
+  if (!h) return JN_ERR_INVALID;
+  if (c && comm_device(c) != h->device) return JN_ERR_INVALID;
+  for (auto& sp_ : h->slots) {                              // no batch in flight
+    std::unique_lock<std::mutex> l(sp_->m);
+    sp_->cv.wait(l, [&] { return !sp_->busy; });
+  }
+  std::lock_guard<std::mutex> g(h->merge_m);
+  h->comm = c; h->submit_seq = 0; h->merge_seq = 0;
+  return JN_OK;
+}
+
+jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms) {
+  if (!h || !ms || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
+  *ms = h->slots[slot]->merge_ms;
   return JN_OK;
 }
 

@@ -94,6 +94,16 @@ class Elas:
         _lib.check(self._L.jn_elas_submit_scan(self._h, slot, n, dI1, dI2, pitch, image_stride, dD1, dD2, C.byref(sp), dLut,
                                                dDispU8, dBins, dMeta, status), "jn_elas_submit_scan")
 
+    def set_comm(self, comm):
+        """Attach a parallel.ScanComm (or None): scan batches then end with the cross-rig MIN reduce (jn_elas_set_comm)."""
+        _lib.check(self._L.jn_elas_set_comm(self._h, comm._h if comm is not None else None), "jn_elas_set_comm")
+
+    def merge_time(self, slot=0):
+        import ctypes as C
+        ms = C.c_float(0)
+        _lib.check(self._L.jn_elas_merge_time(self._h, slot, C.byref(ms)), "jn_elas_merge_time")
+        return ms.value
+
     def wait(self, slot):
         _lib.check(self._L.jn_elas_wait(self._h, slot), "jn_elas_wait")
 

@@ -512,3 +512,52 @@ def test_gpu_arrangement_equals_the_hosts(jn):
         a, b = case(n, 256, 144, 127, force_dup=True)
         dup += (b == 0)
     assert dup >= 1                                             # the coinciding pair was seen and handed back
+
+
+def test_merge_as_the_tail_of_scan_batches(jn, oracle):
+    """jn_elas_set_comm: with a communicator attached every scan batch ends with pack -> ncclAllReduce(MIN) -> unpack, queued by
+    the slot worker in submission order.  One rank here (MIN over one rank is the identity), four slots, twelve batches of
+    different frames in flight: the bins must equal the un-merged run's bit for bit, a merge time is reported, and detaching
+    restores the plain path."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node, parallel
+    W, H, B, S, rounds = 320, 180, 3, 4, 3
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    pairs = [[node.synth_pair(W, H, 30 + 4 * k, 900 + 7 * k + t) for t in range(B)] for k in range(S * rounds)]
+    dLs = [DeviceArray.from_numpy(np.stack([p[0] for p in ps])) for ps in pairs]
+    dRs = [DeviceArray.from_numpy(np.stack([p[1] for p in ps])) for ps in pairs]
+
+    def run_all(e):
+        got = []
+        bufs = [dict(d1=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)), d2=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)),
+                     u8=DeviceArray((B, H, W), np.uint8), bins=DeviceArray((B, sp.bins), np.float64), meta=DeviceArray((B, 4), np.float64),
+                     st=(C.c_int32 * B)()) for _ in range(S)]
+        inflight = []
+        for k in range(S * rounds):
+            slot = k % S
+            if len(inflight) == S:
+                s0, k0 = inflight.pop(0)
+                e.wait(s0)
+                got.append((bufs[s0]["bins"].numpy().copy(), bufs[s0]["meta"].numpy().copy(), e.merge_time(s0)))
+            b = bufs[slot]
+            e.submit_scan(slot, B, dLs[k].ptr, dRs[k].ptr, W, H * W, b["d1"].ptr, b["d2"].ptr, sp, lut.ptr, b["u8"].ptr, b["bins"].ptr, b["meta"].ptr, b["st"])
+            inflight.append((slot, k))
+        for s0, k0 in inflight:
+            e.wait(s0)
+            got.append((bufs[s0]["bins"].numpy().copy(), bufs[s0]["meta"].numpy().copy(), e.merge_time(s0)))
+        return got
+
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=4) as e:
+        plain = run_all(e)
+        comm = parallel.ScanComm(0, 1, 0, lambda raw: raw)
+        e.set_comm(comm)
+        merged = run_all(e)
+        e.set_comm(None)
+        again = run_all(e)
+        comm.close()
+    assert len(plain) == len(merged) == S * rounds
+    for (b0, m0, t0), (b1, m1, t1), (b2, m2, t2) in zip(plain, merged, again):
+        assert np.array_equal(b0, b1) and np.array_equal(m0, m1) and np.array_equal(b0, b2) and np.array_equal(m0, m2)
+        assert t0 == 0.0 and t1 > 0.0 and t2 == 0.0
+    assert (plain[0][0] < 1e9 - 1).any()
