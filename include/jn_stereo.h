@@ -227,11 +227,13 @@ jn_status jn_init_undistort_rectify_map(int32_t device, const double K[9], const
  * for n grey source frames (device).  Source coordinates are quantised to 1/32 pixel
  * (round-half-even, as OpenCV does); the four taps are blended with exact 10-bit weights
  * ((32-fx)(32-fy) ...)/1024, rounded to nearest.
- * PARITY UNPINNED (no OpenCV in the build image).  Known difference from a real OpenCV deployment:
- * cv::remap's 8-bit INTER_LINEAR path blends with a table of weights ROUNDED to 15 bits
- * (INTER_REMAP_COEF_SCALE = 32768, each of the 32x32 weight quadruples rounded and then fixed up to
- * sum to 32768) and rounds the sum once; the exact products used here differ from that table in the
- * last bit for some (fx, fy), so individual output pixels can differ by +-1 grey level. */
+ * This IS cv::remap's 8-bit INTER_LINEAR arithmetic (imgwarp.cpp, OpenCV 2.4 / 3 / 4): its 32x32 table holds the four
+ * weights scaled by INTER_REMAP_COEF_SCALE = 32768 and rounded to short — but (32-fx)(32-fy)/1024 * 32768 = 32 (32-fx)(32-fy)
+ * is an integer, so nothing is rounded and every quadruple sums to 32768 — except the phase (0, 0), whose weight 32768 a short
+ * cannot hold: OpenCV stores 32767 and its fix-up adds the missing unit to another tap, which never changes an 8-bit pixel
+ * ((32767 p + p' + 16384) >> 15 == p).  Its final FixedPtCast, (sum + 16384) >> 15 with sum = 32 acc, equals (acc + 512) >> 10.
+ * tests/test_node_oracle.py rebuilds the table by OpenCV's published recipe and checks all 1024 phases and both identities.  What stays unpinned (no
+ * OpenCV in the build image) is only that the recipe is restated, not linked. */
 jn_status jn_remap_bilinear(int32_t device, int32_t n, const uint8_t* dSrc, int32_t src_width, int32_t src_height,
                             int32_t src_pitch, int64_t src_stride, const float* dMapX, const float* dMapY,
                             uint8_t* dDst, int32_t width, int32_t height, int32_t dst_pitch, int64_t dst_stride);
@@ -280,8 +282,9 @@ jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, 
  * submitting thread is not involved), so jn_elas_wait returns with the ROBOT-level bins in dBins / dMeta.  RCCL needs every
  * rank to issue a communicator's collectives in one order: batches queue their merges in submission order, so every rank
  * must submit the same sequence of scan batches (same n, same bins).  Call with no batch in flight; c = NULL detaches.
- * The communicator must live on the handle's device and outlive its use here.  jn_elas_merge_time: milliseconds from the
- * end of the slot's last scan to its merged bins being in place (queueing behind earlier batches' merges included). */
+ * The communicator must live on the handle's device and outlive its use here.  jn_elas_merge_time: milliseconds on the
+ * worker's clock from the slot's last scan being complete to its merged bins being in place (waiting for its turn in the
+ * submission order included). */
 jn_status jn_elas_set_comm(jn_elas* h, jn_comm* c);
 jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms);
 void jn_comm_destroy(jn_comm* c);

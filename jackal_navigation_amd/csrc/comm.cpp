@@ -123,7 +123,14 @@ jn_status jn_comm_create(const uint8_t id[JN_COMM_ID_BYTES], int32_t rank, int32
     delete c;
     return JN_ERR_COMM;
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { R->CommDestroy(c->comm); delete c; return JN_ERR_NO_DEVICE; }
+  // JN_COMM_PRIORITY=1: the communicator's stream at the highest priority.  Measured on one MI355X (bench.py --force-merge,
+  // profiles/r03_merge_in_worker.txt): it does NOT help — scan -> merged bins 0.94 ms against 0.66 ms on an ordinary stream.
+  int least = 0, greatest = 0;
+  hipError_t se = hipErrorUnknown;
+  if (getenv("JN_COMM_PRIORITY") && atoi(getenv("JN_COMM_PRIORITY")) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+    se = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
+  if (se != hipSuccess) se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (se != hipSuccess) { R->CommDestroy(c->comm); delete c; return JN_ERR_NO_DEVICE; }
   *out = c;
   return JN_OK;
 }

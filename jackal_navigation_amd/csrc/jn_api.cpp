@@ -324,27 +324,33 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   }
   if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
     launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
-  bool merged = false;
-  if (j.merge) {
-    // The path's one exchange step (point_cloud.cpp:264-266 across rigs): the bins of this batch MIN-reduced over the ranks,
-    // as the batch's tail — queued by this worker, behind the scan, on the communicator's stream; the slot's stream picks
-    // up behind the unpack.  RCCL wants every rank to issue a communicator's collectives in one order: batches queue their
-    // merges in submission order (every rank submits the same sequence), whatever order their host stages finished in.
-    std::unique_lock<std::mutex> l(h->merge_m);
-    h->merge_cv.wait(l, [&] { return h->merge_seq == j.seq; });
-    jn_status ms_ = JN_OK;
-    if (hipEventRecord(s.ev_scan, st) != hipSuccess) ms_ = JN_ERR_NO_DEVICE;
-    if (ms_ == JN_OK) ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, s.ev_scan, s.ev_merged);
-    h->merge_seq++;                                        // even on failure: the batches behind must not wait for ever
-    l.unlock();
-    h->merge_cv.notify_all();
-    if (ms_ != JN_OK) return ms_;
-    HIP_TRY(hipStreamWaitEvent(st, s.ev_merged, 0));
-    merged = true;
-  }
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
   HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   HIP_TRY(hipGetLastError());
+  bool merged = false;
+  float merge_host_ms = 0.f;
+  if (j.merge) {
+    // The path's one exchange step (point_cloud.cpp:264-266 across rigs): the bins of this batch MIN-reduced over the ranks,
+    // as the batch's tail, issued by THIS worker (the submitting thread is not involved, the other slots keep the GPU busy).
+    // RCCL wants every rank to issue a communicator's collectives in one order: batches take their turn in submission order
+    // (every rank submits the same sequence), whatever order their host stages finished in.
+    // The scan is complete here (the wait above), so pack -> all-reduce -> unpack need no cross-stream dependency: chaining
+    // them to the slot's stream with events cost 0.66 ms per batch on a busy GPU (two queue hand-overs), this costs the
+    // kernels themselves plus one host wait (profiles/r03_merge_in_worker.txt).
+    const auto t_m0 = std::chrono::steady_clock::now();
+    jn_status ms_ = JN_OK;
+    {
+      std::unique_lock<std::mutex> l(h->merge_m);
+      h->merge_cv.wait(l, [&] { return h->merge_seq == j.seq; });
+      ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, nullptr, s.ev_merged);
+      h->merge_seq++;                                      // even on failure: the batches behind must not wait for ever
+    }
+    h->merge_cv.notify_all();
+    if (ms_ != JN_OK) return ms_;
+    HIP_TRY(wait_event(s.ev_merged, h->wait_spin_us));
+    merge_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_m0).count();
+    merged = true;
+  }
   auto t_end = std::chrono::steady_clock::now();
 
   auto ms = [&](int a, int b) { float v = 0; if (stage_events) hipEventElapsedTime(&v, s.ev[a], s.ev[b]); return v; };
@@ -356,8 +362,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   t.gpu_gap = ms(EV_SPECKLE, EV_GAP); t.gpu_adaptive_mean = ms(EV_GAP, EV_AM);
   t.total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
   s.dense_ms = ms(EV_RASTER, EV_DENSE); s.dense_launches = any_ok && stage_events ? 1 : 0;
-  s.merge_ms = 0.f;
-  if (merged) hipEventElapsedTime(&s.merge_ms, s.ev_scan, s.ev_merged);   // scan done -> merged bins in place (queueing behind earlier merges included)
+  s.merge_ms = merged ? merge_host_ms : 0.f;               // scan complete -> merged bins in place, on the worker's clock (its turn in the order included)
   return JN_OK;
 }
 
