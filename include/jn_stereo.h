@@ -249,6 +249,12 @@ jn_status jn_remap_bilinear(int32_t device, int32_t n, const uint8_t* dSrc, int3
 jn_status jn_jpeg_info(const uint8_t* jpeg, int64_t nbytes, int32_t* width, int32_t* height);
 jn_status jn_jpeg_decode_gray(int32_t device, const uint8_t* jpeg, int64_t nbytes, uint8_t* dOut, int32_t out_pitch, int32_t out_rows,
                               int32_t* width, int32_t* height);
+/* Both eyes of one stereo frame (the reference decodes them in its two image callbacks, point_cloud.cpp:436 and :478): the two
+ * entropy decodes run on two threads (a long-lived helper per calling thread takes the right eye), the two inverse DCTs are
+ * queued together and waited for once.  Same results and errors as two jn_jpeg_decode_gray calls; both frames must have the
+ * same size, returned in *width / *height. */
+jn_status jn_jpeg_decode_gray_pair(int32_t device, const uint8_t* jpegL, int64_t nbytesL, const uint8_t* jpegR, int64_t nbytesR, uint8_t* dOutL,
+                                   uint8_t* dOutR, int32_t out_pitch, int32_t out_rows, int32_t* width, int32_t* height);
 
 /* Host-stage hook (CPU only, like jn_host_triangulate): the entropy-decoded luminance coefficients of a JPEG frame, natural
  * (de-zigzagged) order, not dequantised, blocks_h x blocks_w blocks of 64 (padded to whole MCUs), and the luminance

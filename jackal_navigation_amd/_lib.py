@@ -88,7 +88,7 @@ EXPORTS = [
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
     "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote", "jn_device_support_filters", "jn_host_arrangement", "jn_device_arrangement", "jn_elas_submit_scan", "jn_elas_submit_host",
-    "jn_host_triangulate_parts", "jn_jpeg_info", "jn_jpeg_decode_gray", "jn_host_jpeg_coefficients", "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32", "jn_elas_set_comm", "jn_elas_merge_time",
+    "jn_host_triangulate_parts", "jn_jpeg_info", "jn_jpeg_decode_gray", "jn_host_jpeg_coefficients", "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32", "jn_elas_set_comm", "jn_elas_merge_time", "jn_jpeg_decode_gray_pair",
 ]
 
 _lib = None
@@ -152,6 +152,7 @@ def load():
     L.jn_nav_vote.argtypes = [C.POINTER(NavParams), C.POINTER(NavState), vp, i32, C.POINTER(NavDecision)]
     L.jn_jpeg_info.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32)]
     L.jn_jpeg_decode_gray.argtypes = [i32, vp, i64, vp, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.jn_jpeg_decode_gray_pair.argtypes = [i32, vp, i64, vp, i64, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.jn_host_jpeg_coefficients.argtypes = [vp, i64, vp, i64, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.jn_host_jpeg_coefficients.restype = i64
     L.jn_comm_unique_id.argtypes = [vp]

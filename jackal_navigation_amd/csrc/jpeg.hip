@@ -5,7 +5,10 @@
 #include <stdint.h>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 #include "../../include/jn_stereo.h"
@@ -78,38 +81,109 @@ __global__ void __launch_bounds__(256) k_jpeg_idct_gray(const int16_t* __restric
     }                                                                                       \
   } while (0)
 
-extern "C" {
+// One eye: frame size against the caller's buffer, entropy decoding on the calling thread (the serial part), then upload +
+// inverse DCT.  `sc` is the calling thread's grow-only device scratch for this eye.
+struct JpegScratch { int16_t* p = nullptr; size_t cap = 0; int dev = -1; std::vector<int16_t> coef; jnav::JpegFrame frame; };
 
-jn_status jn_jpeg_decode_gray(int32_t device, const uint8_t* jpeg, int64_t nbytes, uint8_t* dOut, int32_t out_pitch, int32_t out_rows,
-                              int32_t* width, int32_t* height) {
-  if (!jpeg || nbytes < 4 || !dOut || !width || !height) return JN_ERR_INVALID;
+static jn_status jpeg_entropy(const uint8_t* jpeg, int64_t nbytes, int32_t out_pitch, int32_t out_rows, int32_t* width, int32_t* height, JpegScratch& sc) {
+  if (!jpeg || nbytes < 4 || !width || !height) return JN_ERR_INVALID;
   // frame size against the caller's buffer BEFORE any entropy decoding or allocation
   jn_status st = jn_jpeg_info(jpeg, nbytes, width, height);
   if (st != JN_OK) return st;
   if (*width > jnav::kJpegMaxDim || *height > jnav::kJpegMaxDim) return JN_ERR_UNSUPPORTED;
   if (out_pitch < *width || out_rows < *height) return JN_ERR_INVALID;
-  jnav::JpegFrame d;
-  static thread_local std::vector<int16_t> coef;
-  try { st = jnav::jpeg_parse_and_decode(jpeg, (size_t)nbytes, d, coef); } catch (const std::bad_alloc&) { return JN_ERR_INTERNAL; }
+  try { st = jnav::jpeg_parse_and_decode(jpeg, (size_t)nbytes, sc.frame, sc.coef); } catch (const std::bad_alloc&) { return JN_ERR_INTERNAL; }
   if (st != JN_OK) return st;
-  if (d.width != *width || d.height != *height) return JN_ERR_INVALID;          // two frame headers that disagree
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
-  JPG_TRY(hipSetDevice(device));
-  // grow-only device buffer per calling thread and device (no allocation per frame)
-  struct Scratch { int16_t* p = nullptr; size_t cap = 0; int dev = -1; };
-  static thread_local Scratch sc;
-  const size_t need = coef.size() * sizeof(int16_t);
-  if (sc.dev != device || sc.cap < need) {
+  if (sc.frame.width != *width || sc.frame.height != *height) return JN_ERR_INVALID;      // two frame headers that disagree
+  return JN_OK;
+}
+static jn_status jpeg_idct_launch(int32_t device, JpegScratch& sc, uint8_t* dOut, int32_t out_pitch) {
+  const size_t need = sc.coef.size() * sizeof(int16_t);
+  if (sc.dev != device || sc.cap < need) {                  // grow-only device buffer per calling thread, eye and device
     if (sc.p) { hipSetDevice(sc.dev); hipFree(sc.p); hipSetDevice(device); sc.p = nullptr; sc.cap = 0; }
     JPG_TRY(hipMalloc(reinterpret_cast<void**>(&sc.p), need));
     sc.cap = need; sc.dev = device;
   }
-  JPG_TRY(hipMemcpy(sc.p, coef.data(), need, hipMemcpyHostToDevice));
+  JPG_TRY(hipMemcpyAsync(sc.p, sc.coef.data(), need, hipMemcpyHostToDevice, nullptr));
   QuantTable qt;
-  memcpy(qt.q, d.quant, sizeof(qt.q));
-  const int blocks = d.bw * d.bh;
-  hipLaunchKernelGGL(k_jpeg_idct_gray, dim3((blocks + 31) / 32), dim3(256), 0, nullptr, sc.p, qt, d.bw, d.bh, d.width, d.height, dOut, out_pitch);
+  memcpy(qt.q, sc.frame.quant, sizeof(qt.q));
+  const int blocks = sc.frame.bw * sc.frame.bh;
+  hipLaunchKernelGGL(k_jpeg_idct_gray, dim3((blocks + 31) / 32), dim3(256), 0, nullptr, sc.p, qt, sc.frame.bw, sc.frame.bh, sc.frame.width, sc.frame.height, dOut, out_pitch);
+  return JN_OK;
+}
+
+extern "C" {
+
+jn_status jn_jpeg_decode_gray(int32_t device, const uint8_t* jpeg, int64_t nbytes, uint8_t* dOut, int32_t out_pitch, int32_t out_rows,
+                              int32_t* width, int32_t* height) {
+  if (!dOut) return JN_ERR_INVALID;
+  static thread_local JpegScratch sc;
+  jn_status st = jpeg_entropy(jpeg, nbytes, out_pitch, out_rows, width, height, sc);
+  if (st != JN_OK) return st;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  JPG_TRY(hipSetDevice(device));
+  if ((st = jpeg_idct_launch(device, sc, dOut, out_pitch)) != JN_OK) return st;
+  JPG_TRY(hipStreamSynchronize(nullptr));
+  JPG_TRY(hipGetLastError());
+  return JN_OK;
+}
+
+// Both eyes of a stereo frame (point_cloud.cpp:436 and :478 decode them in two callbacks): the two entropy decodes — the
+// serial, host-bound 2 x 0.4 ms of a 640x360 frame pair — run on two threads, then both inverse DCTs are queued and waited
+// for once.  A long-lived helper thread per calling thread takes the right eye (no thread is created per frame).
+namespace {
+struct EyeHelper {
+  std::thread th; std::mutex m; std::condition_variable cv;
+  bool has = false, done = false, quit = false;
+  const uint8_t* jpeg = nullptr; int64_t nbytes = 0; int32_t pitch = 0, rows = 0, w = 0, h = 0; jn_status st = JN_OK;
+  JpegScratch sc;
+  EyeHelper() { th = std::thread([this] { run(); }); }
+  ~EyeHelper() { { std::lock_guard<std::mutex> l(m); quit = true; } cv.notify_all(); th.join(); if (sc.p) hipFree(sc.p); }
+  void run() {
+    std::unique_lock<std::mutex> l(m);
+    for (;;) {
+      cv.wait(l, [&] { return has || quit; });
+      if (quit) return;
+      has = false;
+      l.unlock();
+      const jn_status r = jpeg_entropy(jpeg, nbytes, pitch, rows, &w, &h, sc);
+      l.lock();
+      st = r; done = true;
+      cv.notify_all();
+    }
+  }
+};
+}  // namespace
+
+jn_status jn_jpeg_decode_gray_pair(int32_t device, const uint8_t* jpegL, int64_t nbytesL, const uint8_t* jpegR, int64_t nbytesR, uint8_t* dOutL,
+                                   uint8_t* dOutR, int32_t out_pitch, int32_t out_rows, int32_t* width, int32_t* height) {
+  if (!dOutL || !dOutR || !width || !height) return JN_ERR_INVALID;
+  static thread_local JpegScratch scL;
+  static thread_local std::unique_ptr<EyeHelper> helper;
+  if (!helper) helper.reset(new EyeHelper());
+  EyeHelper& hp = *helper;
+  {
+    std::lock_guard<std::mutex> l(hp.m);
+    hp.jpeg = jpegR; hp.nbytes = nbytesR; hp.pitch = out_pitch; hp.rows = out_rows; hp.has = true; hp.done = false;
+  }
+  hp.cv.notify_all();
+  const jn_status stL = jpeg_entropy(jpegL, nbytesL, out_pitch, out_rows, width, height, scL);
+  jn_status stR;
+  {
+    std::unique_lock<std::mutex> l(hp.m);
+    hp.cv.wait(l, [&] { return hp.done; });
+    stR = hp.st;
+  }
+  if (stL != JN_OK) return stL;
+  if (stR != JN_OK) return stR;
+  if (hp.w != *width || hp.h != *height) return JN_ERR_INVALID;                 // the two eyes must be the same size
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  JPG_TRY(hipSetDevice(device));
+  jn_status st;
+  if ((st = jpeg_idct_launch(device, scL, dOutL, out_pitch)) != JN_OK) return st;
+  if ((st = jpeg_idct_launch(device, hp.sc, dOutR, out_pitch)) != JN_OK) return st;
   JPG_TRY(hipStreamSynchronize(nullptr));
   JPG_TRY(hipGetLastError());
   return JN_OK;

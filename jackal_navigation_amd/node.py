@@ -121,6 +121,17 @@ def imdecode_gray(data, device=0):
     return out
 
 
+def imdecode_gray_pair(left, right, device=0):
+    """Both eyes of a stereo frame, entropy-decoded on two threads (jn_jpeg_decode_gray_pair); returns two DeviceArrays."""
+    bl, br = np.frombuffer(bytes(left), np.uint8), np.frombuffer(bytes(right), np.uint8)
+    w, h = jpeg_info(bl)
+    outs = DeviceArray((h, w), np.uint8, device), DeviceArray((h, w), np.uint8, device)
+    ww, hh = C.c_int32(), C.c_int32()
+    _lib.check(_lib.load().jn_jpeg_decode_gray_pair(device, bl.ctypes.data, bl.size, br.ctypes.data, br.size, outs[0].ptr, outs[1].ptr, w, h,
+                                                    C.byref(ww), C.byref(hh)), "jn_jpeg_decode_gray_pair")
+    return outs
+
+
 def synth_pair(width, height, scene_disp, seed=12345):
     L = np.zeros((height, width), np.uint8)
     R = np.zeros((height, width), np.uint8)

@@ -19,6 +19,7 @@ from jackal_navigation_amd.device import DeviceArray  # noqa: E402
 
 def main():
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    pair = not (len(sys.argv) > 2 and sys.argv[2] == "serial")          # `serial`: the two eyes one after the other (round 2)
     z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_jpeg_pair.npz"))
     jl, jr = np.ascontiguousarray(z["left__jpeg"]), np.ascontiguousarray(z["right__jpeg"])
     from jackal_navigation_amd import _lib
@@ -41,8 +42,12 @@ def main():
         def frame():
             nonlocal t_dec, t_remap, t_match, t_msg
             t0 = time.perf_counter()
-            for buf, out in ((jl, raws[0]), (jr, raws[1])):                         # cv::imdecode(GRAYSCALE), point_cloud.cpp:436, :478
-                _lib.check(L.jn_jpeg_decode_gray(0, buf.ctypes.data, buf.size, out.ptr, 640, 360, C.byref(ww), C.byref(hh)), "jn_jpeg_decode_gray")
+            if pair:                                                                # both eyes, entropy decodes on two threads
+                _lib.check(L.jn_jpeg_decode_gray_pair(0, jl.ctypes.data, jl.size, jr.ctypes.data, jr.size, raws[0].ptr, raws[1].ptr, 640, 360,
+                                                      C.byref(ww), C.byref(hh)), "jn_jpeg_decode_gray_pair")
+            else:
+                for buf, out in ((jl, raws[0]), (jr, raws[1])):                     # cv::imdecode(GRAYSCALE), point_cloud.cpp:436, :478
+                    _lib.check(L.jn_jpeg_decode_gray(0, buf.ctypes.data, buf.size, out.ptr, 640, 360, C.byref(ww), C.byref(hh)), "jn_jpeg_decode_gray")
             t1 = time.perf_counter()
             for i in range(2):
                 node.remap(1, raws[i].ptr, 640, 360, 640, 640 * 360, maps[i][0].ptr, maps[i][1].ptr, rect[i].ptr, W, H, W, W * H)
@@ -61,7 +66,7 @@ def main():
         for _ in range(frames):
             msg = frame()
         el = time.perf_counter() - t0
-    print("node path, 640x360 JPEG pair -> 320x180 ELAS (disp_max 255) -> 90-bin scan: %.3f ms per frame = %.0f frames/s  "
+    print("[%s decode] " % ("two-thread" if pair else "serial") + "node path, 640x360 JPEG pair -> 320x180 ELAS (disp_max 255) -> 90-bin scan: %.3f ms per frame = %.0f frames/s  "
           "(decode x2 %.3f, remap x2 %.3f, ELAS + u8 + scan %.3f, D2H + message %.3f); %d ranges, status %d" %
           (el / frames * 1e3, frames / el, t_dec / frames * 1e3, t_remap / frames * 1e3, t_match / frames * 1e3, t_msg / frames * 1e3,
            len(msg["ranges"]), st[0]))

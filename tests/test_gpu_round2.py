@@ -383,6 +383,44 @@ def test_imdecode_gray_on_the_gpu_equals_libjpeg(jn):
         assert np.array_equal(node.imdecode_gray(buf.getvalue()).numpy(), np.asarray(im)), (k, W, H)
 
 
+def test_both_eyes_decoded_on_two_threads_equal_two_single_decodes(jn):
+    """jn_jpeg_decode_gray_pair: the right eye's entropy decode runs on a helper thread.  Same pixels as two single calls, for the
+    webcam pair and for every same-sized couple of the fixtures, many frames in a row (the helper thread is re-used), from two
+    calling threads at once; a damaged right eye and eyes of different sizes are refused."""
+    import os
+    import threading
+    from jackal_navigation_amd import node, _lib
+    z = np.load(os.path.join(ROOT, "tests", "golden", "stereo_jpeg_pair.npz"))
+    jl, jr = z["left__jpeg"], z["right__jpeg"]
+    one_l, one_r = node.imdecode_gray(jl).numpy(), node.imdecode_gray(jr).numpy()
+    for _ in range(20):
+        a, b = node.imdecode_gray_pair(jl, jr)
+        assert np.array_equal(a.numpy(), one_l) and np.array_equal(b.numpy(), one_r)
+    a, b = node.imdecode_gray_pair(jr, jl)
+    assert np.array_equal(a.numpy(), one_r) and np.array_equal(b.numpy(), one_l)
+    errs = []
+
+    def worker():
+        try:
+            for _ in range(15):
+                a, b = node.imdecode_gray_pair(jl, jr)
+                assert np.array_equal(a.numpy(), one_l) and np.array_equal(b.numpy(), one_r)
+        except Exception as e:            # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=worker) for _ in range(3)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs
+    cases = np.load(os.path.join(ROOT, "tests", "golden", "jpeg_cases.npz"))
+    with pytest.raises(_lib.JnError) as e:
+        node.imdecode_gray_pair(jl, jr[: len(jr) // 3])
+    assert e.value.status == _lib.JN_ERR_INVALID
+    with pytest.raises(_lib.JnError) as e:
+        node.imdecode_gray_pair(jl, cases["ragged_35x21_q95_422__jpeg"])
+    assert e.value.status == _lib.JN_ERR_INVALID
+    a, b = node.imdecode_gray_pair(jl, jr)                                   # and the pair still works afterwards
+    assert np.array_equal(a.numpy(), one_l) and np.array_equal(b.numpy(), one_r)
+
+
 def test_whole_frame_from_jpeg_bytes_to_laser_scan(jn, oracle, same):
     """One frame the way the node sees it (point_cloud.cpp:431-490 -> :406-429 -> :213-296): the two compressed images of
     tests/golden/stereo_jpeg_pair.npz -> imdecode (GPU IDCT, pinned by libjpeg's SHA-256) -> rectification maps of the

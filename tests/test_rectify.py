@@ -119,3 +119,54 @@ def test_rectify_then_elas_end_to_end(jn, oracle, same):
         st = e.process(outs[0], outs[1], D1, D2, (W, H, W))
     st_o, D1o, D2o = oracle.process(oracle.params(0, disp_max=63), outs[0], outs[1])
     assert st == st_o and same(D1, D1o) and same(D2, D2o)
+
+
+def test_stereo_rectify_against_an_independent_restatement(jn):
+    """a25 / f1 had no second implementation.  oracle/rectify_oracle.py restates Bouguet's rectification with other
+    formulas throughout (quaternion half rotation, minimal vector-to-vector rotation, Newton-converged undistortion, float64
+    points); jackal_navigation_amd/csrc/rectify.cpp follows cvStereoRectify's own steps (Rodrigues both ways, five fixed-point
+    undistortion sweeps, float32 points between its calls).  Bounds: rotations agree to 1e-12 (pure double arithmetic on both
+    sides); with the restatement also running cvUndistortPoints' five sweeps, focal length, principal point and Q agree to
+    2e-6 relative (what is left: float32 corner points); with the distortion inverted to convergence instead they move by up to
+    ~1e-3 relative (0.1 - 0.2 pixel of principal point on this lens) — OpenCV 2.4's five sweeps are part of what the node gets.
+    On the reference's calibration (calibration/amrl_jackal_webcam_stereo.yml) and on perturbed rigs, horizontal and vertical."""
+    from jackal_navigation_amd import node
+    from oracle import rectify_oracle as ro
+    rng = np.random.default_rng(11)
+    base = node.stereo_calib()
+
+    def variants():
+        yield base, (320, 180)
+        yield base, (640, 360)
+        yield base, (0, 0)
+        for k in range(6):
+            c = node.stereo_calib()
+            om = rng.normal(0, 0.03, 3)
+            th = np.linalg.norm(om); kx = np.array([[0, -om[2], om[1]], [om[2], 0, -om[0]], [-om[1], om[0], 0]]) / th
+            Rp = np.eye(3) + np.sin(th) * kx + (1 - np.cos(th)) * kx @ kx
+            Rn = Rp @ np.array(c.R).reshape(3, 3)
+            for i in range(9):
+                c.R[i] = float(Rn.ravel()[i])
+            T = np.array(c.T) * (1 + rng.normal(0, 0.1)) + rng.normal(0, 0.002, 3)
+            if k >= 4:
+                T = np.array([T[1], -abs(T[0]), T[2]])            # a vertical rig
+            for i in range(3):
+                c.T[i] = float(T[i])
+            for i in range(5):
+                c.D1[i] *= float(1 + rng.normal(0, 0.2)); c.D2[i] *= float(1 + rng.normal(0, 0.2))
+            yield c, (320, 180) if k % 2 else (1280, 720)
+
+    n = 0
+    for c, size in variants():
+        R1, R2, P1, P2, Q = _mats(node.stereo_rectify(c, *size))
+        args = (np.array(c.K1), np.array(c.D1), np.array(c.K2), np.array(c.D2), np.array(c.R), np.array(c.T), (c.calib_width, c.calib_height), size)
+        o = ro.stereo_rectify(*args, sweeps=5)
+        assert np.abs(R1 - o[0]).max() < 1e-12 and np.abs(R2 - o[1]).max() < 1e-12
+        for got, exp in ((P1, o[2]), (P2, o[3]), (Q, o[4])):
+            scale = np.maximum(np.abs(exp), 1e-3 * np.abs(exp).max())
+            assert (np.abs(got - exp) / scale).max() < 2e-6, (size, got, exp)
+        oc = ro.stereo_rectify(*args)                              # distortion inverted to convergence: close, not equal
+        worst = max((np.abs(got - exp) / np.maximum(np.abs(exp), 1e-3 * np.abs(exp).max())).max() for got, exp in ((P1, oc[2]), (P2, oc[3]), (Q, oc[4])))
+        assert worst < 5e-3, (size, worst)
+        n += 1
+    assert n == 9
