@@ -652,6 +652,26 @@ def run_rank(a):
         check = {"what": "FNV-1a-64 of D1, frame 0 (seed 12345), every slot, after the timed region", "got": sorted(set(got)),
                  "expected": want, "source": "tests/golden/reference_hashes.txt (compiled reference src/elas)" if want else None,
                  "ok": (set(got) == {want}) if want else None}
+        # the node's tail of the same frame: u8 depth map (bit-exact) and the 90 bins + extrema (1e-4, north star) against the
+        # oracle chain on the reference's D1 (tests/golden/scan_golden.json).  Bins only where no cross-rig merge touched them.
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "scan_golden.json"))).get("%d %d %d %d" % (W, H, scene, a.disp - 1))
+        except (OSError, ValueError):
+            gold = None
+        if gold:
+            u8_got = []
+            for s_ in range(S):
+                host = U8[s_][0].cpu().numpy()
+                u8_got.append("%016x" % L.jn_fnv1a64_u32(host.ctypes.data, host.size // 4))
+            check["u8_map"] = {"got": sorted(set(u8_got)), "expected": gold["u8_fnv"], "ok": set(u8_got) == {gold["u8_fnv"]}}
+            if dist is None and not merge_state["attached"]:
+                worst = 0.0
+                for s_ in range(S):
+                    worst = max(worst, float(np.abs(bins[s_][0].cpu().numpy() - np.array(gold["bins"])).max()),
+                                float(np.abs(meta[s_][0].cpu().numpy() - np.array(gold["meta"])).max()))
+                check["scan"] = {"max_abs_diff_bins_and_extrema": worst, "tolerance": 1e-4, "ok": worst <= 1e-4}
+            check["ok"] = bool(check["ok"]) and check["u8_map"]["ok"] and check.get("scan", {"ok": True})["ok"] if want else None
+            check["source_tail"] = "tests/golden/scan_golden.json (oracle/node_oracle.cpp on the compiled reference's D1; OpenCV / ROS side by definition)"
 
     # roofline of the dominant kernel, k_dense: algorithmic bytes per launch (dense L+R = 16 B per pixel per
     # pair, one launch = the whole batch, both sides) over its average duration, measured with HIP events the library
@@ -734,6 +754,46 @@ def run_rank(a):
         except Exception as exc:                     # informational leg: never let it take the headline line down
             extra["block_matching"] = {"error": repr(exc)}
 
+    # the non-reference matchers on the SAME batch, after the timed ELAS regions and outside `value`: BASELINE config 3 names
+    # "SGM 8-path", the reference has only ELAS; these keys let the driver's line record what include/jn_sgm.h / jn_bm.h run at
+    other_modes = None
+    if rank == 0 and world == 1 and not a.no_latency_config and a.disp in (64, 128, 256):
+        other_modes = {}
+        for kind in ("sgm", "bm"):
+            try:
+                disp16 = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
+                if kind == "sgm":
+                    m = jn.Sgm(jn.Sgm.parameters(num_disparities=a.disp), W, H, max_batch=B, device=local_rank)
+                else:
+                    m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4), W, H, max_batch=B, device=local_rank)
+                for _ in range(2):
+                    m.process_batch(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp16.data_ptr())
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                reps_m = 5
+                for _ in range(reps_m):
+                    m.process_batch(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp16.data_ptr())
+                torch.cuda.synchronize()
+                el_m = (time.perf_counter() - t1) / reps_m
+                host = disp16[0].cpu().numpy()
+                got_m = "%016x" % jn.load().jn_fnv1a64_u32(host.ctypes.data, host.size // 2)
+                want_m = None
+                for line in open(os.path.join(ROOT, "tests", "golden", "%s_hashes.txt" % kind)):
+                    f = line.split()
+                    if kind == "sgm" and f[:6] == [str(W), str(H), str(scene), str(a.disp), "0", "12345"]:
+                        want_m = f[6]
+                    if kind == "bm" and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
+                        want_m = f[7]
+                other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_process_batch), same inputs as the ELAS regions" %
+                                                 (W, H, a.disp, "SGM 8 paths" if kind == "sgm" else "9x9 block matching", B, kind),
+                                     "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},
+                                     "check": {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None,
+                                               "source": "tests/golden/%s_hashes.txt (the mode's scalar definition; the reference has no such matcher)" % kind}}
+                m.close()
+                del disp16
+            except Exception as exc:                 # informational legs: never let them take the headline line down
+                other_modes[kind] = {"error": repr(exc)}
+
     # who took part: gathered over the collective backend, so the line shows what the N ranks really ran on
     ranks_info = None
     if dist is not None:
@@ -762,6 +822,7 @@ def run_rank(a):
             "cpu_baseline": cpu,
             "check": check,
             "latency_config": extra,
+            "other_modes": other_modes,
             "host_cpu": host_cpu,
         }
         if merge_report is not None:
