@@ -599,3 +599,48 @@ def test_merge_as_the_tail_of_scan_batches(jn, oracle):
         assert np.array_equal(b0, b1) and np.array_equal(m0, m1) and np.array_equal(b0, b2) and np.array_equal(m0, m2)
         assert t0 == 0.0 and t1 > 0.0 and t2 == 0.0
     assert (plain[0][0] < 1e9 - 1).any()
+
+
+def test_support_count_growing_from_batch_to_batch_on_one_slot(jn, oracle, same, monkeypatch):
+    """k_arrange's LDS space follows the support counts of the slot's last batches.  A batch of nearly textureless
+    frames (few support points) followed by dense ones on the SAME slot hands the larger sides back to the host (ok = 0) — the
+    results must not change: every batch equals the oracle and the run with JN_GPU_ARRANGE=0."""
+    from jackal_navigation_amd.device import DeviceArray
+    W, H, n = 640, 480, 3
+    rng = np.random.default_rng(21)
+    dense = [oracle.synth_pair(W, H, 64, 3000 + b) for b in range(n)]
+    sparse = []
+    for b in range(n):                                        # a small textured window on a flat background: a handful of support points
+        L, R = oracle.synth_pair(W, H, 64, 4000 + b)
+        flat = np.full((H, W), 90, np.uint8)
+        Ls, Rs = flat.copy(), flat.copy()
+        Ls[200:280, 250:390] = L[200:280, 250:390]; Rs[200:280, 250:390] = R[200:280, 250:390]
+        sparse.append((Ls, Rs))
+    p = jn.Elas.parameters(0, disp_max=63)
+    seq = [sparse, dense, sparse, dense, dense]
+
+    def run_seq():
+        outs = []
+        with jn.Elas(p, W, H, max_batch=n, slots=1, host_threads=4) as e:
+            for batch in seq:
+                dL = DeviceArray.from_numpy(np.stack([x[0] for x in batch])); dR = DeviceArray.from_numpy(np.stack([x[1] for x in batch]))
+                d1 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32)); d2 = DeviceArray.from_numpy(np.zeros((n, H, W), np.float32))
+                st = (C.c_int32 * n)()
+                e.submit(0, n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr, st)
+                e.wait(0)
+                outs.append((list(st), d1.numpy().copy(), d2.numpy().copy()))
+        return outs
+
+    monkeypatch.setenv("JN_GPU_ARRANGE", "1")
+    on = run_seq()
+    monkeypatch.setenv("JN_GPU_ARRANGE", "0")
+    off = run_seq()
+    po = oracle.params(0, disp_max=63)
+    for k, (a, b) in enumerate(zip(on, off)):
+        assert a[0] == b[0] and same(a[1], b[1]) and same(a[2], b[2]), k
+        for i in (0, n - 1):
+            sto, D1o, D2o = oracle.process(po, seq[k][i][0], seq[k][i][1])
+            if sto == 0:
+                assert a[0][i] == 0 and same(a[1][i], D1o) and same(a[2][i], D2o), (k, i)
+            else:
+                assert a[0][i] == 1
