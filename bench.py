@@ -51,7 +51,7 @@ STAGE_BYTES_PER_PX = {
     "gpu_gap": 16.0,            # rows+cols 8r+8w
     "gpu_adaptive_mean": 16.0,  # H+V 8r+8w
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 KERNELS_SRC = os.path.join(ROOT, "jackal_navigation_amd", "csrc", "kernels.hip")
 
 

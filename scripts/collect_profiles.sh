@@ -8,10 +8,10 @@ tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rm -rf $out/${tag}_slots1; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_slots1 -- python3 $root/bench.py --steps 10 --warmup 2 --slots 1 --no-cpu-baseline --no-latency-config > $out/${tag}_slots1.log 2>&1
-rm -rf $out/${tag}_default; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_default -- python3 $root/bench.py --no-cpu-baseline --no-latency-config > $out/${tag}_default.log 2>&1
+python3 $root/scripts/fresh_dir.py gpurun_out/${tag}_slots1; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_slots1 -- python3 $root/bench.py --steps 10 --warmup 2 --slots 1 --no-cpu-baseline --no-latency-config > $out/${tag}_slots1.log 2>&1
+python3 $root/scripts/fresh_dir.py gpurun_out/${tag}_default; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_default -- python3 $root/bench.py --no-cpu-baseline --no-latency-config > $out/${tag}_default.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf $out/${tag}_pmc_$c; timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 $root/bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-latency-config > $out/${tag}_pmc_$c.log 2>&1
+  python3 $root/scripts/fresh_dir.py gpurun_out/${tag}_pmc_$c; timeout 150 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/${tag}_pmc_$c -- python3 $root/bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-latency-config > $out/${tag}_pmc_$c.log 2>&1
 done
 cd $root
 python3 scripts/kstats.py $(ls $out/${tag}_slots1/*/*kernel_stats.csv | tail -1) 30 > $out/${tag}_slots1_summary.txt

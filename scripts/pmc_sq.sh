@@ -12,7 +12,7 @@ p2="SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM
 i=0
 for set in "$p1" "$p2"; do
   i=$((i+1))
-  rm -rf $root/gpurun_out/${tag}_sq$i; timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $root/gpurun_out/${tag}_sq$i -- python3 $root/bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-latency-config --no-alone-leg --min-time 0 "$@" > $root/gpurun_out/${tag}_sq$i.log 2>&1
+  python3 $root/scripts/fresh_dir.py gpurun_out/${tag}_sq$i; timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $root/gpurun_out/${tag}_sq$i -- python3 $root/bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-latency-config --no-alone-leg --min-time 0 "$@" > $root/gpurun_out/${tag}_sq$i.log 2>&1
   python3 $root/scripts/pmc.py $(ls $root/gpurun_out/${tag}_sq$i/*/*counter_collection.csv | tail -1) "$pat" > $root/gpurun_out/${tag}_sq$i.txt
   cat $root/gpurun_out/${tag}_sq$i.txt
 done

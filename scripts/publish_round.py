@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Copy the evidence set scripts/round3_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
+profiles/<tag>_manifest.json: every published file, the sha256 of the kernel sources it was measured on, the commit.
+    python3 scripts/publish_round.py <tag>
+Files are taken NEWEST FIRST (gpurun_out/ accumulates merged results of several calls; round 2 published stale ones)."""
+import glob
+import hashlib
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+g, p = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+rnd = tag.split("_")[0]
+
+
+def newest(pattern):
+    files = sorted(glob.glob(os.path.join(g, pattern)), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+def sha(rel):
+    return hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest()
+
+
+published = {}
+
+
+def put(src, name):
+    if src and os.path.exists(src) and os.path.getsize(src) > 0:
+        shutil.copyfile(src, os.path.join(p, name))
+        published[name] = os.path.relpath(src, root)
+
+
+put(newest("%s_slots1/*/*kernel_stats.csv" % tag), "%s_slots1_kernel_stats.csv" % tag)
+put(newest("%s_default/*/*kernel_stats.csv" % tag), "%s_default_bench_kernel_stats.csv" % tag)
+put(newest("%s_sgm/*/*kernel_stats.csv" % tag), "%s_sgm_kernel_stats.csv" % tag)
+put(newest("%s_bm/*/*kernel_stats.csv" % tag), "%s_bm_kernel_stats.csv" % tag)
+for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.json"), ("default_occupancy.txt", "default_bench_occupancy.txt"),
+                  ("pmc_FETCH_SIZE.txt", None), ("pmc_WRITE_SIZE.txt", None), ("bench_line.json", None), ("sgm_bench_line.json", None),
+                  ("sgm_round2_kernels_bench_line.json", None), ("sgm_pmc_FETCH_SIZE.txt", None), ("sgm_pmc_WRITE_SIZE.txt", None), ("sgm_pmc_SQ.txt", None),
+                  ("sgm_strips_ab.txt", None), ("bm_bench_line.json", None), ("bm_config2_bench_line.json", None), ("other_configs.jsonl", None),
+                  ("merge_in_worker.txt", None), ("node_rate.txt", None), ("latency_check.txt", None), ("host_pointer_rate.txt", None),
+                  ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("parity_sweep.txt", None)):
+    put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
+sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
+if sq:
+    open(os.path.join(p, "%s_pmc_SQ.txt" % tag), "w").write(sq)
+    published["%s_pmc_SQ.txt" % tag] = "gpurun_out/%s_sq{1,2}.txt" % tag
+for name in list(published):                      # bench lines: keep only the JSON line
+    if name.endswith("bench_line.json") or name.endswith("under_rocprof.json"):
+        lines = [l for l in open(os.path.join(p, name)) if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(p, name), "w").write(lines[-1])
+subprocess.run([sys.executable, os.path.join(root, "scripts", "make_pmc_json.py"), tag, os.path.join(p, "%s_pmc_traffic.json" % rnd)], check=True, stdout=subprocess.DEVNULL)
+published["%s_pmc_traffic.json" % rnd] = "scripts/make_pmc_json.py %s" % tag
+
+
+def counters(path):
+    res, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            cur = re.sub(r"^void ", "", line.strip()); res[cur] = {}
+        else:
+            f = line.split(); res[cur][f[0]] = float(f[1])
+    return res
+
+
+fs, ws = os.path.join(p, "%s_sgm_pmc_FETCH_SIZE.txt" % tag), os.path.join(p, "%s_sgm_pmc_WRITE_SIZE.txt" % tag)
+if os.path.exists(fs) and os.path.exists(ws):     # SGM traffic from its own PMC passes
+    f, w = counters(fs), counters(ws)
+    ker = {}
+    for k in sorted(set(f) | set(w)):
+        ker[k] = {"FETCH_SIZE_KB": f.get(k, {}).get("FETCH_SIZE"), "WRITE_SIZE_KB": w.get(k, {}).get("WRITE_SIZE")}
+        if None not in ker[k].values():
+            ker[k]["traffic_bytes"] = int(2 * ker[k]["FETCH_SIZE_KB"] * 1024 + ker[k]["WRITE_SIZE_KB"] * 1024)
+    total = sum(v.get("traffic_bytes", 0) for v in ker.values())
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --mode sgm --steps 2 --warmup 1 --no-cpu-baseline",
+               "workload": [1280, 720, 128, 32], "correction": "gfx950: FETCH_SIZE x 2 for 16-byte-per-lane streaming loads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB = 1024 B",
+               "sgm_sweep_sha256": sha("jackal_navigation_amd/csrc/sgm_sweep.hip"), "kernels": ker, "bytes_per_batch": total,
+               "algorithmic_bytes_per_batch": int((4 * 1280 * 720 * 128 + 5 * 1280 * 720) * 32)}, open(os.path.join(p, "%s_sgm_pmc_traffic.json" % rnd), "w"), indent=1)
+    published["%s_sgm_pmc_traffic.json" % rnd] = "from %s_sgm_pmc_*.txt" % tag
+manifest = {"tag": tag, "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
+            "sources_sha256": {f: sha(f) for f in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip",
+                                                   "jackal_navigation_amd/csrc/jn_api.cpp", "bench.py")},
+            "files": published}
+json.dump(manifest, open(os.path.join(p, "%s_manifest.json" % tag), "w"), indent=1)
+open(os.path.join(p, "CURRENT"), "w").write(tag + "\n")
+print("published %d files for %s" % (len(published), tag))

@@ -7,13 +7,13 @@ bash scripts/collect_profiles.sh $tag > gpurun_out/${tag}_collect.log 2>&1
 bash scripts/pmc_sq.sh $tag "k_dense|k_support_lds|k_descriptor" > gpurun_out/${tag}_sq.log 2>&1
 # SGM mode: kernel stats + bench line
 cd /tmp && export TMPDIR=/tmp
-rm -rf $root/gpurun_out/${tag}_sgm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_sgm -- python3 $root/bench.py --mode sgm --steps 5 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${tag}_sgm.log 2>&1
+python3 $root/scripts/fresh_dir.py gpurun_out/${tag}_sgm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_sgm -- python3 $root/bench.py --mode sgm --steps 5 --warmup 1 --no-cpu-baseline > $root/gpurun_out/${tag}_sgm.log 2>&1
 cd $root
 python3 scripts/kstats.py $(ls gpurun_out/${tag}_sgm/*/*kernel_stats.csv | tail -1) 8 > gpurun_out/${tag}_sgm_summary.txt
 python3 bench.py --mode sgm --steps 10 --warmup 2 > gpurun_out/${tag}_sgm_bench_line.json 2> gpurun_out/${tag}_sgm_bench.err
 # block-matching mode: kernel stats + bench lines (BASELINE config 2 = lone 640x480 D=64, and the headline workload's shape)
 cd /tmp
-rm -rf $root/gpurun_out/${tag}_bm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_bm -- python3 $root/bench.py --mode bm --steps 10 --warmup 2 --no-cpu-baseline > $root/gpurun_out/${tag}_bm.log 2>&1
+python3 $root/scripts/fresh_dir.py gpurun_out/${tag}_bm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_bm -- python3 $root/bench.py --mode bm --steps 10 --warmup 2 --no-cpu-baseline > $root/gpurun_out/${tag}_bm.log 2>&1
 cd $root
 python3 scripts/kstats.py $(ls gpurun_out/${tag}_bm/*/*kernel_stats.csv | tail -1) 8 > gpurun_out/${tag}_bm_summary.txt
 python3 bench.py --mode bm --steps 20 --warmup 3 > gpurun_out/${tag}_bm_bench_line.json 2> gpurun_out/${tag}_bm_bench.err
