@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""The numbers README.md quotes, straight from the committed evidence set profiles/CURRENT names.
+    python3 scripts/readme_numbers.py            prints the markdown block
+    python3 scripts/readme_numbers.py --write    replaces the block between the markers in README.md
+tests/test_evidence.py fails when README.md's block differs from what this prints."""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+BEGIN, END = "<!-- numbers:begin (scripts/readme_numbers.py --write) -->", "<!-- numbers:end -->"
+
+
+def line(name):
+    txt = open(os.path.join(P, name)).read()
+    return json.loads([l for l in txt.splitlines() if l.startswith('{"metric"')][-1])
+
+
+def block():
+    tag = open(os.path.join(P, "CURRENT")).read().strip()
+    b = line("%s_bench_line.json" % tag)
+    s = line("%s_sgm_bench_line.json" % tag)
+    m = line("%s_bm_bench_line.json" % tag)
+    other = [json.loads(l) for l in open(os.path.join(P, "%s_other_configs.jsonl" % tag)) if l.startswith("{")]
+
+    def find(sub):
+        for o in other:
+            if sub in o["config"]["workload"]:
+                return o
+        return None
+    node = open(os.path.join(P, "%s_node_rate.txt" % tag)).read().splitlines()
+    node_ms = [re.search(r"scan: ([0-9.]+) ms per frame", l).group(1) for l in node if "ms per frame" in l]
+    merge = [l for l in open(os.path.join(P, "%s_merge_in_worker.txt" % tag)).read().splitlines() if "cost" in l and not l.startswith("#")]
+    cost = [float(l.split("cost")[1]) for l in merge]
+    rows = [
+        ("ELAS 1280x720, D=128, batch 32, one MI355X (`bench.py`, the headline)", "%.1f k pairs/s, %.3f ms per step" % (b["value"] / 1e3, b["ms_per_step"])),
+        ("  roofline of `k_dense2` alone / whole path (fraction of 8 TB/s)", "%.3f / %.3f" % (b["roofline"]["frac"], b["roofline"]["whole_path_frac"])),
+        ("  reference CPU path on the same box (%d cores)" % b["cpu_baseline"]["cores"], "%.0f pairs/s" % b["cpu_baseline"]["value"]),
+        ("ELAS 640x480, D=64, batch 64", "%.1f k pairs/s" % (find("640x480 rectified pairs (scene disparities <= 64), ELAS disp_max=63 (D=64), batch=64")["value"] / 1e3)),
+        ("ELAS 320x180, disp_max 255, batch 128 (the reference's native size)", "%.0f k pairs/s" % (find("320x180")["value"] / 1e3)),
+        ("ELAS 1920x1080, D=256, batch 8", "%.1f k pairs/s" % (find("1920x1080 rectified pairs (scene disparities <= 256), ELAS")["value"] / 1e3)),
+        ("lone 640x480 pair, ELAS (median of 200 calls)", "%.3f ms" % b["latency_config"]["ms_per_frame"]),
+        ("SGM 8 paths 1280x720, D=128, batch 32 (`--mode sgm`)", "%.2f k pairs/s, frac %.3f on SURVEY's B_sgm" % (s["value"] / 1e3, s["roofline"]["frac"])),
+        ("block matching 9x9 1280x720, D=128, batch 32 (`--mode bm`)", "%.1f k pairs/s" % (m["value"] / 1e3)),
+        ("node path, two 640x360 JPEG frames -> LaserScan, one frame at a time", "%s ms (eyes decoded serially: %s ms)" % (node_ms[-1], node_ms[0])),
+        ("cross-rig merge in the slot worker, one-rank communicator", "%.1f-%.1f %% of the pipelined rate" % (100 * min(cost), 100 * max(cost))),
+    ]
+    out = [BEGIN, "Evidence set `profiles/%s_*` (one MI355X; every row is a committed file there):" % tag, "", "| What | Measured |", "|---|---|"]
+    out += ["| %s | %s |" % r for r in rows]
+    out.append(END)
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    blk = block()
+    if "--write" in sys.argv:
+        p = os.path.join(ROOT, "README.md")
+        txt = open(p).read()
+        if BEGIN in txt:
+            txt = txt[:txt.index(BEGIN)] + blk + txt[txt.index(END) + len(END):]
+        else:
+            txt += "\n" + blk + "\n"
+        open(p, "w").write(txt)
+    else:
+        print(blk)
