@@ -173,9 +173,28 @@ int delaunay_parts(const jn_elas* h, int n) {
   return h->split_delaunay ? (threads >= 8 * n ? 4 : (threads >= 4 * n ? 2 : 1)) : 1;
 }
 
+// A scan batch that carries a merge owns one place in the handle's merge order.  If the batch ends early (a HIP error on the
+// way), the place must still be given up, or every later batch of this handle would wait for it for ever.  (The OTHER ranks of
+// the communicator will still wait for this rank's collective: a failed batch on one rank is fatal for the job either way.)
+struct MergeTurn {
+  jn_elas* h; uint64_t seq; bool armed;
+  MergeTurn(jn_elas* h_, const Job& j) : h(h_), seq(j.seq), armed(j.merge) {}
+  void done() { armed = false; }
+  ~MergeTurn() {
+    if (!armed) return;
+    {
+      std::unique_lock<std::mutex> l(h->merge_m);
+      h->merge_cv.wait(l, [&] { return h->merge_seq == seq; });
+      h->merge_seq++;
+    }
+    h->merge_cv.notify_all();
+  }
+};
+
 jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const DevParams& dp = h->dp;
   const int n = j.n;
+  MergeTurn turn(h, j);
   hipStream_t st = s.stream;
   HIP_TRY(hipSetDevice(h->device));
   auto t_begin = std::chrono::steady_clock::now();
@@ -345,6 +364,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, nullptr, s.ev_merged);
       h->merge_seq++;                                      // even on failure: the batches behind must not wait for ever
     }
+    turn.done();
     h->merge_cv.notify_all();
     if (ms_ != JN_OK) return ms_;
     HIP_TRY(wait_event(s.ev_merged, h->wait_spin_us));
