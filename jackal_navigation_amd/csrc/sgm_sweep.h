@@ -11,7 +11,8 @@ struct SwDev {
   int Wp, padl;      // prefiltered rows, x-mirrored and padded: Wp bytes per row, image column x_k = W-1-x at byte padl + x_k
   int NB, xmin;      // sheared blocks of the row sweeps: x' = x_k - (row in sweep order) in [xmin, W-1], NB blocks
   int dbg;           // JN_SGM_DBG profiling switches (results are then WRONG): 1 = horizontal sweep without its stores, 2 = without its per-step loads,
-                     // 4 = row sweeps without volume stores / loads, 8 = row sweeps without the per-row barrier hand-off (no exchange)
+                     // 4 = row sweeps without volume stores / loads, 8 = row sweeps without the per-row barrier, 16 = no quarter-boundary permutes,
+                     // 32 = no per-pixel minimum across lanes
   int wide;          // 3 P2 > 255: the three-path volume is u16, the horizontal volumes are unpacked one by one
 };
 

@@ -91,7 +91,8 @@ DEV void costs(const uint32_t (&w)[NR / 2 + 1], uint32_t ref, uint32_t P2pk, uin
 // The adjoining pairs of the neighbouring quarters: up = the quarter below's j = DPL-1 (high half of its register NR-1) for
 // this lane's j = 0; dn = the quarter above's j = 0 for this lane's j = DPL-1.  Issued ahead of the cells that use them.
 template <int NR>
-DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t& up, uint32_t& dn) {
+DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t& up, uint32_t& dn, int dbg = 0) {
+  if (dbg & 16) { up = X[NR - 1]; dn = X[0]; return; }         // profiling switch: no permutes (results are then WRONG)
   const uint32_t a = bperm((lane - PX) & 63, X[NR - 1]);
   const uint32_t b = bperm((lane + PX) & 63, X[0]);
   up = q == 0 ? 0u : a;
@@ -213,9 +214,9 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t
     costs<NR>(w, ref, P2pk, Cp);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
-    path_neighbours<NR>(X, lane, q, up, dn);
+    path_neighbours<NR>(X, lane, q, up, dn, s.dbg);
     path_cells<NR>(X, up, dn, Cp, acc, Ln, mn, P1pk);
-    path_normalise<NR>(X, Ln, pixel_min(mn), (uint32_t)s.P2);
+    path_normalise<NR>(X, Ln, (s.dbg & 32) ? (mn & 0xFFFFu) : pixel_min(mn), (uint32_t)s.P2);
     if (valid && (!(s.dbg & 1) || X[0] == 0x12345678u)) store_bytes<NR>(vol + (size_t)xk * s.D, q, acc);
     // next pixel: slide the window when the byte phase wraps
     if (!DIR) {
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
     __syncthreads();
     for (int yb = ybs; yb <= ybe; yb++) {
       if (yb < ybe) fetch(yb);
-      __syncthreads();                                         // the computing waves have finished row yb
+      if (!(s.dbg & 8)) __syncthreads();                       // the computing waves have finished row yb (dbg 8: profiling without the row barrier, results WRONG)
       if (j > 0) {
         const uint32_t* src = &exch[yb & 1][0][0];
         uint64_t* dst = reinterpret_cast<uint64_t*>(my_gx + (size_t)yb * slot_stride);
@@ -500,7 +501,7 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
       if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
     }
     if constexpr (AHEAD) cur = nxt;
-    __syncthreads();
+    if (!(s.dbg & 8)) __syncthreads();
   }
 }
 
