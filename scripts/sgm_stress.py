@@ -42,11 +42,20 @@ while time.time() - t0 < budget:
         else:
             pairs.append(o.synth_pair(W, H, min(D, max(8, W // 4)), int(rng.integers(0, 1 << 30))))
     Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
-    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    pitch = W + int(rng.integers(0, 3)) * 8                       # rows of the caller's images may be padded
+    Lp = np.zeros((n, H, pitch), np.uint8); Rp = np.zeros((n, H, pitch), np.uint8)
+    Lp[:, :, :W] = Ls; Rp[:, :, :W] = Rs
+    Lp[:, :, W:] = 199; Rp[:, :, W:] = 7                            # padding bytes must never be read as pixels
+    dL, dR = DeviceArray.from_numpy(Lp), DeviceArray.from_numpy(Rp)
     dD = DeviceArray((n, H, W), np.int16)
-    with jn.Sgm(jn.Sgm.parameters(num_disparities=D, **kw), W, H, max_batch=n) as s:
-        s.process_batch(n, dL.ptr, dR.ptr, W, H * W, dD.ptr)
+    with jn.Sgm(jn.Sgm.parameters(num_disparities=D, **kw), W, H, max_batch=n + int(rng.integers(0, 3))) as s:   # handle larger than the batch
+        if n > 1:                                                    # a smaller batch first: the handle's buffers are re-used
+            s.process_batch(n - 1, dL.ptr + H * pitch, dR.ptr + H * pitch, pitch, H * pitch, dD.ptr)
+            first = dD.numpy()[: n - 1].copy()
+        s.process_batch(n, dL.ptr, dR.ptr, pitch, H * pitch, dD.ptr)
         out = dD.numpy()
+        if n > 1 and not np.array_equal(first, out[1:]):
+            print("MISMATCH between a batch of %d and the same frames inside a batch of %d (%dx%d D=%d %s)" % (n - 1, n, W, H, D, kw)); sys.exit(1)
     po = so.params(D, **kw)
     for b in range(n):
         exp = so.process(po, Ls[b], Rs[b])
