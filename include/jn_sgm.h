@@ -44,7 +44,7 @@ typedef struct jn_sgm_params {
 /* D = 128, P1 = 10, P2 = 60, cap = 31, lr_max_diff = 1, subpixel = 0 */
 void jn_sgm_params_default(jn_sgm_params* p);
 
-typedef struct jn_sgm jn_sgm;   /* opaque: buffers for up to max_batch pairs (8 path volumes of W*H*D bytes each per pair) */
+typedef struct jn_sgm jn_sgm;   /* opaque: buffers for up to max_batch pairs (three byte volumes of W*H*D per pair + boundary columns) */
 
 jn_status jn_sgm_create(const jn_sgm_params* p, int32_t width, int32_t height, int32_t max_batch, int32_t device, jn_sgm** out);
 void jn_sgm_destroy(jn_sgm* h);
@@ -54,7 +54,8 @@ void jn_sgm_destroy(jn_sgm* h);
 jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride,
                                int16_t* dDisp);
 
-/* Milliseconds of the last batch: prefilter, the eight path launches together, sum + WTA + check. */
+/* Milliseconds of the last batch: prefilter; paths = the two horizontal sweeps + the downward sweep; wta = the upward sweep with the
+ * winners + the L/R check (with JN_SGM_IMPL=0: the eight path launches; sum + WTA + check). */
 typedef struct jn_sgm_times { float prefilter, paths, wta, total; } jn_sgm_times;
 jn_status jn_sgm_last_times(jn_sgm* h, jn_sgm_times* out);
 
