@@ -620,7 +620,7 @@ def run_rank(a):
     merge_report = None
     if merge_state["attached"]:
         merge_report = {"kind": merge_kind, "merge_ms_per_step": round(float(np.mean(merge_ms)), 4) if merge_ms else None,
-                        "what": "slot worker's clock: scan complete -> merged bins in place (its turn in the submission order, pack, ncclAllReduce MIN, unpack, "
+                        "what": "slot worker's clock: scan complete -> merged bins in place (its turn in the submission order, ncclAllReduce MIN in place on the buffer the scan kernel packed, unpack, "
                                 "one host wait); runs as the batch's tail in the slot worker, overlapped with the other slots"}
         if a.force_merge and dist is None:
             elas.set_comm(None); merge_state["attached"] = False

@@ -22,7 +22,7 @@ using namespace jnav;
 
 struct jn_comm;
 namespace jnav {
-jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done);
+jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed);
 int comm_device(const jn_comm* c);
 }
 
@@ -152,10 +152,17 @@ jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* devic
 // pack -> all-reduce -> unpack queued on the communicator's stream.  `ready` (may be null) is an event the inputs are
 // complete behind; `done` (may be null) is recorded behind the unpack.  Every collective of a communicator goes through
 // here under its mutex and onto its ONE stream, so all ranks execute them in the order they were queued.
-static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done) {
+static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed = nullptr) {
   std::lock_guard<std::mutex> guard(c->m);
   HIP_TRY_C(hipSetDevice(c->device));
   const size_t count = (size_t)n * (bins + 4);
+  if (packed) {                                              // the caller's own packed buffer (k_scan_finish wrote it): reduce it in place, unpack
+    if (ready) HIP_TRY_C(hipStreamWaitEvent(c->stream, ready, 0));
+    RCCL_TRY(R, R->AllReduce(packed, packed, count, ncclDouble, ncclMin, c->comm, c->stream));
+    launch_scan_pack(c->stream, n, bins, dBins, dMeta, packed, false);
+    if (done) HIP_TRY_C(hipEventRecord(done, c->stream));
+    return JN_OK;
+  }
   if (count > c->cap) {
     HIP_TRY_C(hipStreamSynchronize(c->stream));            // a merge queued earlier may still use the old buffer
     if (c->flat) hipFree(c->flat);
@@ -186,11 +193,11 @@ extern "C++" {
 namespace jnav {
 // The batch pipeline's form (jn_elas_set_comm): nothing waits on the host; the slot's stream continues behind `done`.
 // The flat buffer is shared by consecutive merges: they run one after the other on the communicator's stream.
-jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done) {
+jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed) {
   if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
   Rccl* R = rccl();
   if (!R) return JN_ERR_COMM;
-  return queue_merge(c, R, n, bins, dBins, dMeta, ready, done);
+  return queue_merge(c, R, n, bins, dBins, dMeta, ready, done, packed);
 }
 int comm_device(const jn_comm* c) { return c ? c->device : -1; }
 }  // namespace jnav

@@ -62,6 +62,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev_scan = nullptr, ev_merged = nullptr;          // around the cross-rig merge (created with the slot)
   float merge_ms = 0.f;
+  double* d_flat = nullptr;                                   // the merge's packed buffer of this slot [max_batch][1024 + 4] (written by k_scan_finish)
   hipStream_t stream_a = nullptr;                             // highest-priority stream for stage A (see run_batch); only with JN_STAGE_A_PRIORITY=1
   hipEvent_t ev[EV_COUNT] = {};
   // device
@@ -124,7 +125,7 @@ struct jn_elas {
 };
 
 namespace jnav {
-jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done);
+jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed);
 int comm_device(const jn_comm* c);
 }
 
@@ -342,7 +343,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(mark(e));
   }
   if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
-    launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch);
+    launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch, j.merge ? s.d_flat : nullptr);
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
   HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   HIP_TRY(hipGetLastError());
@@ -361,13 +362,13 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     {
       std::unique_lock<std::mutex> l(h->merge_m);
       h->merge_cv.wait(l, [&] { return h->merge_seq == j.seq; });
-      ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, nullptr, s.ev_merged);
+      ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, nullptr, s.ev_merged, s.d_flat);   // packed by k_scan_finish: all-reduce in place + unpack
       h->merge_seq++;                                      // even on failure: the batches behind must not wait for ever
     }
     turn.done();
     h->merge_cv.notify_all();
     if (ms_ != JN_OK) return ms_;
-    HIP_TRY(wait_event(s.ev_merged, h->wait_spin_us));
+    HIP_TRY(wait_event(s.ev_merged, std::max(h->wait_spin_us, 400)));   // a short wait (two small kernels): poll tightly, a sleep's granularity would show
     merge_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_m0).count();
     merged = true;
   }
@@ -587,6 +588,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     CREATE_TRY(dmalloc(&s->raw, 2 * B * px));
     CREATE_TRY(dmalloc(&s->tmp, B * px)); CREATE_TRY(dmalloc(&s->label, B * px)); CREATE_TRY(dmalloc(&s->size, B * px));
     CREATE_TRY(dmalloc(&s->scan_scratch, B * 4));
+    CREATE_TRY(dmalloc(&s->d_flat, B * (1024 + 4)));
     const size_t grid_words = 2 * B * dp.gw * dp.gh * kGridWords;
     CREATE_TRY(dmalloc(&s->mark, grid_words)); CREATE_TRY(dmalloc(&s->gridbits, grid_words));
     CREATE_TRY(dmalloc(&s->recs, 2 * B * (size_t)h->tri_cap));
@@ -621,7 +623,7 @@ void jn_elas_destroy(jn_elas* h) {
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
     hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
-    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->st_img); hipFree(s->st_D); hipFree(s->arr_scratch);
+    hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->d_flat); hipFree(s->st_img); hipFree(s->st_D); hipFree(s->arr_scratch);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt); hipHostFree(s->h_arr); hipHostFree(s->h_arr_ok);
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);

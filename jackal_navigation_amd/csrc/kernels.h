@@ -73,7 +73,7 @@ void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, ui
 // scratch: [n][4] uint64.  If dD != nullptr the u8 map is produced from it first (fused), else dDisp is read.
 // lut == nullptr selects the -g flavour (points with d >= 2 minus the ground model, point_cloud.cpp:149-211).
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
-                 int W, int H, double* bins, double* meta, unsigned long long* scratch);
+                 int W, int H, double* bins, double* meta, unsigned long long* scratch, double* flat = nullptr);
 // Cross-rig merge: pack (bins, meta with maxima negated) into `flat` [n*bins + n*4] or unpack it back.
 void launch_scan_pack(hipStream_t st, int n, int bins, double* dBins, double* dMeta, double* flat, bool pack);
 // Rectification front end (point_cloud.cpp:440, :481, :553-554).

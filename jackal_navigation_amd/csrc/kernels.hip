@@ -2341,17 +2341,23 @@ __global__ void k_scan_init(int total_bins, int n, unsigned long long* gbins, un
   if (i < total_bins) gbins[i] = ~0ull;
   if (i < n * 4) gmeta[i] = (i & 1) ? 0ull : ~0ull;
 }
-__global__ void k_scan_finish(int total_bins, int n, unsigned long long* gbins, const unsigned long long* gmeta, double* meta) {
+__global__ void k_scan_finish(int total_bins, int n, unsigned long long* gbins, const unsigned long long* gmeta, double* meta, double* flat) {
+  // flat (may be null): the cross-rig merge's packed buffer [bins of all frames | extrema of all frames, maxima negated] — written here
+  // so that a batch with a communicator attached needs no separate pack launch (comm.cpp)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < total_bins) {
     const unsigned long long k = gbins[i];
-    reinterpret_cast<double*>(gbins)[i] = (k == ~0ull) ? 1e9 : dec(k);        // INF of point_cloud.cpp:54
+    const double x = (k == ~0ull) ? 1e9 : dec(k);                              // INF of point_cloud.cpp:54
+    reinterpret_cast<double*>(gbins)[i] = x;
+    if (flat) flat[i] = x;
   }
   if (i < n * 4) {
     const unsigned long long k = gmeta[i];
     const double init[4] = {400., -400., 1e9, -500.};                          // point_cloud.cpp:219-220
     const bool untouched = (i & 1) ? (k == 0ull) : (k == ~0ull);
-    meta[i] = untouched ? init[i & 3] : dec(k);
+    const double x = untouched ? init[i & 3] : dec(k);
+    meta[i] = x;
+    if (flat) flat[total_bins + i] = (i & 1) ? -x : x;
   }
 }
 
@@ -2864,7 +2870,7 @@ void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, ui
   hipLaunchKernelGGL(k_valid_lut, grid2d(W, H, 1), dim3(256), 0, st, to_dev(sp), W, H, lut);
 }
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
-                 int W, int H, double* bins, double* meta, unsigned long long* scratch) {
+                 int W, int H, double* bins, double* meta, unsigned long long* scratch, double* flat) {
   const ScanDev s = to_dev(sp);
   unsigned long long* gb = reinterpret_cast<unsigned long long*>(bins);
   const int total = n * s.bins, m = total > n * 4 ? total : n * 4;
@@ -2872,7 +2878,7 @@ void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* d
   const dim3 sg((W + 255) / 256, (H + kScanRows - 1) / kScanRows, n);
   if (lut) hipLaunchKernelGGL(k_scan<false>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
   else     hipLaunchKernelGGL(k_scan<true>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
-  hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta);
+  hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta, flat);
 }
 void launch_scan_pack(hipStream_t st, int n, int bins, double* dBins, double* dMeta, double* flat, bool pack) {
   const int nb = n * bins, nm = n * 4;
