@@ -14,6 +14,8 @@ struct SwDev {
                      // 4 = row sweeps without volume stores / loads, 8 = row sweeps without the per-row barrier, 16 = no quarter-boundary permutes,
                      // 32 = no per-pixel minimum across lanes
   int wide;          // 3 P2 > 255: the three-path volume is u16, the horizontal volumes are unpacked one by one
+  int flow;          // row sweeps: 1 = k_sw_w (no workgroup barrier, no communication wave; 4 strips per block), 0 = k_sw_v (JN_SGM_FLOW=0)
+  int epoch;         // k_sw_w: 16-bit tag of this launch's boundary columns (set per launch from SweepBuffers::epoch, never 0)
 };
 
 struct SweepSizes { size_t gm, vol, gx, flags, minr, dl; };     // bytes; the F volume takes 2 * vol when SwDev::wide
@@ -23,7 +25,8 @@ struct SweepBuffers {
   uint8_t* volF;          // m of the three downward paths [n][H][W][D] (u8, or u16 when wide)
   uint8_t* volH0;         // m of the horizontal path walking x_k upwards
   uint8_t* volH1;         // ... downwards
-  uint32_t* gx;           // boundary columns handed from block to block [n][NB][H][3][4][D/8]
+  uint32_t* gx;           // boundary columns handed from block to block [n][NB][H][3][4][D/8]; zeroed by the owner when allocated
+  uint32_t epoch;         // launches of k_sw_w on gx so far, modulo 2^16 (sweep_run advances it and zeroes gx when it wraps)
   uint32_t* flags;        // rows done per (frame, block), then the ticket counter
   uint32_t* minr;         // right-image winners [n][H][W] (S << 16 | d)
   uint32_t* dl;           // left winners [n][H][W] (d | d16 << 16), mirrored columns
@@ -34,6 +37,6 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
 // Queues prefilter, the two horizontal paths, the downward sweep, the upward sweep + winners, the L/R check on `st`.
 // ev[0..3] are recorded before the prefilter, before the paths, before the final sweep and at the end.
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                     const SweepBuffers& b, hipEvent_t* ev);
+                     SweepBuffers& b, hipEvent_t* ev);
 
 }  // namespace jnav_sgm

@@ -59,6 +59,7 @@ DEV uint32_t pk_subsat(uint32_t a, uint32_t b) { return u1(__builtin_elementwise
 DEV uint32_t pk_shl3(uint32_t a) { return u1((u16x2)(v2(a) << (u16x2)(3))); }
 DEV uint32_t bperm(int src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v); }
 DEV uint32_t load_u32_unaligned(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+DEV uint64_t load_u64_unaligned(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 
 // REGISTER LAYOUT.  A lane owns DPL = 2 NR disparities j = 0 .. DPL-1 of its quarter (d = DPL q + j); register r holds the
 // pair (j = r, j = r + NR) in its low / high half.  With this "stride-NR" pairing both halves of register r have their
@@ -86,6 +87,20 @@ DEV void costs(const uint32_t (&w)[NR / 2 + 1], uint32_t ref, uint32_t P2pk, uin
 #pragma unroll
   for (int r = 0; r < NR; r++)                                 // (c[r], c[r + NR]): c[j] is half (j & 1) of a[j >> 1]
     Cp[r] = __builtin_amdgcn_perm(a[(r + NR) >> 1], a[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
+}
+
+// the same with the 8-byte windows already paired (ww[k] = bytes 4k .. 4k+7 of the run)
+template <int NR>
+DEV void costs64(const uint64_t (&ww)[NR / 2], uint32_t ref, uint32_t P2pk, uint32_t (&Cp)[NR]) {
+  uint32_t a[NR];
+  const uint64_t p2 = (uint64_t)P2pk | ((uint64_t)P2pk << 32);
+#pragma unroll
+  for (int k = 0; k < NR / 2; k++) {
+    const uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8(ww[k], ref, p2);
+    a[2 * k] = (uint32_t)r; a[2 * k + 1] = (uint32_t)(r >> 32);
+  }
+#pragma unroll
+  for (int r = 0; r < NR; r++) Cp[r] = __builtin_amdgcn_perm(a[(r + NR) >> 1], a[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
 }
 
 // The adjoining pairs of the neighbouring quarters: up = the quarter below's j = DPL-1 (high half of its register NR-1) for
@@ -508,6 +523,362 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
   }
 }
 
+// ---- the same sweep without a workgroup barrier and without a communication wave (SwDev::flow = 1) ----
+// k_sw_v keeps a block's strips in lock-step (one s_barrier per row: every row takes as long as the slowest strip) and spends a
+// quarter of the wave slots — and of the register file — on communication waves.  Here every wave computes, and a strip runs as
+// far ahead of its left neighbour as a ring of RING rows in LDS allows:
+//   * inside a block: strip w publishes its boundary columns of row y in ring[y mod RING][w] and then prog[w] = y + 1; strip w-1
+//     polls prog[w] only when its cached copy is too old, reads the columns and acknowledges with cons[w] = y + 1 (back pressure:
+//     row y + RING overwrites that slot).  LDS executes a wave's instructions in order, so data-then-counter needs no wait; the
+//     fences are "local" ones (lgkmcnt only — an ordinary workgroup release would drain the volume stores every row);
+//   * between blocks: the columns travel as SELF-VALIDATING dwords.  Path values are <= P2 <= 255, so bytes 1 and 3 of every packed
+//     pair are free: they carry a 16-bit launch tag.  The producer (strip 0) stores without draining anything, the consumer (last
+//     strip) loads its producer's row one row AHEAD of its use, checks the tags when it needs the row and only then — the row
+//     was not complete yet — polls.  No progress flags, no store drains, no ordering assumptions between different addresses
+//     (every aligned dword is its own message).  Tags change with every launch on a buffer (SweepBuffers::epoch); the buffer is
+//     zeroed when it is allocated and whenever the 16-bit tag wraps, so a stale row can never carry the current tag.
+//   * the right image's winners: each strip owns a row of LDS minima per quarter and flushes it itself.
+// The ticket order (a block's producer holds the smaller ticket) makes the inter-block wait placement-independent as before.
+DEV int lds_load_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DEV void lds_store_relaxed(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// ds_read_b128 into registers that already hold a value (under the caller's exec mask the other lanes keep theirs).  The compiler does not
+// know about these reads: lds_wait_in_place() waits for them and makes every later use of the registers depend on that wait.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+template <int N>
+DEV void lds_read_in_place(u32x4 (&t)[N], uint32_t addr) {
+#pragma unroll
+  for (int k = 0; k < N; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(t[k]) : "v"(addr), "n"(16 * k) : "memory");
+}
+template <int N>
+DEV void lds_wait_in_place(u32x4 (&a)[N], u32x4 (&b)[N]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]) : : "memory");
+#pragma unroll
+  for (int k = 1; k < N; k++) asm volatile("" : "+v"(a[k]));
+#pragma unroll
+  for (int k = 0; k < N; k++) asm volatile("" : "+v"(b[k]));
+}
+
+template <int NR, int NS, int RING, bool FINAL, bool WIDE>
+__global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
+                                                  const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1, uint32_t* __restrict__ gx,
+                                                  uint32_t* __restrict__ ctr, uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
+  constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = PX + DPL, NG = (SLOT + 63) / 64;
+  static_assert((RING & (RING - 1)) == 0, "ring depth is a power of two");
+  __shared__ uint32_t ring[RING][NS][SLOT];                    // boundary columns [row mod RING][strip][V0 | M0 | M1][quarter][NR]
+  __shared__ uint32_t nextblk[SLOT];                           // the next block's columns for the last strip (written and read by that wave only)
+  __shared__ uint32_t minR[FINAL ? NS : 1][FINAL ? 2 : 1][FINAL ? NQ : 1][FINAL ? MR : 1];   // right-image winners of one row of one strip, per disparity quarter (rows alternate)
+  __shared__ int prog[NS], cons[NS];                           // rows published by strip w / rows of strip w's columns consumed by strip w-1
+  __shared__ int s_ticket;
+  extern __shared__ uint16_t sS[];                             // FINAL + sub-pixel: S of the block's pixels [BLK][D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W = s.W, H = s.H, D = s.D, NB = s.NB;
+  const uint32_t P2pk = (uint32_t)s.P2 * 0x10001u;
+  const uint32_t tagpk = (((uint32_t)s.epoch & 0xFFu) << 8) | (((uint32_t)s.epoch >> 8) << 24);
+  if (tid == 0) s_ticket = (int)atomicAdd(ctr, 1u);
+  for (int k = tid; k < RING * NS * SLOT; k += NS * 64) (&ring[0][0][0])[k] = P2pk;            // X = P2: a path that starts here
+  if (FINAL) for (int k = tid; k < NS * 2 * NQ * MR; k += NS * 64) (&minR[0][0][0][0])[k] = 0xFFFFFFFFu;
+  __syncthreads();
+  const int ticket = s_ticket;
+  // producers (larger j) hold the smaller tickets; the block index is the major order: all frames walk through their parallelogram in phase
+  // and finish together (frame-major tickets were measured: 2 588 against 3 168 pairs/s — the last frames run alone at the end)
+  const int j = NB - 1 - ticket / n, frame = ticket % n;
+  const int x0 = s.xmin + BLK * j;                             // sheared origin of this block: x' in [x0, x0 + BLK)
+  const int ybs = max(0, -(x0 + BLK - 1)), ybe = min(H - 1, W - 1 - x0);
+  if (ybs > ybe) return;
+  if (tid < NS) { prog[tid] = ybs; cons[tid] = ybs - 1; }       // rows < prog published (row ybs - 1 = the initial fill); rows < cons read by the left neighbour
+  __syncthreads();                                             // the only barriers of the kernel: before the first row
+  uint32_t* my_gx = gx + ((size_t)frame * NB + j) * H * (size_t)SLOT;
+  // the producer block (j + 1) and the rows it works on
+  const bool has_prod = j + 1 < NB;
+  const int x0p = x0 + BLK;
+  const int ybsp = max(0, -(x0p + BLK - 1)), ybep = min(H - 1, W - 1 - x0p);
+  const uint32_t* p_gx = gx + ((size_t)frame * NB + j + 1) * H * (size_t)SLOT;
+  const bool last = wave == NS - 1;
+  uint32_t g[NG];                                              // last strip: the producer's row, loaded a row ahead of its use
+#pragma unroll
+  for (int k = 0; k < NG; k++) g[k] = 0u;
+  auto load_prod = [&](int yr, uint32_t (&dst)[NG]) __attribute__((always_inline)) {
+    const uint32_t* src = p_gx + (size_t)yr * SLOT;
+#pragma unroll
+    for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; dst[k] = (SLOT % 64 == 0 || o < SLOT) ? ld_sc1(src + o) : tagpk; }
+  };
+  const int q = lane >> 4, p = lane & 15;
+  const int xl = x0 + PX * wave + p;                           // this lane's sheared column
+  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u;
+  uint32_t V[NR], G[NR], M[NR];                                // X of the pixel this lane computed last, per path: vertical, own diagonal, other diagonal
+#pragma unroll
+  for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = P2pk;
+  const size_t img_rows = (size_t)H * s.Wp;
+  // a row's input bytes.  Every v_mqsad takes an (even-aligned) register pair holding 8 consecutive bytes, and consecutive pairs overlap
+  // by 4 bytes: loading dwords and re-pairing them made the compiler copy registers right behind the loads — and wait for them there, a
+  // row before the bytes are needed.  Each pair is therefore loaded on its own (the same cache lines; 8 instead of 3 load instructions).
+  struct RowIn { uint64_t ww[NR / 2]; uint32_t ref; };
+  const int y0 = flip ? H - 1 - ybs : ybs;
+  const long long row_step = (flip ? -(long long)s.Wp : (long long)s.Wp) + 1;
+  const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs);
+  const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs) + DPL * q;
+  // `more` = there is a row after this one: the pointers only advance then, so that the loop can fetch unconditionally (a fetch under
+  // a condition makes the compiler wait for ALL loads in flight — the row's own included — where the previous row's bytes are used)
+  auto fetch_row = [&](RowIn& in_, bool more) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NR / 2; k++) in_.ww[k] = load_u64_unaligned(rowR + 4 * k);
+    in_.ref = load_u32_unaligned(rowL);
+    const long long st = more ? row_step : 0;
+    rowL += st; rowR += st;
+  };
+  if (last && has_prod && ybs - 1 >= ybsp && ybs - 1 <= ybep) load_prod(ybs - 1, g);
+  RowIn cur;
+  fetch_row(cur, ybs < ybe);
+  // the final sweep's three stored volumes of a pixel (clamped columns: always a valid address, so the loads need no condition)
+  uint32_t fF[FINAL ? (WIDE ? NR : NR / 2) : 1], fH0[FINAL ? NR / 2 : 1], fH1[FINAL ? NR / 2 : 1];
+  auto pixel_of = [&](int yb) __attribute__((always_inline)) {
+    const int y = flip ? H - 1 - yb : yb;
+    return ((size_t)frame * H + y) * W + (size_t)min(max(xl + yb, 0), W - 1);
+  };
+  auto load_volumes = [&](size_t pix) __attribute__((always_inline)) {
+    if constexpr (FINAL) {
+      if constexpr (WIDE) load_words<NR>(volF + pix * D * 2, q, fF); else load_bytes<NR>(volF + pix * D, q, fF);
+      load_bytes<NR>(volH0 + pix * D, q, fH0);
+      load_bytes<NR>(volH1 + pix * D, q, fH1);
+    }
+  };
+  load_volumes(pixel_of(ybs));
+  if constexpr (!FINAL) {
+    // as many stores behind the first row's loads as every later row has (into the slack), so that the loop's first wait — written once
+    // for both ways into the loop — can leave that many operations in flight instead of draining the row's stores
+    uint32_t zero[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) zero[r] = 0u;
+    if constexpr (WIDE) store_words<NR>(volF + (size_t)n * H * W * D * 2, q, zero); else store_bytes<NR>(volF + (size_t)n * H * W * D, q, zero);
+  }
+  // flush one row of this strip's right-image minima (minR[wave][buf]) to the row's global minima
+  auto flush_minima = [&](int yb, int buf) __attribute__((always_inline)) {
+    if constexpr (FINAL) {
+      const int y = flip ? H - 1 - yb : yb;
+      uint32_t* grow = gminR + ((size_t)frame * H + y) * W;
+      uint32_t* mrow = &minR[wave][buf][0][0];
+#pragma unroll
+      for (int k = 0; k < (NQ * MR + 63) / 64; k++) {
+        const int idx = lane + 64 * k;
+        if ((NQ * MR) % 64 == 0 || idx < NQ * MR) {
+          const uint32_t kv = mrow[idx];
+          if (kv != 0xFFFFFFFFu) {
+            mrow[idx] = 0xFFFFFFFFu;
+            const int qq = idx / MR, ee = idx - qq * MR;
+            const int xr = x0 + PX * wave + yb + ee + DPL * qq;
+            if (xr >= 0 && xr < W) atomicMin(grow + xr, kv + (uint32_t)(DPL * qq));
+          }
+        }
+      }
+    }
+  };
+  int known_p = ybs, known_c = ybs - 1;                        // cached prog[wave + 1] / cons[wave]
+  // Order inside a row: everything that was loaded from memory was requested a whole row earlier, into registers that had just
+  // been consumed (no second set of registers, and every wait counts only loads that are a row old):
+  //   costs from the row's bytes -> request the next row's bytes;  [last strip: the producer's columns, requested a row ago]
+  //   -> neighbour columns -> the three paths -> publish -> [final: S from the stored volumes -> request the next row's volumes -> winners]
+  for (int yb = ybs; yb <= ybe; yb++) {
+    const int y = flip ? H - 1 - yb : yb;
+    const int xk = xl + yb;
+    const bool in = xk >= 0 && xk < W;
+    const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
+    uint32_t Cp[NR], acc[NR];
+    costs64<NR>(cur.ww, cur.ref & 0x00FFFFFFu, P2pk, Cp);
+#pragma unroll
+    for (int r = 0; r < NR; r++) asm volatile("" : "+v"(Cp[r]) : : "memory");   // the costs are computed HERE (they would otherwise sink to their first
+    __builtin_amdgcn_sched_barrier(0);                         // use, past the loads that reuse their input registers — which then get copied)
+    fetch_row(cur, yb + 1 < ybe);                              // row yb + 1's bytes (the last row fetches its own again)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < NR; r++) acc[r] = 0u;
+    // ---- last strip: the producer block's columns of row yb - 1 ----
+    if (last) {
+      const int yr = yb - 1;
+      if (has_prod && yr >= ybsp && yr <= ybep) {
+        // g was loaded for exactly this row (before the loop or during the previous row).  The usual case — every tag is this launch's —
+        // has its own code path, so that its wait counts only what is older than g; the retry loop (the producer has not written the
+        // whole row yet) reloads into other registers.
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < NG; k++) ok = ok && (g[k] & 0xFF00FF00u) == tagpk;
+        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
+#pragma unroll
+          for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = g[k] & 0x00FF00FFu; }
+        } else {
+          uint32_t v[NG];
+          do {
+            __builtin_amdgcn_s_sleep(8);
+            load_prod(yr, v);
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < NG; k++) ok = ok && (v[k] & 0xFF00FF00u) == tagpk;
+          } while (__builtin_amdgcn_ballot_w64(!ok) != 0ull);
+#pragma unroll
+          for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = v[k] & 0x00FF00FFu; }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = P2pk; }
+      }
+      if (has_prod && yb >= ybsp && yb <= ybep && yb < ybe) load_prod(yb, g);  // the next row's, speculatively: checked when it is needed
+    }
+    // ---- the right neighbour's columns of row yb - 1 ----
+    const uint32_t* e;
+    if (!last) {
+      while (known_p < yb) {
+        known_p = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&prog[wave + 1]));
+        if (known_p < yb) __builtin_amdgcn_s_sleep(1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      e = &ring[(yb - 1) & (RING - 1)][wave + 1][0];
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      e = nextblk;
+    }
+    // V moves one column to the left, M two (DPP row shifts; the last lanes keep their own value for the moment).  What enters from
+    // the right neighbour — its column 0 of V into lane 15, its columns 0 and 1 of M into lanes 14 and 15 — is read from LDS by those
+    // lanes only, straight into the registers (ds_read_b128 with the shifted value as the tied operand): no temporaries, 2 NR shifts
+    // instead of 3 NR.
+    u32x4 tv[NR / 4], tm[NR / 4];
+    {
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        V[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)V[r], (int)V[r], 0x101, 0xf, 0xf, false);   // row_shl:1
+        M[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)M[r], (int)M[r], 0x102, 0xf, 0xf, false);   // row_shl:2
+      }
+#pragma unroll
+      for (int k = 0; k < NR / 4; k++) { tv[k] = (u32x4){V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]}; tm[k] = (u32x4){M[4 * k], M[4 * k + 1], M[4 * k + 2], M[4 * k + 3]}; }
+      const uint32_t aV = lds_addr(e + (0 * NQ + q) * NR), aM = lds_addr(e + ((p == 14 ? 1 : 2) * NQ + q) * NR);
+      if (p == 15) lds_read_in_place<NR / 4>(tv, aV);
+      if (p >= 14) lds_read_in_place<NR / 4>(tm, aM);
+    }
+    if (!last) {                                               // LDS serves a wave's instructions in order: once this store is visible the reads above are done
+      if (lane == 0) lds_store_relaxed(&cons[wave + 1], yb);
+    }
+    if constexpr (FINAL) { if (yb > ybs) flush_minima(yb - 1, (yb - 1) & 1); }     // the previous row's minima: their atomics were served long ago
+    lds_wait_in_place<NR / 4>(tv, tm);
+#pragma unroll
+    for (int k = 0; k < NR / 4; k++) {
+      V[4 * k] = tv[k].x; V[4 * k + 1] = tv[k].y; V[4 * k + 2] = tv[k].z; V[4 * k + 3] = tv[k].w;
+      M[4 * k] = tm[k].x; M[4 * k + 1] = tm[k].y; M[4 * k + 2] = tm[k].z; M[4 * k + 3] = tm[k].w;
+    }
+    {
+      uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];
+      path_neighbours<NR>(V, lane, q, upV, dnV);
+      path_neighbours<NR>(G, lane, q, upG, dnG);
+      path_neighbours<NR>(M, lane, q, upM, dnM);
+      path_cells<NR>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
+      path_normalise<NR>(V, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_cells<NR>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
+      path_normalise<NR>(G, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_cells<NR>(M, upM, dnM, Cp, acc, Ln, mn, P1pk);
+      path_normalise<NR>(M, Ln, pixel_min(mn), (uint32_t)s.P2);
+    }
+    if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
+#pragma unroll
+      for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : P2pk; G[r] = in ? G[r] : P2pk; M[r] = in ? M[r] : P2pk; }
+    }
+    // ---- publish this strip's first two columns of row yb ----
+    if (wave > 0 || j > 0) {
+      if (wave > 0) {
+        while (known_c < yb - RING + 1) {                      // the slot still holds row yb - RING until the left neighbour has read it
+          known_c = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&cons[wave]));
+          if (known_c < yb - RING + 1) __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      }
+      uint32_t* o = &ring[yb & (RING - 1)][wave][0];
+      if (p == 0) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) { o[(0 * NQ + q) * NR + r] = V[r]; o[(1 * NQ + q) * NR + r] = M[r]; }
+      }
+      if (p == 1) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) o[(2 * NQ + q) * NR + r] = M[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      if (wave > 0) {
+        if (lane == 0) lds_store_relaxed(&prog[wave], yb + 1);
+      } else {                                                 // strip 0: to the next block through memory, tagged
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        uint32_t* dst = my_gx + (size_t)yb * SLOT;
+#pragma unroll
+        for (int k = 0; k < NG; k++) { const int oo = lane + 64 * k; if (SLOT % 64 == 0 || oo < SLOT) st_sc1(dst + oo, o[oo] | tagpk); }
+      }
+    }
+    if (!last && yb < ybe) known_p = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&prog[wave + 1]));   // for the next row: usually already far enough
+    if constexpr (!FINAL) {
+      // pixels outside the image store into the slack behind the volume: an unconditional store keeps the next row's wait for its input
+      // bytes from also waiting for these stores (the compiler can then count them)
+      const size_t vpix = in ? pix : (size_t)n * H * W;
+      if constexpr (WIDE) store_words<NR>(volF + vpix * D * 2, q, acc); else store_bytes<NR>(volF + vpix * D, q, acc);
+    } else {
+      // S = 8 (C + P2) - (the three upward Y + the stored five)
+      uint32_t S[NR];
+#pragma unroll
+      for (int k = 0; k < NR / 2; k++) {
+        uint32_t a, b;
+        if constexpr (WIDE) { a = pk_add(pk_add(fF[2 * k], unpack_lo(fH0[k])), unpack_lo(fH1[k])); b = pk_add(pk_add(fF[2 * k + 1], unpack_hi(fH0[k])), unpack_hi(fH1[k])); }
+        else { const uint32_t hb = fH0[k] + fH1[k];    // bytes <= 2 P2 <= 170: no carry between bytes
+               a = pk_add(unpack_lo(fF[k]), unpack_lo(hb)); b = pk_add(unpack_hi(fF[k]), unpack_hi(hb)); }
+        S[2 * k] = pk_sub(pk_shl3(Cp[2 * k]), pk_add(acc[2 * k], a));
+        S[2 * k + 1] = pk_sub(pk_shl3(Cp[2 * k + 1]), pk_add(acc[2 * k + 1], b));
+      }
+      uint32_t key = 0xFFFFFFFFu;
+      uint32_t* mr = &minR[wave][yb & 1][q][p];
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const uint32_t klo = (S[r] << 16) | (uint32_t)r, khi = (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR);
+        key = min(key, min(klo, khi));
+      }
+      if (in) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+          atomicMin(mr + r, (S[r] << 16) | (uint32_t)r);
+          atomicMin(mr + r + NR, (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR));
+        }
+      }
+      key = in ? key + (uint32_t)(DPL * q) : 0xFFFFFFFFu;
+      {
+        const auto a = __builtin_amdgcn_permlane16_swap(key, key, false, false);
+        key = min(a[0], a[1]);
+        const auto b = __builtin_amdgcn_permlane32_swap(key, key, false, false);
+        key = min(b[0], b[1]);
+      }
+      const int d = (int)(key & 0xFFFFu);
+      int d16 = 16 * d;
+      if (s.subpixel) {
+        uint32_t* my = reinterpret_cast<uint32_t*>(sS + ((size_t)(PX * wave + p) * D + DPL * q));
+#pragma unroll
+        for (int r = 0; r < NR; r += 2) {                      // S in disparity order: low halves are j = r, high halves j = r + NR
+          my[r / 2] = __builtin_amdgcn_perm(S[r + 1], S[r], 0x05040100u);
+          my[(r + NR) / 2] = __builtin_amdgcn_perm(S[r + 1], S[r], 0x07060302u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (in && q == 0 && d > 0 && d < D - 1) {
+          const uint16_t* ps = sS + (size_t)(PX * wave + p) * D;
+          const int sm = ps[d - 1], sc = ps[d], sp = ps[d + 1];
+          const int den = max(sm + sp - 2 * sc, 1);
+          d16 = 16 * d + (16 * (sm - sp) + den) / (2 * den);
+        }
+      }
+      if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
+      __builtin_amdgcn_sched_barrier(0);
+      load_volumes(pixel_of(min(yb + 1, ybe)));                // the next row's volumes, into the registers S consumed; last in the row, so that
+                                                               // the next row's first wait (for its input bytes) leaves exactly these in flight
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (FINAL) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+    flush_minima(ybe, ybe & 1);
+  }
+}
+
 // ---- L/R check: the left winner survives if the right image's winner at x - d agrees ----
 __global__ void __launch_bounds__(256) k_sw_lr(SwDev s, int n, const uint32_t* __restrict__ dLp, const uint32_t* __restrict__ gminR, int16_t* __restrict__ disp) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
@@ -530,8 +901,16 @@ __global__ void __launch_bounds__(256) k_sw_lr(SwDev s, int n, const uint32_t* _
 // ---------------------------------------------------------------- host side ----------------------------------------------------------------
 namespace jnav_sgm {
 
-// computing waves per workgroup (+ 1 communication wave).  D = 256: four waves, one per SIMD, so that 96 pairs of path state plus a row of inputs fit the registers
+// JN_SGM_FLOW=0 selects the round sweeps with one barrier per row and a communication wave (k_sw_v); default is k_sw_w
+static int flow_mode() { const char* e = getenv("JN_SGM_FLOW"); return e ? (atoi(e) != 0) : 1; }
+// computing waves per workgroup.  k_sw_v (+ 1 communication wave): D = 256 runs four waves, one per SIMD, so that 96 pairs of path state plus a row of
+// inputs fit the registers.  k_sw_w: four strips
 static int strips_for(int D) {
+  if (flow_mode()) {                                           // k_sw_w: 4 strips per block (JN_SGM_NS=2 or 8 for A/B; D = 256 always 4)
+    const char* e = getenv("JN_SGM_NS");
+    const int v = e ? atoi(e) : 4;
+    return (D != 256 && (v == 2 || v == 8)) ? v : 4;
+  }
   if (D == 256) return 3;
   const char* e = getenv("JN_SGM_NS");                         // A/B switch: 3 (default), 5 or 7 strips per workgroup
   const int v = e ? atoi(e) : 3;                               // measured at 1280x720 D=128 batch 32: 11.3 / 13.8 / 12.6 ms per batch (profiles/r03_sgm_strips_ab.txt)
@@ -540,6 +919,7 @@ static int strips_for(int D) {
 
 void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch) {
   s->W = W; s->H = H; s->D = D; s->P1 = P1; s->P2 = P2; s->cap = cap; s->lr = lr; s->subpixel = subpixel ? 1 : 0;
+  s->flow = flow_mode(); s->epoch = 0;
   const int BLK = strips_for(D) * PX;
   s->padl = BLK + 32; s->Wp = ((s->padl + W + D + BLK + 64) + 15) / 16 * 16;   // a block's width of padding: lanes outside the image read plain bytes
   s->xmin = -(H - 1);
@@ -548,7 +928,7 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
   s->dbg = getenv("JN_SGM_DBG") ? atoi(getenv("JN_SGM_DBG")) : 0;
   const size_t px = (size_t)W * H;
   z->gm = (size_t)2 * max_batch * H * s->Wp + 256;
-  z->vol = (size_t)max_batch * px * D;                          // one byte volume; the F volume is twice that when wide
+  z->vol = (size_t)max_batch * px * D + 4096;                   // one byte volume (+ slack: where k_sw_w's lanes outside the image store); the F volume is twice that when wide
   z->gx = (size_t)max_batch * s->NB * H * (3 * NQ * (D / 8)) * sizeof(uint32_t);
   z->flags = ((size_t)max_batch * s->NB + 16) * sizeof(uint32_t);
   z->minr = (size_t)max_batch * px * sizeof(uint32_t);
@@ -574,9 +954,37 @@ static hipError_t launch_v(const SwDev& s, int n, bool final, hipStream_t st, co
   return hipGetLastError();
 }
 
+// k_sw_w: every launch on the buffer gets the next 16-bit tag; when the tag wraps the buffer is zeroed (tag 0 is never used), so
+// that rows an earlier, larger batch left behind can never carry the current tag
 template <int NR, int NS>
+static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuffers& b, size_t gx_bytes) {
+  constexpr int RING = NR <= 16 ? 8 : 4;
+  const dim3 grid((unsigned)(n * s.NB)), block(NS * 64);
+  const size_t dyn = final && s.subpixel ? (size_t)NS * PX * s.D * sizeof(uint16_t) : 0;
+  uint32_t* ctr = b.flags + (size_t)n * s.NB;
+  if (++b.epoch > 0xFFFFu) {
+    hipError_t e = hipMemsetAsync(b.gx, 0, gx_bytes, st);
+    if (e != hipSuccess) return e;
+    b.epoch = 1;
+  }
+  s.epoch = (int)b.epoch;
+#define JN_SW_W(FINAL, WIDE)                                                                                                            \
+  do {                                                                                                                                  \
+    if (dyn > 32 * 1024) {                                                                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw_w<NR, NS, RING, FINAL, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+      if (e != hipSuccess) return e;                                                                                                    \
+    }                                                                                                                                   \
+    hipLaunchKernelGGL((k_sw_w<NR, NS, RING, FINAL, WIDE>), grid, block, dyn, st, s, n, FINAL ? 1 : 0, b.gm, b.volF, b.volH0, b.volH1, b.gx, ctr, b.minr, b.dl); \
+  } while (0)
+  if (final) { if (s.wide) JN_SW_W(true, true); else JN_SW_W(true, false); }
+  else { if (s.wide) JN_SW_W(false, true); else JN_SW_W(false, false); }
+#undef JN_SW_W
+  return hipGetLastError();
+}
+
+template <int NR, int NS, bool FLOW>
 static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                          const SweepBuffers& b, hipEvent_t* ev) {
+                          SweepBuffers& b, hipEvent_t* ev) {
   hipError_t e;
   const size_t px = (size_t)s.W * s.H;
   if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
@@ -585,24 +993,34 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   hipLaunchKernelGGL((k_sw_h<NR>), dim3((s.H + 4 * PX - 1) / (4 * PX), n, 2), dim3(256), 0, st, s, n, b.gm, b.volH0, b.volH1);
   const size_t flag_bytes = ((size_t)n * s.NB + 1) * sizeof(uint32_t);
+  const size_t gx_bytes = (size_t)n * s.NB * s.H * (3 * NQ * NR) * sizeof(uint32_t);
+  auto sweep = [&](bool final) -> hipError_t {
+    if constexpr (FLOW) return launch_w<NR, NS>(s, n, final, st, b, gx_bytes);
+    else return launch_v<NR, NS>(s, n, final, st, b);
+  };
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
-  if ((e = launch_v<NR, NS>(s, n, false, st, b)) != hipSuccess) return e;
+  if ((e = sweep(false)) != hipSuccess) return e;
   if ((e = hipEventRecord(ev[2], st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
-  if ((e = launch_v<NR, NS>(s, n, true, st, b)) != hipSuccess) return e;
+  if ((e = sweep(true)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_sw_lr, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, n, b.dl, b.minr, dDisp);
   if ((e = hipEventRecord(ev[3], st)) != hipSuccess) return e;
   return hipGetLastError();
 }
 
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                     const SweepBuffers& b, hipEvent_t* ev) {
-  const int ns = strips_for(s.D);
-  if (s.D == 64) return ns == 3 ? run_all<8, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev) : ns == 5 ? run_all<8, 5>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
-                                                                                                                : run_all<8, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
-  if (s.D == 128) return ns == 3 ? run_all<16, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev) : ns == 5 ? run_all<16, 5>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
-                                                                                                                  : run_all<16, 7>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
-  return run_all<32, 3>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);
+                     SweepBuffers& b, hipEvent_t* ev) {
+  const int ns = (s.padl - 32) / PX;                           // strips per block, as sweep_geometry() chose them (padl = BLK + 32)
+#define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
+  if (s.flow) {
+    if (s.D == 64) return ns == 2 ? JN_RUN(8, 2, true) : ns == 8 ? JN_RUN(8, 8, true) : JN_RUN(8, 4, true);
+    if (s.D == 128) return ns == 2 ? JN_RUN(16, 2, true) : ns == 8 ? JN_RUN(16, 8, true) : JN_RUN(16, 4, true);
+    return JN_RUN(32, 4, true);
+  }
+  if (s.D == 64) return ns == 3 ? JN_RUN(8, 3, false) : ns == 5 ? JN_RUN(8, 5, false) : JN_RUN(8, 7, false);
+  if (s.D == 128) return ns == 3 ? JN_RUN(16, 3, false) : ns == 5 ? JN_RUN(16, 5, false) : JN_RUN(16, 7, false);
+  return JN_RUN(32, 3, false);
+#undef JN_RUN
 }
 
 }  // namespace jnav_sgm

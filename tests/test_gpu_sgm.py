@@ -130,3 +130,48 @@ def test_sgm_round2_kernels_still_agree(jn, sgm, oracle):
             del os.environ["JN_SGM_IMPL"]
         else:
             os.environ["JN_SGM_IMPL"] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,sub", [(64, 0), (128, 1), (256, 0)])
+def test_sgm_row_sweeps_with_and_without_the_workgroup_barrier(jn, sgm, oracle, D, sub):
+    """JN_SGM_FLOW=0 keeps round 3's first row sweeps (one barrier per row, a communication wave) next to the default ones (no barrier,
+    tagged columns between blocks); both give the definition, also on a frame wide enough for several blocks and with sub-pixel output."""
+    import os
+    W, H = 700, 130
+    L, R = oracle.synth_pair(W, H, min(D - 1, 100), 5)
+    exp = sgm.process(sgm.params(D, subpixel=sub), L, R)
+    old = os.environ.get("JN_SGM_FLOW")
+    try:
+        for flow in ("0", "1"):
+            os.environ["JN_SGM_FLOW"] = flow
+            out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D, subpixel=sub), np.stack([L, L]), np.stack([R, R]))
+            assert np.array_equal(out[0], exp), flow
+            assert np.array_equal(out[1], exp), flow
+    finally:
+        if old is None:
+            del os.environ["JN_SGM_FLOW"]
+        else:
+            os.environ["JN_SGM_FLOW"] = old
+
+
+@pytest.mark.gpu
+def test_sgm_launch_tag_wraps_around(jn, sgm, oracle, monkeypatch):
+    """The columns handed from block to block carry a 16-bit launch tag (sgm_sweep.hip); when it wraps the buffer is zeroed.  Start a
+    handle three launches before the wrap, run a larger batch, then smaller ones across the wrap, then the larger one again."""
+    from jackal_navigation_amd.device import DeviceArray
+    monkeypatch.setenv("JN_SGM_EPOCH_START", str(0xFFFF - 3))
+    W, H, D = 300, 90, 64
+    pairs = [oracle.synth_pair(W, H, 40, 900 + b) for b in range(3)]
+    Ls, Rs = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    exp = [sgm.process(sgm.params(D), Ls[b], Rs[b]) for b in range(3)]
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    dD = DeviceArray((3, H, W), np.int16)
+    with jn.Sgm(jn.Sgm.parameters(num_disparities=D), W, H, max_batch=3) as s:
+        for n in (3, 1, 1, 1, 2, 3):
+            s.process_batch(n, dL.ptr, dR.ptr, W, H * W, dD.ptr)
+            out = dD.numpy()
+            for b in range(n):
+                assert np.array_equal(out[b], exp[b]), (n, b)
+    for a in (dL, dR, dD):
+        a.free()
