@@ -205,6 +205,10 @@ __global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __
 // Stores: 64-byte pieces in 16 different image rows per instruction.  Collecting 512 contiguous bytes per row in LDS first (two
 // rows per store instruction) was built and measured: no change (2 824 against 2 827 pairs/s) — the kernel writes 7.5 GB in 2.0 ms,
 // it is the write rate itself, not the shape of the writes, that bounds it next to its 1.25 ms of arithmetic.
+// The loop waits with s_waitcnt vmcnt(0) before every pixel (the stores and the window loads are issued under conditions, which the
+// compiler cannot count).  Two ways around that were built and measured, both bit-exact, both slower than this form (2.1 ms): every
+// v_mqsad operand loaded per pixel as the row sweeps do (4.6 ms — the lanes are 16 different image rows here, each load instruction touches
+// dozens of cache lines), and unconditional stores plus the entering dwords reloaded after every pixel (3.1 ms, same reason).
 template <int NR, int DIR>
 DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t* __restrict__ rowR, uint8_t* __restrict__ vol, bool valid, int lane, int q) {
   constexpr int NW = NR / 2 + 1;                               // dwords of one pixel's run
@@ -632,26 +636,36 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
   RowIn cur;
   fetch_row(cur, ybs < ybe);
   // the final sweep's three stored volumes of a pixel (clamped columns: always a valid address, so the loads need no condition)
-  uint32_t fF[FINAL ? (WIDE ? NR : NR / 2) : 1], fH0[FINAL ? NR / 2 : 1], fH1[FINAL ? NR / 2 : 1];
+  // (kept as the 16-byte vectors they are loaded as: split into dwords they become separate loop-carried values, the compiler gives some of
+  // them other registers at the top of the loop than the load writes, and the copy it then needs waits for the load right behind it)
+  constexpr int NVF = FINAL ? (WIDE ? NR / 4 : NR / 8) : 1, NVH = FINAL ? NR / 8 : 1;
+  u32x4 fF[NVF], fH0[NVH], fH1[NVH];
   auto pixel_of = [&](int yb) __attribute__((always_inline)) {
     const int y = flip ? H - 1 - yb : yb;
     return ((size_t)frame * H + y) * W + (size_t)min(max(xl + yb, 0), W - 1);
   };
   auto load_volumes = [&](size_t pix) __attribute__((always_inline)) {
     if constexpr (FINAL) {
-      if constexpr (WIDE) load_words<NR>(volF + pix * D * 2, q, fF); else load_bytes<NR>(volF + pix * D, q, fF);
-      load_bytes<NR>(volH0 + pix * D, q, fH0);
-      load_bytes<NR>(volH1 + pix * D, q, fH1);
+      const uint8_t* pF = volF + pix * D * (WIDE ? 2 : 1) + 16 * q;
+#pragma unroll
+      for (int c = 0; c < NVF; c++) fF[c] = *reinterpret_cast<const u32x4*>(pF + 64 * c);
+#pragma unroll
+      for (int c = 0; c < NVH; c++) fH0[c] = *reinterpret_cast<const u32x4*>(volH0 + pix * D + 64 * c + 16 * q);
+#pragma unroll
+      for (int c = 0; c < NVH; c++) fH1[c] = *reinterpret_cast<const u32x4*>(volH1 + pix * D + 64 * c + 16 * q);
     }
   };
   load_volumes(pixel_of(ybs));
-  if constexpr (!FINAL) {
-    // as many stores behind the first row's loads as every later row has (into the slack), so that the loop's first wait — written once
-    // for both ways into the loop — can leave that many operations in flight instead of draining the row's stores
-    uint32_t zero[NR];
+  // everything requested so far is complete before the loop starts (uses the compiler must wait for): the waits inside the loop are then
+  // written for what a row leaves in flight, not for the prologue
 #pragma unroll
-    for (int r = 0; r < NR; r++) zero[r] = 0u;
-    if constexpr (WIDE) store_words<NR>(volF + (size_t)n * H * W * D * 2, q, zero); else store_bytes<NR>(volF + (size_t)n * H * W * D, q, zero);
+  for (int k = 0; k < NR / 2; k++) asm volatile("" : : "v"(cur.ww[k]));
+  asm volatile("" : : "v"(cur.ref));
+  if constexpr (FINAL) {
+#pragma unroll
+    for (int k = 0; k < NVF; k++) asm volatile("" : : "v"(fF[k]));
+#pragma unroll
+    for (int k = 0; k < NVH; k++) asm volatile("" : : "v"(fH0[k]), "v"(fH1[k]));
   }
   // flush one row of this strip's right-image minima (minR[wave][buf]) to the row's global minima
   auto flush_minima = [&](int yb, int buf) __attribute__((always_inline)) {
@@ -820,12 +834,16 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
 #pragma unroll
       for (int k = 0; k < NR / 2; k++) {
         uint32_t a, b;
-        if constexpr (WIDE) { a = pk_add(pk_add(fF[2 * k], unpack_lo(fH0[k])), unpack_lo(fH1[k])); b = pk_add(pk_add(fF[2 * k + 1], unpack_hi(fH0[k])), unpack_hi(fH1[k])); }
-        else { const uint32_t hb = fH0[k] + fH1[k];    // bytes <= 2 P2 <= 170: no carry between bytes
-               a = pk_add(unpack_lo(fF[k]), unpack_lo(hb)); b = pk_add(unpack_hi(fF[k]), unpack_hi(hb)); }
+        const uint32_t h0 = fH0[k >> 2][k & 3], h1 = fH1[k >> 2][k & 3];
+        if constexpr (WIDE) { a = pk_add(pk_add(fF[(2 * k) >> 2][(2 * k) & 3], unpack_lo(h0)), unpack_lo(h1)); b = pk_add(pk_add(fF[(2 * k + 1) >> 2][(2 * k + 1) & 3], unpack_hi(h0)), unpack_hi(h1)); }
+        else { const uint32_t hb = h0 + h1, ff = fF[k >> 2][k & 3];    // bytes <= 2 P2 <= 170: no carry between bytes
+               a = pk_add(unpack_lo(ff), unpack_lo(hb)); b = pk_add(unpack_hi(ff), unpack_hi(hb)); }
         S[2 * k] = pk_sub(pk_shl3(Cp[2 * k]), pk_add(acc[2 * k], a));
         S[2 * k + 1] = pk_sub(pk_shl3(Cp[2 * k + 1]), pk_add(acc[2 * k + 1], b));
       }
+      __builtin_amdgcn_sched_barrier(0);
+      load_volumes(pixel_of(min(yb + 1, ybe)));                // the next row's volumes, into the registers S has just consumed
+      __builtin_amdgcn_sched_barrier(0);
       uint32_t key = 0xFFFFFFFFu;
       uint32_t* mr = &minR[wave][yb & 1][q][p];
 #pragma unroll
@@ -866,10 +884,8 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
           d16 = 16 * d + (16 * (sm - sp) + den) / (2 * den);
         }
       }
-      if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
-      __builtin_amdgcn_sched_barrier(0);
-      load_volumes(pixel_of(min(yb + 1, ybe)));                // the next row's volumes, into the registers S consumed; last in the row, so that
-                                                               // the next row's first wait (for its input bytes) leaves exactly these in flight
+      // unconditional (the other lanes write into the slack behind the array): the next row's first wait can then count it
+      dLp[(in && q == 0) ? pix : (size_t)n * H * W + lane] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -932,7 +948,7 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
   z->gx = (size_t)max_batch * s->NB * H * (3 * NQ * (D / 8)) * sizeof(uint32_t);
   z->flags = ((size_t)max_batch * s->NB + 16) * sizeof(uint32_t);
   z->minr = (size_t)max_batch * px * sizeof(uint32_t);
-  z->dl = (size_t)max_batch * px * sizeof(uint32_t);
+  z->dl = ((size_t)max_batch * px + 64) * sizeof(uint32_t);     // + a slack row: where k_sw_w's lanes without a pixel store
 }
 
 template <int NR, int NS>
