@@ -205,15 +205,25 @@ __global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __
 // Stores: 64-byte pieces in 16 different image rows per instruction.  Collecting 512 contiguous bytes per row in LDS first (two
 // rows per store instruction) was built and measured: no change (2 824 against 2 827 pairs/s) — the kernel writes 7.5 GB in 2.0 ms,
 // it is the write rate itself, not the shape of the writes, that bounds it next to its 1.25 ms of arithmetic.
-// The loop waits with s_waitcnt vmcnt(0) before every pixel (the stores and the window loads are issued under conditions, which the
-// compiler cannot count).  Two ways around that were built and measured, both bit-exact, both slower than this form (2.1 ms): every
-// v_mqsad operand loaded per pixel as the row sweeps do (4.6 ms — the lanes are 16 different image rows here, each load instruction touches
-// dozens of cache lines), and unconditional stores plus the entering dwords reloaded after every pixel (3.1 ms, same reason).
+// Where the entering dwords come from.  Loaded from memory under the wrap condition (as in the first form of this kernel) the loop needs a
+// vector-memory wait, and since the compiler cannot count operations issued under conditions that wait is s_waitcnt vmcnt(0) before EVERY
+// pixel: every store of the previous pixel was drained first.  Now the wave stages the next 64 bytes of its 16 rows (+ the other quarters'
+// offsets) in LDS once per 16 wraps — coalesced loads, one full wait per 64 pixels — and the wrap reads its two dwords from there: LDS reads
+// count in lgkmcnt, so nothing in the pixel loop waits for memory and the stores stay in flight.
+// (Also measured, bit-exact, slower: every v_mqsad operand loaded per pixel as the row sweeps do — 4.6 ms instead of 2.1, the lanes are 16
+// different image rows here and each load instruction touches dozens of cache lines; the entering dwords reloaded after every pixel — 3.1 ms.)
+constexpr int HCH = 16;                                        // wraps (dwords per row and quarter) staged at a time
 template <int NR, int DIR>
-DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t* __restrict__ rowR, uint8_t* __restrict__ vol, bool valid, int lane, int q) {
+DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t* __restrict__ gmR, int y0, uint8_t* __restrict__ vol, bool valid, int lane, int q,
+                 uint32_t* __restrict__ sR, uint32_t* __restrict__ sL) {
   constexpr int NW = NR / 2 + 1;                               // dwords of one pixel's run
-  const int W = s.W;
+  constexpr int DPL = 2 * NR, SPAN = HCH + 3 * DPL / 4;        // staged dwords per row of the right image
+  const int W = s.W, p = lane & 15;
   const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
+  // gmL / gmR: column x_k = 0 of image row 0 of this frame's left / right prefiltered image; this lane's row is min(y0 + p, H - 1)
+  const int yc = min(y0 + p, s.H - 1);
+  const uint8_t* rowL = gmL + (size_t)yc * s.Wp;
+  const uint8_t* rowR = gmR + (size_t)yc * s.Wp + DPL * q;
   uint32_t X[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++) X[r] = P2pk;
@@ -227,8 +237,43 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t
 #pragma unroll
   for (int k = 0; k < 3; k++) Lw[k] = *reinterpret_cast<const uint32_t*>(rowL + al + 4 * (DIR ? k - 1 : k));
   // upwards: Rw[k] = dword at al + 4k (k = NW+1 is the one fetched ahead); downwards: Rw[k] = dword at al + 4(k-1) (k = 0 fetched ahead)
+  // the window is complete before the loop starts (uses the compiler must wait for): a wait for it inside the loop would be executed before
+  // every pixel and drain the previous pixel's stores
+#pragma unroll
+  for (int k = 0; k < NW + 2; k++) asm volatile("" : : "v"(Rw[k]));
+#pragma unroll
+  for (int k = 0; k < 3; k++) asm volatile("" : : "v"(Lw[k]));
+  const int lo_byte = -s.padl, hi_byte = s.Wp - s.padl - 4;    // a row's own bytes (staging near the ends clamps into them; those dwords are never used)
+  int wraps_left = 0;                                          // entering dwords still staged
+  int soff = 0;                                                // dword index of the next wrap's entering dword within the staged span
+  const uint32_t* myR = sR + p * SPAN + (DPL / 4) * q;
+  const uint32_t* myL = sL + p * HCH;
   for (int t = 0; t < W; t++) {
     const int sh = (xk - 1) & 3;
+    if (wraps_left == 0) {
+      // the next HCH wraps fetch (upwards) al + 4 (i + 1) + 4 (NW + 1) resp. al + 4 (i + 1) + 8, (downwards) al - 4 (i + 1) - 4 for both rows
+      const int baseR = DIR ? al - 4 * HCH - 4 : al + 4 + 4 * (NW + 1), baseL = DIR ? al - 4 * HCH - 4 : al + 12;
+      constexpr int KR = (16 * SPAN + 63) / 64, KL = 16 * HCH / 64;
+      uint32_t tR[KR], tL[KL];                                 // all loads first, then all LDS writes
+#pragma unroll
+      for (int k = 0; k < KR; k++) {
+        const int i = min(lane + 64 * k, 16 * SPAN - 1), row = i / SPAN, col = i - row * SPAN;
+        tR[k] = *reinterpret_cast<const uint32_t*>(gmR + (size_t)min(y0 + row, s.H - 1) * s.Wp + min(max(baseR + 4 * col, lo_byte), hi_byte));
+      }
+#pragma unroll
+      for (int k = 0; k < KL; k++) {
+        const int i = lane + 64 * k, row = i / HCH, col = i % HCH;
+        tL[k] = *reinterpret_cast<const uint32_t*>(gmL + (size_t)min(y0 + row, s.H - 1) * s.Wp + min(max(baseL + 4 * col, lo_byte), hi_byte));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < KR; k++) { const int i = lane + 64 * k; if ((16 * SPAN) % 64 == 0 || i < 16 * SPAN) sR[i] = tR[k]; }
+#pragma unroll
+      for (int k = 0; k < KL; k++) sL[lane + 64 * k] = tL[k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+      wraps_left = HCH;
+      soff = DIR ? HCH - 1 : 0;
+    }
     uint32_t w[NW], Cp[NR], acc[NR], Ln[NR], up, dn, mn;
 #pragma unroll
     for (int k = 0; k < NW; k++) w[k] = __builtin_amdgcn_alignbyte(Rw[k + 1 + DIR], Rw[k + DIR], sh);
@@ -236,10 +281,10 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t
     costs<NR>(w, ref, P2pk, Cp);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
-    path_neighbours<NR>(X, lane, q, up, dn, s.dbg);
+    path_neighbours<NR>(X, lane, q, up, dn);
     path_cells<NR>(X, up, dn, Cp, acc, Ln, mn, P1pk);
-    path_normalise<NR>(X, Ln, (s.dbg & 32) ? (mn & 0xFFFFu) : pixel_min(mn), (uint32_t)s.P2);
-    if (valid && (!(s.dbg & 1) || X[0] == 0x12345678u)) store_bytes<NR>(vol + (size_t)xk * s.D, q, acc);
+    path_normalise<NR>(X, Ln, pixel_min(mn), (uint32_t)s.P2);
+    if (valid) store_bytes<NR>(vol + (size_t)xk * s.D, q, acc);
     // next pixel: slide the window when the byte phase wraps
     if (!DIR) {
       xk++;
@@ -248,7 +293,8 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t
 #pragma unroll
         for (int k = 0; k < NW + 1; k++) Rw[k] = Rw[k + 1];
         Lw[0] = Lw[1]; Lw[1] = Lw[2];
-        if (!(s.dbg & 2)) { Rw[NW + 1] = *reinterpret_cast<const uint32_t*>(rowR + al + 4 * (NW + 1)); Lw[2] = *reinterpret_cast<const uint32_t*>(rowL + al + 8); }
+        Rw[NW + 1] = myR[soff]; Lw[2] = myL[soff];
+        soff++; wraps_left--;
       }
     } else {
       xk--;
@@ -257,23 +303,27 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ rowL, const uint8_t
 #pragma unroll
         for (int k = NW + 1; k > 0; k--) Rw[k] = Rw[k - 1];
         Lw[2] = Lw[1]; Lw[1] = Lw[0];
-        if (!(s.dbg & 2)) { Rw[0] = *reinterpret_cast<const uint32_t*>(rowR + al - 4); Lw[0] = *reinterpret_cast<const uint32_t*>(rowL + al - 4); }
+        Rw[0] = myR[soff]; Lw[0] = myL[soff];
+        soff--; wraps_left--;
       }
     }
   }
 }
 template <int NR>
 __global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __restrict__ gm, uint8_t* __restrict__ vol0, uint8_t* __restrict__ vol1) {
-  constexpr int DPL = 2 * NR;
+  constexpr int DPL = 2 * NR, SPAN = HCH + 3 * DPL / 4;
+  __shared__ uint32_t sR[4][16 * SPAN], sL[4][16 * HCH];       // per wave: the staged dwords of its 16 rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, p = lane & 15;
-  const int y = (blockIdx.x * 4 + wave) * PX + p, frame = blockIdx.y, dir = blockIdx.z;
+  const int y0 = (blockIdx.x * 4 + wave) * PX, frame = blockIdx.y, dir = blockIdx.z;
+  if (y0 >= s.H) return;
+  const int y = y0 + p;
   const bool valid = y < s.H;
   const int yc = min(y, s.H - 1);
-  const uint8_t* rowL = gm + ((size_t)frame * s.H + yc) * s.Wp + s.padl;
-  const uint8_t* rowR = gm + ((size_t)(n + frame) * s.H + yc) * s.Wp + s.padl + DPL * q;
+  const uint8_t* gmL = gm + (size_t)frame * s.H * s.Wp + s.padl;
+  const uint8_t* gmR = gm + (size_t)(n + frame) * s.H * s.Wp + s.padl;
   const size_t row_px = ((size_t)frame * s.H + yc) * s.W;
-  if (dir == 0) h_sweep<NR, 0>(s, rowL, rowR, vol0 + row_px * s.D, valid, lane, q);
-  else h_sweep<NR, 1>(s, rowL, rowR, vol1 + row_px * s.D, valid, lane, q);
+  if (dir == 0) h_sweep<NR, 0>(s, gmL, gmR, y0, vol0 + row_px * s.D, valid, lane, q, sR[wave], sL[wave]);
+  else h_sweep<NR, 1>(s, gmL, gmR, y0, vol1 + row_px * s.D, valid, lane, q, sR[wave], sL[wave]);
 }
 
 // ---- the three paths of one vertical direction, sheared strips ----
