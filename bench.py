@@ -358,7 +358,7 @@ def run_sgm(a):
         moved = ((16.0 if old else 6.0) * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
         pmc = sgm_pmc_traffic(W, H, D, B) if not old else None
         roofline = {"bound": "hbm", "kernel": ("k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)" if old else
-                                                "k_sw_h + k_sw_v<down> + k_sw_v<up, winners> (+ k_sw_prefilter, k_sw_lr: one batch)"),
+                                                "k_sw_h + k_sw_w<down> + k_sw_w<up, winners> (+ k_sw_prefilter, k_sw_lr: one batch)"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": pmc["bytes"] if pmc else int(moved),
                     "traffic_note": (pmc["note"] if pmc else "computed, not PMC: %s; " % ("8 W H D written by the path kernel + 8 W H D read by the WTA kernel" if old else

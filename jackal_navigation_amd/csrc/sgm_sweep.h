@@ -10,9 +10,9 @@ struct SwDev {
   int W, H, D, P1, P2, lr, subpixel, cap;
   int Wp, padl;      // prefiltered rows, x-mirrored and padded: Wp bytes per row, image column x_k = W-1-x at byte padl + x_k
   int NB, xmin;      // sheared blocks of the row sweeps: x' = x_k - (row in sweep order) in [xmin, W-1], NB blocks
-  int dbg;           // JN_SGM_DBG profiling switches (results are then WRONG): 1 = horizontal sweep without its stores, 2 = without its per-step loads,
-                     // 4 = row sweeps without volume stores / loads, 8 = row sweeps without the per-row barrier, 16 = no quarter-boundary permutes,
-                     // 32 = no per-pixel minimum across lanes
+  int dbg;           // JN_SGM_DBG profiling switches of k_sw_v (JN_SGM_FLOW=0) only, results are then WRONG: 4 = row sweeps without volume stores /
+                     // loads, 8 = without the per-row barrier.  (The switches of the horizontal sweep went with its rewrite; what they measured is in
+                     // profiles/r03_sgm_dbg_switches.txt.)
   int wide;          // 3 P2 > 255: the three-path volume is u16, the horizontal volumes are unpacked one by one
   int flow;          // row sweeps: 1 = k_sw_w (no workgroup barrier, no communication wave; 4 strips per block), 0 = k_sw_v (JN_SGM_FLOW=0)
   int epoch;         // k_sw_w: 16-bit tag of this launch's boundary columns (set per launch from SweepBuffers::epoch, never 0)

@@ -106,8 +106,7 @@ DEV void costs64(const uint64_t (&ww)[NR / 2], uint32_t ref, uint32_t P2pk, uint
 // The adjoining pairs of the neighbouring quarters: up = the quarter below's j = DPL-1 (high half of its register NR-1) for
 // this lane's j = 0; dn = the quarter above's j = 0 for this lane's j = DPL-1.  Issued ahead of the cells that use them.
 template <int NR>
-DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t& up, uint32_t& dn, int dbg = 0) {
-  if (dbg & 16) { up = X[NR - 1]; dn = X[0]; return; }         // profiling switch: no permutes (results are then WRONG)
+DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t& up, uint32_t& dn) {
   const uint32_t a = bperm((lane - PX) & 63, X[NR - 1]);
   const uint32_t b = bperm((lane + PX) & 63, X[0]);
   up = q == 0 ? 0u : a;

@@ -23,7 +23,8 @@ for c in FETCH_SIZE WRITE_SIZE; do python3 scripts/pmc.py $(ls $out/${tag}_sgm_p
 python3 scripts/pmc.py $(ls $out/${tag}_sgm_sq/*/*counter_collection.csv | tail -1) "k_sw_" > $out/${tag}_sgm_pmc_SQ.txt
 python3 bench.py --mode sgm --steps 10 --warmup 2 > $out/${tag}_sgm_bench_line.json 2> $out/${tag}_sgm_bench.err
 JN_SGM_IMPL=0 python3 bench.py --mode sgm --steps 5 --warmup 2 --no-cpu-baseline > $out/${tag}_sgm_round2_kernels_bench_line.json 2>> $out/${tag}_sgm_bench.err
-for ns in 3 5 7; do echo "JN_SGM_NS=$ns $(JN_SGM_NS=$ns python3 bench.py --mode sgm --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done > $out/${tag}_sgm_strips_ab.txt
+{ for f in 1 0; do echo "JN_SGM_FLOW=$f $(JN_SGM_FLOW=$f python3 bench.py --mode sgm --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done
+for ns in 2 4 8; do echo "JN_SGM_FLOW=1 JN_SGM_NS=$ns $(JN_SGM_NS=$ns python3 bench.py --mode sgm --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done; } > $out/${tag}_sgm_strips_ab.txt
 # ---- block-matching mode ----
 cd /tmp
 fresh ${tag}_bm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm -- python3 $R/bench.py --mode bm --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm.log 2>&1
