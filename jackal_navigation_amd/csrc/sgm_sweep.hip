@@ -16,20 +16,21 @@
 //     and what a path contributes beyond the cost, m = L - C, lies in [0, P2]: S = sum_r L_r = 8 C + sum_r m_r.  The
 //     sweeps store sums of m (bytes), and the last sweep adds 8 C, which it computes anyway;
 //   * k_sw_h: the two horizontal paths, lanes = 16 image rows x 4 disparity quarters, walking along x (one volume each);
-//   * k_sw_v<.., FINAL=false>: the three downward paths (0,1), (1,1), (-1,1) in ONE top-to-bottom sweep, summed in
-//     registers, one byte volume out;  k_sw_v<.., FINAL=true>: the three upward paths in one bottom-to-top sweep which
-//     also reads the three stored volumes, forms S, takes the left winner (packed 16-bit keys S*32 + j), the right
-//     image's winners (LDS atomic minima, flushed per row with global atomic minima) and the sub-pixel offset;
-//     k_sw_lr applies the L/R check.
+//   * row sweep <FINAL=false>: the three downward paths (0,1), (1,1), (-1,1) in ONE top-to-bottom sweep, summed in
+//     registers, one byte volume out;  row sweep <FINAL=true>: the three upward paths in one bottom-to-top sweep which
+//     also reads the three stored volumes, forms S, takes the left winner (keys S << 16 | j), the right image's
+//     winners (LDS atomic minima, flushed per row with global atomic minima) and the sub-pixel offset;
+//     k_sw_lr applies the L/R check.  Two forms of the row sweep: k_sw_w (default) and k_sw_v (JN_SGM_FLOW=0, the first one).
 // HBM traffic: 3 volumes written + 3 read = 6 W H D (+ images), against 16 W H D before; SURVEY 8d's bound is 4 W H D.
 //
 // The row sweeps and their one-directional pipeline.  A pixel's three downward paths need the previous row at x, x-1 and
 // x+1, so 16-pixel strips of a row sweep cannot be independent.  In the SHEARED coordinate x' = x - y (a lane keeps x' and
 // so walks along the (1,1) diagonal) the three predecessors sit at x'+0, x'+1 and x'+2: all on ONE side.  A strip then
-// depends only on its right neighbour's first two columns of the previous row — a pipeline, not a lock-step: inside a
-// workgroup (NS strips, one barrier per row) the columns go through LDS; between workgroups through a global buffer with
+// depends only on its right neighbour's first two columns of the previous row — a pipeline, not a lock-step.  k_sw_v: inside
+// a workgroup (NS strips, one barrier per row) the columns go through LDS; between workgroups through a global buffer with
 // a progress flag per block (write-through stores, drain, flag; polled and fetched by a COMMUNICATION wave that does no
-// arithmetic, so no computing wave ever waits on memory latency).  Workgroups take a ticket when they start, and tickets
+// arithmetic).  k_sw_w (see there): no barrier and no communication wave — an LDS ring with row counters between the strips
+// of a block, self-validating tagged columns between blocks.  Workgroups take a ticket when they start, and tickets
 // are numbered so that a block's producer always holds a smaller one: whatever the dispatch order, a waiting block's
 // producer is running or done (placement-independent, no co-residency assumption).
 // The kernels work in x-mirrored image space (x_k = W-1-x), where the right-image tap x - d becomes x_k + d and the bytes a
@@ -595,22 +596,37 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
 DEV int lds_load_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DEV void lds_store_relaxed(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-// ds_read_b128 into registers that already hold a value (under the caller's exec mask the other lanes keep theirs).  The compiler does not
-// know about these reads: lds_wait_in_place() waits for them and makes every later use of the registers depend on that wait.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+// N ds_read_b128 from addrV into tv and N from addrM into tm in the lanes whose address is not 0xFFFFFFFF (the others are switched off
+// with the exec mask around the reads and keep what their registers held: tv / tm are in/out operands), then the wait for them — ONE
+// asm statement, so that the compiler never sees (and never copies or spills) the registers while the reads are in flight.  (s_nop 4: a VALU write of EXEC — the
+// v_cmpx — must be five wait states away from the DPP instructions that follow the statement.)
 template <int N>
-DEV void lds_read_in_place(u32x4 (&t)[N], uint32_t addr) {
-#pragma unroll
-  for (int k = 0; k < N; k++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "+v"(t[k]) : "v"(addr), "n"(16 * k) : "memory");
+DEV void lds_read_lanes(u32x4 (&tv)[N], u32x4 (&tm)[N], uint32_t addrV, uint32_t addrM);
+template <>
+DEV void lds_read_lanes<2>(u32x4 (&tv)[2], u32x4 (&tm)[2], uint32_t addrV, uint32_t addrM) {
+  asm volatile("s_mov_b64 s[2:3], exec\n\tv_cmpx_ne_u32 -1, %5\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16\n\t"
+               "s_mov_b64 exec, s[2:3]\n\tv_cmpx_ne_u32 -1, %4\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\t"
+               "s_mov_b64 exec, s[2:3]\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 4"
+               : "+v"(tv[0]), "+v"(tv[1]), "+v"(tm[0]), "+v"(tm[1]) : "v"(addrV), "v"(addrM) : "s2", "s3", "vcc", "memory");
 }
-template <int N>
-DEV void lds_wait_in_place(u32x4 (&a)[N], u32x4 (&b)[N]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]) : : "memory");
-#pragma unroll
-  for (int k = 1; k < N; k++) asm volatile("" : "+v"(a[k]));
-#pragma unroll
-  for (int k = 0; k < N; k++) asm volatile("" : "+v"(b[k]));
+template <>
+DEV void lds_read_lanes<4>(u32x4 (&tv)[4], u32x4 (&tm)[4], uint32_t addrV, uint32_t addrM) {
+  asm volatile("s_mov_b64 s[2:3], exec\n\tv_cmpx_ne_u32 -1, %9\n\tds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:16\n\tds_read_b128 %6, %9 offset:32\n\tds_read_b128 %7, %9 offset:48\n\t"
+               "s_mov_b64 exec, s[2:3]\n\tv_cmpx_ne_u32 -1, %8\n\tds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\tds_read_b128 %3, %8 offset:48\n\t"
+               "s_mov_b64 exec, s[2:3]\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 4"
+               : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tm[0]), "+v"(tm[1]), "+v"(tm[2]), "+v"(tm[3]) : "v"(addrV), "v"(addrM) : "s2", "s3", "vcc", "memory");
+}
+template <>
+DEV void lds_read_lanes<8>(u32x4 (&tv)[8], u32x4 (&tm)[8], uint32_t addrV, uint32_t addrM) {
+  asm volatile("s_mov_b64 s[2:3], exec\n\tv_cmpx_ne_u32 -1, %17\n\tds_read_b128 %8, %17\n\tds_read_b128 %9, %17 offset:16\n\tds_read_b128 %10, %17 offset:32\n\tds_read_b128 %11, %17 offset:48\n\t"
+               "ds_read_b128 %12, %17 offset:64\n\tds_read_b128 %13, %17 offset:80\n\tds_read_b128 %14, %17 offset:96\n\tds_read_b128 %15, %17 offset:112\n\t"
+               "s_mov_b64 exec, s[2:3]\n\tv_cmpx_ne_u32 -1, %16\n\tds_read_b128 %0, %16\n\tds_read_b128 %1, %16 offset:16\n\tds_read_b128 %2, %16 offset:32\n\tds_read_b128 %3, %16 offset:48\n\t"
+               "ds_read_b128 %4, %16 offset:64\n\tds_read_b128 %5, %16 offset:80\n\tds_read_b128 %6, %16 offset:96\n\tds_read_b128 %7, %16 offset:112\n\t"
+               "s_mov_b64 exec, s[2:3]\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 4"
+               : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]), "+v"(tv[4]), "+v"(tv[5]), "+v"(tv[6]), "+v"(tv[7]),
+                 "+v"(tm[0]), "+v"(tm[1]), "+v"(tm[2]), "+v"(tm[3]), "+v"(tm[4]), "+v"(tm[5]), "+v"(tm[6]), "+v"(tm[7]) : "v"(addrV), "v"(addrM) : "s2", "s3", "vcc", "memory");
 }
 
 template <int NR, int NS, int RING, bool FINAL, bool WIDE>
@@ -756,6 +772,7 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
+    if constexpr (FINAL) { if (yb > ybs) flush_minima(yb - 1, (yb - 1) & 1); }     // the previous row's minima: their atomics were served long ago
     // ---- last strip: the producer block's columns of row yb - 1 ----
     if (last) {
       const int yr = yb - 1;
@@ -802,30 +819,29 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
     }
     // V moves one column to the left, M two (DPP row shifts; the last lanes keep their own value for the moment).  What enters from
     // the right neighbour — its column 0 of V into lane 15, its columns 0 and 1 of M into lanes 14 and 15 — is read from LDS by those
-    // lanes only, straight into the registers (ds_read_b128 with the shifted value as the tied operand): no temporaries, 2 NR shifts
-    // instead of 3 NR.
-    u32x4 tv[NR / 4], tm[NR / 4];
+    // lanes only, straight into the shifted registers: 2 NR shifts (the first form shifted M twice: 3 NR), 8 instead of 12 LDS reads
+    // and no temporaries.  The reads and the wait for them are ONE asm statement with the registers as in/out operands: the other
+    // lanes keep their value (which C++ cannot say without 48 extra moves per row), and the compiler never sees the registers while
+    // the reads are in flight.
     {
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         V[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)V[r], (int)V[r], 0x101, 0xf, 0xf, false);   // row_shl:1
         M[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)M[r], (int)M[r], 0x102, 0xf, 0xf, false);   // row_shl:2
       }
+      u32x4 tv[NR / 4], tm[NR / 4];
 #pragma unroll
       for (int k = 0; k < NR / 4; k++) { tv[k] = (u32x4){V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]}; tm[k] = (u32x4){M[4 * k], M[4 * k + 1], M[4 * k + 2], M[4 * k + 3]}; }
       const uint32_t aV = lds_addr(e + (0 * NQ + q) * NR), aM = lds_addr(e + ((p == 14 ? 1 : 2) * NQ + q) * NR);
-      if (p == 15) lds_read_in_place<NR / 4>(tv, aV);
-      if (p >= 14) lds_read_in_place<NR / 4>(tm, aM);
-    }
-    if (!last) {                                               // LDS serves a wave's instructions in order: once this store is visible the reads above are done
-      if (lane == 0) lds_store_relaxed(&cons[wave + 1], yb);
-    }
-    if constexpr (FINAL) { if (yb > ybs) flush_minima(yb - 1, (yb - 1) & 1); }     // the previous row's minima: their atomics were served long ago
-    lds_wait_in_place<NR / 4>(tv, tm);
+      lds_read_lanes<NR / 4>(tv, tm, p == 15 ? aV : 0xFFFFFFFFu, p >= 14 ? aM : 0xFFFFFFFFu);
 #pragma unroll
-    for (int k = 0; k < NR / 4; k++) {
-      V[4 * k] = tv[k].x; V[4 * k + 1] = tv[k].y; V[4 * k + 2] = tv[k].z; V[4 * k + 3] = tv[k].w;
-      M[4 * k] = tm[k].x; M[4 * k + 1] = tm[k].y; M[4 * k + 2] = tm[k].z; M[4 * k + 3] = tm[k].w;
+      for (int k = 0; k < NR / 4; k++) {
+        V[4 * k] = tv[k].x; V[4 * k + 1] = tv[k].y; V[4 * k + 2] = tv[k].z; V[4 * k + 3] = tv[k].w;
+        M[4 * k] = tm[k].x; M[4 * k + 1] = tm[k].y; M[4 * k + 2] = tm[k].z; M[4 * k + 3] = tm[k].w;
+      }
+      if (!last) {                                             // LDS serves a wave's instructions in order: the reads above are done
+        if (lane == 0) lds_store_relaxed(&cons[wave + 1], yb);
+      }
     }
     {
       uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];

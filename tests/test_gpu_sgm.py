@@ -175,3 +175,15 @@ def test_sgm_launch_tag_wraps_around(jn, sgm, oracle, monkeypatch):
                 assert np.array_equal(out[b], exp[b]), (n, b)
     for a in (dL, dR, dD):
         a.free()
+
+
+@pytest.mark.gpu
+def test_sgm_long_chain_of_blocks(jn, sgm, oracle):
+    """A frame of 3840 columns: 61 blocks hand their columns from one to the next through memory (tagged dwords), each waiting only for
+    its producer; rows few enough for the scalar definition to finish in seconds."""
+    W, H, D = 3840, 72, 128
+    L, R = oracle.synth_pair(W, H, 100, 31)
+    exp = sgm.process(sgm.params(D), L, R)
+    out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D), np.stack([L, L, L]), np.stack([R, R, R]))
+    for b in range(3):
+        assert np.array_equal(out[b], exp), b
