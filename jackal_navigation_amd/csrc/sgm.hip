@@ -329,6 +329,7 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.volH1), z.vol));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.gx), z.gx));
     SGM_CREATE_TRY(hipMemset(h->sb.gx, 0, z.gx));               // tag 0 = "never written" (sgm_sweep.hip, k_sw_w)
+    h->sb.gx_bytes = z.gx;
     if (const char* e = getenv("JN_SGM_EPOCH_START")) h->sb.epoch = (uint32_t)atoi(e) & 0xFFFFu;   // test hook: start next to the tag's wrap-around
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.flags), z.flags));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.minr), z.minr));

@@ -26,6 +26,7 @@ struct SweepBuffers {
   uint8_t* volH0;         // m of the horizontal path walking x_k upwards
   uint8_t* volH1;         // ... downwards
   uint32_t* gx;           // boundary columns handed from block to block [n][NB][H][3][4][D/8]; zeroed by the owner when allocated
+  size_t gx_bytes;        // size of gx (all max_batch frames): what is zeroed when the tag wraps
   uint32_t epoch;         // launches of k_sw_w on gx so far, modulo 2^16 (sweep_run advances it and zeroes gx when it wraps)
   uint32_t* flags;        // rows done per (frame, block), then the ticket counter
   uint32_t* minr;         // right-image winners [n][H][W] (S << 16 | d)

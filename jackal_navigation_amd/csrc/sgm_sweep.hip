@@ -1038,13 +1038,13 @@ static hipError_t launch_v(const SwDev& s, int n, bool final, hipStream_t st, co
 // k_sw_w: every launch on the buffer gets the next 16-bit tag; when the tag wraps the buffer is zeroed (tag 0 is never used), so
 // that rows an earlier, larger batch left behind can never carry the current tag
 template <int NR, int NS>
-static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuffers& b, size_t gx_bytes) {
+static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuffers& b) {
   constexpr int RING = NR <= 16 ? 8 : 4;
   const dim3 grid((unsigned)(n * s.NB)), block(NS * 64);
   const size_t dyn = final && s.subpixel ? (size_t)NS * PX * s.D * sizeof(uint16_t) : 0;
   uint32_t* ctr = b.flags + (size_t)n * s.NB;
   if (++b.epoch > 0xFFFFu) {
-    hipError_t e = hipMemsetAsync(b.gx, 0, gx_bytes, st);
+    hipError_t e = hipMemsetAsync(b.gx, 0, b.gx_bytes, st);     // the WHOLE buffer: frames a smaller batch does not touch keep older tags
     if (e != hipSuccess) return e;
     b.epoch = 1;
   }
@@ -1074,9 +1074,8 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   hipLaunchKernelGGL((k_sw_h<NR>), dim3((s.H + 4 * PX - 1) / (4 * PX), n, 2), dim3(256), 0, st, s, n, b.gm, b.volH0, b.volH1);
   const size_t flag_bytes = ((size_t)n * s.NB + 1) * sizeof(uint32_t);
-  const size_t gx_bytes = (size_t)n * s.NB * s.H * (3 * NQ * NR) * sizeof(uint32_t);
   auto sweep = [&](bool final) -> hipError_t {
-    if constexpr (FLOW) return launch_w<NR, NS>(s, n, final, st, b, gx_bytes);
+    if constexpr (FLOW) return launch_w<NR, NS>(s, n, final, st, b);
     else return launch_v<NR, NS>(s, n, final, st, b);
   };
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
