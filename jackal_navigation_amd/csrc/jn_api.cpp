@@ -61,6 +61,7 @@ enum { EV_BEGIN, EV_DESC, EV_SUPPORT, EV_D2H, EV_H2D0, EV_H2D, EV_RASTER, EV_DEN
 struct Slot {
   hipStream_t stream = nullptr;
   hipEvent_t ev_scan = nullptr, ev_merged = nullptr;          // around the cross-rig merge (created with the slot)
+  hipEvent_t ev_head = nullptr;                                // behind the heavy head of stage A (descriptors + support matches): start-up pacing
   float merge_ms = 0.f;
   double* d_flat = nullptr;                                   // the merge's packed buffer of this slot [max_batch][1024 + 4] (written by k_scan_finish)
   hipStream_t stream_a = nullptr;                             // highest-priority stream for stage A (see run_batch); only with JN_STAGE_A_PRIORITY=1
@@ -116,6 +117,11 @@ struct jn_elas {
   // cross-rig merge as the tail of a scan batch (jn_elas_set_comm): merges are queued in submission order on every rank
   jn_comm* comm = nullptr;
   std::mutex merge_m; std::condition_variable merge_cv;
+  // Start-up pacing (JN_PACE, default on for batch handles).  After a synchronisation several batches are submitted at once and their
+  // descriptor / support kernels share the GPU: all of them reach their host stage late, and the GPU then idles while the pool works
+  // through four host stages.  A batch's stage A therefore waits (on the device) until the batch submitted before it has finished its two
+  // heavy kernels — the phase the pipeline settles into by itself.  In steady state that event is long complete: the wait is a no-op.
+  std::mutex pace_m; hipEvent_t pace_prev = nullptr; bool pace = false;
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
@@ -210,10 +216,18 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   // them together.  Host-pointer jobs stage their images on the ordinary stream and keep everything there.
   hipStream_t sa = (s.stream_a && !j.staged) ? s.stream_a : st;
   auto mark_a = [&](int e) { return stage_events ? hipEventRecord(s.ev[e], sa) : hipSuccess; };
-  HIP_TRY(mark_a(EV_BEGIN));
-  launch_descriptor(sa, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
-  HIP_TRY(mark_a(EV_DESC));
-  launch_support(sa, dp, n, s.desc, s.d_can);
+  {
+    std::unique_lock<std::mutex> pl(h->pace_m, std::defer_lock);
+    if (h->pace) {
+      pl.lock();
+      if (h->pace_prev && h->pace_prev != s.ev_head) HIP_TRY(hipStreamWaitEvent(sa, h->pace_prev, 0));
+    }
+    HIP_TRY(mark_a(EV_BEGIN));
+    launch_descriptor(sa, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
+    HIP_TRY(mark_a(EV_DESC));
+    launch_support(sa, dp, n, s.desc, s.d_can);
+    if (h->pace) { HIP_TRY(hipEventRecord(s.ev_head, sa)); h->pace_prev = s.ev_head; }
+  }
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
       launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
   HIP_TRY(mark_a(EV_SUPPORT));
@@ -561,6 +575,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->stage_events = max_batch > 1;
   h->wait_spin_us = max_batch > 1 ? 60 : 1000;
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
+  h->pace = max_batch > 1 && slots > 1;
+  if (const char* e = getenv("JN_PACE")) h->pace = atoi(e) != 0;
   if (const char* e = getenv("JN_STAGE_EVENTS")) h->stage_events = atoi(e) != 0;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
@@ -580,6 +596,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     // the host stage (and, on a multi-GPU node, the other ranks) could use
     for (int e = 0; e < EV_COUNT; e++) CREATE_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
     CREATE_TRY(hipEventCreate(&s->ev_scan)); CREATE_TRY(hipEventCreate(&s->ev_merged));
+    CREATE_TRY(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
     CREATE_TRY(dmalloc(&s->desc, 2 * B * px));
     CREATE_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     CREATE_TRY(dmalloc(&s->info, B)); CREATE_TRY(dmalloc(&s->payload, B * h->payload_cap));
@@ -629,6 +646,7 @@ void jn_elas_destroy(jn_elas* h) {
     for (int e = 0; e < EV_COUNT; e++) if (s->ev[e]) hipEventDestroy(s->ev[e]);
     if (s->ev_scan) hipEventDestroy(s->ev_scan);
     if (s->ev_merged) hipEventDestroy(s->ev_merged);
+    if (s->ev_head) hipEventDestroy(s->ev_head);
     if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);
   }

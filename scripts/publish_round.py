@@ -45,7 +45,7 @@ for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.
                   ("sgm_round2_kernels_bench_line.json", None), ("sgm_pmc_FETCH_SIZE.txt", None), ("sgm_pmc_WRITE_SIZE.txt", None), ("sgm_pmc_SQ.txt", None),
                   ("sgm_strips_ab.txt", None), ("bm_bench_line.json", None), ("bm_config2_bench_line.json", None), ("other_configs.jsonl", None),
                   ("merge_in_worker.txt", None), ("node_rate.txt", None), ("latency_check.txt", None), ("host_pointer_rate.txt", None),
-                  ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None)):
+                  ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None)):
     put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
 sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
 if sq:

@@ -46,6 +46,8 @@ HT=8 timeout 200 python3 scripts/latency_check.py 2>/dev/null | grep -v amdgpu.i
 timeout 400 python3 scripts/host_pointer_rate.py 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_host_pointer_rate.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/probes/valu_rate_probe.hip -o /tmp/valu_rate_probe && timeout 60 /tmp/valu_rate_probe > $out/${tag}_valu_rate_probe.txt 2>&1
 for v in 0 1; do echo "JN_STAGE_A_PRIORITY=$v $(JN_STAGE_A_PRIORITY=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_stage_a_priority_ab.txt
+for v in 1 0 1 0; do echo "JN_PACE=$v, the driver's command (--gpus 1 --steps 20 --warmup 5): $(JN_PACE=$v python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_pace_ab.txt
+for v in 1 0; do echo "JN_PACE=$v, default 200 steps per region: $(JN_PACE=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done >> $out/${tag}_pace_ab.txt
 timeout 1200 python3 scripts/parity_sweep.py 12 2>&1 | grep -v "Opened result\|amdgpu.ids" > $out/${tag}_parity_sweep.txt
 timeout 400 python3 scripts/sgm_stress.py 120 2>&1 | grep -v amdgpu.ids > $out/${tag}_sgm_stress.txt
 tail -8 $out/${tag}_collect.log | cut -c1-300; cat $out/${tag}_sgm_summary.txt $out/${tag}_sgm_strips_ab.txt $out/${tag}_merge_in_worker.txt $out/${tag}_node_rate.txt; tail -2 $out/${tag}_parity_sweep.txt
