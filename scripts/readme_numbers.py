@@ -34,8 +34,11 @@ def block():
     node_ms = [re.search(r"scan: ([0-9.]+) ms per frame", l).group(1) for l in node if "ms per frame" in l]
     merge = [l for l in open(os.path.join(P, "%s_merge_in_worker.txt" % tag)).read().splitlines() if "cost" in l and not l.startswith("#")]
     cost = [float(l.split("cost")[1]) for l in merge]
+    pace_file = os.path.join(P, "%s_pace_ab.txt" % tag)
+    drv = [float(re.search(r": ([0-9.]+) pairs/s", l).group(1)) for l in open(pace_file) if l.startswith("JN_PACE=1, the driver")] if os.path.exists(pace_file) else []
     rows = [
         ("ELAS 1280x720, D=128, batch 32, one MI355X (`bench.py`, the headline)", "%.1f k pairs/s, %.3f ms per step" % (b["value"] / 1e3, b["ms_per_step"])),
+        ("  the same with the driver's command (`--gpus 1 --steps 20 --warmup 5`: 20-step regions)", ("%.1f k pairs/s" % (sum(drv) / len(drv) / 1e3)) if drv else "n/a"),
         ("  roofline of `k_dense2` alone / whole path (fraction of 8 TB/s)", "%.3f / %.3f" % (b["roofline"]["frac"], b["roofline"]["whole_path_frac"])),
         ("  reference CPU path on the same box (%d cores)" % b["cpu_baseline"]["cores"], "%.0f pairs/s" % b["cpu_baseline"]["value"]),
         ("ELAS 640x480, D=64, batch 64", "%.1f k pairs/s" % (find("640x480 rectified pairs (scene disparities <= 64), ELAS disp_max=63 (D=64), batch=64")["value"] / 1e3)),
