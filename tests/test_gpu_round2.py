@@ -644,3 +644,42 @@ def test_support_count_growing_from_batch_to_batch_on_one_slot(jn, oracle, same,
                 assert a[0][i] == 0 and same(a[1][i], D1o) and same(a[2][i], D2o), (k, i)
             else:
                 assert a[0][i] == 1
+
+
+def test_start_up_pacing_changes_no_result(jn, oracle, monkeypatch):
+    """JN_PACE (default on for batch handles with several slots): a batch's stage A waits on the device for the previous submission's two
+    heavy kernels.  It only orders work in time: four slots, twelve batches submitted as fast as the slots free up, with and without it,
+    and the oracle for one frame of each."""
+    from jackal_navigation_amd.device import DeviceArray
+    W, H, B, S, rounds = 320, 180, 2, 4, 3
+    pairs = [[oracle.synth_pair(W, H, 24 + 3 * k, 400 + 5 * k + t) for t in range(B)] for k in range(S * rounds)]
+    dLs = [DeviceArray.from_numpy(np.stack([p[0] for p in ps])) for ps in pairs]
+    dRs = [DeviceArray.from_numpy(np.stack([p[1] for p in ps])) for ps in pairs]
+    results = {}
+    for pace in ("1", "0"):
+        monkeypatch.setenv("JN_PACE", pace)
+        outs = []
+        with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=4) as e:
+            bufs = [dict(d1=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)), d2=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)),
+                         st=(C.c_int32 * B)()) for _ in range(S)]
+            inflight = []
+            for k in range(S * rounds):
+                slot = k % S
+                if len(inflight) == S:
+                    s0 = inflight.pop(0)
+                    e.wait(s0)
+                    outs.append(bufs[s0]["d1"].numpy().copy())
+                b = bufs[slot]
+                e.submit(slot, B, dLs[k].ptr, dRs[k].ptr, W, H * W, b["d1"].ptr, b["d2"].ptr, b["st"])
+                inflight.append(slot)
+            for s0 in inflight:
+                e.wait(s0)
+                outs.append(bufs[s0]["d1"].numpy().copy())
+        results[pace] = outs
+    assert len(results["1"]) == S * rounds
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a, b)
+    p = oracle.params(0)
+    for k in (0, 5, 11):
+        st, d1, _ = oracle.process(p, pairs[k][0][0], pairs[k][0][1])
+        assert st == 0 and np.array_equal(results["1"][k][0], d1), k
