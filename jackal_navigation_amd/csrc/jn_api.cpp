@@ -560,7 +560,11 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   int nthreads = host_threads > 0 ? host_threads : usable_cpus();
   if (nthreads < 1) nthreads = 1;
   nthreads = std::min(nthreads, std::max(1, 8 * max_batch * slots));   // up to 2 sides x 4 parts per frame can run at once
-  h->pool.reset(new Pool(nthreads, hp));
+  // latency-mode handles keep the pool threads that have just worked polling for 300 us (a lone pair's host stage is two 60 us tasks):
+  // lone 640x480 pair 0.40 -> 0.35 ms.  (Running a synchronous call on the caller's thread instead of slot 0's worker was measured too: no gain.)
+  int pool_spin = max_batch == 1 ? 300 : 0;
+  if (const char* e = getenv("JN_POOL_SPIN_US")) pool_spin = atoi(e);
+  h->pool.reset(new Pool(nthreads, hp, pool_spin));
   h->filter_min_batch = nthreads + 1;
   h->filters_fast = support_filters_fast(h->dp, p->incon_window_size, p->incon_min_support);
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;

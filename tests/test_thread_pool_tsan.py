@@ -41,7 +41,7 @@ int main() {
       w.triangulate_side(1, fs, ref_payload[i].data(), &ref_info[i]);
     }
   }
-  Pool pool(5, hp);
+  Pool pool(5, hp, POOL_SPIN_US);                            // 0: workers sleep at once (batch handles); > 0: they and run() poll first (latency handles)
   int bad = 0;
   std::vector<std::thread> th;
   std::vector<int> bad_per(slots, 0);
@@ -77,11 +77,12 @@ int main() {
 
 
 @pytest.mark.timeout(600)
-def test_pool_under_tsan(tmp_path):
+@pytest.mark.parametrize("spin_us", [0, 200])
+def test_pool_under_tsan(tmp_path, spin_us):
     src = tmp_path / "tsan_driver.cpp"
     src.write_text(DRIVER)
     exe = tmp_path / "tsan_driver"
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-mavx2", "-ffp-contract=off", "-fsanitize=thread", "-I", CSRC, str(src),
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-mavx2", "-ffp-contract=off", "-fsanitize=thread", "-DPOOL_SPIN_US=%d" % spin_us, "-I", CSRC, str(src),
            os.path.join(CSRC, "host_stage.cpp"), os.path.join(CSRC, "delaunay.cpp"), "-o", str(exe), "-lpthread"]
     subprocess.run(cmd, check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
