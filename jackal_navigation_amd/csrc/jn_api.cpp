@@ -122,6 +122,7 @@ struct jn_elas {
   // through four host stages.  A batch's stage A therefore waits (on the device) until the batch submitted before it has finished its two
   // heavy kernels — the phase the pipeline settles into by itself.  In steady state that event is long complete: the wait is a no-op.
   std::mutex pace_m; hipEvent_t pace_prev = nullptr; bool pace = false;
+  bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
@@ -311,11 +312,17 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     max_tri = std::max(max_tri, std::max(fi.ntri[0], fi.ntri[1]));
     max_sup = std::max(max_sup, fi.nsup);
   }
-  if (payload_bytes) HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
+  // A latency-mode handle lets the two kernels that consume the payload read it where the host wrote it (pinned memory is visible to
+  // the device): a lone pair's payload is ~50 KB read once, and the copy plus the pause behind it cost more than that (JN_ZERO_COPY=0/1).
+  const uint8_t* payload = s.payload;
+  if (payload_bytes) {
+    if (h->zero_copy_payload) payload = s.h_payload;
+    else HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
+  }
   HIP_TRY(mark(EV_H2D));
   if (any_ok) {
-    launch_grid(st, dp, n, s.info, s.payload, 0, max_sup, s.mark, s.gridbits);      // offsets in FrameInfo are batch-absolute
-    launch_tri_setup(st, dp, n, s.info, s.payload, 0, max_tri, h->tri_cap, s.recs);
+    launch_grid(st, dp, n, s.info, payload, 0, max_sup, s.mark, s.gridbits);      // offsets in FrameInfo are batch-absolute
+    launch_tri_setup(st, dp, n, s.info, payload, 0, max_tri, h->tri_cap, s.recs);
     launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list);
     HIP_TRY(mark(EV_RASTER));
     launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
@@ -581,6 +588,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
   h->pace = max_batch > 1 && slots > 1;
   if (const char* e = getenv("JN_PACE")) h->pace = atoi(e) != 0;
+  h->zero_copy_payload = max_batch == 1;
+  if (const char* e = getenv("JN_ZERO_COPY")) h->zero_copy_payload = atoi(e) != 0;
   if (const char* e = getenv("JN_STAGE_EVENTS")) h->stage_events = atoi(e) != 0;
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
