@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjn_stereo.so")
+# JN_STEREO_LIB: another build of the same library (A/B runs of kernel variants); there is still no fallback if it does not load
+LIB_PATH = os.environ.get("JN_STEREO_LIB") or os.path.join(HERE, "libjn_stereo.so")
 
 JN_OK, JN_ERR_FEW_SUPPORT, JN_ERR_UNSUPPORTED, JN_ERR_INVALID, JN_ERR_NO_DEVICE, JN_ERR_INTERNAL, JN_ERR_COMM = range(7)
 STATUS_NAMES = ["JN_OK", "JN_ERR_FEW_SUPPORT", "JN_ERR_UNSUPPORTED", "JN_ERR_INVALID", "JN_ERR_NO_DEVICE", "JN_ERR_INTERNAL", "JN_ERR_COMM"]

@@ -104,31 +104,54 @@ DEV void costs64(const uint64_t (&ww)[NR / 2], uint32_t ref, uint32_t P2pk, uint
   for (int r = 0; r < NR; r++) Cp[r] = __builtin_amdgcn_perm(a[(r + NR) >> 1], a[r >> 1], (r & 1) ? 0x07060302u : 0x05040100u);
 }
 
-// The adjoining pairs of the neighbouring quarters: up = the quarter below's j = DPL-1 (high half of its register NR-1) for
-// this lane's j = 0; dn = the quarter above's j = 0 for this lane's j = DPL-1.  Issued ahead of the cells that use them.
+// Three-input packed maxima / minima.  gfx950's v_pk_maximum3_f16 / v_pk_minimum3_f16 compare IEEE halves; every value the recurrence
+// holds is a u16 below 0x7C00 (a positive finite half, denormals included, which these instructions neither flush nor quieten), and on
+// those the order of the halves IS the unsigned order: scripts/probes/pk3_probe.hip checks all 2^30 pairs of such patterns on the device.
+// (Written with the element-wise builtins, which the back end folds into the three-input forms: behind inline assembly the hazard
+// recogniser pads every use of the result with an s_nop.)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+DEV uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {
+  const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
+}
+DEV uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
+  const f16x2 x = __builtin_bit_cast(f16x2, a), y = __builtin_bit_cast(f16x2, b), z = __builtin_bit_cast(f16x2, c);
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_minimum(__builtin_elementwise_minimum(x, y), z));
+}
+
+// The adjoining pairs of the neighbouring quarters, already reduced by P1 (T = X (-) P1: max(a, b) (-) P1 = max(a (-) P1, b (-) P1)):
+// up = the quarter below's j = DPL-1 (high half of its register NR-1) for this lane's j = 0; dn = the quarter above's j = 0 for this
+// lane's j = DPL-1.  Issued ahead of the cells that use them.
 template <int NR>
-DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t& up, uint32_t& dn) {
-  const uint32_t a = bperm((lane - PX) & 63, X[NR - 1]);
-  const uint32_t b = bperm((lane + PX) & 63, X[0]);
+DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t P1pk, uint32_t& up, uint32_t& dn) {
+  const uint32_t a = bperm((lane - PX) & 63, pk_subsat(X[NR - 1], P1pk));
+  const uint32_t b = bperm((lane + PX) & 63, pk_subsat(X[0], P1pk));
   up = q == 0 ? 0u : a;
   dn = q == NQ - 1 ? 0u : b;
 }
-template <int NR>
+// 5.5 packed instructions per register and path: T = X (-) P1, Y = max3(X[r], T[r-1], T[r+1]), sum of Y, Ln = Cp - Y, half a min3 for
+// the minimum of Ln, and (path_normalise) X' = (P2 + min Ln) (-) Ln.
+// SUB: the sum is carried negated (acc -= Y): the final sweep starts acc at 8 (C + P2) - (the five stored paths) and ends with S.
+template <int NR, bool SUB = false>
 DEV void path_cells(const uint32_t (&X)[NR], uint32_t up, uint32_t dn, const uint32_t (&Cp)[NR], uint32_t (&acc)[NR], uint32_t (&Ln)[NR], uint32_t& mn,
                     uint32_t P1pk) {
-  mn = 0xFFFFFFFFu;
-  auto cell = [&](int r, uint32_t nb) __attribute__((always_inline)) {
-    const uint32_t y = pk_max(X[r], pk_subsat(nb, P1pk));
-    acc[r] = pk_add(acc[r], y);
-    Ln[r] = pk_sub(Cp[r], y);
-    mn = pk_min(mn, Ln[r]);
-  };
+  uint32_t T[NR];
 #pragma unroll
-  for (int r = 1; r < NR - 1; r++) cell(r, pk_max(X[r - 1], X[r + 1]));
+  for (int r = 0; r < NR; r++) T[r] = pk_subsat(X[r], P1pk);
+  auto cell = [&](int r, uint32_t lo, uint32_t hi) __attribute__((always_inline)) {
+    const uint32_t y = pk_max3(X[r], lo, hi);
+    acc[r] = SUB ? pk_sub(acc[r], y) : pk_add(acc[r], y);
+    Ln[r] = pk_sub(Cp[r], y);
+  };
   // register 0: j = 0 has j-1 in the quarter below, j = NR has j-1 = NR-1 in the low half of register NR-1
-  cell(0, pk_max(__builtin_amdgcn_perm(X[NR - 1], up, 0x05040302u), X[1]));
+  cell(0, __builtin_amdgcn_perm(T[NR - 1], up, 0x05040302u), T[1]);
+#pragma unroll
+  for (int r = 1; r < NR - 1; r++) cell(r, T[r - 1], T[r + 1]);
   // register NR-1: j = NR-1 has j+1 = NR in the high half of register 0, j = DPL-1 has j+1 in the quarter above
-  cell(NR - 1, pk_max(X[NR - 2], __builtin_amdgcn_perm(dn, X[0], 0x05040302u)));
+  cell(NR - 1, T[NR - 2], __builtin_amdgcn_perm(dn, T[0], 0x05040302u));
+  mn = pk_min(Ln[0], Ln[1]);
+#pragma unroll
+  for (int r = 2; r < NR; r += 2) mn = pk_min3(mn, Ln[r], Ln[r + 1]);
 }
 // minimum over the pixel's four lanes (and both halves) with the gfx950 row / half swaps: pure VALU, no LDS round trip
 DEV uint32_t pixel_min(uint32_t mn) {
@@ -281,7 +304,7 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t*
     costs<NR>(w, ref, P2pk, Cp);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
-    path_neighbours<NR>(X, lane, q, up, dn);
+    path_neighbours<NR>(X, lane, q, P1pk, up, dn);
     path_cells<NR>(X, up, dn, Cp, acc, Ln, mn, P1pk);
     path_normalise<NR>(X, Ln, pixel_min(mn), (uint32_t)s.P2);
     if (valid) store_bytes<NR>(vol + (size_t)xk * s.D, q, acc);
@@ -310,7 +333,7 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t*
   }
 }
 template <int NR>
-__global__ void __launch_bounds__(256) k_sw_h(SwDev s, int n, const uint8_t* __restrict__ gm, uint8_t* __restrict__ vol0, uint8_t* __restrict__ vol1) {
+__global__ void __launch_bounds__(256, NR <= 16 ? 4 : 2) k_sw_h(SwDev s, int n, const uint8_t* __restrict__ gm, uint8_t* __restrict__ vol0, uint8_t* __restrict__ vol1) {
   constexpr int DPL = 2 * NR, SPAN = HCH + 3 * DPL / 4;
   __shared__ uint32_t sR[4][16 * SPAN], sL[4][16 * HCH];       // per wave: the staged dwords of its 16 rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, p = lane & 15;
@@ -349,7 +372,7 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
   for (int k = tid; k < 2 * (NS + 1) * SLOT; k += (NS + 1) * 64) (&exch[0][0][0])[k] = P2pk;     // X = P2: a path that starts here
   if (FINAL) for (int k = tid; k < 2 * NQ * MR; k += (NS + 1) * 64) (&minR[0][0][0])[k] = 0xFFFFFFFFu;
   __syncthreads();
-  const int ticket = s_ticket;
+  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);     // wave-uniform, and known to be: everything derived from it (frame, block, rows) stays scalar
   const int j = NB - 1 - ticket / n, frame = ticket % n;       // producers (larger j) hold the smaller tickets
   const int x0 = s.xmin + BLK * j;                             // sheared origin of this block: x' in [x0, x0 + BLK)
   const int ybs = max(0, -(x0 + BLK - 1)), ybe = min(H - 1, W - 1 - x0);
@@ -486,9 +509,9 @@ __global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip
       // all quarter-boundary permutes first (their LDS round trip overlaps the first path's cells), then one path at a time:
       // side by side the three paths would keep 3 NR unnormalised registers alive and cost a wave per SIMD in occupancy
       uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];
-      path_neighbours<NR>(V, lane, q, upV, dnV);
-      path_neighbours<NR>(G, lane, q, upG, dnG);
-      path_neighbours<NR>(M, lane, q, upM, dnM);
+      path_neighbours<NR>(V, lane, q, P1pk, upV, dnV);
+      path_neighbours<NR>(G, lane, q, P1pk, upG, dnG);
+      path_neighbours<NR>(M, lane, q, P1pk, upM, dnM);
       path_cells<NR>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
       path_normalise<NR>(V, Ln, pixel_min(mn), (uint32_t)s.P2);
       path_cells<NR>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
@@ -597,6 +620,15 @@ DEV int lds_load_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RE
 DEV void lds_store_relaxed(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Profiling switches of k_sw_w (results are then WRONG; attribution only): compiled in with -DJN_SGM_PROFILE (make ... EXTRA=-DJN_SGM_PROFILE),
+// absent from the product build — a switch that is only tested at run time still keeps registers alive across the code it guards.
+//   JN_SGM_DBG bits: 1 no wait for / load of the producer block's columns, 2 no right-image minima (LDS atomics + flush), 4 no volume loads /
+//   stores, 16 no per-row input fetch, 32 no waiting on the neighbour strip's LDS counters
+#ifdef JN_SGM_PROFILE
+#define SW_DBG(bit) (s.dbg & (bit))
+#else
+#define SW_DBG(bit) false
+#endif
 DEV uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 // N ds_read_b128 from addrV into tv and N from addrM into tm in the lanes whose address is not 0xFFFFFFFF (the others are switched off
 // with the exec mask around the reads and keep what their registers held: tv / tm are in/out operands), then the wait for them — ONE
@@ -630,7 +662,7 @@ DEV void lds_read_lanes<8>(u32x4 (&tv)[8], u32x4 (&tm)[8], uint32_t addrV, uint3
 }
 
 template <int NR, int NS, int RING, bool FINAL, bool WIDE>
-__global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
+__global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ? 2 : 1) k_sw_w(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
                                                   const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1, uint32_t* __restrict__ gx,
                                                   uint32_t* __restrict__ ctr, uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
   constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = PX + DPL, NG = (SLOT + 63) / 64;
@@ -649,7 +681,7 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
   for (int k = tid; k < RING * NS * SLOT; k += NS * 64) (&ring[0][0][0])[k] = P2pk;            // X = P2: a path that starts here
   if (FINAL) for (int k = tid; k < NS * 2 * NQ * MR; k += NS * 64) (&minR[0][0][0][0])[k] = 0xFFFFFFFFu;
   __syncthreads();
-  const int ticket = s_ticket;
+  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);     // wave-uniform, and known to be: everything derived from it (frame, block, rows) stays scalar
   // producers (larger j) hold the smaller tickets; the block index is the major order: all frames walk through their parallelogram in phase
   // and finish together (frame-major tickets were measured: 2 588 against 3 168 pairs/s — the last frames run alone at the end)
   const int j = NB - 1 - ticket / n, frame = ticket % n;
@@ -669,9 +701,11 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
 #pragma unroll
   for (int k = 0; k < NG; k++) g[k] = 0u;
   auto load_prod = [&](int yr, uint32_t (&dst)[NG]) __attribute__((always_inline)) {
-    const uint32_t* src = p_gx + (size_t)yr * SLOT;
+    const uint32_t* src = p_gx + (size_t)yr * SLOT;             // wave-uniform
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                                // scalar base + lane offset, formed here: a per-lane 64-bit pointer kept across the loop is two registers the final sweep lacks
 #pragma unroll
-    for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; dst[k] = (SLOT % 64 == 0 || o < SLOT) ? ld_sc1(src + o) : tagpk; }
+    for (int k = 0; k < NG; k++) { const int o = ln + 64 * k; dst[k] = (SLOT % 64 == 0 || o < SLOT) ? ld_sc1(src + o) : tagpk; }
   };
   const int q = lane >> 4, p = lane & 15;
   const int xl = x0 + PX * wave + p;                           // this lane's sheared column
@@ -680,52 +714,90 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
 #pragma unroll
   for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = P2pk;
   const size_t img_rows = (size_t)H * s.Wp;
-  // a row's input bytes.  Every v_mqsad takes an (even-aligned) register pair holding 8 consecutive bytes, and consecutive pairs overlap
-  // by 4 bytes: loading dwords and re-pairing them made the compiler copy registers right behind the loads — and wait for them there, a
-  // row before the bytes are needed.  Each pair is therefore loaded on its own (the same cache lines; 8 instead of 3 load instructions).
-  struct RowIn { uint64_t ww[NR / 2]; uint32_t ref; };
+  // A ROW'S INPUT BYTES travel through LDS.  The lanes of a strip read overlapping windows of the same ~150 bytes of the right row (and 19 of
+  // the left one): loaded per lane into registers a row ahead — 17 loop-carried registers that the final sweep had no room for — they are now
+  // fetched ONCE per wave (8 bytes per lane), two rows ahead, and read from LDS right before the costs.  A lane's window starts at byte
+  // p + DPL q: any alignment, and a misaligned ds_read costs 64 cycles of the CU's LDS pipeline against 4.6 for an aligned one
+  // (scripts/probes/lds_unaligned_probe.hip).  The fetching lanes therefore store FOUR copies of the row, shifted by 0 .. 3 bytes
+  // (v_alignbyte of their two dwords), and a lane reads dword-aligned from copy p & 3.  Two rows of LDS per strip: the commit of row yb + 2
+  // overwrites row yb's slot behind row yb's reads (LDS serves a wave's instructions in order).
+  constexpr int RBYTES = PX - 1 + DPL * (NQ - 1) + 4 * (NR / 2 - 1) + 8;      // right-row bytes a strip touches
+  constexpr int NRD = (RBYTES + 3) / 4, NLD = (PX + 6) / 4, TD = NRD + NLD, NSTG = (TD + 63) / 64;
+  __shared__ uint32_t rowbuf[NS][2][4][NSTG * 64];              // [strip][row parity][byte shift][dword]
   const int y0 = flip ? H - 1 - ybs : ybs;
   const long long row_step = (flip ? -(long long)s.Wp : (long long)s.Wp) + 1;
-  const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs);
-  const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs) + DPL * q;
-  // `more` = there is a row after this one: the pointers only advance then, so that the loop can fetch unconditionally (a fetch under
-  // a condition makes the compiler wait for ALL loads in flight — the row's own included — where the previous row's bytes are used)
-  auto fetch_row = [&](RowIn& in_, bool more) __attribute__((always_inline)) {
+  const uint8_t* gsrc;                                          // left row of the strip's next fetch (wave-uniform; the right image lies n images further)
+  uint32_t soff[NSTG];                                          // this lane's dword of a fetch, relative to gsrc
+  {
+    gsrc = gm + (size_t)frame * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (x0 + PX * wave + ybs);
+    const uint32_t to_right = (uint32_t)((size_t)n * img_rows);
 #pragma unroll
-    for (int k = 0; k < NR / 2; k++) in_.ww[k] = load_u64_unaligned(rowR + 4 * k);
-    in_.ref = load_u32_unaligned(rowL);
-    const long long st = more ? row_step : 0;
-    rowL += st; rowR += st;
+    for (int k = 0; k < NSTG; k++) { const int i = lane + 64 * k; soff[k] = i < NRD ? to_right + 4 * i : 4 * (min(i, TD - 1) - NRD); }
+  }
+  int next_row = ybs;                                           // the row the next fetch is for (rows beyond ybe fetch ybe again: unconditional loads)
+  auto stage_load = [&](uint64_t (&d)[NSTG]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NSTG; k++) d[k] = load_u64_unaligned(gsrc + soff[k]);
+    gsrc += next_row < ybe ? row_step : 0;
+    next_row++;
   };
-  if (last && has_prod && ybs - 1 >= ybsp && ybs - 1 <= ybep) load_prod(ybs - 1, g);
-  RowIn cur;
-  fetch_row(cur, ybs < ybe);
-  // the final sweep's three stored volumes of a pixel (clamped columns: always a valid address, so the loads need no condition)
-  // (kept as the 16-byte vectors they are loaded as: split into dwords they become separate loop-carried values, the compiler gives some of
-  // them other registers at the top of the loop than the load writes, and the copy it then needs waits for the load right behind it)
-  constexpr int NVF = FINAL ? (WIDE ? NR / 4 : NR / 8) : 1, NVH = FINAL ? NR / 8 : 1;
-  u32x4 fF[NVF], fH0[NVH], fH1[NVH];
-  auto pixel_of = [&](int yb) __attribute__((always_inline)) {
-    const int y = flip ? H - 1 - yb : yb;
-    return ((size_t)frame * H + y) * W + (size_t)min(max(xl + yb, 0), W - 1);
-  };
-  auto load_volumes = [&](size_t pix) __attribute__((always_inline)) {
-    if constexpr (FINAL) {
-      const uint8_t* pF = volF + pix * D * (WIDE ? 2 : 1) + 16 * q;
+  auto stage_write = [&](int row, const uint64_t (&d)[NSTG]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int c = 0; c < NVF; c++) fF[c] = *reinterpret_cast<const u32x4*>(pF + 64 * c);
-#pragma unroll
-      for (int c = 0; c < NVH; c++) fH0[c] = *reinterpret_cast<const u32x4*>(volH0 + pix * D + 64 * c + 16 * q);
-#pragma unroll
-      for (int c = 0; c < NVH; c++) fH1[c] = *reinterpret_cast<const u32x4*>(volH1 + pix * D + 64 * c + 16 * q);
+    for (int k = 0; k < NSTG; k++) {
+      const uint32_t lo = (uint32_t)d[k], hi = (uint32_t)(d[k] >> 32);
+      uint32_t* dst = &rowbuf[wave][row & 1][0][lane + 64 * k];
+      dst[0] = lo;
+      dst[NSTG * 64] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+      dst[2 * NSTG * 64] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+      dst[3 * NSTG * 64] = __builtin_amdgcn_alignbyte(hi, lo, 3);
     }
   };
-  load_volumes(pixel_of(ybs));
+  struct RowIn { uint64_t ww[NR / 2]; uint32_t ref; };
+  const int rd_at = (p & 3) * (NSTG * 64) + (p >> 2) + (DPL / 4) * q;   // this lane's first dword inside a staged row: copy p & 3, dword-aligned
+  auto read_row = [&](int row, RowIn& in_) __attribute__((always_inline)) {
+    const uint32_t* rb = &rowbuf[wave][row & 1][0][0] + rd_at;
+#pragma unroll
+    for (int k = 0; k < NR / 2; k++) in_.ww[k] = (uint64_t)rb[k] | ((uint64_t)rb[k + 1] << 32);      // each pair on its own (ds_read2_b32): one v_mqsad operand, no re-pairing
+    in_.ref = (&rowbuf[wave][row & 1][0][0])[(p & 3) * (NSTG * 64) + NRD + (p >> 2)];
+  };
+  if (last && has_prod && ybs - 1 >= ybsp && ybs - 1 <= ybep) load_prod(ybs - 1, g);
+  uint64_t stg[NSTG];                                           // the fetch in flight: row yb + 2 at the top of row yb
+  {
+    uint64_t d0[NSTG], d1[NSTG];
+    stage_load(d0); stage_load(d1); stage_load(stg);
+    stage_write(ybs, d0); stage_write(ybs + 1, d1);
+  }
+  // The volumes are addressed as ROW BUFFERS: a buffer resource over the row's W * D bytes (scalar registers, rebuilt per row) and one 32-bit
+  // offset per lane.  Lanes outside the image have an offset outside the buffer (a negative column wraps to ~2^32): their loads return zeros
+  // nobody uses and their stores are dropped — every instruction stays unconditional (the compiler can count what is in flight), no
+  // clamping, and no 64-bit address arithmetic per lane (it cost ~15 vector instructions and 6 registers per row).
+  // The final sweep's three stored volumes are kept as the 16-byte vectors they are loaded as: split into dwords they become separate
+  // loop-carried values, the compiler gives some of them other registers at the top of the loop than the load writes, and the copy it then
+  // needs waits for the load right behind it.
+  constexpr int NVF = FINAL ? (WIDE ? NR / 4 : NR / 8) : 1, NVH = FINAL ? NR / 8 : 1;
+  constexpr int FB = WIDE ? 2 : 1;                              // bytes per cell of the F volume
+  u32x4 fF[NVF], fH0[NVH], fH1[NVH];
+  auto row_rsrc = [&](const uint8_t* vol, int yb, int cell_bytes) __attribute__((always_inline)) {
+    const int y = flip ? H - 1 - yb : yb;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(vol + ((size_t)frame * H + y) * W * D * cell_bytes), 0, W * D * cell_bytes, 0x00020000);
+  };
+  auto load_volumes = [&](int yb) __attribute__((always_inline)) {
+    if constexpr (FINAL) {
+      const __amdgpu_buffer_rsrc_t rF = row_rsrc(volF, yb, FB), r0 = row_rsrc(volH0, yb, 1), r1 = row_rsrc(volH1, yb, 1);
+      const int off = (xl + yb) * D + 16 * q, offF = (xl + yb) * D * FB + 16 * q;
+#pragma unroll
+      for (int c = 0; c < NVF; c++) fF[c] = __builtin_amdgcn_raw_buffer_load_b128(rF, offF + 64 * c, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NVH; c++) fH0[c] = __builtin_amdgcn_raw_buffer_load_b128(r0, off + 64 * c, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NVH; c++) fH1[c] = __builtin_amdgcn_raw_buffer_load_b128(r1, off + 64 * c, 0, 0);
+    }
+  };
+  load_volumes(ybs);
   // everything requested so far is complete before the loop starts (uses the compiler must wait for): the waits inside the loop are then
   // written for what a row leaves in flight, not for the prologue
 #pragma unroll
-  for (int k = 0; k < NR / 2; k++) asm volatile("" : : "v"(cur.ww[k]));
-  asm volatile("" : : "v"(cur.ref));
+  for (int k = 0; k < NSTG; k++) asm volatile("" : : "v"(stg[k]));
   if constexpr (FINAL) {
 #pragma unroll
     for (int k = 0; k < NVF; k++) asm volatile("" : : "v"(fF[k]));
@@ -738,9 +810,11 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
       const int y = flip ? H - 1 - yb : yb;
       uint32_t* grow = gminR + ((size_t)frame * H + y) * W;
       uint32_t* mrow = &minR[wave][buf][0][0];
+      int ln = lane;
+      asm volatile("" : "+v"(ln));                              // the index arithmetic below is redone per row: hoisted out of the loop it costs a dozen registers the kernel does not have
 #pragma unroll
       for (int k = 0; k < (NQ * MR + 63) / 64; k++) {
-        const int idx = lane + 64 * k;
+        const int idx = ln + 64 * k;
         if ((NQ * MR) % 64 == 0 || idx < NQ * MR) {
           const uint32_t kv = mrow[idx];
           if (kv != 0xFFFFFFFFu) {
@@ -762,21 +836,26 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
     const int y = flip ? H - 1 - yb : yb;
     const int xk = xl + yb;
     const bool in = xk >= 0 && xk < W;
-    const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
     uint32_t Cp[NR], acc[NR];
-    costs64<NR>(cur.ww, cur.ref & 0x00FFFFFFu, P2pk, Cp);
+    {
+      RowIn cur;
+      read_row(yb, cur);
+      costs64<NR>(cur.ww, cur.ref & 0x00FFFFFFu, P2pk, Cp);
+    }
 #pragma unroll
     for (int r = 0; r < NR; r++) asm volatile("" : "+v"(Cp[r]) : : "memory");   // the costs are computed HERE (they would otherwise sink to their first
     __builtin_amdgcn_sched_barrier(0);                         // use, past the loads that reuse their input registers — which then get copied)
-    fetch_row(cur, yb + 1 < ybe);                              // row yb + 1's bytes (the last row fetches its own again)
+    if (!SW_DBG(16)) { stage_write(yb + 2, stg); stage_load(stg); }   // row yb + 2 (fetched during row yb - 1) into the ring; request row yb + 3
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!FINAL) {
 #pragma unroll
-    for (int r = 0; r < NR; r++) acc[r] = 0u;
-    if constexpr (FINAL) { if (yb > ybs) flush_minima(yb - 1, (yb - 1) & 1); }     // the previous row's minima: their atomics were served long ago
+      for (int r = 0; r < NR; r++) acc[r] = 0u;
+    }
+    if constexpr (FINAL) { if (yb > ybs && !SW_DBG(2)) flush_minima(yb - 1, (yb - 1) & 1); }     // the previous row's minima: their atomics were served long ago
     // ---- last strip: the producer block's columns of row yb - 1 ----
     if (last) {
       const int yr = yb - 1;
-      if (has_prod && yr >= ybsp && yr <= ybep) {
+      if (has_prod && yr >= ybsp && yr <= ybep && !SW_DBG(1)) {
         // g was loaded for exactly this row (before the loop or during the previous row).  The usual case — every tag is this launch's —
         // has its own code path, so that its wait counts only what is older than g; the retry loop (the producer has not written the
         // whole row yet) reloads into other registers.
@@ -802,12 +881,12 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
 #pragma unroll
         for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = P2pk; }
       }
-      if (has_prod && yb >= ybsp && yb <= ybep && yb < ybe) load_prod(yb, g);  // the next row's, speculatively: checked when it is needed
+      if (has_prod && yb >= ybsp && yb <= ybep && yb < ybe && !SW_DBG(1)) load_prod(yb, g);  // the next row's, speculatively: checked when it is needed
     }
     // ---- the right neighbour's columns of row yb - 1 ----
     const uint32_t* e;
     if (!last) {
-      while (known_p < yb) {
+      while (known_p < yb && !SW_DBG(32)) {
         known_p = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&prog[wave + 1]));
         if (known_p < yb) __builtin_amdgcn_s_sleep(1);
       }
@@ -843,17 +922,40 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
         if (lane == 0) lds_store_relaxed(&cons[wave + 1], yb);
       }
     }
+    if constexpr (FINAL) {
+      // S starts as 8 (C + P2) - (the five stored paths) and the three upward paths subtract their Y from it.  The stored volumes — requested
+      // after the previous row's paths — are consumed HERE, before the cells: their 24 registers are free while the cells hold their
+      // temporaries (the kernel then fits three waves per SIMD), at the price of a shorter lead for those loads.
+#pragma unroll
+      for (int k = 0; k < NR / 2; k++) {
+        uint32_t a, b;
+        const uint32_t h0 = fH0[k >> 2][k & 3], h1 = fH1[k >> 2][k & 3];
+        if constexpr (WIDE) { a = pk_add(pk_add(fF[(2 * k) >> 2][(2 * k) & 3], unpack_lo(h0)), unpack_lo(h1)); b = pk_add(pk_add(fF[(2 * k + 1) >> 2][(2 * k + 1) & 3], unpack_hi(h0)), unpack_hi(h1)); }
+        else { const uint32_t hb = h0 + h1, ff = fF[k >> 2][k & 3];    // bytes <= 2 P2 <= 170: no carry between bytes
+               a = pk_add(unpack_lo(ff), unpack_lo(hb)); b = pk_add(unpack_hi(ff), unpack_hi(hb)); }
+        acc[2 * k] = pk_sub(pk_shl3(Cp[2 * k]), a);
+        acc[2 * k + 1] = pk_sub(pk_shl3(Cp[2 * k + 1]), b);
+      }
+#pragma unroll
+      for (int r = 0; r < NR; r++) asm volatile("" : "+v"(acc[r]));
+      __builtin_amdgcn_sched_barrier(0);
+    }
     {
       uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];
-      path_neighbours<NR>(V, lane, q, upV, dnV);
-      path_neighbours<NR>(G, lane, q, upG, dnG);
-      path_neighbours<NR>(M, lane, q, upM, dnM);
-      path_cells<NR>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
+      path_neighbours<NR>(V, lane, q, P1pk, upV, dnV);
+      path_neighbours<NR>(G, lane, q, P1pk, upG, dnG);
+      path_neighbours<NR>(M, lane, q, P1pk, upM, dnM);
+      path_cells<NR, FINAL>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
       path_normalise<NR>(V, Ln, pixel_min(mn), (uint32_t)s.P2);
-      path_cells<NR>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
+      path_cells<NR, FINAL>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
       path_normalise<NR>(G, Ln, pixel_min(mn), (uint32_t)s.P2);
-      path_cells<NR>(M, upM, dnM, Cp, acc, Ln, mn, P1pk);
+      path_cells<NR, FINAL>(M, upM, dnM, Cp, acc, Ln, mn, P1pk);
       path_normalise<NR>(M, Ln, pixel_min(mn), (uint32_t)s.P2);
+    }
+    if constexpr (FINAL) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (!SW_DBG(4)) load_volumes(min(yb + 1, ybe));   // the next row's volumes: in flight during the winners, the publishing and the next row's costs
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
 #pragma unroll
@@ -862,7 +964,7 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
     // ---- publish this strip's first two columns of row yb ----
     if (wave > 0 || j > 0) {
       if (wave > 0) {
-        while (known_c < yb - RING + 1) {                      // the slot still holds row yb - RING until the left neighbour has read it
+        while (known_c < yb - RING + 1 && !SW_DBG(32)) {                      // the slot still holds row yb - RING until the left neighbour has read it
           known_c = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&cons[wave]));
           if (known_c < yb - RING + 1) __builtin_amdgcn_s_sleep(1);
         }
@@ -883,32 +985,31 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
       } else {                                                 // strip 0: to the next block through memory, tagged
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
         uint32_t* dst = my_gx + (size_t)yb * SLOT;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int k = 0; k < NG; k++) { const int oo = lane + 64 * k; if (SLOT % 64 == 0 || oo < SLOT) st_sc1(dst + oo, o[oo] | tagpk); }
+        for (int k = 0; k < NG; k++) { const int oo = ln + 64 * k; if (SLOT % 64 == 0 || oo < SLOT) st_sc1(dst + oo, o[oo] | tagpk); }
       }
     }
     if (!last && yb < ybe) known_p = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&prog[wave + 1]));   // for the next row: usually already far enough
     if constexpr (!FINAL) {
       // pixels outside the image store into the slack behind the volume: an unconditional store keeps the next row's wait for its input
       // bytes from also waiting for these stores (the compiler can then count them)
-      const size_t vpix = in ? pix : (size_t)n * H * W;
-      if constexpr (WIDE) store_words<NR>(volF + vpix * D * 2, q, acc); else store_bytes<NR>(volF + vpix * D, q, acc);
-    } else {
-      // S = 8 (C + P2) - (the three upward Y + the stored five)
-      uint32_t S[NR];
+      if (!SW_DBG(4)) {
+        const __amdgpu_buffer_rsrc_t rF = row_rsrc(volF, yb, FB);
+        const int off = xk * D * FB + 16 * q;
+        if constexpr (WIDE) {
 #pragma unroll
-      for (int k = 0; k < NR / 2; k++) {
-        uint32_t a, b;
-        const uint32_t h0 = fH0[k >> 2][k & 3], h1 = fH1[k >> 2][k & 3];
-        if constexpr (WIDE) { a = pk_add(pk_add(fF[(2 * k) >> 2][(2 * k) & 3], unpack_lo(h0)), unpack_lo(h1)); b = pk_add(pk_add(fF[(2 * k + 1) >> 2][(2 * k + 1) & 3], unpack_hi(h0)), unpack_hi(h1)); }
-        else { const uint32_t hb = h0 + h1, ff = fF[k >> 2][k & 3];    // bytes <= 2 P2 <= 170: no carry between bytes
-               a = pk_add(unpack_lo(ff), unpack_lo(hb)); b = pk_add(unpack_hi(ff), unpack_hi(hb)); }
-        S[2 * k] = pk_sub(pk_shl3(Cp[2 * k]), pk_add(acc[2 * k], a));
-        S[2 * k + 1] = pk_sub(pk_shl3(Cp[2 * k + 1]), pk_add(acc[2 * k + 1], b));
+          for (int c = 0; c < NR / 4; c++) __builtin_amdgcn_raw_buffer_store_b128((u32x4){acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]}, rF, off + 64 * c, 0, 0);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NR / 8; c++)
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack4(acc[8 * c], acc[8 * c + 1]), pack4(acc[8 * c + 2], acc[8 * c + 3]), pack4(acc[8 * c + 4], acc[8 * c + 5]),
+                                                           pack4(acc[8 * c + 6], acc[8 * c + 7])}, rF, off + 64 * c, 0, 0);
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      load_volumes(pixel_of(min(yb + 1, ybe)));                // the next row's volumes, into the registers S has just consumed
-      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      const uint32_t (&S)[NR] = acc;                           // S = 8 (C + P2) - (the three upward Y + the stored five)
       uint32_t key = 0xFFFFFFFFu;
       uint32_t* mr = &minR[wave][yb & 1][q][p];
 #pragma unroll
@@ -916,7 +1017,7 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
         const uint32_t klo = (S[r] << 16) | (uint32_t)r, khi = (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR);
         key = min(key, min(klo, khi));
       }
-      if (in) {
+      if (in && !SW_DBG(2)) {
 #pragma unroll
         for (int r = 0; r < NR; r++) {
           atomicMin(mr + r, (S[r] << 16) | (uint32_t)r);
@@ -950,7 +1051,10 @@ __global__ void __launch_bounds__(NS * 64, (NR == 16 && !FINAL) ? 3 : 1) k_sw_w(
         }
       }
       // unconditional (the other lanes write into the slack behind the array): the next row's first wait can then count it
-      dLp[(in && q == 0) ? pix : (size_t)n * H * W + lane] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
+      {
+        const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(dLp + ((size_t)frame * H + y) * W, 0, W * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32((uint32_t)d | ((uint32_t)(uint16_t)d16 << 16), rD, q == 0 ? xk * 4 : -1, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -259,7 +259,8 @@ def test_bench_gpus_2_starts_two_ranks_itself():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and len(j["ranks"]) == 2 and {r["rank"] for r in j["ranks"]} == {0, 1}
-    assert j["check"]["ok"] is True and j["check"]["expected"] == "7653a9cf7e239d04"
+    # every frame of both slots against the compiled reference's recorded answers (tests/golden/bench_batch_golden.json)
+    assert j["check"]["ok"] is True and j["check"]["frames_checked"]["D1"] == 2 * 4 and j["check"]["n_mismatches"] == 0
     assert j["value"] > 0 and j["config"]["pairs_failed"] == 0
     assert "roofline" in j and j["roofline"]["ms_per_launch"] > 0
     # the two ranks were given disjoint host cores (when there are at least two cores to share)
