@@ -471,6 +471,7 @@ def run_rank(a):
                          "torch.distributed.run with --nproc-per-node N" % (a.gpus, world))
     W, H, B, S = a.width, a.height, a.batch, a.slots
     scene = a.scene_disp or a.disp
+    started = start_watchdog(a)
 
     # CPU baseline first: it forks worker processes, which must happen before this process touches the GPU.
     cpu = None
@@ -631,6 +632,7 @@ def run_rank(a):
 
     run(a.warmup)
     sync()
+    started.set()                                 # through start-up: the watchdog stands down
     stage_acc.clear()
     del dense_ms[:]
     cpu0, cg0, t_cpu0 = thread_cpu_seconds(), cgroup_cpu_stat(), time.perf_counter()
@@ -880,8 +882,41 @@ def run_rank(a):
         raise SystemExit("bench.py: D1 of the timed path differs from the reference's golden hash: %s" % check)
 
 
+def enough_gpus(a):
+    """--gpus N needs N devices (one rank per GPU; RCCL refuses two ranks on one device).  torch.cuda.device_count() reads the driver's
+    list without initialising the GPU, so this is safe before ranks are spawned."""
+    if a.share_gpu or a.gpus <= 1:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit("bench.py: --gpus %d but this machine shows %d GPU%s (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = %s / %s); nothing was started.  "
+                         "For a dry run of the N > 1 path on one GPU: --dist-backend gloo --share-gpu"
+                         % (a.gpus, have, "" if have == 1 else "s", os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES")))
+
+
+def start_watchdog(a):
+    """A rank that is stuck before its first timed region (rendezvous, communicator creation: a peer that never arrives) must not hang the
+    job: after JN_BENCH_STARTUP_TIMEOUT_S (default 300) without the `started` event the process exits non-zero; spawn_ranks / the launcher
+    then ends the other ranks.  A thread that only ever calls os._exit — never an exec."""
+    import threading
+    started = threading.Event()
+    limit = float(os.environ.get("JN_BENCH_STARTUP_TIMEOUT_S", "300"))
+
+    def guard():
+        if not started.wait(limit):
+            sys.stderr.write("bench.py rank %s: not through start-up (process group, communicator, first batch) after %.0f s: exiting 3\n"
+                             % (os.environ.get("RANK", "0"), limit))
+            sys.stderr.flush()
+            os._exit(3)
+    if a.gpus > 1 and limit > 0:
+        threading.Thread(target=guard, daemon=True).start()
+    return started
+
+
 def main():
     a = parse_args()
+    enough_gpus(a)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
     run_rank(a)

@@ -284,14 +284,25 @@ jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* devic
  * complete (e.g. after jn_elas_wait); returns when the merged values are in place. */
 jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta);
 /* The merge as the TAIL OF EVERY SCAN BATCH: with a communicator attached, jn_elas_submit_scan's batches finish with
- * pack -> ncclAllReduce(MIN) -> unpack, queued by the slot's worker behind the scan (no host thread waits for it, the
- * submitting thread is not involved), so jn_elas_wait returns with the ROBOT-level bins in dBins / dMeta.  RCCL needs every
- * rank to issue a communicator's collectives in one order: batches queue their merges in submission order, so every rank
- * must submit the same sequence of scan batches (same n, same bins).  Call with no batch in flight; c = NULL detaches.
- * The communicator must live on the handle's device and outlive its use here.  jn_elas_merge_time: milliseconds on the
- * worker's clock from the slot's last scan being complete to its merged bins being in place (waiting for its turn in the
- * submission order included). */
+ * ncclAllReduce(MIN) -> unpack on the buffer the scan kernel packed, queued by the slot's WORKER thread once the scan is complete;
+ * the worker (not the submitting thread) waits for its turn and for the merged bins, so jn_elas_wait returns with the
+ * ROBOT-level bins in dBins / dMeta.  RCCL needs every rank to issue a communicator's collectives in one order: batches queue
+ * their merges in submission order, so every rank must submit the same sequence of scan batches (same n, same bins).
+ * Failure behaviour: a batch that fails on THIS rank before its merge still takes its turn and contributes the identity of the
+ * reduction (+inf), so the peers are not left inside the collective — they get the other rigs' scan, this rank's jn_elas_wait
+ * reports the batch's error.  A merge that does not complete within JN_COMM_TIMEOUT_MS (default 30000; 0 = wait for ever) —
+ * a peer died or never issued its collective — is aborted (ncclCommAbort), the handle's communicator is marked dead and the
+ * batch, like every later scan batch of the handle, returns JN_ERR_COMM instead of hanging.
+ * Do not mix: while a communicator is attached to a handle, jn_scan_allreduce must not be called on it from other threads
+ * unless every rank interleaves the two in the same order (the collectives of one communicator are totally ordered).
+ * Call with no batch in flight; c = NULL detaches.  The communicator must live on the handle's device and outlive its use
+ * here.  jn_elas_merge_time: milliseconds on the worker's clock from the slot's last scan being complete to its merged bins
+ * being in place (waiting for its turn in the submission order included). */
 jn_status jn_elas_set_comm(jn_elas* h, jn_comm* c);
+/* Testing aid: the submission numbers of the last scan batches of `h` in the order their merges were QUEUED (at most `cap`,
+ * oldest first; returns how many were written).  In a correct run this is 0, 1, 2, ... whatever order the batches' host
+ * stages finished in. */
+int32_t jn_elas_merge_order(jn_elas* h, uint64_t* out, int32_t cap);
 jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms);
 void jn_comm_destroy(jn_comm* c);
 

@@ -14,7 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <cmath>
 #include <mutex>
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -23,6 +28,9 @@ using namespace jnav;
 struct jn_comm;
 namespace jnav {
 jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed);
+jn_status comm_merge_identity(jn_comm* c, int n, int bins);
+void comm_abort(jn_comm* c);
+bool comm_dead(const jn_comm* c);
 int comm_device(const jn_comm* c);
 }
 
@@ -33,6 +41,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;            // optional
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
@@ -55,7 +64,7 @@ Rccl* rccl() {
 #define JN_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name))
     JN_SYM(GetUniqueId, "ncclGetUniqueId"); JN_SYM(CommInitRank, "ncclCommInitRank"); JN_SYM(CommDestroy, "ncclCommDestroy");
     JN_SYM(CommCount, "ncclCommCount"); JN_SYM(CommCuDevice, "ncclCommCuDevice"); JN_SYM(CommUserRank, "ncclCommUserRank");
-    JN_SYM(AllReduce, "ncclAllReduce"); JN_SYM(GetErrorString, "ncclGetErrorString");
+    JN_SYM(AllReduce, "ncclAllReduce"); JN_SYM(GetErrorString, "ncclGetErrorString"); JN_SYM(CommAbort, "ncclCommAbort");
 #undef JN_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.CommCount && r.CommCuDevice && r.CommUserRank && r.AllReduce &&
            r.GetErrorString;
@@ -90,6 +99,7 @@ struct jn_comm {
   double* flat = nullptr;          // packed [n*bins | n*4] doubles, grow-only
   size_t cap = 0;
   std::mutex m;
+  std::atomic<bool> dead{false};   // aborted after a merge that did not complete (comm_abort): every later collective returns JN_ERR_COMM
 };
 
 extern "C" {
@@ -154,6 +164,7 @@ jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* devic
 // here under its mutex and onto its ONE stream, so all ranks execute them in the order they were queued.
 static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed = nullptr) {
   std::lock_guard<std::mutex> guard(c->m);
+  if (c->dead.load()) return JN_ERR_COMM;
   HIP_TRY_C(hipSetDevice(c->device));
   const size_t count = (size_t)n * (bins + 4);
   if (packed) {                                              // the caller's own packed buffer (k_scan_finish wrote it): reduce it in place, unpack
@@ -180,11 +191,25 @@ static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins
 
 jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta) {
   if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
+  if (c->dead.load()) return JN_ERR_COMM;
   Rccl* R = rccl();
   if (!R) return JN_ERR_COMM;
   const jn_status st = queue_merge(c, R, n, bins, dBins, dMeta, nullptr, nullptr);
   if (st != JN_OK) return st;
-  HIP_TRY_C(hipStreamSynchronize(c->stream));
+  // bounded (JN_COMM_TIMEOUT_MS, default 30 s, 0 = for ever): a peer that never joins must not hang this rank
+  int timeout_ms = 30000;
+  if (const char* e = getenv("JN_COMM_TIMEOUT_MS")) timeout_ms = atoi(e);
+  if (timeout_ms <= 0) { HIP_TRY_C(hipStreamSynchronize(c->stream)); }
+  else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) { HIP_TRY_C(q); }
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms)) { comm_abort(c); return JN_ERR_COMM; }
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
   HIP_TRY_C(hipGetLastError());
   return JN_OK;
 }
@@ -199,6 +224,39 @@ jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* d
   if (!R) return JN_ERR_COMM;
   return queue_merge(c, R, n, bins, dBins, dMeta, ready, done, packed);
 }
+// A batch that failed on this rank before its merge: take part in the collective with the identity of MIN (+inf everywhere), so that
+// the other ranks, which are already inside or about to enter the same all-reduce, get the remaining rigs' scan instead of
+// waiting for ever.  Synchronous (the failure path is not a hot path).
+jn_status comm_merge_identity(jn_comm* c, int n, int bins) {
+  if (!c || n < 1 || bins < 1) return JN_ERR_INVALID;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  std::lock_guard<std::mutex> guard(c->m);
+  if (c->dead.load()) return JN_ERR_COMM;
+  HIP_TRY_C(hipSetDevice(c->device));
+  const size_t count = (size_t)n * (bins + 4);
+  if (count > c->cap) {
+    HIP_TRY_C(hipStreamSynchronize(c->stream));
+    if (c->flat) hipFree(c->flat);
+    c->flat = nullptr; c->cap = 0;
+    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
+    c->cap = count;
+  }
+  const std::vector<double> ident(count, INFINITY);
+  HIP_TRY_C(hipMemcpyAsync(c->flat, ident.data(), count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
+  HIP_TRY_C(hipStreamSynchronize(c->stream));
+  return JN_OK;
+}
+// A collective that does not complete (a peer died or never joined): ncclCommAbort ends the kernel this rank is stuck in and
+// releases the communicator's resources; the handle stays allocated (jn_comm_destroy frees it) but is dead from here on.
+void comm_abort(jn_comm* c) {
+  if (!c || c->dead.exchange(true)) return;
+  Rccl* R = rccl();
+  fprintf(stderr, "libjn_stereo: cross-rig merge on rank %d of %d did not complete in time: aborting the communicator\n", c->rank, c->world);
+  if (R && R->CommAbort && c->comm) { R->CommAbort(c->comm); c->comm = nullptr; }
+}
+bool comm_dead(const jn_comm* c) { return c && c->dead.load(); }
 int comm_device(const jn_comm* c) { return c ? c->device : -1; }
 }  // namespace jnav
 }  // extern "C++"
@@ -206,7 +264,7 @@ int comm_device(const jn_comm* c) { return c ? c->device : -1; }
 void jn_comm_destroy(jn_comm* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  if (c->stream) { hipStreamSynchronize(c->stream); }
+  if (c->stream && !c->dead.load()) { hipStreamSynchronize(c->stream); }
   if (Rccl* R = rccl()) if (c->comm) R->CommDestroy(c->comm);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->flat) hipFree(c->flat);

@@ -124,6 +124,10 @@ struct jn_elas {
   std::mutex pace_m; hipEvent_t pace_prev = nullptr; bool pace = false;
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
+  std::vector<uint64_t> merge_log;                            // submission numbers in the order their merges were queued (the last 4096; jn_elas_merge_order)
+  int comm_timeout_ms = 30000;                                // JN_COMM_TIMEOUT_MS: a merge not complete by then is aborted (0: wait for ever)
+  long long test_fail_seq = -1;                               // JN_TEST_FAIL_SEQ=k: the scan batch with submission number k fails before its kernels (tests: a rank's batch dies, the merge order must survive)
+  std::vector<int> test_slot_delay_us;                        // JN_TEST_SLOT_DELAY_US="a,b,c,d": slot i's batches pause that long before their merge turn (tests: host stages of unequal length)
   std::unique_ptr<Pool> pool;
   std::vector<std::unique_ptr<Slot>> slots;
   // staging for the host-pointer drop-in call
@@ -133,6 +137,9 @@ struct jn_elas {
 
 namespace jnav {
 jn_status comm_merge_async(jn_comm* c, int n, int bins, double* dBins, double* dMeta, hipEvent_t ready, hipEvent_t done, double* packed);
+jn_status comm_merge_identity(jn_comm* c, int n, int bins);
+void comm_abort(jn_comm* c);
+bool comm_dead(const jn_comm* c);
 int comm_device(const jn_comm* c);
 }
 
@@ -161,6 +168,20 @@ hipError_t wait_event(hipEvent_t ev, int spin_us) {
   }
 }
 
+// The same with a deadline: hipErrorNotReady when `timeout_ms` (> 0) passed without the event completing.
+hipError_t wait_event_bounded(hipEvent_t ev, int spin_us, int timeout_ms) {
+  if (timeout_ms <= 0) return wait_event(ev, spin_us);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    const auto waited = std::chrono::steady_clock::now() - t0;
+    if (waited > std::chrono::milliseconds(timeout_ms)) return hipErrorNotReady;
+    if (waited < std::chrono::microseconds(std::max(spin_us, 0))) { __builtin_ia32_pause(); continue; }
+    std::this_thread::sleep_for(std::chrono::microseconds(waited < std::chrono::microseconds(500) ? 20 : 50));
+  }
+}
+
 // CPUs this process may really use: its affinity mask, cut down to the container's CPU quota (cgroup v2 cpu.max) — a pool
 // sized by the machine's core count inside a container with a smaller quota gets the whole container throttled.
 int usable_cpus() {
@@ -182,17 +203,21 @@ int delaunay_parts(const jn_elas* h, int n) {
 }
 
 // A scan batch that carries a merge owns one place in the handle's merge order.  If the batch ends early (a HIP error on the
-// way), the place must still be given up, or every later batch of this handle would wait for it for ever.  (The OTHER ranks of
-// the communicator will still wait for this rank's collective: a failed batch on one rank is fatal for the job either way.)
+// way), the place must still be given up, or every later batch of this handle would wait for it for ever — and the OTHER ranks
+// of the communicator are inside, or about to enter, the same all-reduce: this rank still takes part in it, contributing the
+// identity of MIN (comm_merge_identity), so the peers get the remaining rigs' scan while this rank reports its error.
 struct MergeTurn {
-  jn_elas* h; uint64_t seq; bool armed;
-  MergeTurn(jn_elas* h_, const Job& j) : h(h_), seq(j.seq), armed(j.merge) {}
+  jn_elas* h; uint64_t seq; bool armed; int n, bins;
+  MergeTurn(jn_elas* h_, const Job& j) : h(h_), seq(j.seq), armed(j.merge), n(j.n), bins(j.sp.bins) {}
   void done() { armed = false; }
   ~MergeTurn() {
     if (!armed) return;
     {
       std::unique_lock<std::mutex> l(h->merge_m);
       h->merge_cv.wait(l, [&] { return h->merge_seq == seq; });
+      if (h->comm) comm_merge_identity(h->comm, n, bins);
+      if (h->merge_log.size() >= 4096) h->merge_log.erase(h->merge_log.begin(), h->merge_log.begin() + 2048);
+      h->merge_log.push_back(seq);
       h->merge_seq++;
     }
     h->merge_cv.notify_all();
@@ -203,6 +228,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const DevParams& dp = h->dp;
   const int n = j.n;
   MergeTurn turn(h, j);
+  if (j.merge && h->test_fail_seq >= 0 && (long long)j.seq == h->test_fail_seq) return JN_ERR_INTERNAL;
   hipStream_t st = s.stream;
   HIP_TRY(hipSetDevice(h->device));
   auto t_begin = std::chrono::steady_clock::now();
@@ -380,16 +406,30 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     // kernels themselves plus one host wait (profiles/r03_merge_in_worker.txt).
     const auto t_m0 = std::chrono::steady_clock::now();
     jn_status ms_ = JN_OK;
+    if (!h->test_slot_delay_us.empty()) {                  // tests only: this slot's host side takes longer, so batches reach their merge out of submission order
+      size_t si = 0;
+      while (si < h->slots.size() && h->slots[si].get() != &s) si++;
+      const int us = h->test_slot_delay_us[si % h->test_slot_delay_us.size()];
+      if (us > 0) std::this_thread::sleep_for(std::chrono::microseconds(us));
+    }
     {
       std::unique_lock<std::mutex> l(h->merge_m);
       h->merge_cv.wait(l, [&] { return h->merge_seq == j.seq; });
       ms_ = comm_merge_async(h->comm, n, j.sp.bins, j.dBins, j.dMeta, nullptr, s.ev_merged, s.d_flat);   // packed by k_scan_finish: all-reduce in place + unpack
+      if (h->merge_log.size() >= 4096) h->merge_log.erase(h->merge_log.begin(), h->merge_log.begin() + 2048);
+      h->merge_log.push_back(j.seq);
       h->merge_seq++;                                      // even on failure: the batches behind must not wait for ever
     }
     turn.done();
     h->merge_cv.notify_all();
     if (ms_ != JN_OK) return ms_;
-    HIP_TRY(wait_event(s.ev_merged, std::max(h->wait_spin_us, 400)));   // a short wait (two small kernels): poll tightly, a sleep's granularity would show
+    {
+      // a short wait (two small kernels): poll tightly, a sleep's granularity would show.  Bounded: a peer that died or never issued its
+      // collective must not hang this rank — the communicator is aborted and this and all later scan batches return JN_ERR_COMM.
+      const hipError_t we = wait_event_bounded(s.ev_merged, std::max(h->wait_spin_us, 400), h->comm_timeout_ms);
+      if (we == hipErrorNotReady) { comm_abort(h->comm); return JN_ERR_COMM; }
+      HIP_TRY(we);
+    }
     merge_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_m0).count();
     merged = true;
   }
@@ -586,6 +626,11 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->stage_events = max_batch > 1;
   h->wait_spin_us = max_batch > 1 ? 60 : 1000;
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
+  if (const char* e = getenv("JN_COMM_TIMEOUT_MS")) h->comm_timeout_ms = atoi(e);
+  if (const char* e = getenv("JN_TEST_FAIL_SEQ")) h->test_fail_seq = atoll(e);
+  if (const char* e = getenv("JN_TEST_SLOT_DELAY_US")) {
+    for (const char* q = e; *q;) { h->test_slot_delay_us.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
+  }
   h->pace = max_batch > 1 && slots > 1;
   if (const char* e = getenv("JN_PACE")) h->pace = atoi(e) != 0;
   h->zero_copy_payload = max_batch == 1;
@@ -736,8 +781,17 @@ jn_status jn_elas_set_comm(jn_elas* h, jn_comm* c) {
     sp_->cv.wait(l, [&] { return !sp_->busy; });
   }
   std::lock_guard<std::mutex> g(h->merge_m);
-  h->comm = c; h->submit_seq = 0; h->merge_seq = 0;
+  if (c && comm_dead(c)) return JN_ERR_COMM;
+  h->comm = c; h->submit_seq = 0; h->merge_seq = 0; h->merge_log.clear();
   return JN_OK;
+}
+
+int32_t jn_elas_merge_order(jn_elas* h, uint64_t* out, int32_t cap) {
+  if (!h || !out || cap < 1) return 0;
+  std::lock_guard<std::mutex> g(h->merge_m);
+  const size_t k = std::min<size_t>(h->merge_log.size(), (size_t)cap);
+  std::copy(h->merge_log.end() - k, h->merge_log.end(), out);
+  return (int32_t)k;
 }
 
 jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms) {

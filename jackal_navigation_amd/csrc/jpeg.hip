@@ -83,7 +83,18 @@ __global__ void __launch_bounds__(256) k_jpeg_idct_gray(const int16_t* __restric
 
 // One eye: frame size against the caller's buffer, entropy decoding on the calling thread (the serial part), then upload +
 // inverse DCT.  `sc` is the calling thread's grow-only device scratch for this eye.
-struct JpegScratch { int16_t* p = nullptr; size_t cap = 0; int dev = -1; std::vector<int16_t> coef; jnav::JpegFrame frame; };
+// Coefficients travel host -> device from PINNED memory (grow-only, hipHostMalloc): from a pageable vector hipMemcpyAsync is staged and
+// synchronous, and the pair call's two uploads + inverse DCTs would not be "queued together, waited for once".  The scratch belongs to a
+// thread (thread_local) or to an EyeHelper; its destructor releases the device and pinned buffers when that thread ends.
+struct JpegScratch {
+  int16_t* p = nullptr; size_t cap = 0; int dev = -1;
+  int16_t* pinned = nullptr; size_t pinned_cap = 0;
+  std::vector<int16_t> coef; jnav::JpegFrame frame;
+  ~JpegScratch() {
+    if (p) { hipSetDevice(dev); hipFree(p); }
+    if (pinned) hipHostFree(pinned);
+  }
+};
 
 static jn_status jpeg_entropy(const uint8_t* jpeg, int64_t nbytes, int32_t out_pitch, int32_t out_rows, int32_t* width, int32_t* height, JpegScratch& sc) {
   if (!jpeg || nbytes < 4 || !width || !height) return JN_ERR_INVALID;
@@ -104,7 +115,13 @@ static jn_status jpeg_idct_launch(int32_t device, JpegScratch& sc, uint8_t* dOut
     JPG_TRY(hipMalloc(reinterpret_cast<void**>(&sc.p), need));
     sc.cap = need; sc.dev = device;
   }
-  JPG_TRY(hipMemcpyAsync(sc.p, sc.coef.data(), need, hipMemcpyHostToDevice, nullptr));
+  if (sc.pinned_cap < need) {
+    if (sc.pinned) { hipHostFree(sc.pinned); sc.pinned = nullptr; sc.pinned_cap = 0; }
+    JPG_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.pinned), need, hipHostMallocDefault));
+    sc.pinned_cap = need;
+  }
+  memcpy(sc.pinned, sc.coef.data(), need);
+  JPG_TRY(hipMemcpyAsync(sc.p, sc.pinned, need, hipMemcpyHostToDevice, nullptr));
   QuantTable qt;
   memcpy(qt.q, sc.frame.quant, sizeof(qt.q));
   const int blocks = sc.frame.bw * sc.frame.bh;
@@ -139,7 +156,7 @@ struct EyeHelper {
   const uint8_t* jpeg = nullptr; int64_t nbytes = 0; int32_t pitch = 0, rows = 0, w = 0, h = 0; jn_status st = JN_OK;
   JpegScratch sc;
   EyeHelper() { th = std::thread([this] { run(); }); }
-  ~EyeHelper() { { std::lock_guard<std::mutex> l(m); quit = true; } cv.notify_all(); th.join(); if (sc.p) hipFree(sc.p); }
+  ~EyeHelper() { { std::lock_guard<std::mutex> l(m); quit = true; } cv.notify_all(); th.join(); }   // sc frees its own buffers
   void run() {
     std::unique_lock<std::mutex> l(m);
     for (;;) {

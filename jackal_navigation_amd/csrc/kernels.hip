@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
   // A candidate's four lanes read 4 consecutive columns and candidates are 5 columns apart: candidates i and i' share a
   // column mod 16 unless 5i and 5i' differ by at least 4 (mod 16), which holds exactly for i = i' (mod 4).  So each group
   // gets the four candidates of one residue class (round 2 took them in lane order: 59 % of the LDS cycles were conflicts).
+  static_assert(LANES == 4, "the candidate permutation below is written for four lanes per candidate (16 candidates per wave); launch_support_pitch starts whole waves");
   const int quad = (threadIdx.x >> 2) & 15;
   const int cand_in_wave = (int)((0xFEAB6732DC894510ull >> (4 * quad)) & 15u);
   const int cand_in_wg = (threadIdx.x >> 6) * 16 + cand_in_wave;

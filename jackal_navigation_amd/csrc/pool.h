@@ -15,6 +15,15 @@
 
 namespace jnav {
 
+// a polite spin: x86 `pause`, a yield elsewhere (this header is plain host code, also built by the thread-sanitizer test)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#else
+  std::this_thread::yield();
+#endif
+}
+
 class Pool {
  public:
   // spin_us > 0 (latency-mode handles): a worker that has just run a task polls the queue for that long before it goes back to sleep,
@@ -42,8 +51,16 @@ class Pool {
     if (n >= (int)threads_.size()) cv_.notify_all();
     else for (int i = 0; i < n; i++) cv_.notify_one();      // wake only as many workers as there are tasks (spinning ones need no wake-up)
     if (spin_us_ > 0) {
+      // The caller polls for its group only while that can pay: at most 4 x spin_us (a lone pair's host stage is two ~60 us tasks), and not
+      // at all once every task has been picked up and the deadline of one task's length has passed — a long task is then cheaper to sleep
+      // through (the caller's core is part of the container's CPU quota, which the host stage itself needs).
       const auto t0 = std::chrono::steady_clock::now();
-      while (!g.done.load(std::memory_order_acquire) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(20 * spin_us_)) __builtin_ia32_pause();
+      const auto limit = std::chrono::microseconds(4 * spin_us_), picked_up_limit = std::chrono::microseconds(spin_us_);
+      while (!g.done.load(std::memory_order_acquire)) {
+        const auto waited = std::chrono::steady_clock::now() - t0;
+        if (waited >= limit || (waited >= picked_up_limit && queued_.load(std::memory_order_acquire) == 0)) break;
+        cpu_relax();
+      }
     }
     std::unique_lock<std::mutex> l(g.m);
     g.cv.wait(l, [&g] { return g.left == 0; });
@@ -60,7 +77,7 @@ class Pool {
       Item it;
       if (hot && spin_us_ > 0) {                             // poll for the next task before going back to sleep
         const auto t0 = std::chrono::steady_clock::now();
-        while (queued_.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) __builtin_ia32_pause();
+        while (queued_.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(spin_us_)) cpu_relax();
       }
       {
         std::unique_lock<std::mutex> l(m_);

@@ -43,8 +43,11 @@ class Elas:
 
     def close(self):
         if getattr(self, "_h", None):
+            if getattr(self, "_comm", None) is not None:      # detach first (waits for the batches in flight), then let go of the communicator
+                self._L.jn_elas_set_comm(self._h, None)
             self._L.jn_elas_destroy(self._h)
             self._h = None
+        self._comm = None
 
     def __del__(self):
         try:
@@ -97,6 +100,14 @@ class Elas:
     def set_comm(self, comm):
         """Attach a parallel.ScanComm (or None): scan batches then end with the cross-rig MIN reduce (jn_elas_set_comm)."""
         _lib.check(self._L.jn_elas_set_comm(self._h, comm._h if comm is not None else None), "jn_elas_set_comm")
+        self._comm = comm            # the library keeps the raw jn_comm*: the ScanComm must outlive its use there (its __del__ destroys the communicator)
+
+    def merge_order(self, cap=4096):
+        """Submission numbers of the last scan batches in the order their merges were queued (jn_elas_merge_order; a testing aid)."""
+        import ctypes as C
+        buf = (C.c_uint64 * cap)()
+        k = self._L.jn_elas_merge_order(self._h, buf, cap)
+        return list(buf[:k])
 
     def merge_time(self, slot=0):
         import ctypes as C

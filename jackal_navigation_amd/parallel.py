@@ -95,7 +95,25 @@ class ScanComm:
         raw = exchange_id(bytes(ident) if rank == 0 else None)
         ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         h = C.c_void_p()
-        _lib.check(self._L.jn_comm_create(ident, rank, world, device, C.byref(h)), "jn_comm_create")
+        # ncclCommInitRank is a collective with no deadline of its own: a peer that never calls it would hang this rank for ever.  A watchdog
+        # thread ends the process (exit code 3, never an exec) when JN_COMM_INIT_TIMEOUT_S (default 120, 0 = none) passes first.
+        import sys
+        import threading
+        done = threading.Event()
+        limit = float(os.environ.get("JN_COMM_INIT_TIMEOUT_S", "120"))
+
+        def guard():
+            if not done.wait(limit):
+                sys.stderr.write("jackal_navigation_amd: jn_comm_create(rank %d of %d, device %d) not complete after %.0f s "
+                                 "(a peer rank is missing): exiting 3\n" % (rank, world, device, limit))
+                sys.stderr.flush()
+                os._exit(3)
+        if world > 1 and limit > 0:
+            threading.Thread(target=guard, daemon=True).start()
+        try:
+            _lib.check(self._L.jn_comm_create(ident, rank, world, device, C.byref(h)), "jn_comm_create")
+        finally:
+            done.set()
         self._h = h
 
     def info(self):

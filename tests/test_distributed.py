@@ -113,7 +113,21 @@ def test_bench_refuses_a_world_size_mismatch_and_spawns_ranks_without_a_launcher
     if torch.cuda.is_available():
         return
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"],
+    # (--share-gpu: the dry-run switch skips the "N GPUs present" check, so the spawn path itself is what runs here)
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--no-cpu-baseline", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=env)
     # the parent terminates the surviving rank as soon as one fails, so the second message may not get out
     assert out.returncode != 0 and 1 <= out.stderr.count("needs a GPU") <= 2, out.stderr[-2000:]
+
+
+def test_bench_refuses_more_gpus_than_the_machine_has():
+    """`bench.py --gpus N` on a machine with fewer GPUs: a clear message and a non-zero exit BEFORE any rank is started (VERDICT r03 #4b)."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode != 0
+    assert "--gpus %d but this machine shows" % n in out.stderr and "nothing was started" in out.stderr

@@ -684,3 +684,76 @@ def test_start_up_pacing_changes_no_result(jn, oracle, monkeypatch):
     for k in (0, 5, 11):
         st, d1, _ = oracle.process(p, pairs[k][0][0], pairs[k][0][1])
         assert st == 0 and np.array_equal(results["1"][k][0], d1), k
+
+
+def _scan_rounds(jn, W, H, B, S, rounds, comm_env, monkeypatch, fail_seq=None):
+    """S slots x `rounds` scan batches of different frames with a one-rank communicator attached; returns (bins per batch or the
+    JnError of the batch, the order the merges were queued in)."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node, parallel, _lib
+    for k, v in comm_env.items():
+        monkeypatch.setenv(k, v)
+    if fail_seq is not None:
+        monkeypatch.setenv("JN_TEST_FAIL_SEQ", str(fail_seq))
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    pairs = [[node.synth_pair(W, H, 30 + 4 * k, 900 + 7 * k + t) for t in range(B)] for k in range(S * rounds)]
+    dLs = [DeviceArray.from_numpy(np.stack([p[0] for p in ps])) for ps in pairs]
+    dRs = [DeviceArray.from_numpy(np.stack([p[1] for p in ps])) for ps in pairs]
+    got = [None] * (S * rounds)
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=4) as e:
+        comm = parallel.ScanComm(0, 1, 0, lambda raw: raw)
+        e.set_comm(comm)
+        bufs = [dict(d1=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)), d2=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)),
+                     u8=DeviceArray((B, H, W), np.uint8), bins=DeviceArray((B, sp.bins), np.float64), meta=DeviceArray((B, 4), np.float64),
+                     st=(C.c_int32 * B)()) for _ in range(S)]
+
+        def finish(s0, k0):
+            try:
+                e.wait(s0)
+                got[k0] = bufs[s0]["bins"].numpy().copy()
+            except _lib.JnError as err:
+                got[k0] = err
+        inflight = []
+        for k in range(S * rounds):
+            slot = k % S
+            if len(inflight) == S:
+                finish(*inflight.pop(0))
+            b = bufs[slot]
+            e.submit_scan(slot, B, dLs[k].ptr, dRs[k].ptr, W, H * W, b["d1"].ptr, b["d2"].ptr, sp, lut.ptr, b["u8"].ptr, b["bins"].ptr, b["meta"].ptr, b["st"])
+            inflight.append((slot, k))
+        for s0, k0 in inflight:
+            finish(s0, k0)
+        order = e.merge_order()
+        e.set_comm(None)
+        comm.close()
+    return got, order
+
+
+def test_merges_are_queued_in_submission_order_when_slots_finish_out_of_order(jn, monkeypatch):
+    """the only cross-rank ordering logic (merge_seq / submit_seq) under skew.  Slots 1 and 3 are held up before their
+    merge turn (JN_TEST_SLOT_DELAY_US: what a longer host stage does), so batches reach the merge out of submission order; RCCL
+    needs every rank to queue a communicator's collectives in ONE order: the queue order must still be 0, 1, 2, ... and the bins
+    must equal the unskewed run's."""
+    W, H, B, S, rounds = 320, 180, 2, 4, 3
+    plain, order0 = _scan_rounds(jn, W, H, B, S, rounds, {}, monkeypatch)
+    skew, order1 = _scan_rounds(jn, W, H, B, S, rounds, {"JN_TEST_SLOT_DELAY_US": "0,6000,0,3000"}, monkeypatch)
+    assert order0 == list(range(S * rounds)) and order1 == list(range(S * rounds)), (order0, order1)
+    for a, b in zip(plain, skew):
+        assert isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and np.array_equal(a, b)
+
+
+def test_a_failing_batch_keeps_its_turn_and_feeds_the_collective_the_identity(jn, monkeypatch):
+    """A batch that dies on this rank before its merge (JN_TEST_FAIL_SEQ) must not strand anybody: it still takes its turn in the
+    merge order and contributes the identity of MIN to the all-reduce its peers are waiting in, its jn_elas_wait reports the error,
+    and every later batch completes with the right bins."""
+    from jackal_navigation_amd import _lib
+    W, H, B, S, rounds = 320, 180, 2, 4, 3
+    plain, _ = _scan_rounds(jn, W, H, B, S, rounds, {}, monkeypatch)
+    got, order = _scan_rounds(jn, W, H, B, S, rounds, {"JN_TEST_SLOT_DELAY_US": "0,2000,0,0"}, monkeypatch, fail_seq=5)
+    assert order == list(range(S * rounds)), order
+    for k, (a, b) in enumerate(zip(plain, got)):
+        if k == 5:
+            assert isinstance(b, _lib.JnError) and b.status == _lib.JN_ERR_INTERNAL
+        else:
+            assert isinstance(b, np.ndarray) and np.array_equal(a, b), k
