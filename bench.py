@@ -130,6 +130,9 @@ def parse_args():
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
     ap.add_argument("--subpixel", type=int, default=0, help="sgm / bm mode: 1/16-pixel refinement")
     ap.add_argument("--block-radius", type=int, default=4, help="bm mode: block radius r (2, 3, 4)")
+    ap.add_argument("--bm-cost", default="sad", choices=["sad", "ssd"],
+                    help="bm mode: sad = absolute differences (v_qsad kernel, default); ssd = squared differences as a banded int8 contraction on the matrix "
+                         "cores (v_mfma_i32_32x32x32_i8, csrc/bm_mfma.hip; BASELINE config 5's \"int8 cost volume (CDNA4 MFMA path)\")")
     return ap.parse_args()
 
 
@@ -240,6 +243,25 @@ def sgm_cpu_baseline(W, H, scene, D, sub, radius=0):
                       % (procs * per_proc, W, H, D, procs, wall, "bm" if radius else "sgm", 1.0 / t1)}
 
 
+def bm_ssd_roofline(W, H, D, B, radius, ms):
+    """The squared-difference block matcher on the matrix cores: bound "mfma" in the contract's vocabulary.  Algorithmic work = the cross
+    terms the definition needs, 2 (2r+1)^2 W H D multiply-adds... per pair and side; what the kernel ISSUES is one 32x32x32 int8 MFMA per 32 x 32
+    tile of (candidate, column) pairs and row (both the entering and the leaving row of the window in its K = 32), i.e. 65 536 int8 operations
+    for 2 (2r+1) x 2 x 1024 useful ones.  `achieved` is the ISSUED rate (what the matrix cores did) against the dense int8 peak; `useful` next to
+    it.  The pass is bound by vector issue (keys and minima), not by the matrix cores: see DESIGN.md 4c."""
+    sides = 2
+    tiles = ((W + 31) // 32) * (D // 32 + 1) * H * B * sides
+    issued = tiles * 2.0 * 32 * 32 * 32
+    useful = 2.0 * (2 * radius + 1) ** 2 * W * H * D * B * sides
+    t = ms["match"] * 1e-3
+    peak = 5000.0                                              # TOP/s dense int8 (MI355X_MICROARCH.md; the 2:1-sparsity figure is not used)
+    return {"bound": "mfma", "kernel": "k_bmq_match x2 (v_mfma_i32_32x32x32_i8; + prefilter, patch norms, finish: one batch)", "achieved": round(issued / t / 1e12, 2),
+            "peak": peak, "unit": "TOP/s", "frac": round(issued / t / 1e12 / peak, 4), "traffic": None, "useful_TOPs": round(useful / t / 1e12, 2),
+            "ms_per_launch": round(ms["match"] / sides, 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
+            "note": "issued int8 operations of the matching passes / their GPU time; useful = the definition's 2 (2r+1)^2 W H D per side.  Bound by vector issue "
+                    "(one shift-add and half a min3 per candidate pair), the matrix cores are ~1/4 busy"}
+
+
 def bm_roofline(W, H, D, B, radius, sub, ms):
     """Block matching streams ~13 bytes per pixel (2 in, a 4-byte winner record per side, 2 out, u8 map + LUT + scan) and spends
     W H D block costs of (2r+1)^2 absolute differences on them: the bound is vector issue, not HBM (PMC, DESIGN.md 4c: the VALU
@@ -306,7 +328,8 @@ def run_sgm(a):
     u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
     bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
     if bm:
-        sgm = jn.Bm(jn.Bm.parameters(num_disparities=D, block_radius=a.block_radius, subpixel=a.subpixel), W, H, max_batch=B, device=local_rank)
+        sgm = jn.Bm(jn.Bm.parameters(num_disparities=D, block_radius=a.block_radius, subpixel=a.subpixel, cost_function=1 if a.bm_cost == "ssd" else 0),
+                    W, H, max_batch=B, device=local_rank)
     else:
         sgm = jn.Sgm(jn.Sgm.parameters(num_disparities=D, subpixel=a.subpixel), W, H, max_batch=B, device=local_rank)
     sp = node.scan_params(W, H)
@@ -357,7 +380,7 @@ def run_sgm(a):
     if rank == 0:
         want = None
         try:
-            for line in open(os.path.join(ROOT, "tests", "golden", "bm_hashes.txt" if bm else "sgm_hashes.txt")):
+            for line in open(os.path.join(ROOT, "tests", "golden", ("bm_ssd_hashes.txt" if a.bm_cost == "ssd" else "bm_hashes.txt") if bm else "sgm_hashes.txt")):
                 f = line.split()
                 key = [W, H, scene, D, a.block_radius, a.subpixel, 12345] if bm else [W, H, scene, D, a.subpixel, 12345]
                 if not line.startswith("#") and len(f) == len(key) + 1 and [int(x) for x in f[:-1]] == key:
@@ -375,7 +398,7 @@ def run_sgm(a):
     # this decomposition really moves: eight u8 volumes written by the path kernel and read by the WTA kernel.
     b_sgm = (4.0 * W * H * D + 5.0 * W * H) * B
     if bm:
-        roofline = bm_roofline(W, H, D, B, a.block_radius, a.subpixel, ms)
+        roofline = bm_ssd_roofline(W, H, D, B, a.block_radius, ms) if a.bm_cost == "ssd" else bm_roofline(W, H, D, B, a.block_radius, a.subpixel, ms)
     if not bm:
         achieved = b_sgm / (ms["total"] * 1e-3) / 1e9
         old = os.environ.get("JN_SGM_IMPL") == "0"
@@ -798,13 +821,13 @@ def run_rank(a):
     other_modes = None
     if rank == 0 and world == 1 and not a.no_latency_config and a.disp in (64, 128, 256):
         other_modes = {}
-        for kind in ("sgm", "bm"):
+        for kind in ("sgm", "bm", "bm_ssd"):
             try:
                 disp16 = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
                 if kind == "sgm":
                     m = jn.Sgm(jn.Sgm.parameters(num_disparities=a.disp), W, H, max_batch=B, device=local_rank)
                 else:
-                    m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4), W, H, max_batch=B, device=local_rank)
+                    m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4, cost_function=1 if kind == "bm_ssd" else 0), W, H, max_batch=B, device=local_rank)
                 for _ in range(2):
                     m.process_batch(B, dLs[0].data_ptr(), dRs[0].data_ptr(), W, H * W, disp16.data_ptr())
                 torch.cuda.synchronize()
@@ -821,10 +844,11 @@ def run_rank(a):
                     f = line.split()
                     if kind == "sgm" and f[:6] == [str(W), str(H), str(scene), str(a.disp), "0", "12345"]:
                         want_m = f[6]
-                    if kind == "bm" and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
+                    if kind in ("bm", "bm_ssd") and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
                         want_m = f[7]
                 other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_process_batch), same inputs as the ELAS regions" %
-                                                 (W, H, a.disp, "SGM 8 paths" if kind == "sgm" else "9x9 block matching", B, kind),
+                                                 (W, H, a.disp, {"sgm": "SGM 8 paths", "bm": "9x9 block matching (SAD, v_qsad)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8)"}[kind], B,
+                                                  "bm" if kind == "bm_ssd" else kind),
                                      "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},
                                      "check": {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None,
                                                "source": "tests/golden/%s_hashes.txt (the mode's scalar definition; the reference has no such matcher)" % kind}}

@@ -11,6 +11,11 @@
  *   cost       CL(x,y,d) = sum_{j=-r..r} sum_{i=-r..r} | gL(cl(x+i), cr(y+j)) - gR(cl(x+i-d), cr(y+j)) |
  *              CR(x,y,d) = sum_{j=-r..r} sum_{i=-r..r} | gR(cl(x+i), cr(y+j)) - gL(cl(x+i+d), cr(y+j)) |
  *              cl = clamp to [0, W-1], cr = clamp to [0, H-1]        (<= (2r+1)^2 * 2 cap, fits 16 bits)
+ *              cost_function = JN_BM_COST_SSD: the same with (a - b)^2 in place of |a - b|  (<= (2r+1)^2 * (2 cap)^2 < 2^19).
+ *              This is BASELINE.json config 5's "int8 cost volume (CDNA4 MFMA path)": sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum a b,
+ *              and the cross term over all (x, x-d) pairs of a row is a banded product of the two images' patch matrices — an
+ *              int8 contraction for the matrix cores (csrc/bm_mfma.hip).  A different cost function, hence a different (equally
+ *              self-defined) result than SAD; all of WTA / L-R check / sub-pixel below apply to it unchanged.
  *   WTA        dL(x,y) = smallest d minimising CL(x,y,d);  dR(x,y) = smallest d minimising CR(x,y,d)
  *   L/R check  dL(p) is kept iff x - dL >= 0 and |dL(p) - dR(x - dL, y)| <= lr_max_diff, else invalid (lr_max_diff < 0: all kept)
  *   sub-pixel  (optional) for 0 < d < D-1, with C = CL(x,y,.): den = max(C(d-1) + C(d+1) - 2 C(d), 1),
@@ -33,9 +38,12 @@ typedef struct jn_bm_params {
   int32_t prefilter_cap;     /* Sobel clip, 1..31 */
   int32_t lr_max_diff;       /* L/R check tolerance; < 0 disables the check (and the right-referenced pass) */
   int32_t subpixel;          /* 0: integer disparities, 1: 1/16 pixel */
+  int32_t cost_function;     /* JN_BM_COST_SAD (default) or JN_BM_COST_SSD (then D must be a multiple of 32 in [32, 256]) */
 } jn_bm_params;
+#define JN_BM_COST_SAD 0
+#define JN_BM_COST_SSD 1
 
-/* D = 64, r = 4, cap = 31, lr_max_diff = 1, subpixel = 0 */
+/* D = 64, r = 4, cap = 31, lr_max_diff = 1, subpixel = 0, cost_function = JN_BM_COST_SAD */
 void jn_bm_params_default(jn_bm_params* p);
 
 typedef struct jn_bm jn_bm;   /* opaque: padded prefiltered rows and one 8-byte winner record per pixel and side for max_batch pairs */

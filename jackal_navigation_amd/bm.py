@@ -9,7 +9,10 @@ from . import _lib
 
 class BmParams(C.Structure):
     _fields_ = [("num_disparities", C.c_int32), ("block_radius", C.c_int32), ("prefilter_cap", C.c_int32),
-                ("lr_max_diff", C.c_int32), ("subpixel", C.c_int32)]
+                ("lr_max_diff", C.c_int32), ("subpixel", C.c_int32), ("cost_function", C.c_int32)]
+
+
+COST_SAD, COST_SSD = 0, 1
 
 
 class BmTimes(C.Structure):

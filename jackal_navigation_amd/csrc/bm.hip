@@ -29,6 +29,7 @@
 #include <cstring>
 #include "../../include/jn_bm.h"
 #include "kernels.h"          // launch_scan: the node's tail on the same stream (jn_bm_process_scan)
+#include "bm_mfma.h"          // JN_BM_COST_SSD: the matrix-core kernels
 
 namespace {
 
@@ -272,6 +273,8 @@ struct jn_bm {
   uint8_t* g = nullptr;        // prefiltered rows [2 * max_batch][H][Wp]
   uint32_t* keys = nullptr;    // winners [2][max_batch][H][W]: cost << 8 | d
   unsigned long long* scan_scratch = nullptr;   // [max_batch][4], the scan tail's extrema
+  jnav_bmq::QDev qdev = {};    // JN_BM_COST_SSD: geometry of the matrix-core path (g then holds its plain prefiltered rows)
+  int32_t* q = nullptr;        //                  key halves / squared patch norms [2 * max_batch][H][Wp]
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
   jn_bm_times times = {};
@@ -331,14 +334,14 @@ hipError_t launch_bm_finish(hipStream_t st, const BmDev& s, int n, const uint8_t
 extern "C" {
 
 void jn_bm_params_default(jn_bm_params* p) {
-  p->num_disparities = 64; p->block_radius = 4; p->prefilter_cap = 31; p->lr_max_diff = 1; p->subpixel = 0;
+  p->num_disparities = 64; p->block_radius = 4; p->prefilter_cap = 31; p->lr_max_diff = 1; p->subpixel = 0; p->cost_function = JN_BM_COST_SAD;
 }
 
 void jn_bm_destroy(jn_bm* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  hipFree(h->g); hipFree(h->keys); hipFree(h->scan_scratch);
+  hipFree(h->g); hipFree(h->keys); hipFree(h->scan_scratch); hipFree(h->q);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
@@ -350,6 +353,9 @@ jn_status jn_bm_create(const jn_bm_params* p, int32_t W, int32_t H, int32_t max_
   const int D = p->num_disparities;
   if (D < 8 || D > 256 || (D & 7) || p->block_radius < 2 || p->block_radius > 4 || p->prefilter_cap < 1 || p->prefilter_cap > 31)
     return JN_ERR_UNSUPPORTED;
+  const bool ssd = p->cost_function == JN_BM_COST_SSD;
+  if (p->cost_function != JN_BM_COST_SAD && !ssd) return JN_ERR_UNSUPPORTED;
+  if (ssd && (D & 31)) return JN_ERR_UNSUPPORTED;              // the matrix-core path covers the band with whole tiles of 32 candidates
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
   BM_TRY(hipSetDevice(device));
@@ -359,7 +365,14 @@ jn_status jn_bm_create(const jn_bm_params* p, int32_t W, int32_t H, int32_t max_
   s.W = W; s.H = H; s.D = D; s.r = p->block_radius; s.cap = p->prefilter_cap; s.lr = p->lr_max_diff; s.subpixel = p->subpixel ? 1 : 0;
   s.padx = D + kBmPad; s.Wp = (W + 2 * s.padx + 3) & ~3;
 #define BM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_bm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
-  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
+  size_t g_bytes = (size_t)2 * max_batch * H * s.Wp + 64;
+  if (ssd) {
+    jnav_bmq::Sizes z;
+    jnav_bmq::geometry(W, H, D, p->block_radius, p->prefilter_cap, p->lr_max_diff, p->subpixel, &h->qdev, &z, max_batch);
+    g_bytes = z.g;
+    BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->q), z.q));
+  }
+  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), g_bytes));
   BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->keys), (size_t)2 * max_batch * H * W * sizeof(uint32_t)));
   BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->scan_scratch), sizeof(unsigned long long) * 4 * max_batch));
   BM_CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -376,6 +389,20 @@ static jn_status bm_run(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* 
   const BmDev& s = h->dev;
   hipStream_t st = h->stream;
   BM_TRY(hipEventRecord(h->ev[0], st));
+  if (h->p.cost_function == JN_BM_COST_SSD) {                  // squared differences: the banded int8 contraction on the matrix cores (bm_mfma.hip)
+    uint32_t* kL = h->keys;
+    uint32_t* kR = h->keys + (size_t)h->max_batch * s.H * s.W;
+    BM_TRY(jnav_bmq::run(h->qdev, n, dI1, dI2, pitch, (long long)image_stride, h->g, h->q, kL, kR, dDisp, dU8, st, h->ev));
+    if (sp) jnav::launch_scan(st, *sp, n, nullptr, dU8, dLut, s.W, s.H, dBins, dMeta, h->scan_scratch);
+    BM_TRY(hipEventRecord(h->ev[3], st));
+    BM_TRY(hipStreamSynchronize(st));
+    BM_TRY(hipGetLastError());
+    hipEventElapsedTime(&h->times.prefilter, h->ev[0], h->ev[1]);
+    hipEventElapsedTime(&h->times.match, h->ev[1], h->ev[2]);
+    hipEventElapsedTime(&h->times.finish, h->ev[2], h->ev[3]);
+    hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
+    return JN_OK;
+  }
   hipLaunchKernelGGL(k_bm_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, h->g);
   BM_TRY(hipEventRecord(h->ev[1], st));
   // Rows per band: whole turns of the kernel's ring (band + 2r = k (2r+1)) so that no staged row is wasted, as many as

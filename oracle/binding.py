@@ -328,7 +328,7 @@ class SgmOracle:
 
 class BmParams(C.Structure):
     _fields_ = [("num_disparities", C.c_int32), ("block_radius", C.c_int32), ("prefilter_cap", C.c_int32),
-                ("lr_max_diff", C.c_int32), ("subpixel", C.c_int32)]
+                ("lr_max_diff", C.c_int32), ("subpixel", C.c_int32), ("cost_function", C.c_int32)]
 
 
 class BmOracle:
@@ -342,12 +342,14 @@ class BmOracle:
         self.lib.orc_bm_cost.restype = C.c_int32
 
     @staticmethod
-    def params(num_disparities=64, block_radius=4, prefilter_cap=31, lr_max_diff=1, subpixel=0):
-        return BmParams(num_disparities, block_radius, prefilter_cap, lr_max_diff, subpixel)
+    def params(num_disparities=64, block_radius=4, prefilter_cap=31, lr_max_diff=1, subpixel=0, cost_function=0):
+        return BmParams(num_disparities, block_radius, prefilter_cap, lr_max_diff, subpixel, cost_function)
 
-    def cost(self, gL, gR, r, side, x, y, d):
+    def cost(self, gL, gR, r, side, x, y, d, squared=False):
         H, W = gL.shape
-        return int(self.lib.orc_bm_cost(_p(np.ascontiguousarray(gL)), _p(np.ascontiguousarray(gR)), W, H, r, side, x, y, d))
+        f = self.lib.orc_bm_cost_ssd if squared else self.lib.orc_bm_cost
+        f.restype = C.c_int32
+        return int(f(_p(np.ascontiguousarray(gL)), _p(np.ascontiguousarray(gR)), W, H, r, side, x, y, d))
 
     def process(self, p, L, R):
         L = np.ascontiguousarray(L, np.uint8); R = np.ascontiguousarray(R, np.uint8)

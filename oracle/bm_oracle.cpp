@@ -13,28 +13,34 @@
 
 extern "C" {
 
-typedef struct orc_bm_params { int32_t num_disparities, block_radius, prefilter_cap, lr_max_diff, subpixel; } orc_bm_params;
+typedef struct orc_bm_params { int32_t num_disparities, block_radius, prefilter_cap, lr_max_diff, subpixel, cost_function; } orc_bm_params;   // cost_function 1: squared differences (jn_bm.h JN_BM_COST_SSD)
 
 void orc_sgm_prefilter(const uint8_t* I, int32_t W, int32_t H, int32_t cap, uint8_t* g);     // sgm_oracle.cpp: the same prefilter
 
 // The cost by its definition: five nested loops.  side 0: CL(x,y,d), side 1: CR(x,y,d).
-int32_t orc_bm_cost(const uint8_t* gL, const uint8_t* gR, int32_t W, int32_t H, int32_t r, int32_t side, int32_t x, int32_t y, int32_t d) {
+static int32_t bm_cost_fn(const uint8_t* gL, const uint8_t* gR, int32_t W, int32_t H, int32_t r, int32_t side, int32_t x, int32_t y, int32_t d, int32_t squared) {
   auto cl = [&](int v) { return std::min(std::max(v, 0), W - 1); };
   auto cr = [&](int v) { return std::min(std::max(v, 0), H - 1); };
   int c = 0;
   for (int j = -r; j <= r; j++)
     for (int i = -r; i <= r; i++) {
       const size_t row = (size_t)cr(y + j) * W;
-      if (side == 0) c += std::abs((int)gL[row + cl(x + i)] - (int)gR[row + cl(x + i - d)]);
-      else           c += std::abs((int)gR[row + cl(x + i)] - (int)gL[row + cl(x + i + d)]);
+      const int e = side == 0 ? (int)gL[row + cl(x + i)] - (int)gR[row + cl(x + i - d)] : (int)gR[row + cl(x + i)] - (int)gL[row + cl(x + i + d)];
+      c += squared ? e * e : std::abs(e);
     }
   return c;
+}
+int32_t orc_bm_cost(const uint8_t* gL, const uint8_t* gR, int32_t W, int32_t H, int32_t r, int32_t side, int32_t x, int32_t y, int32_t d) {
+  return bm_cost_fn(gL, gR, W, H, r, side, x, y, d, 0);
+}
+int32_t orc_bm_cost_ssd(const uint8_t* gL, const uint8_t* gR, int32_t W, int32_t H, int32_t r, int32_t side, int32_t x, int32_t y, int32_t d) {
+  return bm_cost_fn(gL, gR, W, H, r, side, x, y, d, 1);
 }
 
 // All costs of one side, [H][W][D] u16, by separable sums of the absolute-difference image of every d (the same numbers
 // as orc_bm_cost, tests compare the two): AD_d(x,y) = |a(x) - b(x -/+ d)| needs the clamp INSIDE the window, so the
 // horizontal sum runs over clamped x+i for a and clamped x+i-/+d for b, not over a clamped AD image.
-static void bm_costs(const uint8_t* gL, const uint8_t* gR, int W, int H, int D, int r, int side, std::vector<uint16_t>& out) {
+static void bm_costs(const uint8_t* gL, const uint8_t* gR, int W, int H, int D, int r, int side, int squared, std::vector<uint32_t>& out) {
   out.assign((size_t)W * H * D, 0);
   auto cl = [&](int v) { return std::min(std::max(v, 0), W - 1); };
   std::vector<int> hrow((size_t)W * H);
@@ -45,7 +51,7 @@ static void bm_costs(const uint8_t* gL, const uint8_t* gR, int W, int H, int D, 
       const int s = side == 0 ? -d : d;
       for (int x = 0; x < W; x++) {
         int c = 0;
-        for (int i = -r; i <= r; i++) c += std::abs((int)a[cl(x + i)] - (int)b[cl(x + i + s)]);
+        for (int i = -r; i <= r; i++) { const int e = (int)a[cl(x + i)] - (int)b[cl(x + i + s)]; c += squared ? e * e : std::abs(e); }
         hrow[(size_t)y * W + x] = c;
       }
     }
@@ -53,7 +59,7 @@ static void bm_costs(const uint8_t* gL, const uint8_t* gR, int W, int H, int D, 
       for (int x = 0; x < W; x++) {
         int c = 0;
         for (int j = -r; j <= r; j++) c += hrow[(size_t)std::min(std::max(y + j, 0), H - 1) * W + x];
-        out[((size_t)y * W + x) * D + d] = (uint16_t)c;
+        out[((size_t)y * W + x) * D + d] = (uint32_t)c;
       }
   }
 }
@@ -66,16 +72,17 @@ int32_t orc_bm_process(const orc_bm_params* p, const uint8_t* L, const uint8_t* 
   std::vector<uint8_t> gL(px), gR(px);
   orc_sgm_prefilter(L, W, H, p->prefilter_cap, gL.data());
   orc_sgm_prefilter(R, W, H, p->prefilter_cap, gR.data());
-  std::vector<uint16_t> CL, CR;
-  bm_costs(gL.data(), gR.data(), W, H, D, r, 0, CL);
-  bm_costs(gL.data(), gR.data(), W, H, D, r, 1, CR);
-  auto argmin = [&](const uint16_t* c) { int best = 0; for (int d = 1; d < D; d++) if (c[d] < c[best]) best = d; return best; };   // smallest d attaining the minimum
+  if (p->cost_function != 0 && p->cost_function != 1) return -1;
+  std::vector<uint32_t> CL, CR;
+  bm_costs(gL.data(), gR.data(), W, H, D, r, 0, p->cost_function, CL);
+  bm_costs(gL.data(), gR.data(), W, H, D, r, 1, p->cost_function, CR);
+  auto argmin = [&](const uint32_t* c) { int best = 0; for (int d = 1; d < D; d++) if (c[d] < c[best]) best = d; return best; };   // smallest d attaining the minimum
   std::vector<int> dR(px);
   for (size_t i = 0; i < px; i++) dR[i] = argmin(&CR[i * D]);
   const int scale = p->subpixel ? 16 : 1;
   for (int y = 0; y < H; y++)
     for (int x = 0; x < W; x++) {
-      const uint16_t* c = &CL[((size_t)y * W + x) * D];
+      const uint32_t* c = &CL[((size_t)y * W + x) * D];
       const int d = argmin(c);
       bool ok = true;
       if (p->lr_max_diff >= 0) ok = x - d >= 0 && std::abs(d - dR[(size_t)y * W + x - d]) <= p->lr_max_diff;

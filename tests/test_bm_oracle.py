@@ -24,13 +24,14 @@ def sgm():
     return SgmOracle()
 
 
-def _cost(gA, gB, r, x, y, shift):
-    """sum over the block of |a(cl(x+i), cr(y+j)) - b(cl(x+i+shift), cr(y+j))| with numpy index clamps"""
+def _cost(gA, gB, r, x, y, shift, squared=False):
+    """sum over the block of |a(cl(x+i), cr(y+j)) - b(cl(x+i+shift), cr(y+j))| (or its square: JN_BM_COST_SSD) with numpy index clamps"""
     H, W = gA.shape
     ys = np.clip(np.arange(y - r, y + r + 1), 0, H - 1)
     xa = np.clip(np.arange(x - r, x + r + 1), 0, W - 1)
     xb = np.clip(np.arange(x - r, x + r + 1) + shift, 0, W - 1)
-    return int(np.abs(gA[np.ix_(ys, xa)].astype(int) - gB[np.ix_(ys, xb)].astype(int)).sum())
+    e = gA[np.ix_(ys, xa)].astype(int) - gB[np.ix_(ys, xb)].astype(int)
+    return int((e * e).sum() if squared else np.abs(e).sum())
 
 
 @pytest.mark.parametrize("r", [2, 3, 4])
@@ -41,19 +42,21 @@ def test_cost_function_against_numpy(bm, r):
     for (x, y, d) in [(0, 0, 0), (0, 0, 5), (16, 12, 3), (8, 6, 7), (3, 11, 15), (16, 0, 2)]:
         assert bm.cost(gL, gR, r, 0, x, y, d) == _cost(gL, gR, r, x, y, -d)
         assert bm.cost(gL, gR, r, 1, x, y, d) == _cost(gR, gL, r, x, y, d)
+        assert bm.cost(gL, gR, r, 0, x, y, d, squared=True) == _cost(gL, gR, r, x, y, -d, True)
+        assert bm.cost(gL, gR, r, 1, x, y, d, squared=True) == _cost(gR, gL, r, x, y, d, True)
 
 
-@pytest.mark.parametrize("r,sub,lr", [(2, 0, 1), (3, 1, 1), (4, 1, 0), (4, 0, -1)])
-def test_whole_mode_on_a_small_case_restated(bm, sgm, r, sub, lr):
+@pytest.mark.parametrize("r,sub,lr,sq", [(2, 0, 1, 0), (3, 1, 1, 0), (4, 1, 0, 0), (4, 0, -1, 0), (4, 1, 1, 1), (2, 0, 0, 1), (3, 1, -1, 1)])
+def test_whole_mode_on_a_small_case_restated(bm, sgm, r, sub, lr, sq):
     """Prefilter, both cost volumes by the literal five-loop cost, first-minimum WTA on each side, L/R check, 1/16 formula."""
     rng = np.random.default_rng(11 + r)
     H, W, D = 12, 26, 8
     base = rng.integers(0, 256, (H, W + D)).astype(np.uint8)
     R = base[:, D:].copy(); L = base[:, D - 3:W + D - 3].copy()          # true disparity 3
-    got = bm.process(bm.params(D, r, 31, lr, sub), L, R)
+    got = bm.process(bm.params(D, r, 31, lr, sub, sq), L, R)
     gL, gR = sgm.prefilter(L), sgm.prefilter(R)
-    CL = np.array([[[_cost(gL, gR, r, x, y, -d) for d in range(D)] for x in range(W)] for y in range(H)])
-    CR = np.array([[[_cost(gR, gL, r, x, y, d) for d in range(D)] for x in range(W)] for y in range(H)])
+    CL = np.array([[[_cost(gL, gR, r, x, y, -d, bool(sq)) for d in range(D)] for x in range(W)] for y in range(H)])
+    CR = np.array([[[_cost(gR, gL, r, x, y, d, bool(sq)) for d in range(D)] for x in range(W)] for y in range(H)])
     dL, dR = CL.argmin(axis=2), CR.argmin(axis=2)                        # numpy argmin = first minimum
     exp = np.zeros((H, W), int)
     for y in range(H):
@@ -88,17 +91,29 @@ def test_oracle_recovers_the_synthetic_ground_truth(bm, sgm, oracle, W, H, D, sc
     assert u8[~v].max(initial=0) == 0 and np.abs(u8[v].astype(int) - disp[v]).max() <= 1
 
 
-def test_committed_hashes_are_the_oracles(bm, oracle):
-    rows = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "bm_hashes.txt")) if not l.startswith("#")]
+@pytest.mark.parametrize("name,cf", [("bm_hashes.txt", 0), ("bm_ssd_hashes.txt", 1)])
+def test_committed_hashes_are_the_oracles(bm, oracle, name, cf):
+    rows = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", name)) if not l.startswith("#")]
     W, H, scene, D, r, sub, seed, h = rows[0]
     L, R = oracle.synth_pair(int(W), int(H), int(scene), int(seed))
-    d = bm.process(bm.params(int(D), int(r), subpixel=int(sub)), L, R)
+    d = bm.process(bm.params(int(D), int(r), subpixel=int(sub), cost_function=cf), L, R)
     assert "%016x" % oracle.fnv(d.view(np.uint32)) == h
+
+
+def test_ssd_cost_recovers_the_synthetic_ground_truth_too(bm, oracle):
+    W, H, D, scene = 320, 180, 64, 48
+    L, R = oracle.synth_pair(W, H, scene, 12345)
+    disp = bm.process(bm.params(D, cost_function=1), L, R)
+    yy, xx = np.mgrid[0:H, 0:W]
+    gt = (yy / H * (scene * 0.6)).astype(int) + 2
+    gt[(xx > W // 3) & (xx < W // 2) & (yy > H // 3) & (yy < 2 * H // 3)] = int(scene * 0.7)
+    v = disp >= 0
+    assert v.mean() > 0.85 and (np.abs(disp[v] - gt[v]) <= 1).mean() > 0.97
 
 
 def test_parameters_outside_the_definition_are_refused(bm):
     L = np.zeros((16, 16), np.uint8)
-    for kw in ({"prefilter_cap": 40}, {"block_radius": 0}, {"num_disparities": 300}):
+    for kw in ({"prefilter_cap": 40}, {"block_radius": 0}, {"num_disparities": 300}, {"cost_function": 2}):
         with pytest.raises(ValueError):
             bm.process(bm.params(**kw), L, L)
 

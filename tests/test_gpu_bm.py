@@ -152,3 +152,70 @@ def test_bench_modes_on_baseline_config_2(mode, extra, expected):
     assert j["metric"] == "stereo_pairs_per_sec" and j["n_gpus"] == 1 and j["value"] > 0 and j["config"]["mode"] == mode
     assert j["check"]["ok"] is True and j["check"]["expected"] == expected
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["ms_per_launch"] > 0 and 0 < j["roofline"]["frac"] < 1
+
+
+# ---- JN_BM_COST_SSD: the banded int8 contraction on the matrix cores (csrc/bm_mfma.hip; BASELINE config 5's "int8 cost volume (CDNA4 MFMA path)") ----
+@pytest.mark.parametrize("W,H,D,scene,n,kw", [
+    (640, 480, 64, 64, 2, {}),                                     # 640x480 D=64
+    (1280, 720, 128, 128, 1, {"subpixel": 1}),                     # config 3's frame and range, 1/16 pixel
+    (320, 180, 256, 48, 2, {"subpixel": 1, "block_radius": 3}),    # D = 256 (9 tiles of candidates), 7x7
+    (333, 101, 64, 30, 3, {"block_radius": 2, "prefilter_cap": 15}),   # ragged size (partial tile of 32 columns, partial band), 5x5
+    (200, 150, 128, 90, 2, {"lr_max_diff": -1}),                   # no L/R check (no right-referenced pass)
+    (96, 64, 128, 20, 1, {"lr_max_diff": 0, "subpixel": 1}),       # image narrower than the disparity range
+    (70, 9, 32, 5, 2, {"block_radius": 4}),                        # fewer rows than the block is high, smallest range (two tiles)
+    (640, 480, 96, 64, 1, {"block_radius": 3, "subpixel": 1}),     # an even number of tiles
+])
+def test_bm_ssd_on_the_matrix_cores_bit_exact_vs_its_definition(jn, bm, sgm, oracle, W, H, D, scene, n, kw):
+    Ls = np.stack([oracle.synth_pair(W, H, scene, 700 + b)[0] for b in range(n)])
+    Rs = np.stack([oracle.synth_pair(W, H, scene, 700 + b)[1] for b in range(n)])
+    out, u8, t = run(jn, jn.Bm.parameters(num_disparities=D, cost_function=1, **kw), Ls, Rs)
+    po = bm.params(D, cost_function=1, **kw)
+    for b in range(n):
+        exp = bm.process(po, Ls[b], Rs[b])
+        assert np.array_equal(out[b], exp), (b, int((out[b] != exp).sum()), np.argwhere(out[b] != exp)[:5])
+        assert np.array_equal(u8[b], sgm.to_u8(exp, kw.get("subpixel", 0)))
+    assert t["match"] > 0 and t["total"] >= t["match"]
+
+
+@pytest.mark.parametrize("band", ["1", "7", "16", "37", "200"])
+def test_bm_ssd_band_heights_give_the_same_map(jn, bm, oracle, monkeypatch, band):
+    """rows per wave (JN_BMQ_BAND overrides the launch's choice): the running sums restart per band, the bits must not change"""
+    monkeypatch.setenv("JN_BMQ_BAND", band)
+    L, R = oracle.synth_pair(320, 200, 40, 9)
+    for sub in (0, 1):
+        out, _, _ = run(jn, jn.Bm.parameters(num_disparities=64, subpixel=sub, cost_function=1), L[None], R[None])
+        assert np.array_equal(out[0], bm.process(bm.params(64, subpixel=sub, cost_function=1), L, R))
+
+
+def test_bm_ssd_on_other_scenes_and_random_images(jn, bm):
+    from scenes import make_scene
+    W, H, D = 320, 240, 64
+    pairs = [make_scene(k, W, H, 60, 5 + i) for i, k in enumerate(["strips", "patches", "slanted", "photometric", "blobs"])]
+    rng = np.random.default_rng(9)
+    pairs.append((rng.integers(0, 256, (H, W)).astype(np.uint8), rng.integers(0, 256, (H, W)).astype(np.uint8)))   # no structure at all
+    pairs.append((np.full((H, W), 77, np.uint8), np.full((H, W), 77, np.uint8)))                                    # flat: every cost ties (smallest d must win)
+    Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
+    for sub in (0, 1):
+        out, _, _ = run(jn, jn.Bm.parameters(num_disparities=D, subpixel=sub, cost_function=1), Ls, Rs)
+        for b in range(len(pairs)):
+            assert np.array_equal(out[b], bm.process(bm.params(D, subpixel=sub, cost_function=1), Ls[b], Rs[b])), (sub, b)
+
+
+def test_bm_ssd_committed_hashes_incl_1080p_d256(jn, oracle):
+    """tests/golden/bm_ssd_hashes.txt (oracle/bm_oracle.cpp with cost_function = 1, generator committed): 640x480 D=64 and config 5's
+    frame 1920x1080 D=256 with the sub-pixel option — a size the scalar definition takes too long for inside the GPU suite."""
+    rows = [l.split() for l in open(os.path.join(ROOT, "tests", "golden", "bm_ssd_hashes.txt")) if not l.startswith("#")]
+    assert len(rows) >= 3
+    for W, H, scene, D, r, sub, seed, h in rows:
+        L, R = oracle.synth_pair(int(W), int(H), int(scene), int(seed))
+        out, _, _ = run(jn, jn.Bm.parameters(num_disparities=int(D), block_radius=int(r), subpixel=int(sub), cost_function=1), L[None], R[None])
+        assert "%016x" % oracle.fnv(out[0].view(np.uint32)) == h, (W, H, D, sub)
+
+
+def test_bm_ssd_refuses_ranges_it_does_not_tile(jn):
+    from jackal_navigation_amd import _lib
+    with pytest.raises(_lib.JnError) as e:
+        jn.Bm(jn.Bm.parameters(num_disparities=72, cost_function=1), 320, 240)
+    assert e.value.status == _lib.JN_ERR_UNSUPPORTED
+    with pytest.raises(_lib.JnError):
+        jn.Bm(jn.Bm.parameters(num_disparities=64, cost_function=7), 320, 240)
