@@ -51,7 +51,15 @@ STAGE_BYTES_PER_PX = {
     "gpu_gap": 16.0,            # rows+cols 8r+8w
     "gpu_adaptive_mean": 16.0,  # H+V 8r+8w
 }
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+def _evidence_round():
+    """round of the committed evidence set (profiles/CURRENT, e.g. "r04" or "r03_i" -> "r03")"""
+    try:
+        return open(os.path.join(ROOT, "profiles", "CURRENT")).read().strip().split("_")[0]
+    except OSError:
+        return "r00"
+
+
+PMC_FILE = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % _evidence_round())
 KERNELS_SRC = os.path.join(ROOT, "jackal_navigation_amd", "csrc", "kernels.hip")
 
 
@@ -279,14 +287,15 @@ def bm_roofline(W, H, D, B, radius, sub, ms):
 
 
 def sgm_pmc_traffic(W, H, D, B):
-    """HBM bytes per batch of the sweep kernels from the committed PMC passes (profiles/r03_sgm_pmc_traffic.json), if they were
+    """HBM bytes per batch of the sweep kernels from the committed PMC passes (profiles/<round>_sgm_pmc_traffic.json), if they were
     taken on this source (sha256 of sgm_sweep.hip) and this workload."""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r03_sgm_pmc_traffic.json")))
+        name = "%s_sgm_pmc_traffic.json" % _evidence_round()
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
         src = os.path.join(ROOT, "jackal_navigation_amd", "csrc", "sgm_sweep.hip")
         if j.get("sgm_sweep_sha256") != hashlib.sha256(open(src, "rb").read()).hexdigest() or j.get("workload") != [W, H, D, B]:
             return None
-        return {"bytes": int(j["bytes_per_batch"]), "note": "PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, profiles/r03_sgm_pmc_traffic.json);"}
+        return {"bytes": int(j["bytes_per_batch"]), "note": "PMC (FETCH_SIZE x 2 + WRITE_SIZE, separate passes, profiles/%s);" % name}
     except (OSError, ValueError, KeyError):
         return None
 

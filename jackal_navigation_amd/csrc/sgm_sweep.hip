@@ -122,8 +122,9 @@ DEV uint32_t pk_min3(uint32_t a, uint32_t b, uint32_t c) {
 // The adjoining pairs of the neighbouring quarters, already reduced by P1 (T = X (-) P1: max(a, b) (-) P1 = max(a (-) P1, b (-) P1)):
 // up = the quarter below's j = DPL-1 (high half of its register NR-1) for this lane's j = 0; dn = the quarter above's j = 0 for this
 // lane's j = DPL-1.  Issued ahead of the cells that use them.
-template <int NR>
+template <int NR, int LQ = 4>
 DEV void path_neighbours(const uint32_t (&X)[NR], int lane, int q, uint32_t P1pk, uint32_t& up, uint32_t& dn) {
+  constexpr int NQ = LQ, PX = 64 / LQ;                         // lanes per pixel, pixels per wave (the file-scope values are the 4-lane layout's)
   const uint32_t a = bperm((lane - PX) & 63, pk_subsat(X[NR - 1], P1pk));
   const uint32_t b = bperm((lane + PX) & 63, pk_subsat(X[0], P1pk));
   up = q == 0 ? 0u : a;
@@ -154,8 +155,10 @@ DEV void path_cells(const uint32_t (&X)[NR], uint32_t up, uint32_t dn, const uin
   for (int r = 2; r < NR; r += 2) mn = pk_min3(mn, Ln[r], Ln[r + 1]);
 }
 // minimum over the pixel's four lanes (and both halves) with the gfx950 row / half swaps: pure VALU, no LDS round trip
+template <int LQ = 4>
 DEV uint32_t pixel_min(uint32_t mn) {
   uint32_t m = min(mn & 0xFFFFu, mn >> 16);
+  if constexpr (LQ == 8) m = min(m, (uint32_t)__builtin_amdgcn_update_dpp((int)m, (int)m, 0x128, 0xf, 0xf, false));   // row_ror:8: the lane 8 further, inside the 16-lane DPP row
   const auto a = __builtin_amdgcn_permlane16_swap(m, m, false, false);
   m = min(a[0], a[1]);
   const auto b = __builtin_amdgcn_permlane32_swap(m, m, false, false);
@@ -175,32 +178,32 @@ DEV uint32_t unpack_hi(uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c030
 // VOLUME LAYOUT.  A pixel's D bytes are stored as 16-byte pieces: piece c of quarter q at byte 64 c + 16 q, so that the four
 // lanes of a pixel write (and read) 64 contiguous bytes per instruction.  Within a lane, piece c holds registers 8c .. 8c+7
 // as pack4 pairs.  Only these kernels read the volumes, so the order of the disparities inside a pixel is theirs to choose.
-template <int NR>
+template <int NR, int LQ = 4>
 DEV void store_bytes(uint8_t* pixel_base, int q, const uint32_t (&acc)[NR]) {
 #pragma unroll
   for (int c = 0; c < NR / 8; c++)
-    *reinterpret_cast<uint4*>(pixel_base + 64 * c + 16 * q) = make_uint4(pack4(acc[8 * c], acc[8 * c + 1]), pack4(acc[8 * c + 2], acc[8 * c + 3]),
+    *reinterpret_cast<uint4*>(pixel_base + 16 * LQ * c + 16 * q) = make_uint4(pack4(acc[8 * c], acc[8 * c + 1]), pack4(acc[8 * c + 2], acc[8 * c + 3]),
                                                                           pack4(acc[8 * c + 4], acc[8 * c + 5]), pack4(acc[8 * c + 6], acc[8 * c + 7]));
 }
-template <int NR>
+template <int NR, int LQ = 4>
 DEV void load_bytes(const uint8_t* pixel_base, int q, uint32_t (&f)[NR / 2]) {
 #pragma unroll
   for (int c = 0; c < NR / 8; c++) {
-    const uint4 v = *reinterpret_cast<const uint4*>(pixel_base + 64 * c + 16 * q);
+    const uint4 v = *reinterpret_cast<const uint4*>(pixel_base + 16 * LQ * c + 16 * q);
     f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
   }
 }
 // 16-bit form (three-path sums beyond 255): piece c of quarter q holds registers 4c .. 4c+3 as they are
-template <int NR>
+template <int NR, int LQ = 4>
 DEV void store_words(uint8_t* pixel_base, int q, const uint32_t (&acc)[NR]) {
 #pragma unroll
-  for (int c = 0; c < NR / 4; c++) *reinterpret_cast<uint4*>(pixel_base + 64 * c + 16 * q) = make_uint4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
+  for (int c = 0; c < NR / 4; c++) *reinterpret_cast<uint4*>(pixel_base + 16 * LQ * c + 16 * q) = make_uint4(acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]);
 }
-template <int NR>
+template <int NR, int LQ = 4>
 DEV void load_words(const uint8_t* pixel_base, int q, uint32_t (&f)[NR]) {
 #pragma unroll
   for (int c = 0; c < NR / 4; c++) {
-    const uint4 v = *reinterpret_cast<const uint4*>(pixel_base + 64 * c + 16 * q);
+    const uint4 v = *reinterpret_cast<const uint4*>(pixel_base + 16 * LQ * c + 16 * q);
     f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
   }
 }
@@ -236,12 +239,13 @@ __global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __
 // (Also measured, bit-exact, slower: every v_mqsad operand loaded per pixel as the row sweeps do — 4.6 ms instead of 2.1, the lanes are 16
 // different image rows here and each load instruction touches dozens of cache lines; the entering dwords reloaded after every pixel — 3.1 ms.)
 constexpr int HCH = 16;                                        // wraps (dwords per row and quarter) staged at a time
-template <int NR, int DIR>
+template <int NR, int DIR, int LQ>
 DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t* __restrict__ gmR, int y0, uint8_t* __restrict__ vol, bool valid, int lane, int q,
                  uint32_t* __restrict__ sR, uint32_t* __restrict__ sL) {
   constexpr int NW = NR / 2 + 1;                               // dwords of one pixel's run
-  constexpr int DPL = 2 * NR, SPAN = HCH + 3 * DPL / 4;        // staged dwords per row of the right image
-  const int W = s.W, p = lane & 15;
+  constexpr int NQ = LQ, PX = 64 / LQ;                         // lanes per pixel, image rows per wave
+  constexpr int DPL = 2 * NR, SPAN = HCH + (NQ - 1) * DPL / 4; // staged dwords per row of the right image
+  const int W = s.W, p = lane & (PX - 1);
   const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u, P2pk = (uint32_t)s.P2 * 0x10001u;
   // gmL / gmR: column x_k = 0 of image row 0 of this frame's left / right prefiltered image; this lane's row is min(y0 + p, H - 1)
   const int yc = min(y0 + p, s.H - 1);
@@ -276,11 +280,11 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t*
     if (wraps_left == 0) {
       // the next HCH wraps fetch (upwards) al + 4 (i + 1) + 4 (NW + 1) resp. al + 4 (i + 1) + 8, (downwards) al - 4 (i + 1) - 4 for both rows
       const int baseR = DIR ? al - 4 * HCH - 4 : al + 4 + 4 * (NW + 1), baseL = DIR ? al - 4 * HCH - 4 : al + 12;
-      constexpr int KR = (16 * SPAN + 63) / 64, KL = 16 * HCH / 64;
+      constexpr int KR = (PX * SPAN + 63) / 64, KL = PX * HCH / 64;
       uint32_t tR[KR], tL[KL];                                 // all loads first, then all LDS writes
 #pragma unroll
       for (int k = 0; k < KR; k++) {
-        const int i = min(lane + 64 * k, 16 * SPAN - 1), row = i / SPAN, col = i - row * SPAN;
+        const int i = min(lane + 64 * k, PX * SPAN - 1), row = i / SPAN, col = i - row * SPAN;
         tR[k] = *reinterpret_cast<const uint32_t*>(gmR + (size_t)min(y0 + row, s.H - 1) * s.Wp + min(max(baseR + 4 * col, lo_byte), hi_byte));
       }
 #pragma unroll
@@ -290,7 +294,7 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t*
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < KR; k++) { const int i = lane + 64 * k; if ((16 * SPAN) % 64 == 0 || i < 16 * SPAN) sR[i] = tR[k]; }
+      for (int k = 0; k < KR; k++) { const int i = lane + 64 * k; if ((PX * SPAN) % 64 == 0 || i < PX * SPAN) sR[i] = tR[k]; }
 #pragma unroll
       for (int k = 0; k < KL; k++) sL[lane + 64 * k] = tL[k];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -304,10 +308,10 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t*
     costs<NR>(w, ref, P2pk, Cp);
 #pragma unroll
     for (int r = 0; r < NR; r++) acc[r] = 0u;
-    path_neighbours<NR>(X, lane, q, P1pk, up, dn);
+    path_neighbours<NR, LQ>(X, lane, q, P1pk, up, dn);
     path_cells<NR>(X, up, dn, Cp, acc, Ln, mn, P1pk);
-    path_normalise<NR>(X, Ln, pixel_min(mn), (uint32_t)s.P2);
-    if (valid) store_bytes<NR>(vol + (size_t)xk * s.D, q, acc);
+    path_normalise<NR>(X, Ln, pixel_min<LQ>(mn), (uint32_t)s.P2);
+    if (valid) store_bytes<NR, LQ>(vol + (size_t)xk * s.D, q, acc);
     // next pixel: slide the window when the byte phase wraps
     if (!DIR) {
       xk++;
@@ -332,11 +336,12 @@ DEV void h_sweep(const SwDev& s, const uint8_t* __restrict__ gmL, const uint8_t*
     }
   }
 }
-template <int NR>
+template <int NR, int LQ>
 __global__ void __launch_bounds__(256, NR <= 16 ? 4 : 2) k_sw_h(SwDev s, int n, const uint8_t* __restrict__ gm, uint8_t* __restrict__ vol0, uint8_t* __restrict__ vol1) {
-  constexpr int DPL = 2 * NR, SPAN = HCH + 3 * DPL / 4;
-  __shared__ uint32_t sR[4][16 * SPAN], sL[4][16 * HCH];       // per wave: the staged dwords of its 16 rows
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, p = lane & 15;
+  constexpr int NQ = LQ, PX = 64 / LQ;
+  constexpr int DPL = 2 * NR, SPAN = HCH + (NQ - 1) * DPL / 4;
+  __shared__ uint32_t sR[4][PX * SPAN], sL[4][PX * HCH];       // per wave: the staged dwords of its PX rows
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane / PX, p = lane & (PX - 1);
   const int y0 = (blockIdx.x * 4 + wave) * PX, frame = blockIdx.y, dir = blockIdx.z;
   if (y0 >= s.H) return;
   const int y = y0 + p;
@@ -345,8 +350,8 @@ __global__ void __launch_bounds__(256, NR <= 16 ? 4 : 2) k_sw_h(SwDev s, int n, 
   const uint8_t* gmL = gm + (size_t)frame * s.H * s.Wp + s.padl;
   const uint8_t* gmR = gm + (size_t)(n + frame) * s.H * s.Wp + s.padl;
   const size_t row_px = ((size_t)frame * s.H + yc) * s.W;
-  if (dir == 0) h_sweep<NR, 0>(s, gmL, gmR, y0, vol0 + row_px * s.D, valid, lane, q, sR[wave], sL[wave]);
-  else h_sweep<NR, 1>(s, gmL, gmR, y0, vol1 + row_px * s.D, valid, lane, q, sR[wave], sL[wave]);
+  if (dir == 0) h_sweep<NR, 0, LQ>(s, gmL, gmR, y0, vol0 + row_px * s.D, valid, lane, q, sR[wave], sL[wave]);
+  else h_sweep<NR, 1, LQ>(s, gmL, gmR, y0, vol1 + row_px * s.D, valid, lane, q, sR[wave], sL[wave]);
 }
 
 // ---- the three paths of one vertical direction, sheared strips ----
@@ -661,10 +666,12 @@ DEV void lds_read_lanes<8>(u32x4 (&tv)[8], u32x4 (&tm)[8], uint32_t addrV, uint3
                  "+v"(tm[0]), "+v"(tm[1]), "+v"(tm[2]), "+v"(tm[3]), "+v"(tm[4]), "+v"(tm[5]), "+v"(tm[6]), "+v"(tm[7]) : "v"(addrV), "v"(addrM) : "s2", "s3", "vcc", "memory");
 }
 
-template <int NR, int NS, int RING, bool FINAL, bool WIDE>
+template <int NR, int NS, int RING, bool FINAL, bool WIDE, int LQ>
 __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ? 2 : 1) k_sw_w(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
                                                   const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1, uint32_t* __restrict__ gx,
                                                   uint32_t* __restrict__ ctr, uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
+  constexpr int NQ = LQ, PX = 64 / LQ;                         // lanes per pixel (4, or 8 for D = 256: 16 disparity pairs per lane either way), pixels per strip
+  constexpr bool LATE_PROD = FINAL && LQ == 8;                 // where the last strip requests its producer block's columns (see there)
   constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = PX + DPL, NG = (SLOT + 63) / 64;
   static_assert((RING & (RING - 1)) == 0, "ring depth is a power of two");
   __shared__ uint32_t ring[RING][NS][SLOT];                    // boundary columns [row mod RING][strip][V0 | M0 | M1][quarter][NR]
@@ -707,7 +714,7 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
 #pragma unroll
     for (int k = 0; k < NG; k++) { const int o = ln + 64 * k; dst[k] = (SLOT % 64 == 0 || o < SLOT) ? ld_sc1(src + o) : tagpk; }
   };
-  const int q = lane >> 4, p = lane & 15;
+  const int q = lane / PX, p = lane & (PX - 1);
   const int xl = x0 + PX * wave + p;                           // this lane's sheared column
   const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u;
   uint32_t V[NR], G[NR], M[NR];                                // X of the pixel this lane computed last, per path: vertical, own diagonal, other diagonal
@@ -722,8 +729,8 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
   // (v_alignbyte of their two dwords), and a lane reads dword-aligned from copy p & 3.  Two rows of LDS per strip: the commit of row yb + 2
   // overwrites row yb's slot behind row yb's reads (LDS serves a wave's instructions in order).
   constexpr int RBYTES = PX - 1 + DPL * (NQ - 1) + 4 * (NR / 2 - 1) + 8;      // right-row bytes a strip touches
-  constexpr int NRD = (RBYTES + 3) / 4, NLD = (PX + 6) / 4, TD = NRD + NLD, NSTG = (TD + 63) / 64;
-  __shared__ uint32_t rowbuf[NS][2][4][NSTG * 64];              // [strip][row parity][byte shift][dword]
+  constexpr int NRD = (RBYTES + 3) / 4, NLD = (PX + 6) / 4, TD = NRD + NLD, NSTG = (TD + 63) / 64, RS = (TD + 3) & ~3;
+  __shared__ uint32_t rowbuf[NS][2][4][RS];                     // [strip][row parity][byte shift][dword]
   const int y0 = flip ? H - 1 - ybs : ybs;
   const long long row_step = (flip ? -(long long)s.Wp : (long long)s.Wp) + 1;
   const uint8_t* gsrc;                                          // left row of the strip's next fetch (wave-uniform; the right image lies n images further)
@@ -745,20 +752,21 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
 #pragma unroll
     for (int k = 0; k < NSTG; k++) {
       const uint32_t lo = (uint32_t)d[k], hi = (uint32_t)(d[k] >> 32);
+      if (TD % 64 != 0 && lane + 64 * k >= TD) continue;        // (the last lanes fetched a copy of dword TD - 1)
       uint32_t* dst = &rowbuf[wave][row & 1][0][lane + 64 * k];
       dst[0] = lo;
-      dst[NSTG * 64] = __builtin_amdgcn_alignbyte(hi, lo, 1);
-      dst[2 * NSTG * 64] = __builtin_amdgcn_alignbyte(hi, lo, 2);
-      dst[3 * NSTG * 64] = __builtin_amdgcn_alignbyte(hi, lo, 3);
+      dst[RS] = __builtin_amdgcn_alignbyte(hi, lo, 1);
+      dst[2 * RS] = __builtin_amdgcn_alignbyte(hi, lo, 2);
+      dst[3 * RS] = __builtin_amdgcn_alignbyte(hi, lo, 3);
     }
   };
   struct RowIn { uint64_t ww[NR / 2]; uint32_t ref; };
-  const int rd_at = (p & 3) * (NSTG * 64) + (p >> 2) + (DPL / 4) * q;   // this lane's first dword inside a staged row: copy p & 3, dword-aligned
+  const int rd_at = (p & 3) * RS + (p >> 2) + (DPL / 4) * q;   // this lane's first dword inside a staged row: copy p & 3, dword-aligned
   auto read_row = [&](int row, RowIn& in_) __attribute__((always_inline)) {
     const uint32_t* rb = &rowbuf[wave][row & 1][0][0] + rd_at;
 #pragma unroll
     for (int k = 0; k < NR / 2; k++) in_.ww[k] = (uint64_t)rb[k] | ((uint64_t)rb[k + 1] << 32);      // each pair on its own (ds_read2_b32): one v_mqsad operand, no re-pairing
-    in_.ref = (&rowbuf[wave][row & 1][0][0])[(p & 3) * (NSTG * 64) + NRD + (p >> 2)];
+    in_.ref = (&rowbuf[wave][row & 1][0][0])[(p & 3) * RS + NRD + (p >> 2)];
   };
   if (last && has_prod && ybs - 1 >= ybsp && ybs - 1 <= ybep) load_prod(ybs - 1, g);
   uint64_t stg[NSTG];                                           // the fetch in flight: row yb + 2 at the top of row yb
@@ -786,11 +794,11 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
       const __amdgpu_buffer_rsrc_t rF = row_rsrc(volF, yb, FB), r0 = row_rsrc(volH0, yb, 1), r1 = row_rsrc(volH1, yb, 1);
       const int off = (xl + yb) * D + 16 * q, offF = (xl + yb) * D * FB + 16 * q;
 #pragma unroll
-      for (int c = 0; c < NVF; c++) fF[c] = __builtin_amdgcn_raw_buffer_load_b128(rF, offF + 64 * c, 0, 0);
+      for (int c = 0; c < NVF; c++) fF[c] = __builtin_amdgcn_raw_buffer_load_b128(rF, offF + 16 * NQ * c, 0, 0);
 #pragma unroll
-      for (int c = 0; c < NVH; c++) fH0[c] = __builtin_amdgcn_raw_buffer_load_b128(r0, off + 64 * c, 0, 0);
+      for (int c = 0; c < NVH; c++) fH0[c] = __builtin_amdgcn_raw_buffer_load_b128(r0, off + 16 * NQ * c, 0, 0);
 #pragma unroll
-      for (int c = 0; c < NVH; c++) fH1[c] = __builtin_amdgcn_raw_buffer_load_b128(r1, off + 64 * c, 0, 0);
+      for (int c = 0; c < NVH; c++) fH1[c] = __builtin_amdgcn_raw_buffer_load_b128(r1, off + 16 * NQ * c, 0, 0);
     }
   };
   load_volumes(ybs);
@@ -881,7 +889,7 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
 #pragma unroll
         for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = P2pk; }
       }
-      if (has_prod && yb >= ybsp && yb <= ybep && yb < ybe && !SW_DBG(1)) load_prod(yb, g);  // the next row's, speculatively: checked when it is needed
+      if constexpr (!LATE_PROD) { if (has_prod && yb >= ybsp && yb <= ybep && yb < ybe && !SW_DBG(1)) load_prod(yb, g); }  // the next row's, speculatively: checked when it is needed
     }
     // ---- the right neighbour's columns of row yb - 1 ----
     const uint32_t* e;
@@ -911,8 +919,8 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
       u32x4 tv[NR / 4], tm[NR / 4];
 #pragma unroll
       for (int k = 0; k < NR / 4; k++) { tv[k] = (u32x4){V[4 * k], V[4 * k + 1], V[4 * k + 2], V[4 * k + 3]}; tm[k] = (u32x4){M[4 * k], M[4 * k + 1], M[4 * k + 2], M[4 * k + 3]}; }
-      const uint32_t aV = lds_addr(e + (0 * NQ + q) * NR), aM = lds_addr(e + ((p == 14 ? 1 : 2) * NQ + q) * NR);
-      lds_read_lanes<NR / 4>(tv, tm, p == 15 ? aV : 0xFFFFFFFFu, p >= 14 ? aM : 0xFFFFFFFFu);
+      const uint32_t aV = lds_addr(e + (0 * NQ + q) * NR), aM = lds_addr(e + ((p == PX - 2 ? 1 : 2) * NQ + q) * NR);
+      lds_read_lanes<NR / 4>(tv, tm, p == PX - 1 ? aV : 0xFFFFFFFFu, p >= PX - 2 ? aM : 0xFFFFFFFFu);
 #pragma unroll
       for (int k = 0; k < NR / 4; k++) {
         V[4 * k] = tv[k].x; V[4 * k + 1] = tv[k].y; V[4 * k + 2] = tv[k].z; V[4 * k + 3] = tv[k].w;
@@ -942,15 +950,15 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
     }
     {
       uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];
-      path_neighbours<NR>(V, lane, q, P1pk, upV, dnV);
-      path_neighbours<NR>(G, lane, q, P1pk, upG, dnG);
-      path_neighbours<NR>(M, lane, q, P1pk, upM, dnM);
+      path_neighbours<NR, LQ>(V, lane, q, P1pk, upV, dnV);
+      path_neighbours<NR, LQ>(G, lane, q, P1pk, upG, dnG);
+      path_neighbours<NR, LQ>(M, lane, q, P1pk, upM, dnM);
       path_cells<NR, FINAL>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
-      path_normalise<NR>(V, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_normalise<NR>(V, Ln, pixel_min<LQ>(mn), (uint32_t)s.P2);
       path_cells<NR, FINAL>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
-      path_normalise<NR>(G, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_normalise<NR>(G, Ln, pixel_min<LQ>(mn), (uint32_t)s.P2);
       path_cells<NR, FINAL>(M, upM, dnM, Cp, acc, Ln, mn, P1pk);
-      path_normalise<NR>(M, Ln, pixel_min(mn), (uint32_t)s.P2);
+      path_normalise<NR>(M, Ln, pixel_min<LQ>(mn), (uint32_t)s.P2);
     }
     if constexpr (FINAL) {
       __builtin_amdgcn_sched_barrier(0);
@@ -960,6 +968,16 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
     if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
 #pragma unroll
       for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : P2pk; G[r] = in ? G[r] : P2pk; M[r] = in ? M[r] : P2pk; }
+    }
+    if constexpr (LATE_PROD) {
+      // (final sweep with eight lanes per pixel: six registers of producer columns do not fit next to the cells' temporaries — held across the
+      // cells they are spilled, and a spill right behind the load is a synchronous wait.  Requested behind the cells instead, defined on every
+      // path so that no old value stays alive around the loop.)
+      if (last && has_prod && yb >= ybsp && yb <= ybep && yb < ybe && !SW_DBG(1)) load_prod(yb, g);
+      else {
+#pragma unroll
+        for (int k = 0; k < NG; k++) g[k] = 0u;
+      }
     }
     // ---- publish this strip's first two columns of row yb ----
     if (wave > 0 || j > 0) {
@@ -1000,12 +1018,12 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
         const int off = xk * D * FB + 16 * q;
         if constexpr (WIDE) {
 #pragma unroll
-          for (int c = 0; c < NR / 4; c++) __builtin_amdgcn_raw_buffer_store_b128((u32x4){acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]}, rF, off + 64 * c, 0, 0);
+          for (int c = 0; c < NR / 4; c++) __builtin_amdgcn_raw_buffer_store_b128((u32x4){acc[4 * c], acc[4 * c + 1], acc[4 * c + 2], acc[4 * c + 3]}, rF, off + 16 * NQ * c, 0, 0);
         } else {
 #pragma unroll
           for (int c = 0; c < NR / 8; c++)
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack4(acc[8 * c], acc[8 * c + 1]), pack4(acc[8 * c + 2], acc[8 * c + 3]), pack4(acc[8 * c + 4], acc[8 * c + 5]),
-                                                           pack4(acc[8 * c + 6], acc[8 * c + 7])}, rF, off + 64 * c, 0, 0);
+                                                           pack4(acc[8 * c + 6], acc[8 * c + 7])}, rF, off + 16 * NQ * c, 0, 0);
         }
       }
     } else {
@@ -1026,6 +1044,7 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
       }
       key = in ? key + (uint32_t)(DPL * q) : 0xFFFFFFFFu;
       {
+        if constexpr (LQ == 8) key = min(key, (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x128, 0xf, 0xf, false));   // row_ror:8
         const auto a = __builtin_amdgcn_permlane16_swap(key, key, false, false);
         key = min(a[0], a[1]);
         const auto b = __builtin_amdgcn_permlane32_swap(key, key, false, false);
@@ -1102,10 +1121,20 @@ static int strips_for(int D) {
   return v == 5 || v == 7 ? v : 3;
 }
 
+// Lanes per pixel.  D = 256 with four lanes per pixel means 32 disparity pairs per lane and path: 96 registers of path state, ~320 with the
+// temporaries — one wave per SIMD, and one wave issues a vector instruction every ~8 cycles at best (scripts/probes/dep_chain_probe.hip): half
+// the SIMD's rate.  With EIGHT lanes per pixel (strips of 8 pixels) a lane holds 16 pairs as at D = 128: the same code, three waves per SIMD.
+// JN_SGM_LQ=4 keeps the four-lane layout for A/B.  (k_sw_v, JN_SGM_FLOW=0, always uses four.)
+static int lanes_per_pixel(int D) {
+  if (!flow_mode() || D != 256) return 4;
+  const char* e = getenv("JN_SGM_LQ");
+  return e && atoi(e) == 4 ? 4 : 8;
+}
+
 void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch) {
   s->W = W; s->H = H; s->D = D; s->P1 = P1; s->P2 = P2; s->cap = cap; s->lr = lr; s->subpixel = subpixel ? 1 : 0;
   s->flow = flow_mode(); s->epoch = 0;
-  const int BLK = strips_for(D) * PX;
+  const int BLK = strips_for(D) * (64 / lanes_per_pixel(D));
   s->padl = BLK + 32; s->Wp = ((s->padl + W + D + BLK + 64) + 15) / 16 * 16;   // a block's width of padding: lanes outside the image read plain bytes
   s->xmin = -(H - 1);
   s->NB = (W + H - 1 + BLK - 1) / BLK;
@@ -1141,9 +1170,9 @@ static hipError_t launch_v(const SwDev& s, int n, bool final, hipStream_t st, co
 
 // k_sw_w: every launch on the buffer gets the next 16-bit tag; when the tag wraps the buffer is zeroed (tag 0 is never used), so
 // that rows an earlier, larger batch left behind can never carry the current tag
-template <int NR, int NS>
+template <int NR, int NS, int LQ>
 static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuffers& b) {
-  constexpr int RING = NR <= 16 ? 8 : 4;
+  constexpr int RING = (NR <= 16 && LQ == 4) ? 8 : 4, PX = 64 / LQ;     // rows of boundary columns a strip may run ahead of its left neighbour (LDS: 3 x 4 NR x lanes-per-pixel dwords per strip and row)
   const dim3 grid((unsigned)(n * s.NB)), block(NS * 64);
   const size_t dyn = final && s.subpixel ? (size_t)NS * PX * s.D * sizeof(uint16_t) : 0;
   uint32_t* ctr = b.flags + (size_t)n * s.NB;
@@ -1156,10 +1185,10 @@ static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuff
 #define JN_SW_W(FINAL, WIDE)                                                                                                            \
   do {                                                                                                                                  \
     if (dyn > 32 * 1024) {                                                                                                              \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw_w<NR, NS, RING, FINAL, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw_w<NR, NS, RING, FINAL, WIDE, LQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
       if (e != hipSuccess) return e;                                                                                                    \
     }                                                                                                                                   \
-    hipLaunchKernelGGL((k_sw_w<NR, NS, RING, FINAL, WIDE>), grid, block, dyn, st, s, n, FINAL ? 1 : 0, b.gm, b.volF, b.volH0, b.volH1, b.gx, ctr, b.minr, b.dl); \
+    hipLaunchKernelGGL((k_sw_w<NR, NS, RING, FINAL, WIDE, LQ>), grid, block, dyn, st, s, n, FINAL ? 1 : 0, b.gm, b.volF, b.volH0, b.volH1, b.gx, ctr, b.minr, b.dl); \
   } while (0)
   if (final) { if (s.wide) JN_SW_W(true, true); else JN_SW_W(true, false); }
   else { if (s.wide) JN_SW_W(false, true); else JN_SW_W(false, false); }
@@ -1167,7 +1196,7 @@ static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuff
   return hipGetLastError();
 }
 
-template <int NR, int NS, bool FLOW>
+template <int NR, int NS, bool FLOW, int LQ = 4>
 static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
                           SweepBuffers& b, hipEvent_t* ev) {
   hipError_t e;
@@ -1176,10 +1205,11 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
   if ((e = hipMemsetAsync(b.minr, 0xFF, (size_t)n * px * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sw_h<NR>), dim3((s.H + 4 * PX - 1) / (4 * PX), n, 2), dim3(256), 0, st, s, n, b.gm, b.volH0, b.volH1);
+  constexpr int PXL = 64 / LQ;                                  // image rows per wave of the horizontal sweep = pixels per strip of the row sweeps
+  hipLaunchKernelGGL((k_sw_h<NR, LQ>), dim3((s.H + 4 * PXL - 1) / (4 * PXL), n, 2), dim3(256), 0, st, s, n, b.gm, b.volH0, b.volH1);
   const size_t flag_bytes = ((size_t)n * s.NB + 1) * sizeof(uint32_t);
   auto sweep = [&](bool final) -> hipError_t {
-    if constexpr (FLOW) return launch_w<NR, NS>(s, n, final, st, b);
+    if constexpr (FLOW) return launch_w<NR, NS, LQ>(s, n, final, st, b);
     else return launch_v<NR, NS>(s, n, final, st, b);
   };
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
@@ -1194,11 +1224,13 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
 
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
                      SweepBuffers& b, hipEvent_t* ev) {
-  const int ns = (s.padl - 32) / PX;                           // strips per block, as sweep_geometry() chose them (padl = BLK + 32)
+  const int lq = lanes_per_pixel(s.D);
+  const int ns = (s.padl - 32) / (64 / lq);                    // strips per block, as sweep_geometry() chose them (padl = BLK + 32)
 #define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
   if (s.flow) {
     if (s.D == 64) return ns == 2 ? JN_RUN(8, 2, true) : ns == 8 ? JN_RUN(8, 8, true) : JN_RUN(8, 4, true);
     if (s.D == 128) return ns == 2 ? JN_RUN(16, 2, true) : ns == 8 ? JN_RUN(16, 8, true) : JN_RUN(16, 4, true);
+    if (lq == 8) return run_all<16, 4, true, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);     // D = 256: eight lanes per pixel, 16 pairs per lane
     return JN_RUN(32, 4, true);
   }
   if (s.D == 64) return ns == 3 ? JN_RUN(8, 3, false) : ns == 5 ? JN_RUN(8, 5, false) : JN_RUN(8, 7, false);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the evidence set scripts/round3_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
+"""Copy the evidence set scripts/round4_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
 profiles/<tag>_manifest.json: every published file, the sha256 of the kernel sources it was measured on, the commit.
     python3 scripts/publish_round.py <tag>
 Files are taken NEWEST FIRST (gpurun_out/ accumulates merged results of several calls; round 2 published stale ones)."""
@@ -29,6 +29,18 @@ def sha(rel):
 
 published = {}
 
+# A refresh with nothing new is a no-op (VERDICT r03 #7d): the manifest remembers the newest modification time among the inputs it
+# was made from; if no gpurun_out/<tag>_* file is newer, nothing is rewritten (git then sees no change at all).
+_inputs = [f for f in glob.glob(os.path.join(g, "%s_*" % tag)) + glob.glob(os.path.join(g, "%s_*/*/*" % tag)) if os.path.isfile(f)]
+_newest_in = max([os.path.getmtime(f) for f in _inputs], default=0.0)
+try:
+    _old = json.load(open(os.path.join(p, "%s_manifest.json" % tag)))
+    if _inputs and _old.get("inputs_newest_mtime") == _newest_in and "--force" not in sys.argv:
+        print("profiles/%s_*: nothing new under gpurun_out/ since the manifest was written: no-op" % tag)
+        sys.exit(0)
+except (OSError, ValueError):
+    pass
+
 
 def put(src, name):
     if src and os.path.exists(src) and os.path.getsize(src) > 0:
@@ -40,12 +52,15 @@ put(newest("%s_slots1/*/*kernel_stats.csv" % tag), "%s_slots1_kernel_stats.csv" 
 put(newest("%s_default/*/*kernel_stats.csv" % tag), "%s_default_bench_kernel_stats.csv" % tag)
 put(newest("%s_sgm/*/*kernel_stats.csv" % tag), "%s_sgm_kernel_stats.csv" % tag)
 put(newest("%s_bm/*/*kernel_stats.csv" % tag), "%s_bm_kernel_stats.csv" % tag)
+put(newest("%s_bm_ssd/*/*kernel_stats.csv" % tag), "%s_bm_ssd_kernel_stats.csv" % tag)
 for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.json"), ("default_occupancy.txt", "default_bench_occupancy.txt"),
                   ("pmc_FETCH_SIZE.txt", None), ("pmc_WRITE_SIZE.txt", None), ("bench_line.json", None), ("sgm_bench_line.json", None),
                   ("sgm_round2_kernels_bench_line.json", None), ("sgm_pmc_FETCH_SIZE.txt", None), ("sgm_pmc_WRITE_SIZE.txt", None), ("sgm_pmc_SQ.txt", None),
                   ("sgm_strips_ab.txt", None), ("bm_bench_line.json", None), ("bm_config2_bench_line.json", None), ("other_configs.jsonl", None),
                   ("merge_in_worker.txt", None), ("node_rate.txt", None), ("latency_check.txt", None), ("host_pointer_rate.txt", None),
-                  ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None)):
+                  ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None),
+                  ("bm_ssd_bench_line.json", None), ("bm_ssd_1080p_bench_line.json", None), ("bm_sad_1080p_bench_line.json", None), ("bm_ssd_pmc_mfma.txt", None),
+                  ("host_threads.txt", None), ("pk3_probe.txt", None), ("dep_chain_probe.txt", None), ("lds_unaligned_probe.txt", None), ("gpu_tests.txt", None)):
     put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
 sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
 if sq:
@@ -85,9 +100,9 @@ if os.path.exists(fs) and os.path.exists(ws):     # SGM traffic from its own PMC
                "algorithmic_bytes_per_batch": int((4 * 1280 * 720 * 128 + 5 * 1280 * 720) * 32)}, open(os.path.join(p, "%s_sgm_pmc_traffic.json" % rnd), "w"), indent=1)
     published["%s_sgm_pmc_traffic.json" % rnd] = "from %s_sgm_pmc_*.txt" % tag
 manifest = {"tag": tag, "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
-            "sources_sha256": {f: sha(f) for f in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip",
+            "sources_sha256": {f: sha(f) for f in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip", "jackal_navigation_amd/csrc/bm_mfma.hip",
                                                    "jackal_navigation_amd/csrc/jn_api.cpp", "bench.py")},
-            "files": published}
+            "inputs_newest_mtime": _newest_in, "files": published}
 json.dump(manifest, open(os.path.join(p, "%s_manifest.json" % tag), "w"), indent=1)
 open(os.path.join(p, "CURRENT"), "w").write(tag + "\n")
 print("published %d files for %s" % (len(published), tag))

@@ -1,9 +1,9 @@
 #!/bin/bash
-# The round's evidence set in ONE gpurun call:  bash scripts/round3_profiles.sh <tag>      (e.g. r03_a)
+# The round's evidence set in ONE gpurun call:  bash scripts/round4_profiles.sh <tag>      (e.g. r04; ONE tag per round: a refresh overwrites the same files)
 # Every rocprofv3 output directory is emptied (scripts/fresh_dir.py) before the run that fills it; nothing here combines --pmc
 # with a tracing domain other than --kernel-trace.  scripts/publish_round.py <tag> then copies the set into profiles/.
 tag=$1
-[ -n "$tag" ] || { echo "usage: round3_profiles.sh <tag>"; exit 1; }
+[ -n "$tag" ] || { echo "usage: round4_profiles.sh <tag>"; exit 1; }
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 out=gpurun_out
@@ -32,6 +32,17 @@ cd $R
 python3 scripts/kstats.py $(ls $out/${tag}_bm/*/*kernel_stats.csv | tail -1) 8 > $out/${tag}_bm_summary.txt
 python3 bench.py --mode bm --steps 20 --warmup 3 > $out/${tag}_bm_bench_line.json 2> $out/${tag}_bm_bench.err
 python3 bench.py --mode bm --width 640 --height 480 --disp 64 --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/${tag}_bm_config2_bench_line.json 2>> $out/${tag}_bm_bench.err
+# ---- block matching with the squared-difference cost on the matrix cores (csrc/bm_mfma.hip), next to the v_qsad kernel ----
+cd /tmp
+fresh ${tag}_bm_ssd; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm_ssd -- python3 $R/bench.py --mode bm --bm-cost ssd --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm_ssd.log 2>&1
+rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $R/$out/${tag}_mfma_counters_available.txt
+fresh ${tag}_bm_ssd_pmc; timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $R/$out/${tag}_bm_ssd_pmc -- python3 $R/bench.py --mode bm --bm-cost ssd --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_bm_ssd_pmc.log 2>&1
+cd $R
+python3 scripts/kstats.py $(ls $out/${tag}_bm_ssd/*/*kernel_stats.csv | tail -1) 8 > $out/${tag}_bm_ssd_summary.txt
+{ echo "# counters with MFMA in their name on this box: $(tr '\n' ' ' < $out/${tag}_mfma_counters_available.txt)"; python3 scripts/pmc.py $(ls $out/${tag}_bm_ssd_pmc/*/*counter_collection.csv | tail -1) "k_bmq_"; } > $out/${tag}_bm_ssd_pmc_mfma.txt 2>&1
+python3 bench.py --mode bm --bm-cost ssd --steps 20 --warmup 3 > $out/${tag}_bm_ssd_bench_line.json 2>> $out/${tag}_bm_bench.err
+python3 bench.py --mode bm --bm-cost ssd --width 1920 --height 1080 --disp 256 --batch 8 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bm_ssd_1080p_bench_line.json 2>> $out/${tag}_bm_bench.err
+python3 bench.py --mode bm --bm-cost sad --width 1920 --height 1080 --disp 256 --batch 8 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bm_sad_1080p_bench_line.json 2>> $out/${tag}_bm_bench.err
 # ---- the north star's other frame sizes, one JSON line each ----
 : > $out/${tag}_other_configs.jsonl
 for a in "--width 640 --height 480 --disp 64 --batch 32" "--width 640 --height 480 --disp 64 --batch 64" "--width 320 --height 180 --disp 256 --scene-disp 48 --batch 128" "--width 1920 --height 1080 --disp 256 --batch 8"; do
@@ -45,9 +56,11 @@ timeout 300 python3 scripts/node_rate.py 300 serial 2>/dev/null | tail -1 > $out
 HT=8 timeout 200 python3 scripts/latency_check.py 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_latency_check.txt
 timeout 400 python3 scripts/host_pointer_rate.py 2>/dev/null | grep -v amdgpu.ids > $out/${tag}_host_pointer_rate.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/probes/valu_rate_probe.hip -o /tmp/valu_rate_probe && timeout 60 /tmp/valu_rate_probe > $out/${tag}_valu_rate_probe.txt 2>&1
+for pr in pk3 dep_chain lds_unaligned; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/probes/${pr}_probe.hip -o /tmp/${pr}_probe && timeout 120 /tmp/${pr}_probe > $out/${tag}_${pr}_probe.txt 2>&1; done
+bash scripts/host_threads_sweep.sh "2 4 8 12 16" > $out/${tag}_host_threads.txt 2>&1
 for v in 0 1; do echo "JN_STAGE_A_PRIORITY=$v $(JN_STAGE_A_PRIORITY=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_stage_a_priority_ab.txt
 for v in 1 0 1 0; do echo "JN_PACE=$v, the driver's command (--gpus 1 --steps 20 --warmup 5): $(JN_PACE=$v python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_pace_ab.txt
 for v in 1 0; do echo "JN_PACE=$v, default 200 steps per region: $(JN_PACE=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done >> $out/${tag}_pace_ab.txt
 timeout 1200 python3 scripts/parity_sweep.py 12 2>&1 | grep -v "Opened result\|amdgpu.ids" > $out/${tag}_parity_sweep.txt
 timeout 400 python3 scripts/sgm_stress.py 120 2>&1 | grep -v amdgpu.ids > $out/${tag}_sgm_stress.txt
-tail -8 $out/${tag}_collect.log | cut -c1-300; cat $out/${tag}_sgm_summary.txt $out/${tag}_sgm_strips_ab.txt $out/${tag}_merge_in_worker.txt $out/${tag}_node_rate.txt; tail -2 $out/${tag}_parity_sweep.txt
+cat $out/${tag}_bm_ssd_summary.txt $out/${tag}_bm_ssd_pmc_mfma.txt | head -30; tail -8 $out/${tag}_collect.log | cut -c1-300; cat $out/${tag}_sgm_summary.txt $out/${tag}_sgm_strips_ab.txt $out/${tag}_merge_in_worker.txt $out/${tag}_node_rate.txt; tail -2 $out/${tag}_parity_sweep.txt

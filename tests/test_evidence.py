@@ -22,8 +22,8 @@ def test_manifest_lists_existing_files_and_was_taken_on_this_source():
     assert man["tag"] == tag and len(man["files"]) >= 20
     for name in man["files"]:
         assert os.path.getsize(os.path.join(P, name)) > 0, name
-    # kernel sources: the profiles describe THIS tree's kernels (re-publish after touching them: scripts/round3_profiles.sh + publish_round.py)
-    for src in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip"):
+    # kernel sources: the profiles describe THIS tree's kernels (re-publish after touching them: scripts/round4_profiles.sh + publish_round.py)
+    for src in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip", "jackal_navigation_amd/csrc/bm_mfma.hip"):
         sha = hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest()
         assert man["sources_sha256"][src] == sha, "%s changed after profiles/%s_* were taken" % (src, tag)
 
@@ -70,7 +70,7 @@ def test_readme_quotes_the_committed_numbers():
 def test_design_names_the_current_evidence_set():
     tag = current()
     txt = open(os.path.join(ROOT, "DESIGN.md")).read()
-    cited = set(re.findall(r"profiles/(r\d\d_[a-z]_[A-Za-z0-9_]+\.(?:csv|json|txt|jsonl))", txt)) | set(re.findall(r"`(r\d\d_[a-z]_[A-Za-z0-9_]+\.(?:csv|json|txt|jsonl))`", txt))
+    cited = set(re.findall(r"profiles/(r\d\d_(?:[a-z]_)?[A-Za-z0-9_]+\.(?:csv|json|txt|jsonl))", txt)) | set(re.findall(r"`(r\d\d_(?:[a-z]_)?[A-Za-z0-9_]+\.(?:csv|json|txt|jsonl))`", txt))
     assert cited, "DESIGN.md cites no evidence file"
     for name in cited:
         assert os.path.exists(os.path.join(P, name)), "DESIGN.md cites profiles/%s, which is not tracked" % name
