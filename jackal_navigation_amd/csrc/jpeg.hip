@@ -83,16 +83,18 @@ __global__ void __launch_bounds__(256) k_jpeg_idct_gray(const int16_t* __restric
 
 // One eye: frame size against the caller's buffer, entropy decoding on the calling thread (the serial part), then upload +
 // inverse DCT.  `sc` is the calling thread's grow-only device scratch for this eye.
-// Coefficients travel host -> device from PINNED memory (grow-only, hipHostMalloc): from a pageable vector hipMemcpyAsync is staged and
-// synchronous, and the pair call's two uploads + inverse DCTs would not be "queued together, waited for once".  The scratch belongs to a
-// thread (thread_local) or to an EyeHelper; its destructor releases the device and pinned buffers when that thread ends.
+// Coefficients travel host -> device from PINNED memory: from a pageable vector hipMemcpyAsync is staged and synchronous, and the pair
+// call's two uploads + inverse DCTs would not be "queued together, waited for once".  The decoder's own vector is page-locked in place
+// (hipHostRegister, redone only when the vector has moved or grown) — no second copy of the coefficients.  The scratch belongs to a thread
+// (thread_local) or to an EyeHelper; its destructor releases the device buffer and the registration when that thread ends.
 struct JpegScratch {
   int16_t* p = nullptr; size_t cap = 0; int dev = -1;
-  int16_t* pinned = nullptr; size_t pinned_cap = 0;
+  void* reg_ptr = nullptr; size_t reg_bytes = 0;
   std::vector<int16_t> coef; jnav::JpegFrame frame;
+  void unregister() { if (reg_ptr) { hipHostUnregister(reg_ptr); reg_ptr = nullptr; reg_bytes = 0; } }
   ~JpegScratch() {
+    unregister();
     if (p) { hipSetDevice(dev); hipFree(p); }
-    if (pinned) hipHostFree(pinned);
   }
 };
 
@@ -103,7 +105,13 @@ static jn_status jpeg_entropy(const uint8_t* jpeg, int64_t nbytes, int32_t out_p
   if (st != JN_OK) return st;
   if (*width > jnav::kJpegMaxDim || *height > jnav::kJpegMaxDim) return JN_ERR_UNSUPPORTED;
   if (out_pitch < *width || out_rows < *height) return JN_ERR_INVALID;
-  try { st = jnav::jpeg_parse_and_decode(jpeg, (size_t)nbytes, sc.frame, sc.coef); } catch (const std::bad_alloc&) { return JN_ERR_INTERNAL; }
+  // room for every luminance block the frame can have (MCUs of up to 16x16 pixels), reserved BEFORE decoding: the decoder then never moves
+  // the vector, so a page-locked (registered) vector is only ever released here, after its registration
+  const size_t worst = (size_t)((*width + 15) / 16 * 2) * (size_t)((*height + 15) / 16 * 2) * 64;
+  try {
+    if (sc.coef.capacity() < worst) { sc.unregister(); sc.coef.reserve(worst); }
+    st = jnav::jpeg_parse_and_decode(jpeg, (size_t)nbytes, sc.frame, sc.coef);
+  } catch (const std::bad_alloc&) { return JN_ERR_INTERNAL; }
   if (st != JN_OK) return st;
   if (sc.frame.width != *width || sc.frame.height != *height) return JN_ERR_INVALID;      // two frame headers that disagree
   return JN_OK;
@@ -115,13 +123,13 @@ static jn_status jpeg_idct_launch(int32_t device, JpegScratch& sc, uint8_t* dOut
     JPG_TRY(hipMalloc(reinterpret_cast<void**>(&sc.p), need));
     sc.cap = need; sc.dev = device;
   }
-  if (sc.pinned_cap < need) {
-    if (sc.pinned) { hipHostFree(sc.pinned); sc.pinned = nullptr; sc.pinned_cap = 0; }
-    JPG_TRY(hipHostMalloc(reinterpret_cast<void**>(&sc.pinned), need, hipHostMallocDefault));
-    sc.pinned_cap = need;
+  const size_t have = sc.coef.capacity() * sizeof(int16_t);
+  if (sc.reg_ptr != sc.coef.data() || sc.reg_bytes < need) {  // the vector moved or grew since it was page-locked
+    sc.unregister();
+    if (hipHostRegister(sc.coef.data(), have, hipHostRegisterDefault) == hipSuccess) { sc.reg_ptr = sc.coef.data(); sc.reg_bytes = have; }
+    else (void)hipGetLastError();                              // not fatal: the copy below is then staged by the runtime
   }
-  memcpy(sc.pinned, sc.coef.data(), need);
-  JPG_TRY(hipMemcpyAsync(sc.p, sc.pinned, need, hipMemcpyHostToDevice, nullptr));
+  JPG_TRY(hipMemcpyAsync(sc.p, sc.coef.data(), need, hipMemcpyHostToDevice, nullptr));
   QuantTable qt;
   memcpy(qt.q, sc.frame.quant, sizeof(qt.q));
   const int blocks = sc.frame.bw * sc.frame.bh;

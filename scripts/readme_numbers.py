@@ -11,6 +11,27 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
 BEGIN, END = "<!-- numbers:begin (scripts/readme_numbers.py --write) -->", "<!-- numbers:end -->"
+RBEGIN, REND = "<!-- rates:begin (scripts/readme_numbers.py --write) -->", "<!-- rates:end -->"
+
+
+def rates_block():
+    """INTEGRATION.md's host-pointer rates (PCIe inclusive), from the evidence set's host_pointer_rate.txt"""
+    tag = open(os.path.join(P, "CURRENT")).read().strip()
+    txt = open(os.path.join(P, "%s_host_pointer_rate.txt" % tag)).read()
+
+    def rate(prefix):
+        for l in txt.splitlines():
+            if l.startswith(prefix):
+                return float(re.search(r"[:=] *([0-9.]+) pairs/s", l).group(1))
+        raise KeyError(prefix)
+    sync720, sync480 = rate("1280x720 jn_elas_process"), rate("640x480 jn_elas_process")
+    best720 = max(float(re.search(r": ([0-9.]+) pairs/s", l).group(1)) for l in txt.splitlines() if l.startswith("1280x720 jn_elas_submit_host"))
+    best480 = max(float(re.search(r": ([0-9.]+) pairs/s", l).group(1)) for l in txt.splitlines() if l.startswith("640x480 jn_elas_submit_host"))
+    return "\n".join([RBEGIN,
+                      "Measured through host pointers, PCIe included (`profiles/%s_host_pointer_rate.txt`, `scripts/host_pointer_rate.py`): `jn_elas_process`, one synchronous call per pair, "
+                      "%.2f k pairs/s at 1280x720 and %.2f k at 640x480; `jn_elas_submit_host` on 4 slots (best batch size of the sweep) %.1f k at 1280x720 and %.1f k at 640x480."
+                      % (tag, sync720 / 1e3, sync480 / 1e3, best720 / 1e3, best480 / 1e3), REND])
+
 
 
 def line(name):
@@ -46,7 +67,10 @@ def block():
         ("ELAS 1920x1080, D=256, batch 8", "%.1f k pairs/s" % (find("1920x1080 rectified pairs (scene disparities <= 256), ELAS")["value"] / 1e3)),
         ("lone 640x480 pair, ELAS (median of 200 calls)", "%.3f ms" % b["latency_config"]["ms_per_frame"]),
         ("SGM 8 paths 1280x720, D=128, batch 32 (`--mode sgm`)", "%.2f k pairs/s, frac %.3f on SURVEY's B_sgm" % (s["value"] / 1e3, s["roofline"]["frac"])),
-        ("block matching 9x9 1280x720, D=128, batch 32 (`--mode bm`)", "%.1f k pairs/s" % (m["value"] / 1e3)),
+        ("block matching 9x9 1280x720, D=128, batch 32 (`--mode bm`, SAD, `v_qsad`)", "%.1f k pairs/s" % (m["value"] / 1e3)),
+        ("  the same with the squared-difference cost on the matrix cores (`--bm-cost ssd`, `v_mfma_i32_32x32x32_i8`)", "%.1f k pairs/s" % (line("%s_bm_ssd_bench_line.json" % tag)["value"] / 1e3)),
+        ("  1920x1080, D=256, batch 8: SSD on the matrix cores / SAD", "%.2f k / %.2f k pairs/s" % (line("%s_bm_ssd_1080p_bench_line.json" % tag)["value"] / 1e3, line("%s_bm_sad_1080p_bench_line.json" % tag)["value"] / 1e3)),
+        ("SGM 1920x1080, D=256 + 1/16 pixel, batch 8 (config 5's share of one GPU)", "%.0f pairs/s" % find("SGM 8 paths D=256")["value"]),
         ("node path, two 640x360 JPEG frames -> LaserScan, one frame at a time", "%s ms (eyes decoded serially: %s ms)" % (node_ms[-1], node_ms[0])),
         ("cross-rig merge in the slot worker, one-rank communicator", "%.1f-%.1f %% of the pipelined rate" % (100 * min(cost), 100 * max(cost))),
     ]
@@ -66,5 +90,11 @@ if __name__ == "__main__":
         else:
             txt += "\n" + blk + "\n"
         open(p, "w").write(txt)
+        p = os.path.join(ROOT, "INTEGRATION.md")
+        txt = open(p).read()
+        txt = txt[:txt.index(RBEGIN)] + rates_block() + txt[txt.index(REND) + len(REND):]
+        open(p, "w").write(txt)
+    elif "--rates" in sys.argv:
+        print(rates_block())
     else:
         print(blk)
