@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256, 2) k_bmq_match(QDev s, int n, int band, c
       }
       if (t > 0) {
 #pragma unroll
-        for (int v = 0; v < 16; v += 2) m = min(m, min(val[v], val[v + 1]));
+        for (int v = 0; v < 16; v += 2) m = min(min(m, val[v]), val[v + 1]);       // v_min3_i32: two candidates per instruction
       }
     }
     {

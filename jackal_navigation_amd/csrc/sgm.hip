@@ -292,6 +292,7 @@ void jn_sgm_destroy(jn_sgm* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->g); hipFree(h->Lr);
+  jnav_sgm::sweep_release(h->sb);
   hipFree(h->sb.gm); hipFree(h->sb.volF); hipFree(h->sb.volH0); hipFree(h->sb.volH1); hipFree(h->sb.gx); hipFree(h->sb.flags); hipFree(h->sb.minr); hipFree(h->sb.dl);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);

@@ -31,7 +31,13 @@ struct SweepBuffers {
   uint32_t* flags;        // rows done per (frame, block), then the ticket counter
   uint32_t* minr;         // right-image winners [n][H][W] (S << 16 | d)
   uint32_t* dl;           // left winners [n][H][W] (d | d16 << 16), mirrored columns
+  // The horizontal sweep and the downward sweep are independent (both read the prefiltered rows, they write different volumes): they run
+  // CONCURRENTLY, the horizontal one on this side stream (created by the first sweep_run, destroyed by sweep_release), forked and joined
+  // with the two events.  One is bound by its volume writes, the other by issue and synchronisation: together they fill the GPU better.
+  hipStream_t side;
+  hipEvent_t ev_fork, ev_join;
 };
+void sweep_release(SweepBuffers& b);     // the side stream and its events (the device buffers belong to the caller)
 
 void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch);
 

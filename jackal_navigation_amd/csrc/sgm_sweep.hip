@@ -677,6 +677,7 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
   __shared__ uint32_t ring[RING][NS][SLOT];                    // boundary columns [row mod RING][strip][V0 | M0 | M1][quarter][NR]
   __shared__ uint32_t nextblk[SLOT];                           // the next block's columns for the last strip (written and read by that wave only)
   __shared__ uint32_t minR[FINAL ? NS : 1][FINAL ? 2 : 1][FINAL ? NQ : 1][FINAL ? MR : 1];   // right-image winners of one row of one strip, per disparity quarter (rows alternate)
+  __shared__ uint32_t minR_trash[FINAL ? NS : 1][FINAL ? NQ : 1][FINAL ? MR : 1];              // where lanes outside the image send theirs
   __shared__ int prog[NS], cons[NS];                           // rows published by strip w / rows of strip w's columns consumed by strip w-1
   __shared__ int s_ticket;
   extern __shared__ uint16_t sS[];                             // FINAL + sub-pixel: S of the block's pixels [BLK][D]
@@ -820,17 +821,22 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
       uint32_t* mrow = &minR[wave][buf][0][0];
       int ln = lane;
       asm volatile("" : "+v"(ln));                              // the index arithmetic below is redone per row: hoisted out of the loop it costs a dozen registers the kernel does not have
+      constexpr int KF = (NQ * MR + 63) / 64;
+      uint32_t kvs[KF];
 #pragma unroll
-      for (int k = 0; k < (NQ * MR + 63) / 64; k++) {
+      for (int k = 0; k < KF; k++) {                            // every read first: one LDS round trip for the row instead of one per 64 entries
         const int idx = ln + 64 * k;
-        if ((NQ * MR) % 64 == 0 || idx < NQ * MR) {
-          const uint32_t kv = mrow[idx];
-          if (kv != 0xFFFFFFFFu) {
-            mrow[idx] = 0xFFFFFFFFu;
-            const int qq = idx / MR, ee = idx - qq * MR;
-            const int xr = x0 + PX * wave + yb + ee + DPL * qq;
-            if (xr >= 0 && xr < W) atomicMin(grow + xr, kv + (uint32_t)(DPL * qq));
-          }
+        kvs[k] = ((NQ * MR) % 64 == 0 || idx < NQ * MR) ? mrow[idx] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int k = 0; k < KF; k++) {
+        const int idx = ln + 64 * k;
+        const uint32_t kv = kvs[k];
+        if (kv != 0xFFFFFFFFu) {
+          mrow[idx] = 0xFFFFFFFFu;
+          const int qq = idx / MR, ee = idx - qq * MR;
+          const int xr = x0 + PX * wave + yb + ee + DPL * qq;
+          if (xr >= 0 && xr < W) atomicMin(grow + xr, kv + (uint32_t)(DPL * qq));
         }
       }
     }
@@ -847,7 +853,12 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
     uint32_t Cp[NR], acc[NR];
     {
       RowIn cur;
-      read_row(yb, cur);
+      read_row(yb, cur);                                       // LDS reads of the row's bytes ...
+      if constexpr (FINAL) {                                   // ... in flight while the previous row's minima are flushed (their atomics were served long ago)
+        __builtin_amdgcn_sched_barrier(0);
+        if (yb > ybs && !SW_DBG(2)) flush_minima(yb - 1, (yb - 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       costs64<NR>(cur.ww, cur.ref & 0x00FFFFFFu, P2pk, Cp);
     }
 #pragma unroll
@@ -859,7 +870,6 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
 #pragma unroll
       for (int r = 0; r < NR; r++) acc[r] = 0u;
     }
-    if constexpr (FINAL) { if (yb > ybs && !SW_DBG(2)) flush_minima(yb - 1, (yb - 1) & 1); }     // the previous row's minima: their atomics were served long ago
     // ---- last strip: the producer block's columns of row yb - 1 ----
     if (last) {
       const int yr = yb - 1;
@@ -1029,18 +1039,14 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
     } else {
       const uint32_t (&S)[NR] = acc;                           // S = 8 (C + P2) - (the three upward Y + the stored five)
       uint32_t key = 0xFFFFFFFFu;
-      uint32_t* mr = &minR[wave][yb & 1][q][p];
+      // lanes outside the image aim their minima at a trash row: the atomics are unconditional and can be issued between the instructions
+      // that build the keys (32 of them back to back fill the LDS queue and stall the wave)
+      uint32_t* mr = in ? &minR[wave][yb & 1][q][p] : &minR_trash[wave][q][p];
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         const uint32_t klo = (S[r] << 16) | (uint32_t)r, khi = (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR);
-        key = min(key, min(klo, khi));
-      }
-      if (in && !SW_DBG(2)) {
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-          atomicMin(mr + r, (S[r] << 16) | (uint32_t)r);
-          atomicMin(mr + r + NR, (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR));
-        }
+        if (!SW_DBG(2)) { atomicMin(mr + r, klo); atomicMin(mr + r + NR, khi); }
+        key = min(min(key, klo), khi);
       }
       key = in ? key + (uint32_t)(DPL * q) : 0xFFFFFFFFu;
       {
@@ -1206,7 +1212,21 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   if ((e = hipMemsetAsync(b.minr, 0xFF, (size_t)n * px * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   constexpr int PXL = 64 / LQ;                                  // image rows per wave of the horizontal sweep = pixels per strip of the row sweeps
-  hipLaunchKernelGGL((k_sw_h<NR, LQ>), dim3((s.H + 4 * PXL - 1) / (4 * PXL), n, 2), dim3(256), 0, st, s, n, b.gm, b.volH0, b.volH1);
+  // the horizontal sweep on the side stream, next to the downward sweep (JN_SGM_OVERLAP=0: one after the other on `st`, for A/B)
+  static const bool overlap = !(getenv("JN_SGM_OVERLAP") && atoi(getenv("JN_SGM_OVERLAP")) == 0);
+  hipStream_t hs = st;
+  if (overlap) {
+    if (!b.side) {
+      if ((e = hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
+      if ((e = hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    if ((e = hipEventRecord(b.ev_fork, st)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(b.side, b.ev_fork, 0)) != hipSuccess) return e;
+    hs = b.side;
+  }
+  hipLaunchKernelGGL((k_sw_h<NR, LQ>), dim3((s.H + 4 * PXL - 1) / (4 * PXL), n, 2), dim3(256), 0, hs, s, n, b.gm, b.volH0, b.volH1);
+  if (overlap && (e = hipEventRecord(b.ev_join, b.side)) != hipSuccess) return e;
   const size_t flag_bytes = ((size_t)n * s.NB + 1) * sizeof(uint32_t);
   auto sweep = [&](bool final) -> hipError_t {
     if constexpr (FLOW) return launch_w<NR, NS, LQ>(s, n, final, st, b);
@@ -1214,12 +1234,19 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   };
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
   if ((e = sweep(false)) != hipSuccess) return e;
+  if (overlap && (e = hipStreamWaitEvent(st, b.ev_join, 0)) != hipSuccess) return e;   // the final sweep reads the horizontal volumes
   if ((e = hipEventRecord(ev[2], st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
   if ((e = sweep(true)) != hipSuccess) return e;
   hipLaunchKernelGGL(k_sw_lr, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, n, b.dl, b.minr, dDisp);
   if ((e = hipEventRecord(ev[3], st)) != hipSuccess) return e;
   return hipGetLastError();
+}
+
+void sweep_release(SweepBuffers& b) {
+  if (b.side) { hipStreamSynchronize(b.side); hipStreamDestroy(b.side); b.side = nullptr; }
+  if (b.ev_fork) { hipEventDestroy(b.ev_fork); b.ev_fork = nullptr; }
+  if (b.ev_join) { hipEventDestroy(b.ev_join); b.ev_join = nullptr; }
 }
 
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,

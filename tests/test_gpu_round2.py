@@ -757,3 +757,78 @@ def test_a_failing_batch_keeps_its_turn_and_feeds_the_collective_the_identity(jn
             assert isinstance(b, _lib.JnError) and b.status == _lib.JN_ERR_INTERNAL
         else:
             assert isinstance(b, np.ndarray) and np.array_equal(a, b), k
+
+
+def _two_gpus():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs: RCCL refuses two ranks on one device (runs on the driver's multi-GPU node only)")
+def test_bench_two_ranks_over_rccl_when_two_gpus_exist():
+    """Config 4 in small: `bench.py --gpus 2` over RCCL with the merge as the batch's tail through the C-ABI communicator.  Skipped on
+    the 1-GPU boxes this build sees; written so that the first machine with two GPUs exercises the N > 1 path end to end."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "4", "--slots", "2", "--min-time", "0",
+           "--no-cpu-baseline", "--no-latency-config"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=800, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and {r["rank"] for r in j["ranks"]} == {0, 1} and {r["device"] for r in j["ranks"]} == {0, 1}
+    assert all(r["rccl_comm"] and r["rccl_comm"][1] == 2 for r in j["ranks"])          # RCCL itself reports a two-rank communicator on both
+    assert j["check"]["ok"] is True and j["check"]["frames_checked"]["D1"] == 2 * 4     # D1 / u8 maps are per rig: unaffected by the merge
+    assert j["value"] > 0 and j["config"]["pairs_failed"] == 0
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs")
+def test_a_batch_failing_on_one_rank_does_not_strand_the_other(tmp_path):
+    """Two ranks over RCCL, rank 1's third scan batch fails before its kernels (JN_TEST_FAIL_SEQ): rank 0 must get ITS OWN scan for that
+    batch (rank 1 contributes the identity of MIN) and finish; rank 1 reports the error for that batch only."""
+    script = tmp_path / "two_ranks.py"
+    script.write_text('''
+import ctypes as C, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+rank = int(os.environ["RANK"])
+if rank == 1:
+    os.environ["JN_TEST_FAIL_SEQ"] = "2"
+os.environ["JN_COMM_TIMEOUT_MS"] = "20000"
+import jackal_navigation_amd as jn
+from jackal_navigation_amd import node, parallel, _lib
+from jackal_navigation_amd.device import DeviceArray
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+def exchange(raw):
+    t = torch.zeros(128, dtype=torch.uint8)
+    if raw is not None: t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+    dist.broadcast(t, src=0); return bytes(t.numpy().tobytes())
+W, H, B = 320, 180, 2
+sp = node.scan_params(W, H); lut = node.build_valid_disp_lut(sp, W, H, device=rank)
+comm = parallel.ScanComm(rank, 2, rank, exchange)
+res = []
+with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, device=rank, slots=2, host_threads=4) as e:
+    e.set_comm(comm)
+    for k in range(4):
+        Ls = np.stack([node.synth_pair(W, H, 40, 100 * rank + 10 * k + t)[0] for t in range(B)]); Rs = np.stack([node.synth_pair(W, H, 40, 100 * rank + 10 * k + t)[1] for t in range(B)])
+        dL, dR = DeviceArray.from_numpy(Ls, device=rank), DeviceArray.from_numpy(Rs, device=rank)
+        d1, d2 = DeviceArray((B, H, W), np.float32, device=rank), DeviceArray((B, H, W), np.float32, device=rank)
+        u8, bins, meta = DeviceArray((B, H, W), np.uint8, device=rank), DeviceArray((B, sp.bins), np.float64, device=rank), DeviceArray((B, 4), np.float64, device=rank)
+        st = (C.c_int32 * B)()
+        e.submit_scan(0, B, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr, sp, lut.ptr, u8.ptr, bins.ptr, meta.ptr, st)
+        try:
+            e.wait(0); res.append("ok %%d" %% int((bins.numpy() < 1e9 - 1).sum()))
+        except _lib.JnError as err:
+            res.append("err %%d" %% err.status)
+    e.set_comm(None)
+comm.close()
+print("RANK", rank, res, flush=True)
+''' % ROOT)
+    port = 29000 + os.getpid() % 900
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r0 = [l for l in outs[0].splitlines() if l.startswith("RANK 0")][0]
+    r1 = [l for l in outs[1].splitlines() if l.startswith("RANK 1")][0]
+    assert r0.count("ok") == 4 and "err" not in r0, r0
+    assert r1.count("ok") == 3 and "err %d" % 5 in r1, r1                      # JN_ERR_INTERNAL for batch 2 only
