@@ -557,7 +557,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   *out = nullptr;
   const int radius = (int)std::max((float)std::ceil(p->sigma * p->sradius), 2.0f);        // elas.cpp:806
   if (p->subsampling || p->disp_max > 255 || p->disp_max < 10 ||
-      p->disp_min != 0 || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
+      p->disp_min > p->disp_max || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
       p->grid_size < 1 || radius > 7 || p->incon_window_size < 0)
     return JN_ERR_UNSUPPORTED;
   int ndev = 0;
@@ -581,7 +581,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   DevParams& dp = h->dp;
   memset(&dp, 0, sizeof(dp));
   dp.W = W; dp.H = H; dp.pitch = (W + 63) / 64 * 64;
-  dp.disp_max = p->disp_max; dp.support_texture = p->support_texture; dp.step = p->candidate_stepsize;
+  dp.disp_max = p->disp_max; dp.disp_min = std::max(p->disp_min, 0); dp.support_texture = p->support_texture; dp.step = p->candidate_stepsize;
   dp.lr_threshold = p->lr_threshold; dp.support_threshold = p->support_threshold;
   dp.cw = (W + dp.step - 1) / dp.step; dp.ch = (H + dp.step - 1) / dp.step;            // elas.cpp:384-387
   dp.grid_size = p->grid_size;

@@ -50,6 +50,7 @@ struct FrameInfo {
 struct DevParams {
   int32_t W, H, pitch;       // image width/height, bytes per internal image row
   int32_t disp_max;
+  int32_t disp_min;                 // max(param.disp_min, 0): first disparity the support matching tries (elas.cpp:323; nothing else reads it)
   int32_t support_texture, step, lr_threshold;
   float   support_threshold;
   int32_t cw, ch;            // candidate lattice size (elas.cpp:384-387)

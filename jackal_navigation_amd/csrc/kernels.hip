@@ -203,12 +203,13 @@ DEV int match_candidate(const DevParams& dp, const uint4* __restrict__ A, const 
   const int W = dp.W, H = dp.H;
   if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;            // :283
   if (texture16(A[(size_t)v * W + u]) < dp.support_texture) return -1;       // :301-305
-  const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326 (disp_min = 0)
-  if (dmax < 10) return -1;                                                  // :329
+  const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326
+  const int dmin = dp.disp_min;                                              // :323 (max(disp_min, 0), taken by the host)
+  if (dmax - dmin < 10) return -1;                                           // :329
   const size_t top = (size_t)(v - 2) * W, bot = (size_t)(v + 2) * W;
   const uint4 a0 = A[top + u - 2], a1 = A[top + u + 2], a2 = A[bot + u - 2], a3 = A[bot + u + 2];
   Best b{32767, -1, 32767};
-  for (int d = lane; d <= dmax; d += 64) {
+  for (int d = dmin + lane; d <= dmax; d += 64) {                            // :333
     const int uw = right ? u + d : u - d;
     const int s = sad16(a0, B[top + uw - 2]) + sad16(a1, B[top + uw + 2]) + sad16(a2, B[bot + uw - 2]) + sad16(a3, B[bot + uw + 2]);
     if (s < b.e1) { b.e2 = b.e1; b.e1 = s; b.d1 = d; }
@@ -219,7 +220,7 @@ DEV int match_candidate(const DevParams& dp, const uint4* __restrict__ A, const 
     const int e1 = __shfl_xor(b.e1, off), d1 = __shfl_xor(b.d1, off), e2 = __shfl_xor(b.e2, off);
     b = merge(b, e1, d1, e2);
   }
-  // :366 — dmax >= 10 guarantees a second-best exists
+  // :366 — dmax - dmin >= 10 guarantees a second-best exists
   if (b.d1 >= 0 && (float)b.e1 < dp.support_threshold * (float)b.e2) return b.d1;
   return -1;
 }
@@ -270,10 +271,11 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
   bool ok = active && u >= 5 && u <= W - 6;                                   // :283 (rows checked by the caller)
   if (ok) ok = texture16(Arow_v[u]) >= dp.support_texture;                    // :301-305
   const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326
-  ok = ok && dmax >= 10;                                                      // :329
+  const int dmin = dp.disp_min;                                               // :323
+  ok = ok && dmax - dmin >= 10;                                               // :329
   constexpr unsigned kNone = 0x7FFFFFFFu;
   unsigned k1 = kNone, k2 = kNone;
-  if (ok && j <= dmax) {
+  if (ok && dmin + j <= dmax) {
     // Stepping d by 4 moves the matched column by 4 = the distance between the two tap columns, so the tap pair that
     // led (column +/- 2 in the direction of motion) is the trailing pair of the next step: one new (top, bottom) pair
     // is read from LDS per disparity instead of two.  Three register sets rotate through lead / trail / prefetch,
@@ -283,7 +285,7 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
     const uint4 am_t = a[0], ap_t = a[4], am_b = a[PITCH], ap_b = a[PITCH + 4];  // descriptors at u-2 / u+2, top / bottom row
     const uint4 aL_t = right ? ap_t : am_t, aL_b = right ? ap_b : am_b;       // partner of the leading pair
     const uint4 aT_t = right ? am_t : ap_t, aT_b = right ? am_b : ap_b;       // partner of the trailing pair
-    int d = j;
+    int d = dmin + j;                                                         // :333 (lane j walks dmin + j, dmin + j + 4, ...)
     const uint4* b = Bt + (u + dir * d);                                      // column matched at disparity d
     uint4 p0_t = b[-2 * dir], p0_b = b[PITCH - 2 * dir];                      // trailing pair
     uint4 p1_t = b[2 * dir], p1_b = b[PITCH + 2 * dir];                       // leading pair

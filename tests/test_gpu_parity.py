@@ -111,13 +111,15 @@ def test_known_answer_hashes_on_other_scenes_on_gpu(jn, oracle):
     {"support_threshold": 0.95, "support_texture": 20}, {"lr_threshold": 1, "match_texture": 5}, {"grid_size": 16, "sradius": 3.0},
     {"candidate_stepsize": 4, "incon_window_size": 3, "incon_min_support": 3}, {"gamma": 5.0, "beta": 0.03, "sigma": 1.5},
     {"filter_median": 1}, {"filter_median": 1, "filter_adaptive_mean": 0, "postprocess_only_left": 0},
+    {"disp_min": 6}, {"disp_min": 20, "postprocess_only_left": 0}, {"disp_min": -5}, {"disp_min": 70},   # the last: no candidate has 10 disparities left -> no support points
 ])
 def test_parameter_variations(jn, oracle, same, kw):
     W, H = 320, 240
     L, R = jn.node.synth_pair(W, H, 40, 21)
     st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, disp_max=79, **kw), L, R)
     st_o, D1o, D2o = oracle.process(oracle.params(0, disp_max=79, **kw), L, R)
-    assert st == st_o == 0 and same(D1, D1o) and same(D2, D2o), kw
+    assert st == st_o and same(D1, D1o) and same(D2, D2o), kw
+    assert st == (1 if kw.get("disp_min", 0) == 70 else 0)                      # JN_ERR_FEW_SUPPORT: outputs untouched, as elas.cpp:66-71
 
 
 def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypatch):

@@ -29,6 +29,7 @@ def test_process_bit_exact(oracle, reference, same, W, H, sd, dmax, seed, both):
 @pytest.mark.parametrize("kw", [
     {"filter_median": 1}, {"filter_median": 1, "filter_adaptive_mean": 0, "postprocess_only_left": 0},
     {"incon_window_size": 3, "incon_min_support": 3}, {"ipol_gap_width": 7, "speckle_size": 50},
+    {"disp_min": 6}, {"disp_min": 20, "postprocess_only_left": 0}, {"disp_min": -5},      # elas.cpp:323-333: only the support matching reads disp_min
 ])
 def test_process_bit_exact_with_other_parameters(oracle, reference, same, kw):
     """The optional median filter (elas.cpp:1494-1560, off in the node's preset) and a few non-default tunables."""
