@@ -6,8 +6,8 @@
 // OpenCV is not part of the reference tree and not installed here, so this is a restatement of the
 // published algorithm (Bouguet's rectification as implemented by cvStereoRectify in OpenCV 2.4,
 // 5-coefficient Brown distortion).  OpenCV's own bits stay UNPINNED; what pins this
-// file is an independent second implementation with other formulas throughout (oracle/rectify_oracle.py:
-// quaternion half rotation, vector-to-vector alignment, Newton or five-sweep undistortion), which it agrees
+// file is an independent second implementation with other formulas throughout, kept with the test infrastructure
+// (tests/test_rectify.py names it: quaternion half rotation, vector-to-vector alignment, Newton or five-sweep undistortion), which it agrees
 // with to 1e-12 (rotations) / 2e-6 (P, Q) on nine rigs (tests/test_rectify.py), plus geometric properties.
 #include "../../include/jn_stereo.h"
 #include <cfloat>
