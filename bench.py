@@ -138,6 +138,9 @@ def parse_args():
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
     ap.add_argument("--subpixel", type=int, default=0, help="sgm / bm mode: 1/16-pixel refinement")
     ap.add_argument("--block-radius", type=int, default=4, help="bm mode: block radius r (2, 3, 4)")
+    ap.add_argument("--sgm-slots", type=int, default=4,
+                    help="sgm mode: batches in flight (jn_sgm_submit_scan / jn_sgm_wait; 1 = one synchronous batch at a time as in rounds 2-3; each further "
+                         "slot holds its own three W*H*D byte volumes per pair of the batch)")
     ap.add_argument("--bm-cost", default="sad", choices=["sad", "ssd"],
                     help="bm mode: sad = absolute differences (v_qsad kernel, default); ssd = squared differences as a banded int8 contraction on the matrix "
                          "cores (v_mfma_i32_32x32x32_i8, csrc/bm_mfma.hip; BASELINE config 5's \"int8 cost volume (CDNA4 MFMA path)\")")
@@ -336,6 +339,10 @@ def run_sgm(a):
     disp = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
     u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
     bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+    # SGM: batches pipelined over --sgm-slots slots (jn_sgm_submit_scan / jn_sgm_wait), each with its own outputs and its own copy of the inputs
+    SS = 1 if bm else max(1, min(6, a.sgm_slots))
+    slot_in = [(dL, dR)] + [(dL.clone(), dR.clone()) for _ in range(SS - 1)]
+    slot_out = [(disp, u8, bins, meta)] + [(torch.zeros_like(disp), torch.zeros_like(u8), torch.zeros_like(bins), torch.zeros_like(meta)) for _ in range(SS - 1)]
     if bm:
         sgm = jn.Bm(jn.Bm.parameters(num_disparities=D, block_radius=a.block_radius, subpixel=a.subpixel, cost_function=1 if a.bm_cost == "ssd" else 0),
                     W, H, max_batch=B, device=local_rank)
@@ -352,11 +359,29 @@ def run_sgm(a):
             for k, v in sgm.last_times().items():
                 acc.setdefault(k, []).append(v)
             return
-        sgm.process_batch(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp.data_ptr())
-        for k, v in sgm.last_times().items():
-            acc.setdefault(k, []).append(v)
-        sgm.to_u8(disp.data_ptr(), u8.data_ptr(), B * H * W)
-        node.obstacle_scan(sp, B, u8.data_ptr(), lut.ptr, W, H, bins.data_ptr(), meta.data_ptr(), device=local_rank)
+        if SS == 1:                                          # one batch at a time: three synchronous calls
+            sgm.process_batch(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp.data_ptr())
+            for k, v in sgm.last_times().items():
+                acc.setdefault(k, []).append(v)
+            sgm.to_u8(disp.data_ptr(), u8.data_ptr(), B * H * W)
+            node.obstacle_scan(sp, B, u8.data_ptr(), lut.ptr, W, H, bins.data_ptr(), meta.data_ptr(), device=local_rank)
+            return
+        slot = step.count % SS
+        step.count += 1
+        if slot in step.inflight:                            # the slot's previous batch first
+            sgm.wait(slot); step.inflight.discard(slot)
+            for k, v in sgm.last_times().items():
+                acc.setdefault(k, []).append(v)
+        (iL, iR), (od, ou, ob, om) = slot_in[slot], slot_out[slot]
+        sgm.submit_scan(slot, B, iL.data_ptr(), iR.data_ptr(), W, H * W, od.data_ptr(), sp, lut.ptr, ou.data_ptr(), ob.data_ptr(), om.data_ptr())
+        step.inflight.add(slot)
+    step.count = 0
+    step.inflight = set()
+
+    def drain():
+        for slot in sorted(step.inflight):
+            sgm.wait(slot)
+        step.inflight.clear()
 
     def sync():
         if dist is not None:
@@ -368,6 +393,7 @@ def run_sgm(a):
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
+        drain()                                              # every batch of the region complete inside the region
         sync()
         el = time.perf_counter() - t0
         if dist is not None:
@@ -378,6 +404,7 @@ def run_sgm(a):
 
     for _ in range(a.warmup):
         step()
+    drain()
     acc.clear()
     regions = [region()]
     for _ in range(max(1, min(200, int(math.ceil(a.min_time / max(regions[0], 1e-6))))) - 1):
@@ -409,7 +436,10 @@ def run_sgm(a):
     if bm:
         roofline = bm_ssd_roofline(W, H, D, B, a.block_radius, ms) if a.bm_cost == "ssd" else bm_roofline(W, H, D, B, a.block_radius, a.subpixel, ms)
     if not bm:
-        achieved = b_sgm / (ms["total"] * 1e-3) / 1e9
+        # one batch at a time: the batch's own GPU time (HIP events); pipelined: batches overlap, a batch's events then span the other
+        # batches' kernels too, so the time a batch COSTS is the step time
+        batch_ms = ms["total"] if SS == 1 else elapsed / a.steps * 1e3
+        achieved = b_sgm / (batch_ms * 1e-3) / 1e9
         old = os.environ.get("JN_SGM_IMPL") == "0"
         moved = ((16.0 if old else 6.0) * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
         pmc = sgm_pmc_traffic(W, H, D, B) if not old else None
@@ -419,8 +449,8 @@ def run_sgm(a):
                     "traffic": pmc["bytes"] if pmc else int(moved),
                     "traffic_note": (pmc["note"] if pmc else "computed, not PMC: %s; " % ("8 W H D written by the path kernel + 8 W H D read by the WTA kernel" if old else
                                      "3 byte volumes of W H D written (two horizontal sweeps, the downward sweep) and read once by the upward sweep")) +
-                                    " moved bytes / time = %.0f GB/s" % ((pmc["bytes"] if pmc else moved) / (ms["total"] * 1e-3) / 1e9),
-                    "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4),
+                                    " moved bytes / time = %.0f GB/s" % ((pmc["bytes"] if pmc else moved) / (batch_ms * 1e-3) / 1e9),
+                    "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4), "ms_per_batch_pipelined": round(batch_ms, 4), "slots": SS,
                     "algorithmic_bytes_per_launch": int(b_sgm),
                     "bound_note": "the sweeps are integer-VALU bound, not HBM bound: ~100 packed 16-bit wave-instructions per pixel against the chip's "
                                   "~540 G wave-instructions/s (scripts/probes/valu_rate_probe.hip); frac is still quoted on SURVEY 8d's byte count"}
@@ -837,13 +867,26 @@ def run_rank(a):
                     m = jn.Sgm(jn.Sgm.parameters(num_disparities=a.disp), W, H, max_batch=B, device=local_rank)
                 else:
                     m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4, cost_function=1 if kind == "bm_ssd" else 0), W, H, max_batch=B, device=local_rank)
-                for _ in range(2):
-                    m.process_batch(B, dLs[0].data_ptr(), dRs[0].data_ptr(), W, H * W, disp16.data_ptr())
+                reps_m = 24 if kind == "sgm" else 8   # the pipelined leg needs enough batches for its fill and drain not to weigh
+                if kind == "sgm":                            # four batches in flight (jn_sgm_submit_scan / jn_sgm_wait), as `--mode sgm` runs it
+                    nsl = 4
+                    outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
+
+                    def run_m(k):
+                        for i in range(k):
+                            if i >= nsl:
+                                m.wait(i % nsl)
+                            m.submit_scan(i % nsl, B, dLs[(i % nsl) % len(dLs)].data_ptr(), dRs[(i % nsl) % len(dRs)].data_ptr(), W, H * W, outs_m[i % nsl].data_ptr())
+                        for sl in range(nsl):
+                            m.wait(sl)
+                else:
+                    def run_m(k):
+                        for _ in range(k):
+                            m.process_batch(B, dLs[0].data_ptr(), dRs[0].data_ptr(), W, H * W, disp16.data_ptr())
+                run_m(4)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                reps_m = 5
-                for _ in range(reps_m):
-                    m.process_batch(B, dLs[0].data_ptr(), dRs[0].data_ptr(), W, H * W, disp16.data_ptr())
+                run_m(reps_m)
                 torch.cuda.synchronize()
                 el_m = (time.perf_counter() - t1) / reps_m
                 host = disp16[0].cpu().numpy()
@@ -856,7 +899,7 @@ def run_rank(a):
                     if kind in ("bm", "bm_ssd") and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
                         want_m = f[7]
                 other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_process_batch), same inputs as the ELAS regions" %
-                                                 (W, H, a.disp, {"sgm": "SGM 8 paths", "bm": "9x9 block matching (SAD, v_qsad)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8)"}[kind], B,
+                                                 (W, H, a.disp, {"sgm": "SGM 8 paths (four batches in flight)", "bm": "9x9 block matching (SAD, v_qsad)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8)"}[kind], B,
                                                   "bm" if kind == "bm_ssd" else kind),
                                      "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},
                                      "check": {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None,

@@ -25,6 +25,7 @@
 #include <cstring>
 #include "../../include/jn_sgm.h"
 #include "sgm_sweep.h"
+#include "kernels.h"            // launch_scan: the node's tail on a slot's stream (jn_sgm_submit_scan)
 
 namespace {
 
@@ -266,10 +267,19 @@ struct jn_sgm {
   uint8_t* g = nullptr;        // impl 0: prefiltered rows [2 * max_batch][H][Wp]
   uint8_t* Lr = nullptr;       // impl 0: path volumes [8][max_batch][H][W][D]
   jnav_sgm::SwDev sw = {};     // impl 1
+  jnav_sgm::SweepSizes sizes = {};
   jnav_sgm::SweepBuffers sb = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
   jn_sgm_times times = {};
+  // Pipelined form (jn_sgm_submit_scan / jn_sgm_wait): slot 0 is the set above, slots 1 .. kSgmSlots-1 get their own stream, events and
+  // buffers the first time they are used.  Batches on different slots overlap on the GPU: the upward sweep's tail (the last blocks of
+  // its parallelogram run alone) is filled by the next batch's horizontal and downward sweeps.
+  struct Extra { jnav_sgm::SweepBuffers sb = {}; hipStream_t stream = nullptr; hipEvent_t ev[4] = {}; jn_sgm_times times = {}; bool ready = false; };
+  enum { kSgmSlots = 6 };
+  Extra extra[kSgmSlots - 1];
+  unsigned long long* scan_scratch[kSgmSlots] = {};   // [max_batch][4] per slot, the scan tail's extrema
+  bool pending[kSgmSlots] = {};
 };
 
 #define SGM_TRY(expr)                                                                       \
@@ -292,6 +302,14 @@ void jn_sgm_destroy(jn_sgm* h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->g); hipFree(h->Lr);
+  for (auto& x : h->extra) {
+    if (x.stream) hipStreamSynchronize(x.stream);
+    jnav_sgm::sweep_release(x.sb);
+    hipFree(x.sb.gm); hipFree(x.sb.volF); hipFree(x.sb.volH0); hipFree(x.sb.volH1); hipFree(x.sb.gx); hipFree(x.sb.flags); hipFree(x.sb.minr); hipFree(x.sb.dl);
+    for (auto& e : x.ev) if (e) hipEventDestroy(e);
+    if (x.stream) hipStreamDestroy(x.stream);
+  }
+  for (auto& q : h->scan_scratch) hipFree(q);
   jnav_sgm::sweep_release(h->sb);
   hipFree(h->sb.gm); hipFree(h->sb.volF); hipFree(h->sb.volH0); hipFree(h->sb.volH1); hipFree(h->sb.gx); hipFree(h->sb.flags); hipFree(h->sb.minr); hipFree(h->sb.dl);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
@@ -322,7 +340,7 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), (size_t)2 * max_batch * H * s.Wp + 64));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->Lr), (size_t)8 * max_batch * H * W * D));
   } else {
-    jnav_sgm::SweepSizes z;
+    jnav_sgm::SweepSizes& z = h->sizes;
     jnav_sgm::sweep_geometry(W, H, D, p->P1, p->P2, p->prefilter_cap, p->lr_max_diff, p->subpixel, &h->sw, &z, max_batch);
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.gm), z.gm));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.volF), z.vol * (h->sw.wide ? 2 : 1)));
@@ -349,7 +367,7 @@ jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const u
   const SgmDev& s = h->dev;
   hipStream_t st = h->stream;
   if (h->impl != 0) {
-    SGM_TRY(jnav_sgm::sweep_run(h->sw, n, dI1, dI2, pitch, (long long)image_stride, dDisp, st, h->sb, h->ev));
+    SGM_TRY(jnav_sgm::sweep_run(h->sw, n, dI1, dI2, pitch, (long long)image_stride, dDisp, st, h->sb, h->ev, true));
     SGM_TRY(hipStreamSynchronize(st));
     SGM_TRY(hipGetLastError());
     hipEventElapsedTime(&h->times.prefilter, h->ev[0], h->ev[1]);
@@ -380,6 +398,71 @@ jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const u
   hipEventElapsedTime(&h->times.paths, h->ev[1], h->ev[2]);
   hipEventElapsedTime(&h->times.wta, h->ev[2], h->ev[3]);
   hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
+  return JN_OK;
+}
+
+// A slot beyond the first: its own buffers, stream and events, allocated when it is first used.
+static jn_status sgm_ensure_slot(jn_sgm* h, int slot) {
+  if (slot == 0) return JN_OK;
+  jn_sgm::Extra& x = h->extra[slot - 1];
+  if (x.ready) return JN_OK;
+  const jnav_sgm::SweepSizes& z = h->sizes;
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.gm), z.gm));
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.volF), z.vol * (h->sw.wide ? 2 : 1)));
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.volH0), z.vol));
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.volH1), z.vol));
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.gx), z.gx));
+  SGM_TRY(hipMemset(x.sb.gx, 0, z.gx));
+  x.sb.gx_bytes = z.gx;
+  x.sb.epoch = h->sb.epoch;                                     // (tests start it next to the tag's wrap-around)
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.flags), z.flags));
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.minr), z.minr));
+  SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.dl), z.dl));
+  SGM_TRY(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+  for (auto& e : x.ev) SGM_TRY(hipEventCreate(&e));
+  x.ready = true;
+  return JN_OK;
+}
+
+jn_status jn_sgm_submit_scan(jn_sgm* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
+                             const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dDispU8, double* dBins, double* dMeta) {
+  if (!h || slot < 0 || slot >= jn_sgm::kSgmSlots || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dDisp || pitch < h->W) return JN_ERR_INVALID;
+  if (sp && (!dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024)) return JN_ERR_INVALID;
+  if (h->impl == 0) return JN_ERR_UNSUPPORTED;                  // the round-2 kernels exist for A/B through jn_sgm_process_batch only
+  if (h->pending[slot]) return JN_ERR_INVALID;                  // one batch per slot: jn_sgm_wait first
+  SGM_TRY(hipSetDevice(h->device));
+  const jn_status es = sgm_ensure_slot(h, slot);
+  if (es != JN_OK) return es;
+  if (sp && !h->scan_scratch[slot]) SGM_TRY(hipMalloc(reinterpret_cast<void**>(&h->scan_scratch[slot]), sizeof(unsigned long long) * 4 * h->max_batch));
+  jnav_sgm::SweepBuffers& sb = slot == 0 ? h->sb : h->extra[slot - 1].sb;
+  hipStream_t st = slot == 0 ? h->stream : h->extra[slot - 1].stream;
+  hipEvent_t* ev = slot == 0 ? h->ev : h->extra[slot - 1].ev;
+  SGM_TRY(jnav_sgm::sweep_run(h->sw, n, dI1, dI2, pitch, (long long)image_stride, dDisp, st, sb, ev, false));
+  if (sp) {                                                    // the node's tail on the same stream: mono8 map (point_cloud.cpp:422 semantics) + LUT scan
+    const long long px = (long long)n * h->W * h->H;
+    hipLaunchKernelGGL(k_sgm_to_u8, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, dDisp, h->p.subpixel ? 1 : 0, dDispU8, px);
+    jnav::launch_scan(st, *sp, n, nullptr, dDispU8, dLut, h->W, h->H, dBins, dMeta, h->scan_scratch[slot]);
+  }
+  SGM_TRY(hipGetLastError());
+  h->pending[slot] = true;
+  return JN_OK;
+}
+
+jn_status jn_sgm_wait(jn_sgm* h, int32_t slot) {
+  if (!h || slot < 0 || slot >= jn_sgm::kSgmSlots) return JN_ERR_INVALID;
+  if (!h->pending[slot]) return JN_OK;
+  SGM_TRY(hipSetDevice(h->device));
+  hipStream_t st = slot == 0 ? h->stream : h->extra[slot - 1].stream;
+  hipEvent_t* ev = slot == 0 ? h->ev : h->extra[slot - 1].ev;
+  jn_sgm_times& t = slot == 0 ? h->times : h->extra[slot - 1].times;
+  h->pending[slot] = false;
+  SGM_TRY(hipStreamSynchronize(st));
+  SGM_TRY(hipGetLastError());
+  hipEventElapsedTime(&t.prefilter, ev[0], ev[1]);
+  hipEventElapsedTime(&t.paths, ev[1], ev[2]);
+  hipEventElapsedTime(&t.wta, ev[2], ev[3]);
+  hipEventElapsedTime(&t.total, ev[0], ev[3]);
+  if (slot != 0) h->times = t;                                  // jn_sgm_last_times: the batch waited for last
   return JN_OK;
 }
 

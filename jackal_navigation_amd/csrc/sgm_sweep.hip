@@ -1204,7 +1204,7 @@ static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuff
 
 template <int NR, int NS, bool FLOW, int LQ = 4>
 static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                          SweepBuffers& b, hipEvent_t* ev) {
+                          SweepBuffers& b, hipEvent_t* ev, bool side_overlap) {
   hipError_t e;
   const size_t px = (size_t)s.W * s.H;
   if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
@@ -1213,7 +1213,8 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   constexpr int PXL = 64 / LQ;                                  // image rows per wave of the horizontal sweep = pixels per strip of the row sweeps
   // the horizontal sweep on the side stream, next to the downward sweep (JN_SGM_OVERLAP=0: one after the other on `st`, for A/B)
-  static const bool overlap = !(getenv("JN_SGM_OVERLAP") && atoi(getenv("JN_SGM_OVERLAP")) == 0);
+  static const int overlap_env = getenv("JN_SGM_OVERLAP") ? atoi(getenv("JN_SGM_OVERLAP")) : -1;
+  const bool overlap = overlap_env >= 0 ? overlap_env != 0 : side_overlap;      // default: on for a lone synchronous batch, off when batches are pipelined over slots (the other slots fill the GPU; measured neutral to -3 % there)
   hipStream_t hs = st;
   if (overlap) {
     if (!b.side) {
@@ -1250,14 +1251,14 @@ void sweep_release(SweepBuffers& b) {
 }
 
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                     SweepBuffers& b, hipEvent_t* ev) {
+                     SweepBuffers& b, hipEvent_t* ev, bool side_overlap) {
   const int lq = lanes_per_pixel(s.D);
   const int ns = (s.padl - 32) / (64 / lq);                    // strips per block, as sweep_geometry() chose them (padl = BLK + 32)
-#define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev)
+#define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap)
   if (s.flow) {
     if (s.D == 64) return ns == 2 ? JN_RUN(8, 2, true) : ns == 8 ? JN_RUN(8, 8, true) : JN_RUN(8, 4, true);
     if (s.D == 128) return ns == 2 ? JN_RUN(16, 2, true) : ns == 8 ? JN_RUN(16, 8, true) : JN_RUN(16, 4, true);
-    if (lq == 8) return run_all<16, 4, true, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev);     // D = 256: eight lanes per pixel, 16 pairs per lane
+    if (lq == 8) return run_all<16, 4, true, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap);     // D = 256: eight lanes per pixel, 16 pairs per lane
     return JN_RUN(32, 4, true);
   }
   if (s.D == 64) return ns == 3 ? JN_RUN(8, 3, false) : ns == 5 ? JN_RUN(8, 5, false) : JN_RUN(8, 7, false);

@@ -30,12 +30,14 @@ def _bind():
         L.jn_sgm_disparity_to_u8.argtypes = [i32, vp, i32, vp, i64]
         L.jn_sgm_debug_ptr.argtypes = [vp, i32, C.POINTER(i32 * 5)]
         L.jn_sgm_debug_ptr.restype = vp
+        L.jn_sgm_submit_scan.argtypes = [vp, i32, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp]
+        L.jn_sgm_wait.argtypes = [vp, i32]
         L._sgm_bound = True
     return L
 
 
 SGM_EXPORTS = ["jn_sgm_params_default", "jn_sgm_create", "jn_sgm_destroy", "jn_sgm_process_batch", "jn_sgm_last_times",
-               "jn_sgm_disparity_to_u8", "jn_sgm_debug_ptr"]
+               "jn_sgm_disparity_to_u8", "jn_sgm_debug_ptr", "jn_sgm_submit_scan", "jn_sgm_wait"]
 
 
 class Sgm:
@@ -58,6 +60,14 @@ class Sgm:
 
     def process_batch(self, n, dI1, dI2, pitch, image_stride, dDisp):
         _lib.check(self._L.jn_sgm_process_batch(self._h, n, dI1, dI2, pitch, image_stride, dDisp), "jn_sgm_process_batch")
+
+    def submit_scan(self, slot, n, dI1, dI2, pitch, image_stride, dDisp, scan_params=None, dLut=None, dU8=None, dBins=None, dMeta=None):
+        """Asynchronous: the whole mode (+ u8 map + LUT scan when scan_params is given) queued on the slot's stream (jn_sgm_submit_scan)."""
+        _lib.check(self._L.jn_sgm_submit_scan(self._h, slot, n, dI1, dI2, pitch, image_stride, dDisp,
+                                              C.byref(scan_params) if scan_params is not None else None, dLut, dU8, dBins, dMeta), "jn_sgm_submit_scan")
+
+    def wait(self, slot):
+        _lib.check(self._L.jn_sgm_wait(self._h, slot), "jn_sgm_wait")
 
     def last_times(self):
         t = SgmTimes()

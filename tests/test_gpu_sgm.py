@@ -187,3 +187,46 @@ def test_sgm_long_chain_of_blocks(jn, sgm, oracle):
     out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D), np.stack([L, L, L]), np.stack([R, R, R]))
     for b in range(3):
         assert np.array_equal(out[b], exp), b
+
+
+def test_sgm_pipelined_slots_equal_the_synchronous_call(jn, oracle):
+    """jn_sgm_submit_scan / jn_sgm_wait: four batches of different frames in flight on four slots (slots 1-3 allocate their own volumes), with
+    the node's tail on the slot's stream — disparities, u8 maps and scans must equal what the synchronous calls give for the same frames,
+    twice over (the slots are reused), and a second submit on a busy slot is refused."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node, _lib
+    W, H, D, n, S = 320, 180, 64, 2, 4
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    frames = [[oracle.synth_pair(W, H, 48, 300 + 10 * k + t) for t in range(n)] for k in range(2 * S)]
+    dL = [DeviceArray.from_numpy(np.stack([f[0] for f in fs])) for fs in frames]
+    dR = [DeviceArray.from_numpy(np.stack([f[1] for f in fs])) for fs in frames]
+    with jn.Sgm(jn.Sgm.parameters(num_disparities=D, subpixel=1), W, H, max_batch=n) as m:
+        want = []
+        for k in range(2 * S):                                 # the synchronous route: three calls per batch
+            dd = DeviceArray((n, H, W), np.int16); du = DeviceArray((n, H, W), np.uint8)
+            bins = DeviceArray((n, sp.bins), np.float64); meta = DeviceArray((n, 4), np.float64)
+            m.process_batch(n, dL[k].ptr, dR[k].ptr, W, H * W, dd.ptr)
+            m.to_u8(dd.ptr, du.ptr, n * H * W)
+            node.obstacle_scan(sp, n, du.ptr, lut.ptr, W, H, bins.ptr, meta.ptr)
+            want.append((dd.numpy().copy(), du.numpy().copy(), bins.numpy().copy(), meta.numpy().copy()))
+        outs = [dict(dd=DeviceArray((n, H, W), np.int16), du=DeviceArray((n, H, W), np.uint8), bins=DeviceArray((n, sp.bins), np.float64),
+                     meta=DeviceArray((n, 4), np.float64)) for _ in range(S)]
+        got = [None] * (2 * S)
+        for k in range(2 * S):
+            s = k % S
+            if k >= S:
+                m.wait(s)
+                got[k - S] = tuple(outs[s][x].numpy().copy() for x in ("dd", "du", "bins", "meta"))
+            o = outs[s]
+            m.submit_scan(s, n, dL[k].ptr, dR[k].ptr, W, H * W, o["dd"].ptr, sp, lut.ptr, o["du"].ptr, o["bins"].ptr, o["meta"].ptr)
+            if k == 0:
+                with pytest.raises(_lib.JnError):               # one batch per slot
+                    m.submit_scan(0, n, dL[k].ptr, dR[k].ptr, W, H * W, o["dd"].ptr)
+        for k in range(S, 2 * S):
+            m.wait(k % S)
+            got[k] = tuple(outs[k % S][x].numpy().copy() for x in ("dd", "du", "bins", "meta"))
+    for k in range(2 * S):
+        for a, b in zip(want[k], got[k]):
+            assert np.array_equal(a, b), k
+        assert (want[k][0] >= 0).mean() > 0.5
