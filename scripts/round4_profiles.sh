@@ -12,19 +12,22 @@ bash scripts/collect_profiles.sh $tag > $out/${tag}_collect.log 2>&1
 bash scripts/pmc_sq.sh $tag "k_dense|k_support_lds|k_descriptor" > $out/${tag}_sq.log 2>&1
 # ---- SGM mode: kernel stats, bench line, PMC traffic (FETCH / WRITE in separate passes), SQ pass ----
 cd /tmp && export TMPDIR=/tmp
-fresh ${tag}_sgm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_sgm -- python3 $R/bench.py --mode sgm --steps 5 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_sgm.log 2>&1
+fresh ${tag}_sgm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_sgm -- python3 $R/bench.py --mode sgm --sgm-slots 1 --steps 5 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_sgm.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  fresh ${tag}_sgm_pmc_$c; timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$out/${tag}_sgm_pmc_$c -- python3 $R/bench.py --mode sgm --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_sgm_pmc_$c.log 2>&1
+  fresh ${tag}_sgm_pmc_$c; timeout 200 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$out/${tag}_sgm_pmc_$c -- python3 $R/bench.py --mode sgm --sgm-slots 1 --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_sgm_pmc_$c.log 2>&1
 done
-fresh ${tag}_sgm_sq; timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $R/$out/${tag}_sgm_sq -- python3 $R/bench.py --mode sgm --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_sgm_sq.log 2>&1
+fresh ${tag}_sgm_sq; timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d $R/$out/${tag}_sgm_sq -- python3 $R/bench.py --mode sgm --sgm-slots 1 --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_sgm_sq.log 2>&1
 cd $R
 python3 scripts/kstats.py $(ls $out/${tag}_sgm/*/*kernel_stats.csv | tail -1) 8 > $out/${tag}_sgm_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do python3 scripts/pmc.py $(ls $out/${tag}_sgm_pmc_$c/*/*counter_collection.csv | tail -1) "k_sw_" > $out/${tag}_sgm_pmc_$c.txt; done
 python3 scripts/pmc.py $(ls $out/${tag}_sgm_sq/*/*counter_collection.csv | tail -1) "k_sw_" > $out/${tag}_sgm_pmc_SQ.txt
-python3 bench.py --mode sgm --steps 10 --warmup 2 > $out/${tag}_sgm_bench_line.json 2> $out/${tag}_sgm_bench.err
-JN_SGM_IMPL=0 python3 bench.py --mode sgm --steps 5 --warmup 2 --no-cpu-baseline > $out/${tag}_sgm_round2_kernels_bench_line.json 2>> $out/${tag}_sgm_bench.err
-{ for f in 1 0; do echo "JN_SGM_FLOW=$f $(JN_SGM_FLOW=$f python3 bench.py --mode sgm --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done
-for ns in 2 4 8; do echo "JN_SGM_FLOW=1 JN_SGM_NS=$ns $(JN_SGM_NS=$ns python3 bench.py --mode sgm --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done; } > $out/${tag}_sgm_strips_ab.txt
+python3 bench.py --mode sgm --steps 20 --warmup 6 > $out/${tag}_sgm_bench_line.json 2> $out/${tag}_sgm_bench.err
+{ for ss in 1 2 3 4 6 4 1; do echo "--sgm-slots $ss: $(python3 bench.py --mode sgm --sgm-slots $ss --steps 12 --warmup 6 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch, frac", j["roofline"]["frac"])')"; done
+  for ss in 1 4; do echo "1920x1080 D=256 + 1/16 px batch 8, --sgm-slots $ss: $(python3 bench.py --mode sgm --sgm-slots $ss --width 1920 --height 1080 --disp 256 --batch 8 --subpixel 1 --steps 8 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch")')"; done
+  for lq in 8 4; do echo "1920x1080 D=256 + 1/16 px batch 8, one batch at a time, JN_SGM_LQ=$lq: $(JN_SGM_LQ=$lq python3 bench.py --mode sgm --sgm-slots 1 --width 1920 --height 1080 --disp 256 --batch 8 --subpixel 1 --steps 4 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done; } > $out/${tag}_sgm_slots_ab.txt
+JN_SGM_IMPL=0 python3 bench.py --mode sgm --sgm-slots 1 --steps 5 --warmup 2 --no-cpu-baseline > $out/${tag}_sgm_round2_kernels_bench_line.json 2>> $out/${tag}_sgm_bench.err
+{ for f in 1 0; do echo "JN_SGM_FLOW=$f $(JN_SGM_FLOW=$f python3 bench.py --mode sgm --sgm-slots 1 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done
+for ns in 2 4 8; do echo "JN_SGM_FLOW=1 JN_SGM_NS=$ns $(JN_SGM_NS=$ns python3 bench.py --mode sgm --sgm-slots 1 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done; } > $out/${tag}_sgm_strips_ab.txt
 # ---- block-matching mode ----
 cd /tmp
 fresh ${tag}_bm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm -- python3 $R/bench.py --mode bm --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm.log 2>&1
@@ -48,8 +51,8 @@ python3 bench.py --mode bm --bm-cost sad --width 1920 --height 1080 --disp 256 -
 for a in "--width 640 --height 480 --disp 64 --batch 32" "--width 640 --height 480 --disp 64 --batch 64" "--width 320 --height 180 --disp 256 --scene-disp 48 --batch 128" "--width 1920 --height 1080 --disp 256 --batch 8"; do
   python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-latency-config $a 2>> $out/${tag}_bench.err | grep '^{"metric"' >> $out/${tag}_other_configs.jsonl
 done
-for m in sgm bm; do python3 bench.py --mode $m --width 640 --height 480 --disp 64 --batch 32 --steps 20 --warmup 3 --no-cpu-baseline 2>> $out/${tag}_bench.err | grep '^{"metric"' >> $out/${tag}_other_configs.jsonl; done
-python3 bench.py --mode sgm --width 1920 --height 1080 --disp 256 --batch 8 --subpixel 1 --steps 5 --warmup 2 --no-cpu-baseline 2>> $out/${tag}_bench.err | grep '^{"metric"' >> $out/${tag}_other_configs.jsonl
+for m in sgm bm; do python3 bench.py --mode $m --width 640 --height 480 --disp 64 --batch 32 --steps 24 --warmup 6 --no-cpu-baseline 2>> $out/${tag}_bench.err | grep '^{"metric"' >> $out/${tag}_other_configs.jsonl; done
+python3 bench.py --mode sgm --width 1920 --height 1080 --disp 256 --batch 8 --subpixel 1 --steps 12 --warmup 4 --no-cpu-baseline 2>> $out/${tag}_bench.err | grep '^{"metric"' >> $out/${tag}_other_configs.jsonl
 # ---- merge in the slot worker (one-rank communicator), node rate, lone-pair latency, host-pointer rates, probes ----
 for i in 1 2; do python3 bench.py --no-cpu-baseline --force-merge --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); m=j["merge"]; print(j["value"], "pairs/s with the merge;", m["merge_ms_per_step"], "ms per step;", m["pairs_per_sec_without_merge"], "pairs/s without; cost", m["cost_frac"])'; done > $out/${tag}_merge_in_worker.txt 2>&1
 timeout 300 python3 scripts/node_rate.py 300 serial 2>/dev/null | tail -1 > $out/${tag}_node_rate.txt; timeout 300 python3 scripts/node_rate.py 300 2>/dev/null | tail -1 >> $out/${tag}_node_rate.txt
