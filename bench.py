@@ -867,7 +867,7 @@ def run_rank(a):
                     m = jn.Sgm(jn.Sgm.parameters(num_disparities=a.disp), W, H, max_batch=B, device=local_rank)
                 else:
                     m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4, cost_function=1 if kind == "bm_ssd" else 0), W, H, max_batch=B, device=local_rank)
-                reps_m = 24 if kind == "sgm" else 8   # the pipelined leg needs enough batches for its fill and drain not to weigh
+                reps_m = 60 if kind == "sgm" else 8   # the pipelined leg needs enough batches (0.4 s) for its fill and drain not to weigh
                 if kind == "sgm":                            # four batches in flight (jn_sgm_submit_scan / jn_sgm_wait), as `--mode sgm` runs it
                     nsl = 4
                     outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
