@@ -29,7 +29,8 @@
 #include <cstring>
 #include "../../include/jn_bm.h"
 #include "kernels.h"          // launch_scan: the node's tail on the same stream (jn_bm_process_scan)
-#include "bm_mfma.h"          // JN_BM_COST_SSD: the matrix-core kernels
+#include "bm_mfma.h"
+#include "prefilter.h"          // JN_BM_COST_SSD: the matrix-core kernels
 
 namespace {
 
@@ -48,14 +49,21 @@ constexpr int kBmPA = 80;             // LDS row of the reference-side image: co
 // of its disparity inside its quad (4 (81 x 62) + 3 < 2^16). ----
 __global__ void __launch_bounds__(256) k_bm_prefilter(BmDev s, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2, int pitch,
                                                       long long stride, int n, uint8_t* __restrict__ g) {
-  const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+  const int xp = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, img = blockIdx.z;      // four padded columns per thread (Wp is a multiple of 4)
   if (xp >= s.Wp) return;
   const uint8_t* I = img < n ? I1 + (long long)img * stride : I2 + (long long)(img - n) * stride;
-  const int x = min(max(xp - s.padx, 0), s.W - 1);
-  const int xm = max(x - 1, 0), xq = min(x + 1, s.W - 1), ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
+  const int ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
   const uint8_t* r0 = I + (size_t)ym * pitch; const uint8_t* r1 = I + (size_t)y * pitch; const uint8_t* r2 = I + (size_t)yq * pitch;
-  const int sx = ((int)r0[xq] - (int)r0[xm]) + 2 * ((int)r1[xq] - (int)r1[xm]) + ((int)r2[xq] - (int)r2[xm]);
-  g[((size_t)img * s.H + y) * s.Wp + xp] = (uint8_t)(4 * (min(max(sx, -s.cap), s.cap) + s.cap + 1));
+  int v[4];
+  const int x0 = xp - s.padx;
+  if (x0 >= 0 && x0 + 3 <= s.W - 1) jnav_pre::sobel4<1>(r0, r1, r2, x0, s.W, s.cap, v);
+  else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = min(max(jnav_pre::sobel_x_clamped(r0, r1, r2, min(max(x0 + k, 0), s.W - 1), s.W), -s.cap), s.cap);
+  }
+  const uint32_t c1 = (uint32_t)(s.cap + 1);
+  *reinterpret_cast<uint32_t*>(g + ((size_t)img * s.H + y) * s.Wp + xp) =
+      (4u * ((uint32_t)v[0] + c1)) | ((4u * ((uint32_t)v[1] + c1)) << 8) | ((4u * ((uint32_t)v[2] + c1)) << 16) | ((4u * ((uint32_t)v[3] + c1)) << 24);
 }
 
 DEV uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t shift) { return __builtin_amdgcn_alignbyte(hi, lo, shift); }
@@ -403,7 +411,7 @@ static jn_status bm_run(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* 
     hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
     return JN_OK;
   }
-  hipLaunchKernelGGL(k_bm_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, h->g);
+  hipLaunchKernelGGL(k_bm_prefilter, dim3((s.Wp / 4 + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, h->g);
   BM_TRY(hipEventRecord(h->ev[1], st));
   // Rows per band: whole turns of the kernel's ring (band + 2r = k (2r+1)) so that no staged row is wasted, as many as
   // fit 64 rows (halo overhead 2r / band), fewer turns while the launch would leave most of the 256 CUs idle (a lone pair).

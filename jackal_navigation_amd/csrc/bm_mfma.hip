@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "bm_mfma.h"
+#include "prefilter.h"
 
 namespace jnav_bmq {
 
@@ -41,14 +42,21 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 // padded by padx columns: no window ever needs a clamp in x ----
 __global__ void __launch_bounds__(256) k_bmq_prefilter(QDev s, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2, int pitch, long long stride,
                                                        int n, uint8_t* __restrict__ g) {
-  const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+  const int xp = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, img = blockIdx.z;      // four padded columns per thread (Wp is a multiple of 16)
   if (xp >= s.Wp) return;
   const uint8_t* I = img < n ? I1 + (long long)img * stride : I2 + (long long)(img - n) * stride;
-  const int x = min(max(xp - s.padx, 0), s.W - 1);
-  const int xm = max(x - 1, 0), xq = min(x + 1, s.W - 1), ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
+  const int ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
   const uint8_t* r0 = I + (size_t)ym * pitch; const uint8_t* r1 = I + (size_t)y * pitch; const uint8_t* r2 = I + (size_t)yq * pitch;
-  const int sx = ((int)r0[xq] - (int)r0[xm]) + 2 * ((int)r1[xq] - (int)r1[xm]) + ((int)r2[xq] - (int)r2[xm]);
-  g[((size_t)img * s.H + y) * s.Wp + xp] = (uint8_t)(min(max(sx, -s.cap), s.cap) + s.cap);
+  int v[4];
+  const int x0 = xp - s.padx;
+  if (x0 >= 0 && x0 + 3 <= s.W - 1) jnav_pre::sobel4<1>(r0, r1, r2, x0, s.W, s.cap, v);
+  else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = min(max(jnav_pre::sobel_x_clamped(r0, r1, r2, min(max(x0 + k, 0), s.W - 1), s.W), -s.cap), s.cap);
+  }
+  const uint32_t c = (uint32_t)s.cap;
+  *reinterpret_cast<uint32_t*>(g + ((size_t)img * s.H + y) * s.Wp + xp) =
+      ((uint32_t)v[0] + c) | (((uint32_t)v[1] + c) << 8) | (((uint32_t)v[2] + c) << 16) | (((uint32_t)v[3] + c) << 24);
 }
 
 // bytes [sh, sh + taps) of the 12 bytes d0 d1 d2, as three dwords with everything beyond `taps` zero
@@ -340,7 +348,7 @@ static hipError_t launch_match_any(hipStream_t st, const QDev& s, int n, int ban
 hipError_t run(const QDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, uint8_t* g, int32_t* Q, uint32_t* keysL, uint32_t* keysR,
                int16_t* dDisp, uint8_t* dU8, hipStream_t st, hipEvent_t* ev) {
   hipError_t e;
-  hipLaunchKernelGGL(k_bmq_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, g);
+  hipLaunchKernelGGL(k_bmq_prefilter, dim3((s.Wp / 4 + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, g);
   const dim3 bgrid((s.Wp + 255) / 256, (s.H + kBoxBand - 1) / kBoxBand, 2 * n);
   switch (s.r) {
     case 2: hipLaunchKernelGGL(k_bmq_box<2>, bgrid, dim3(256), 0, st, s, n, g, Q); break;

@@ -41,6 +41,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "sgm_sweep.h"
+#include "prefilter.h"
 
 namespace jnav_sgm {
 
@@ -213,15 +214,24 @@ DEV void load_words(const uint8_t* pixel_base, int q, uint32_t (&f)[NR]) {
 // the cost's coordinate clamps become plain reads).  +1 keeps every byte non-zero for v_mqsad's mask.
 __global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2, int pitch,
                                                       long long stride, int n, uint8_t* __restrict__ gm) {
-  const int xp = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, img = blockIdx.z;
+  const int xp = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, img = blockIdx.z;      // four padded columns per thread (Wp is a multiple of 16)
   if (xp >= s.Wp) return;
   const uint8_t* I = img < n ? I1 + (long long)img * stride : I2 + (long long)(img - n) * stride;
-  const int xk = min(max(xp - s.padl, 0), s.W - 1);
-  const int x = s.W - 1 - xk;
-  const int xm = max(x - 1, 0), xq = min(x + 1, s.W - 1), ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
+  const int ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
   const uint8_t* r0 = I + (size_t)ym * pitch; const uint8_t* r1 = I + (size_t)y * pitch; const uint8_t* r2 = I + (size_t)yq * pitch;
-  const int sx = ((int)r0[xq] - (int)r0[xm]) + 2 * ((int)r1[xq] - (int)r1[xm]) + ((int)r2[xq] - (int)r2[xm]);
-  gm[((size_t)img * s.H + y) * s.Wp + xp] = (uint8_t)(min(max(sx, -s.cap), s.cap) + s.cap + 1);
+  int g[4];
+  const int xk0 = xp - s.padl;                                  // mirrored column of the first of the four; the image column DEscends with it
+  if (xk0 >= 0 && xk0 + 3 <= s.W - 1) jnav_pre::sobel4<-1>(r0, r1, r2, s.W - 1 - xk0, s.W, s.cap, g);
+  else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                               // the row's padding: replicas of the outermost columns
+      const int x = s.W - 1 - min(max(xk0 + k, 0), s.W - 1);
+      g[k] = min(max(jnav_pre::sobel_x_clamped(r0, r1, r2, x, s.W), -s.cap), s.cap);
+    }
+  }
+  const uint32_t c1 = (uint32_t)(s.cap + 1);
+  *reinterpret_cast<uint32_t*>(gm + ((size_t)img * s.H + y) * s.Wp + xp) =
+      ((uint32_t)g[0] + c1) | (((uint32_t)g[1] + c1) << 8) | (((uint32_t)g[2] + c1) << 16) | (((uint32_t)g[3] + c1) << 24);
 }
 
 // ---- horizontal paths: lanes = 16 rows x 4 disparity quarters; blockIdx.z = 0 walks x_k upwards, 1 downwards ----
@@ -1208,7 +1218,7 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   hipError_t e;
   const size_t px = (size_t)s.W * s.H;
   if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
+  hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp / 4 + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
   if ((e = hipMemsetAsync(b.minr, 0xFF, (size_t)n * px * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   constexpr int PXL = 64 / LQ;                                  // image rows per wave of the horizontal sweep = pixels per strip of the row sweeps
