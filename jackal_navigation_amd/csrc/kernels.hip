@@ -1325,28 +1325,39 @@ typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
     asm("v_bfe_i32 %0, %1, " #pos ", 1" : "=v"(sx__) : "v"(m));                                             \
     asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(w) : "v"(sx__), "s"(bit));                                     \
   } while (0)
+// LDS byte address of a pointer into __shared__ memory, and a 16-byte read at such an address
+typedef __attribute__((address_space(3))) const jn_u32x4 jn_lds_u4;
+DEV uint32_t lds_addr(const uint4* p) { return (uint32_t)(uintptr_t)(jn_lds_u4*)p; }
+DEV uint4 lds_read16(uint32_t a) { const jn_u32x4 t = *(jn_lds_u4*)a; return make_uint4(t.x, t.y, t.z, t.w); }
 template <int NW>
 __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, const FrameInfo* __restrict__ info,
                                                const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
                                                const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
-                                               const uint4* __restrict__ desc, int16_t* __restrict__ raw, int nbx, int nby, int xcd_order, int dbg) {
+                                               const uint4* __restrict__ desc, int16_t* __restrict__ raw, int nbx, int nby, int xcd_order, int dbg, uint32_t nbx_magic, uint32_t nby_magic) {
   static_assert(kDenseThreads / 64 == kTileH, "one wave stages one strip row");
   __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
   __shared__ uint4 s_plane[kStripTiles][kBinLds];                 // (pa, pb, pc, flags) of a tile's listed triangles, by rank
   __shared__ int s_cnt[kStripTiles];
-  __shared__ uint16_t s_cover[kStripTiles][kTileH][kTileW];       // per pixel: bit k set <=> the k-th smallest listed triangle covers it
+  __shared__ uint16_t s_cover[kStripTiles][kTileW][kTileH];       // per pixel (column, row): bit k set <=> the k-th smallest listed triangle covers it
   extern __shared__ uint4 s_Bx[];                            // kDense2Slack + [kTileH][kStripW + disp_max] + kDense2Slack
+  // Every kernel argument the block will need is pulled into scalar registers HERE, behind one wait: left alone the compiler fetches
+  // them one basic block at a time, each fetch a scalar-cache round trip in series with the loads below.
+  asm volatile("" :: "s"(info), "s"(bin_count), "s"(bin_list), "s"(gridbits), "s"(desc), "s"(raw),
+               "s"(dp.W), "s"(dp.H), "s"(dp.disp_max), "s"(dp.gw), "s"(dp.gh), "s"(dp.grid_magic), "s"(dp.radius), "s"(dp.match_texture),
+               "s"(dp.P[0]), "s"(dp.P[1]), "s"(dp.P[2]), "s"(n), "s"(nbx), "s"(nby), "s"(dbg), "s"(nbx_magic), "s"(nby_magic));
   const int total = nbx * nby * 2 * n;
   int item = blockIdx.x;
   if (xcd_order) { const int per_xcd = (total + 7) / 8; item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); }   // see k_dense
   if (item >= total) return;
+  // item -> (side, bx, by, frame): the two divisions by multiply-high with the host's ceil(2^32 / n) (exact while x n < 2^32, which
+  // launch_dense() checks) — the compiler's division sequence is ~28 dependent instructions each, in front of the block's first load
   const int side = item & 1;
-  int rest = item >> 1;
-  const int bx = rest % nbx; rest /= nbx;
-  const int by = rest % nby;
-  const int frame = rest / nby;
+  const unsigned rest = (unsigned)item >> 1;
+  const unsigned rest2 = nbx == 1 ? rest : __umulhi(rest, nbx_magic);     // ceil(2^32 / 1) does not fit
+  const int bx = (int)(rest - rest2 * (unsigned)nbx);
+  const int frame = (int)(nby == 1 ? rest2 : __umulhi(rest2, nby_magic));
+  const int by = (int)(rest2 - (unsigned)frame * (unsigned)nby);
   const FrameInfo& fi = info[frame];
-  if (!fi.ok) return;
   const int W = dp.W, H = dp.H;
   const int tid = threadIdx.x;
   const int u0 = bx * kStripW, v0 = by * kTileH;
@@ -1364,19 +1375,22 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
   const int lw = tid >> 6, lane = tid & 63;                  // waves 4..7 (second pixel pair) have no list duty
   const int wave = __builtin_amdgcn_readfirstlane(lw);
   const bool list_wave = wave < kStripTiles && bx * kStripTiles + wave < tiles_x;
-  int cnt = 0, c16 = 0, myt = 0x7FFFFFFF;
+  // The prologue is a chain of memory round trips with the vector pipes idle, and a block's lifetime is what bounds the kernel (the CU's
+  // LDS and wave slots are full at four blocks): nothing here waits for an earlier load.  The list's first kBinLds entries are read whole
+  // (kBinCap >= kBinLds of them always exist) instead of `count` entries after the count has arrived.
+  static_assert(kBinCap >= kBinLds && kBinLds * kBinWords == 256, "four loads of 64 words cover the LDS-resident part of a list");
+  // The two wave-uniform words (frame ok, list length) are read with VECTOR loads (an index the compiler cannot prove uniform): a scalar
+  // load would have to be waited for before the next scalar load, vector loads return in order behind everything issued here.
+  int vzero = 0;
+  asm volatile("" : "+v"(vzero));
+  const int ok_v = (&fi.ok)[vzero];
+  int cnt_v = 0;
   uint32_t lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0;
   if (list_wave) {
     const size_t bin = bin_row + bx * kStripTiles + wave;
-    cnt = bin_count[bin];
-    c16 = min(cnt, (int)kBinLds);
-    const int words = c16 * kBinWords;
+    cnt_v = bin_count[bin + vzero];
     const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
-    if (lane < words) lw0 = src[lane];
-    if (lane + 64 < words) lw1 = src[lane + 64];
-    if (lane + 128 < words) lw2 = src[lane + 128];
-    if (lane + 192 < words) lw3 = src[lane + 192];
-    if (lane < c16) myt = (int)src[lane * kBinWords];
+    lw0 = src[lane]; lw1 = src[lane + 64]; lw2 = src[lane + 128]; lw3 = src[lane + 192];
   }
   // own descriptors and grid-cell candidate sets of the thread's two pixels
   uint4 a4[kPxPerThread];
@@ -1401,42 +1415,57 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
     const uint4* rowp = B + (size_t)max(min(v0 + wave, H - 3), 2) * W;    // :701 row clamp
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(rowp), 0, W * 16, 0x00020000);
     uint4* dst = s_B + wave * span;
-    int goff = (base + lane) * 16;                           // byte offset inside the row
-    int li = side ? lane : span - 1 - lane;                  // LDS slot
-    for (int c = lane; c < span; c += 64) {
-      const jn_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff, 0, 0);
-      dst[li] = make_uint4(t.x, t.y, t.z, t.w);
-      goff += 64 * 16; li += side ? 64 : -64;
-    }
+    const int goff = (base + lane) * 16;                     // byte offset inside the row
+    const int li = side ? lane : span - 1 - lane;            // LDS slot
+    // span <= 128 + 32 NW - 1: all the row's loads are issued together (a load past the window is harmless: it stays inside the row or
+    // reads as zero), then stored — one memory round trip per wave instead of one per 64 columns
+    constexpr int kLoads = (kStripW + 32 * NW + 62) / 64;
+    jn_u32x4 t[kLoads];
+#pragma unroll
+    for (int i = 0; i < kLoads; i++) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff + i * 1024, 0, 0);
+#pragma unroll
+    for (int i = 0; i < kLoads; i++)
+      if (lane + 64 * i < span) dst[li + (side ? 64 * i : -64 * i)] = make_uint4(t[i].x, t[i].y, t[i].z, t[i].w);
   }
+  if (!__builtin_amdgcn_readfirstlane(ok_v)) return;         // uniform over the block
+  const int cnt = __builtin_amdgcn_readfirstlane(cnt_v);
   if (list_wave) {
-    const int words = c16 * kBinWords;
-    if (lane < words) s_list[wave][lane] = lw0;
-    if (lane + 64 < words) s_list[wave][lane + 64] = lw1;
-    if (lane + 128 < words) s_list[wave][lane + 128] = lw2;
-    if (lane + 192 < words) s_list[wave][lane + 192] = lw3;
+    s_list[wave][lane] = lw0; s_list[wave][lane + 64] = lw1; s_list[wave][lane + 128] = lw2; s_list[wave][lane + 192] = lw3;
     // rank among the listed triangles (indices are distinct): a pixel's owner is the covering triangle with the
     // LARGEST index = the highest set bit of its cover word; the planes are stored by rank so that the owner's plane is
     // one read.  v_readlane on compile-time / loop-uniform lanes instead of shuffles.
-    const int c16u = __builtin_amdgcn_readfirstlane(c16);
+    const int c16u = __builtin_amdgcn_readfirstlane(min(cnt, (int)kBinLds));
+    const int myt = lane < c16u ? (int)s_list[wave][(lane & (kBinLds - 1)) * kBinWords] : 0x7FFFFFFF;
     int rank = 0;
     for (int jj = 0; jj < c16u; jj++) rank += __builtin_amdgcn_readlane(myt, jj) < myt ? 1 : 0;
     if (lane < c16u) {
       const uint32_t* e = &s_list[wave][lane * kBinWords];
       s_plane[wave][rank] = make_uint4(e[9], e[10], e[11], e[12]);
     }
-    // lane (xx, half) accumulates rows half*4 .. half*4+3 of column xx over all listed candidates
+    // lane (xx, half) accumulates rows half*4 .. half*4+3 of column xx over all listed candidates.  The candidate's four row bits n are
+    // spread to bit 0 of four bytes ((n * 0x204081) & 0x01010101: bit j lands on bit 8 j, no two products collide there) and shifted to
+    // the triangle's rank inside the byte — ranks 0..7 in one word, 8..15 in the other (the rank is wave-uniform: a scalar branch).
     const int xx = lane & (kTileW - 1), half = lane >> 5;
     const uint32_t* mrow = &s_list[wave][1 + (xx >> 2)];
     const int sh = (xx & 3) * 8 + half * 4;
-    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-    for (int c = 0; c < c16u; c++) {
-      const unsigned m = mrow[c * kBinWords] >> sh;          // bits 0..3 = rows half*4 .. +3 of this column
-      const unsigned bit = 1u << __builtin_amdgcn_readlane(rank, c);
-      or_bit_if(w0, m, 0, bit); or_bit_if(w1, m, 1, bit); or_bit_if(w2, m, 2, bit); or_bit_if(w3, m, 3, bit);
+    unsigned acc_lo = 0, acc_hi = 0;
+    for (int c0 = 0; c0 < c16u; c0 += 4) {                   // four mask reads in flight (c0 + 3 <= 15: inside the tile's 16 entries)
+      unsigned m[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) m[k] = mrow[(c0 + k) * kBinWords];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (c0 + k >= c16u) break;                           // uniform
+        const unsigned spread = (((m[k] >> sh) & 15u) * 0x204081u) & 0x01010101u;
+        const int rk = __builtin_amdgcn_readlane(rank, c0 + k);
+        if (rk < 8) acc_lo |= spread << rk; else acc_hi |= spread << (rk - 8);
+      }
     }
-    s_cover[wave][half * 4 + 0][xx] = (uint16_t)w0; s_cover[wave][half * 4 + 1][xx] = (uint16_t)w1;
-    s_cover[wave][half * 4 + 2][xx] = (uint16_t)w2; s_cover[wave][half * 4 + 3][xx] = (uint16_t)w3;
+    // row j's word = byte j of acc_lo | byte j of acc_hi << 8; the four rows of a column are adjacent: one 8-byte store
+    uint2 cw;
+    cw.x = __builtin_amdgcn_perm(acc_hi, acc_lo, 0x05010400u);
+    cw.y = __builtin_amdgcn_perm(acc_hi, acc_lo, 0x07030602u);
+    *reinterpret_cast<uint2*>(&s_cover[wave][xx][half * 4]) = cw;
   }
   if (lw < kStripTiles && lane == 0) s_cnt[lw] = cnt;
   __syncthreads();
@@ -1462,7 +1491,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
     int t = -1; float pa = 0, pb = 0, pc = 0; bool valid = false;
     if (inw) {
       if (cntk <= kBinLds) {
-        const unsigned cover = s_cover[k][r][x];
+        const unsigned cover = s_cover[k][x][r];
         if (cover) {
           const uint4 pl = s_plane[k][31 - __clz(cover)];
           t = 0;
@@ -1498,27 +1527,24 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
     const int phi = min(hi, dmax_ok);
 
     // ---- grid candidates outside the plane range (:742-750): per-lane bit scan, one (different) disparity per lane and round ----
+    // Keys here are (SAD << 16) + LDS byte address of the candidate's descriptor: the address is what the read needs anyway, it orders
+    // like d, and d = (address - address of Bu[0]) / 16 is recovered once at the end (the bias the plane keys carry is added there too).
     unsigned best1 = kNoKey;
-    const bool no_range = hi < lo;
+    const uint32_t bu_a = lds_addr(Bu);
     if (elig && !(dbg & 1)) {
-      // the plane range [lo, hi] (at most 15 wide) as a bit mask over the set, built 64 bits at a time: 64-bit word j
-      // holds M << (lo - 64 j), or the spill M >> (64 j - lo) of a range that starts in the word below
-      const unsigned long long M = no_range ? 0ull : ((2ull << (hi - lo)) - 1ull);
-      uint32_t excl[NW];
-#pragma unroll
-      for (int j = 0; j < NW / 2; j++) {
-        const int sft = lo - 64 * j;
-        const unsigned long long m = (sft >= 0) ? (sft < 64 ? M << sft : 0ull) : (sft > -16 ? M >> -sft : 0ull);
-        excl[2 * j] = (uint32_t)m; excl[2 * j + 1] = (uint32_t)(m >> 32);
-      }
+      // The plane range [lo, hi] (at most 15 wide) sits as ones in bits 16.. of T; word w of the exclusion mask is the HIGH half of
+      // T << (lo + 16 - 32 w) with the shift clamped to [0, 63]: below 0 and from 48 up nothing of T lands in bits 32..63, in between it
+      // is M << (lo - 32 w) or the spill M >> (32 w - lo) of a range that starts in the word below.  (hi < lo: T = 0.)
+      const unsigned long long T = (unsigned long long)(((1u << max(hi - lo + 1, 0)) - 1u) << 16);
 #pragma unroll
       for (int w = 0; w < NW; w++) {
-        uint32_t bits = cellw[q][w] & ~excl[w];
+        const uint32_t excl = (uint32_t)((T << min(max(lo + 16 - 32 * w, 0), 63)) >> 32);
+        uint32_t bits = cellw[q][w] & ~excl;
         if (border) bits &= range_mask(0, dmax_ok, w);
         while (bits) {
-          const int d = (w << 5) + __builtin_ctz(bits);
+          const uint32_t ad = bu_a + (uint32_t)((w << 5) + __builtin_ctz(bits)) * 16u;
           bits &= bits - 1;
-          best1 = min(best1, sadhi16(a, Bu[d], ((unsigned)kCellBias << 16) | (unsigned)d));
+          best1 = min(best1, sadhi16(a, lds_read16(ad), ad));
         }
       }
     }
@@ -1538,10 +1564,10 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
         const unsigned i0 = ((unsigned)(kCellBias + dp.P[2]) << 16), i1 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 1u,
                        i2 = ((unsigned)(kCellBias + dp.P[0]) << 16) + 2u, i3 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 3u,
                        i4 = ((unsigned)(kCellBias + dp.P[2]) << 16) + 4u;
-        const unsigned dl = (unsigned)dlow;
-        const unsigned k0 = sadhi16(a, nb[0], i0 + dl), k1 = sadhi16(a, nb[1], i1 + dl), k2 = sadhi16(a, nb[2], i2 + dl),
-                       k3 = sadhi16(a, nb[3], i3 + dl), k4 = sadhi16(a, nb[4], i4 + dl);
-        best2 = min(min(min(k0, k1), min(k2, k3)), k4);
+        // keys relative to dlow (scalar bases), dlow added to the minimum: 0 <= dlow and dlow + 4 <= 255, no carry into the cost
+        const unsigned k0 = sadhi16(a, nb[0], i0), k1 = sadhi16(a, nb[1], i1), k2 = sadhi16(a, nb[2], i2),
+                       k3 = sadhi16(a, nb[3], i3), k4 = sadhi16(a, nb[4], i4);
+        best2 = min(min(min(k0, k1), min(k2, k3)), k4) + (unsigned)dlow;
       } else {
         const unsigned prior_on = valid ? 0xFFFFFFFFu : 0u;
 #pragma unroll
@@ -1564,9 +1590,11 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
         }
       }
     }
-    const unsigned best = (best2 >> 16) < (best1 >> 16) ? best2 : best1;   // the plane phase wins only with a strictly smaller cost
+    // the plane phase wins only with a strictly smaller cost; a missing grid key (0xFFFF + bias) loses to every plane key, a missing plane
+    // key (cost field 0xFFFF) to every grid key (SAD <= 4080); both missing: the plane branch answers -1
+    const bool plane_wins = (best2 >> 16) < (best1 >> 16) + (unsigned)kCellBias;
     int result = -10;                                                      // :797-798
-    if (elig) result = best == kNoKey ? -1 : (int)(best & 255u);          // :778-779
+    if (elig) result = plane_wins ? (best2 == kNoKey ? -1 : (int)(best2 & 255u)) : (int)(((best1 & 0xFFFFu) - bu_a) >> 4);   // :778-779
     if (inw) out[u] = (int16_t)result;
   }
 }
@@ -2779,14 +2807,17 @@ void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* i
   const int total = nbx * nby * 2 * n;
   const int blocks = xcd_order ? (total + 7) / 8 * 8 : total;
   const size_t lds = (size_t)kTileH * (kStripW + dp.disp_max) * sizeof(uint4);   // 32.6 KB at disp_max 127, 49 KB at 255
-  if (dense2_applies(dp)) {
+  const unsigned long long items_half = (unsigned long long)nbx * nby * n;          // the largest dividend of k_dense2's item decode
+  const bool magic_ok = items_half * (unsigned long long)max(nbx, nby) < (1ull << 32);
+  if (dense2_applies(dp) && magic_ok) {
+    const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + nbx - 1) / nbx), nby_magic = (uint32_t)(((1ull << 32) + nby - 1) / nby);
     static const int dbg = getenv("JN_DENSE_DBG") ? atoi(getenv("JN_DENSE_DBG")) : 0;
     if (dp.disp_max < 128)
       hipLaunchKernelGGL(k_dense2<4>, dim3(blocks), dim3(kDenseThreads), lds + 2 * kDense2Slack * sizeof(uint4), st, dp, n, info, recs, tri_cap, bin_count,
-                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg);
+                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
     else
       hipLaunchKernelGGL(k_dense2<8>, dim3(blocks), dim3(kDenseThreads), lds + 2 * kDense2Slack * sizeof(uint4), st, dp, n, info, recs, tri_cap, bin_count,
-                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg);
+                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
     return;
   }
   hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(kDenseThreads), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
