@@ -1349,6 +1349,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
   int item = blockIdx.x;
   if (xcd_order) { const int per_xcd = (total + 7) / 8; item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); }   // see k_dense
   if (item >= total) return;
+  if (dbg & 64) return;                                     // JN_DENSE_DBG profiling switches (results are then WRONG): 64 = empty blocks,
+                                                            // 8 / 16 = no window / own descriptor loads, 4 = stop after the prologue, 1 / 2 = no grid / plane candidates
   // item -> (side, bx, by, frame): the two divisions by multiply-high with the host's ceil(2^32 / n) (exact while x n < 2^32, which
   // launch_dense() checks) — the compiler's division sequence is ~28 dependent instructions each, in front of the block's first load
   const int side = item & 1;
@@ -1400,7 +1402,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
 #pragma unroll
   for (int q = 0; q < kPxPerThread; q++) {
     const int u = min(u0 + (grp + 2 * q) * kTileW + x, W - 1);
-    a4[q] = A[(size_t)vr * W + u];
+    a4[q] = (dbg & 16) ? make_uint4(u, u, u, u) : A[(size_t)vr * W + u];
     const uint32_t* cell = cells + (size_t)__umulhi((unsigned)u, dp.grid_magic) * kGridWords;
 #pragma unroll
     for (int w = 0; w < NW; w++) cellw[q][w] = cell[w];
@@ -1422,7 +1424,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
     constexpr int kLoads = (kStripW + 32 * NW + 62) / 64;
     jn_u32x4 t[kLoads];
 #pragma unroll
-    for (int i = 0; i < kLoads; i++) t[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff + i * 1024, 0, 0);
+    for (int i = 0; i < kLoads; i++) t[i] = (dbg & 8) ? jn_u32x4{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff + i * 1024, 0, 0);
 #pragma unroll
     for (int i = 0; i < kLoads; i++)
       if (lane + 64 * i < span) dst[li + (side ? 64 * i : -64 * i)] = make_uint4(t[i].x, t[i].y, t[i].z, t[i].w);

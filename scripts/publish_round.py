@@ -60,7 +60,8 @@ for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.
                   ("merge_in_worker.txt", None), ("node_rate.txt", None), ("latency_check.txt", None), ("host_pointer_rate.txt", None),
                   ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None),
                   ("bm_ssd_bench_line.json", None), ("bm_ssd_1080p_bench_line.json", None), ("bm_sad_1080p_bench_line.json", None), ("bm_ssd_pmc_mfma.txt", None),
-                  ("host_threads.txt", None), ("pk3_probe.txt", None), ("dep_chain_probe.txt", None), ("lds_unaligned_probe.txt", None), ("gpu_tests.txt", None)):
+                  ("host_threads.txt", None), ("pk3_probe.txt", None), ("dep_chain_probe.txt", None), ("lds_unaligned_probe.txt", None), ("op_rate_probe.txt", None),
+                  ("dense_dbg_switches.txt", None), ("gpu_tests.txt", None)):
     put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
 sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
 if sq:
@@ -100,7 +101,7 @@ if os.path.exists(fs) and os.path.exists(ws):     # SGM traffic from its own PMC
                "algorithmic_bytes_per_batch": int((4 * 1280 * 720 * 128 + 5 * 1280 * 720) * 32)}, open(os.path.join(p, "%s_sgm_pmc_traffic.json" % rnd), "w"), indent=1)
     published["%s_sgm_pmc_traffic.json" % rnd] = "from %s_sgm_pmc_*.txt" % tag
 manifest = {"tag": tag, "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
-            "sources_sha256": {f: sha(f) for f in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip", "jackal_navigation_amd/csrc/bm_mfma.hip",
+            "sources_sha256": {f: sha(f) for f in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip", "jackal_navigation_amd/csrc/bm_mfma.hip", "jackal_navigation_amd/csrc/prefilter.h",
                                                    "jackal_navigation_amd/csrc/jn_api.cpp", "bench.py")},
             "inputs_newest_mtime": _newest_in, "files": published}
 json.dump(manifest, open(os.path.join(p, "%s_manifest.json" % tag), "w"), indent=1)
