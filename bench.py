@@ -860,6 +860,10 @@ def run_rank(a):
     other_modes = None
     if rank == 0 and world == 1 and not a.no_latency_config and a.disp in (64, 128, 256):
         other_modes = {}
+        # The ELAS handle is done: it is closed before these legs.  Left open, its four slot streams keep hardware queues (the runtime
+        # has GPU_MAX_HW_QUEUES of them, 8 here), the SGM slots' streams then share queues among themselves and batches that should
+        # overlap run one after the other: 4.37 k instead of 4.9 k pairs/s (profiles/*_hw_queues_ab.txt).
+        elas.close()
         for kind in ("sgm", "bm", "bm_ssd"):
             try:
                 disp16 = torch.zeros((B, H, W), dtype=torch.int16, device=dev)
@@ -867,7 +871,7 @@ def run_rank(a):
                     m = jn.Sgm(jn.Sgm.parameters(num_disparities=a.disp), W, H, max_batch=B, device=local_rank)
                 else:
                     m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4, cost_function=1 if kind == "bm_ssd" else 0), W, H, max_batch=B, device=local_rank)
-                reps_m = 60 if kind == "sgm" else 8   # the pipelined leg needs enough batches (0.4 s) for its fill and drain not to weigh
+                reps_m = 120 if kind == "sgm" else 8   # the pipelined leg needs enough batches (0.8 s) for its fill and drain not to weigh
                 if kind == "sgm":                            # four batches in flight (jn_sgm_submit_scan / jn_sgm_wait), as `--mode sgm` runs it
                     nsl = 4
                     outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
@@ -883,7 +887,7 @@ def run_rank(a):
                     def run_m(k):
                         for _ in range(k):
                             m.process_batch(B, dLs[0].data_ptr(), dRs[0].data_ptr(), W, H * W, disp16.data_ptr())
-                run_m(4)
+                run_m(16 if kind == "sgm" else 4)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 run_m(reps_m)

@@ -65,6 +65,7 @@ struct Slot {
   float merge_ms = 0.f;
   double* d_flat = nullptr;                                   // the merge's packed buffer of this slot [max_batch][1024 + 4] (written by k_scan_finish)
   hipStream_t stream_a = nullptr;                             // highest-priority stream for stage A (see run_batch); only with JN_STAGE_A_PRIORITY=1
+  uint32_t* gate = nullptr; uint32_t gate_seq = 0;            // latency mode: the word stage B's queued launches wait on (hipMallocSignalMemory), see run_batch
   hipEvent_t ev[EV_COUNT] = {};
   // device
   uint4* desc = nullptr; int16_t* d_can = nullptr;
@@ -123,6 +124,7 @@ struct jn_elas {
   // heavy kernels — the phase the pipeline settles into by itself.  In steady state that event is long complete: the wait is a no-op.
   std::mutex pace_m; hipEvent_t pace_prev = nullptr; bool pace = false;
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
+  bool gate_stage_b = false;        // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
   std::vector<uint64_t> merge_log;                            // submission numbers in the order their merges were queued (the last 4096; jn_elas_merge_order)
   int comm_timeout_ms = 30000;                                // JN_COMM_TIMEOUT_MS: a merge not complete by then is aborted (0: wait for ever)
@@ -278,6 +280,84 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipMemcpyAsync(s.h_can, s.d_can, can_bytes * n, hipMemcpyDeviceToHost, sa));
   }
   HIP_TRY(hipEventRecord(s.ev[EV_D2H], sa));
+
+  // ---- stage B, as a function of what the host stage yields: the largest support / triangle counts (launch sizes), whether any frame
+  // has a triangulation, where the payload is read from, and whether the two clears were queued ahead ----
+  const bool fused = gap_mean_fusable(dp, n) && ((dp.W * dp.H) & 3) == 0;
+  auto queue_stage_b = [&](int max_sup, int max_tri, bool any_ok, const uint8_t* payload, size_t payload_bytes, bool cleared) -> jn_status {
+    HIP_TRY(mark(EV_H2D0));
+    HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
+    if (payload_bytes && payload == s.payload) HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(mark(EV_H2D));
+    if (any_ok) {
+      launch_grid(st, dp, n, s.info, payload, 0, max_sup, s.mark, s.gridbits, !cleared);      // offsets in FrameInfo are batch-absolute
+      launch_tri_setup(st, dp, n, s.info, payload, 0, max_tri, h->tri_cap, s.recs);
+      launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list, !cleared);
+      HIP_TRY(mark(EV_RASTER));
+      launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
+      HIP_TRY(mark(EV_DENSE));
+      // Post-processing.  When gap interpolation and adaptive mean can run as one pass (gap_mean_fusable), the left image
+      // travels raw -> tmp (L/R check) -> tmp (speckle, run lists in the still idle output image) -> D1 (fused pass), so that
+      // every stage reads and writes the image once; otherwise the stages run in place on D1 with tmp as scratch.
+      launch_lr(st, dp, n, s.info, s.raw, fused ? s.tmp : j.dD1, j.dD2);
+      HIP_TRY(mark(EV_LR));
+      if (fused) {
+        launch_speckle(st, dp, n, s.info, s.tmp, s.label, s.size, j.dD1);
+        HIP_TRY(mark(EV_SPECKLE));
+        launch_gap_mean_fused(st, dp, n, s.info, s.tmp, j.dD1, h->p.filter_adaptive_mean != 0);
+        if (!h->p.postprocess_only_left) {                     // right image: in place, fused pass into tmp, copied back
+          launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
+          launch_gap_mean_fused(st, dp, n, s.info, j.dD2, s.tmp, h->p.filter_adaptive_mean != 0);
+          launch_copy_ok(st, dp, n, s.info, s.tmp, j.dD2);
+        }
+        HIP_TRY(mark(EV_GAP));
+      } else {
+        launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
+        if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
+        HIP_TRY(mark(EV_SPECKLE));
+        launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
+        if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);
+        HIP_TRY(mark(EV_GAP));
+        if (h->p.filter_adaptive_mean) {
+          launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
+          if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
+        }
+      }
+      if (h->p.filter_median) {                                                            // elas.cpp:133-139
+        launch_median(st, dp, n, s.info, j.dD1, s.tmp);
+        if (!h->p.postprocess_only_left) launch_median(st, dp, n, s.info, j.dD2, s.tmp);
+      }
+      HIP_TRY(mark(EV_AM));
+    } else {
+      for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(mark(e));
+    }
+    if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
+      launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch, j.merge ? s.d_flat : nullptr);
+    HIP_TRY(hipEventRecord(s.ev[EV_END], st));
+    return JN_OK;
+  };
+  // Latency mode (a handle of max_batch 1): a lone pair's stage B is two dozen launches of a few microseconds each, and queued after the
+  // host stage they reach the GPU slower than it finishes them (~30 us of idle gaps at 640x480).  They are queued NOW instead, while the
+  // GPU runs stage A, behind a wait on a word of signal memory that the host sets when its stage is done (hipStreamWaitValue32).  What
+  // the host stage decides is then not known at launch time: the three launches sized by support / triangle counts take their capacity
+  // (the kernels return on indices beyond the frame's counts), the payload and FrameInfo are read where the host will have written them,
+  // and the two clears that depend on nothing run ahead of the gate.  Whatever happens afterwards, the gate is opened (GateGuard): a
+  // stream left waiting would hang the handle.
+  struct GateGuard {
+    volatile uint32_t* word = nullptr; uint32_t value = 0;
+    void open() { if (word) { std::atomic_thread_fence(std::memory_order_seq_cst); *word = value; word = nullptr; } }
+    ~GateGuard() { open(); }
+  } gate;
+  const bool gated = h->gate_stage_b && s.gate && filtered && h->zero_copy_payload && sa == st;
+  if (gated) {
+    launch_grid_clear(st, dp, n, s.mark);
+    launch_bin_clear(st, dp, n, s.bin_count);
+    const uint32_t v = ++s.gate_seq;
+    HIP_TRY(hipStreamWaitValue32(st, s.gate, v, hipStreamWaitValueEq, 0xFFFFFFFFu));
+    gate.word = s.gate; gate.value = v;
+    const jn_status qs = queue_stage_b(list_cap + HostWorker::kCornerPoints, h->tri_cap, true, s.h_payload, 0, true);
+    if (qs != JN_OK) return qs;
+  }
   HIP_TRY(wait_event(s.ev[EV_D2H], h->wait_spin_us));
 
   auto t_host0 = std::chrono::steady_clock::now();
@@ -327,8 +407,6 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   }
   auto t_host1 = std::chrono::steady_clock::now();
 
-  HIP_TRY(mark(EV_H2D0));
-  HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
   int max_tri = 0, max_sup = 0, any_ok = 0;
   for (int i = 0; i < n; i++) {
     const FrameInfo& fi = s.h_info[i];
@@ -338,60 +416,13 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     max_tri = std::max(max_tri, std::max(fi.ntri[0], fi.ntri[1]));
     max_sup = std::max(max_sup, fi.nsup);
   }
-  // A latency-mode handle lets the two kernels that consume the payload read it where the host wrote it (pinned memory is visible to
-  // the device): a lone pair's payload is ~50 KB read once, and the copy plus the pause behind it cost more than that (JN_ZERO_COPY=0/1).
-  const uint8_t* payload = s.payload;
-  if (payload_bytes) {
-    if (h->zero_copy_payload) payload = s.h_payload;
-    else HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
+  if (gated) gate.open();
+  else {
+    // A latency-mode handle lets the two kernels that consume the payload read it where the host wrote it (pinned memory is visible to
+    // the device): a lone pair's payload is ~50 KB read once, and the copy plus the pause behind it cost more than that (JN_ZERO_COPY=0/1).
+    const jn_status qs = queue_stage_b(max_sup, max_tri, any_ok != 0, h->zero_copy_payload ? s.h_payload : s.payload, payload_bytes, false);
+    if (qs != JN_OK) return qs;
   }
-  HIP_TRY(mark(EV_H2D));
-  if (any_ok) {
-    launch_grid(st, dp, n, s.info, payload, 0, max_sup, s.mark, s.gridbits);      // offsets in FrameInfo are batch-absolute
-    launch_tri_setup(st, dp, n, s.info, payload, 0, max_tri, h->tri_cap, s.recs);
-    launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list);
-    HIP_TRY(mark(EV_RASTER));
-    launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
-    HIP_TRY(mark(EV_DENSE));
-    // Post-processing.  When gap interpolation and adaptive mean can run as one pass (gap_mean_fusable), the left image
-    // travels raw -> tmp (L/R check) -> tmp (speckle, run lists in the still idle output image) -> D1 (fused pass), so that
-    // every stage reads and writes the image once; otherwise the stages run in place on D1 with tmp as scratch.
-    const bool fused = gap_mean_fusable(dp, n) && ((dp.W * dp.H) & 3) == 0;
-    launch_lr(st, dp, n, s.info, s.raw, fused ? s.tmp : j.dD1, j.dD2);
-    HIP_TRY(mark(EV_LR));
-    if (fused) {
-      launch_speckle(st, dp, n, s.info, s.tmp, s.label, s.size, j.dD1);
-      HIP_TRY(mark(EV_SPECKLE));
-      launch_gap_mean_fused(st, dp, n, s.info, s.tmp, j.dD1, h->p.filter_adaptive_mean != 0);
-      if (!h->p.postprocess_only_left) {                     // right image: in place, fused pass into tmp, copied back
-        launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
-        launch_gap_mean_fused(st, dp, n, s.info, j.dD2, s.tmp, h->p.filter_adaptive_mean != 0);
-        launch_copy_ok(st, dp, n, s.info, s.tmp, j.dD2);
-      }
-      HIP_TRY(mark(EV_GAP));
-    } else {
-      launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
-      if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
-      HIP_TRY(mark(EV_SPECKLE));
-      launch_gap(st, dp, n, s.info, j.dD1, s.tmp);
-      if (!h->p.postprocess_only_left) launch_gap(st, dp, n, s.info, j.dD2, s.tmp);
-      HIP_TRY(mark(EV_GAP));
-      if (h->p.filter_adaptive_mean) {
-        launch_adaptive_mean(st, dp, n, s.info, j.dD1, s.tmp);
-        if (!h->p.postprocess_only_left) launch_adaptive_mean(st, dp, n, s.info, j.dD2, s.tmp);
-      }
-    }
-    if (h->p.filter_median) {                                                            // elas.cpp:133-139
-      launch_median(st, dp, n, s.info, j.dD1, s.tmp);
-      if (!h->p.postprocess_only_left) launch_median(st, dp, n, s.info, j.dD2, s.tmp);
-    }
-    HIP_TRY(mark(EV_AM));
-  } else {
-    for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(mark(e));
-  }
-  if (j.scan)                                            // the node's tail: depth map + obstacle scan of whatever D1 now holds
-    launch_scan(st, j.sp, n, j.dD1, j.dDispU8, j.dLut, dp.W, dp.H, j.dBins, j.dMeta, s.scan_scratch, j.merge ? s.d_flat : nullptr);
-  HIP_TRY(hipEventRecord(s.ev[EV_END], st));
   HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   HIP_TRY(hipGetLastError());
   bool merged = false;
@@ -636,6 +667,12 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->zero_copy_payload = max_batch == 1;
   if (const char* e = getenv("JN_ZERO_COPY")) h->zero_copy_payload = atoi(e) != 0;
   if (const char* e = getenv("JN_STAGE_EVENTS")) h->stage_events = atoi(e) != 0;
+  {
+    int can_wait = 0;
+    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device);
+    h->gate_stage_b = max_batch == 1 && can_wait;
+    if (const char* e = getenv("JN_GATE_STAGE_B")) h->gate_stage_b = atoi(e) != 0 && can_wait;
+  }
 
   const size_t px = (size_t)W * H, B = (size_t)max_batch;
   for (int i = 0; i < slots; i++) {
@@ -655,6 +692,10 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     for (int e = 0; e < EV_COUNT; e++) CREATE_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
     CREATE_TRY(hipEventCreate(&s->ev_scan)); CREATE_TRY(hipEventCreate(&s->ev_merged));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
+    if (h->gate_stage_b) {                                   // no signal memory: the handle simply queues stage B after the host stage
+      if (hipExtMallocWithFlags((void**)&s->gate, 8, hipMallocSignalMemory) == hipSuccess) { s->gate[0] = 0; s->gate[1] = 0; }
+      else { (void)hipGetLastError(); s->gate = nullptr; }
+    }
     CREATE_TRY(dmalloc(&s->desc, 2 * B * px));
     CREATE_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     CREATE_TRY(dmalloc(&s->info, B)); CREATE_TRY(dmalloc(&s->payload, B * h->payload_cap));
@@ -705,6 +746,7 @@ void jn_elas_destroy(jn_elas* h) {
     if (s->ev_scan) hipEventDestroy(s->ev_scan);
     if (s->ev_merged) hipEventDestroy(s->ev_merged);
     if (s->ev_head) hipEventDestroy(s->ev_head);
+    if (s->gate) hipFree(s->gate);
     if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);
   }

@@ -42,13 +42,15 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
 // GPU stage B -------------------------------------------------------------------------------
 // Grid prior (elas.cpp:579-659) from the support points: mark/gridbits [n][2][gh*gw][8] uint32.
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
-                 int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits);
+                 int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits, bool clear = true);
+void launch_grid_clear(hipStream_t st, const DevParams& dp, int n, uint32_t* mark);      // the clear alone (queued ahead by a latency-mode handle)
 // Plane fits + edge lines per triangle (elas.cpp:507-577, :847-872): recs [n][2][tri_cap].
 void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                       int64_t payload_stride, int max_tri, int tri_cap, TriRec* recs);
 // Triangle candidates per 32x8 tile with their row masks: bin_count [n][2][tiles], bin_list [n][2][tiles][kBinCap].
 void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                int max_tri, int32_t* bin_count, BinEntry* bin_list);
+                int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear = true);
+void launch_bin_clear(hipStream_t st, const DevParams& dp, int n, int32_t* bin_count);
 // Dense MAP matching with in-kernel triangle lookup (elas.cpp:683-907): raw [n][2][H][W] float.
 void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
                   const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, int16_t* raw);

@@ -2776,10 +2776,12 @@ void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* c
 void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap) {
   hipLaunchKernelGGL(k_support_list, dim3(n), dim3(kFilterThreads), 0, st, dp, d_can, list, count, cap);
 }
+void launch_grid_clear(hipStream_t st, const DevParams& dp, int n, uint32_t* mark) {
+  hipMemsetAsync(mark, 0, (size_t)n * 2 * dp.gw * dp.gh * kGridWords * sizeof(uint32_t), st);
+}
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
-                 int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits) {
-  const size_t words = (size_t)n * 2 * dp.gw * dp.gh * kGridWords;
-  hipMemsetAsync(mark, 0, words * sizeof(uint32_t), st);
+                 int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits, bool clear) {
+  if (clear) launch_grid_clear(st, dp, n, mark);
   if (max_sup > 0)
     hipLaunchKernelGGL(k_grid_mark, dim3((max_sup + 255) / 256, n), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, mark);
   hipLaunchKernelGGL(k_grid_dilate, dim3((dp.gw * dp.gh * kGridWords + 255) / 256, 2 * n), dim3(256), 0, st, dp, info, mark, gridbits);
@@ -2789,10 +2791,13 @@ void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInf
   if (max_tri <= 0) return;
   hipLaunchKernelGGL(k_tri_setup, dim3((max_tri + 255) / 256, n, 2), dim3(256), 0, st, dp, info, payload, (long long)payload_stride, tri_cap, recs);
 }
-void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                int max_tri, int32_t* bin_count, BinEntry* bin_list) {
+void launch_bin_clear(hipStream_t st, const DevParams& dp, int n, int32_t* bin_count) {
   const int tiles = ((dp.W + kTileW - 1) / kTileW) * ((dp.H + kTileH - 1) / kTileH);
   hipMemsetAsync(bin_count, 0, (size_t)n * 2 * tiles * sizeof(int32_t), st);
+}
+void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear) {
+  if (clear) launch_bin_clear(st, dp, n, bin_count);
   if (max_tri <= 0) return;
   hipLaunchKernelGGL(k_bin, dim3((max_tri + kBinTris - 1) / kBinTris, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }

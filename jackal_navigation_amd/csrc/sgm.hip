@@ -275,7 +275,7 @@ struct jn_sgm {
   // Pipelined form (jn_sgm_submit_scan / jn_sgm_wait): slot 0 is the set above, slots 1 .. kSgmSlots-1 get their own stream, events and
   // buffers the first time they are used.  Batches on different slots overlap on the GPU: the upward sweep's tail (the last blocks of
   // its parallelogram run alone) is filled by the next batch's horizontal and downward sweeps.
-  struct Extra { jnav_sgm::SweepBuffers sb = {}; hipStream_t stream = nullptr; hipEvent_t ev[4] = {}; jn_sgm_times times = {}; bool ready = false; };
+  struct Extra { jnav_sgm::SweepBuffers sb = {}; hipStream_t stream = nullptr; hipEvent_t ev[4] = {}; jn_sgm_times times = {}; bool ready = false, shared = false; };
   enum { kSgmSlots = 6 };
   Extra extra[kSgmSlots - 1];
   unsigned long long* scan_scratch[kSgmSlots] = {};   // [max_batch][4] per slot, the scan tail's extrema
@@ -303,11 +303,11 @@ void jn_sgm_destroy(jn_sgm* h) {
   if (h->stream) hipStreamSynchronize(h->stream);
   hipFree(h->g); hipFree(h->Lr);
   for (auto& x : h->extra) {
-    if (x.stream) hipStreamSynchronize(x.stream);
+    if (x.stream && !x.shared) hipStreamSynchronize(x.stream);
     jnav_sgm::sweep_release(x.sb);
     hipFree(x.sb.gm); hipFree(x.sb.volF); hipFree(x.sb.volH0); hipFree(x.sb.volH1); hipFree(x.sb.gx); hipFree(x.sb.flags); hipFree(x.sb.minr); hipFree(x.sb.dl);
     for (auto& e : x.ev) if (e) hipEventDestroy(e);
-    if (x.stream) hipStreamDestroy(x.stream);
+    if (x.stream && !x.shared) hipStreamDestroy(x.stream);
   }
   for (auto& q : h->scan_scratch) hipFree(q);
   jnav_sgm::sweep_release(h->sb);
@@ -418,7 +418,15 @@ static jn_status sgm_ensure_slot(jn_sgm* h, int slot) {
   SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.flags), z.flags));
   SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.minr), z.minr));
   SGM_TRY(hipMalloc(reinterpret_cast<void**>(&x.sb.dl), z.dl));
-  SGM_TRY(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+  {
+    static const int share = getenv("JN_SGM_STREAMS") ? atoi(getenv("JN_SGM_STREAMS")) : 0;     // experiment: slot s queues on the stream of slot s % share
+    if (share > 0 && slot >= share) {
+      const int lower = slot % share;
+      const jn_status el = sgm_ensure_slot(h, lower);
+      if (el != JN_OK) return el;
+      x.stream = lower == 0 ? h->stream : h->extra[lower - 1].stream; x.shared = true;
+    } else SGM_TRY(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+  }
   for (auto& e : x.ev) SGM_TRY(hipEventCreate(&e));
   x.ready = true;
   return JN_OK;
@@ -456,7 +464,7 @@ jn_status jn_sgm_wait(jn_sgm* h, int32_t slot) {
   hipEvent_t* ev = slot == 0 ? h->ev : h->extra[slot - 1].ev;
   jn_sgm_times& t = slot == 0 ? h->times : h->extra[slot - 1].times;
   h->pending[slot] = false;
-  SGM_TRY(hipStreamSynchronize(st));
+  SGM_TRY(hipEventSynchronize(ev[3]));                          // the slot's own end (its stream may carry a later slot's batch)
   SGM_TRY(hipGetLastError());
   hipEventElapsedTime(&t.prefilter, ev[0], ev[1]);
   hipEventElapsedTime(&t.paths, ev[1], ev[2]);

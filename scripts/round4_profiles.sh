@@ -62,6 +62,7 @@ timeout 400 python3 scripts/host_pointer_rate.py 2>/dev/null | grep -v amdgpu.id
 for pr in pk3 dep_chain lds_unaligned op_rate; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w scripts/probes/${pr}_probe.hip -o /tmp/${pr}_probe && timeout 120 /tmp/${pr}_probe > $out/${tag}_${pr}_probe.txt 2>&1; done
 # k_dense2's phases by its JN_DENSE_DBG switches (results wrong, timing only): the kernel alone, ms per launch by HIP events
 { for d in 0 1 2 3 4 12 20 28 64 0; do echo "JN_DENSE_DBG=$d: $(JN_DENSE_DBG=$d python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); r=j["roofline"]; print(r.get("ms_per_launch"), "ms alone,", r.get("ms_per_launch_pipelined"), "ms pipelined,", j["value"], "pairs/s")')"; done; } > $out/${tag}_dense_dbg_switches.txt
+bash scripts/hwq_ab.sh > $out/${tag}_hw_queues_ab.txt 2>&1
 bash scripts/host_threads_sweep.sh "2 4 8 12 16" > $out/${tag}_host_threads.txt 2>&1
 for v in 0 1; do echo "JN_STAGE_A_PRIORITY=$v $(JN_STAGE_A_PRIORITY=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_stage_a_priority_ab.txt
 for v in 1 0 1 0; do echo "JN_PACE=$v, the driver's command (--gpus 1 --steps 20 --warmup 5): $(JN_PACE=$v python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_pace_ab.txt
@@ -69,3 +70,4 @@ for v in 1 0; do echo "JN_PACE=$v, default 200 steps per region: $(JN_PACE=$v py
 timeout 1200 python3 scripts/parity_sweep.py 12 2>&1 | grep -v "Opened result\|amdgpu.ids" > $out/${tag}_parity_sweep.txt
 timeout 400 python3 scripts/sgm_stress.py 120 2>&1 | grep -v amdgpu.ids > $out/${tag}_sgm_stress.txt
 cat $out/${tag}_bm_ssd_summary.txt $out/${tag}_bm_ssd_pmc_mfma.txt | head -30; tail -8 $out/${tag}_collect.log | cut -c1-300; cat $out/${tag}_sgm_summary.txt $out/${tag}_sgm_strips_ab.txt $out/${tag}_merge_in_worker.txt $out/${tag}_node_rate.txt; tail -2 $out/${tag}_parity_sweep.txt
+python3 -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/${tag}_gpu_tests.txt; cat $out/${tag}_gpu_tests.txt

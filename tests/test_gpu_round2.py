@@ -832,3 +832,32 @@ print("RANK", rank, res, flush=True)
     r1 = [l for l in outs[1].splitlines() if l.startswith("RANK 1")][0]
     assert r0.count("ok") == 4 and "err" not in r0, r0
     assert r1.count("ok") == 3 and "err %d" % 5 in r1, r1                      # JN_ERR_INTERNAL for batch 2 only
+
+
+@pytest.mark.gpu
+def test_stage_b_queued_behind_the_gate_changes_no_result(jn, oracle, same, monkeypatch):
+    """A latency-mode handle (max_batch 1) queues stage B while the GPU still runs stage A, behind a hipStreamWaitValue32 gate that the
+    host opens after its stage; launch sizes are then capacities.  With the gate and without it (JN_GATE_STAGE_B=0, read at create time)
+    the maps are the oracle's — through device pointers and through host pointers, for a scene with support points and for one with
+    none (JN_ERR_FEW_SUPPORT: outputs untouched, the gate must still open), several calls on one handle."""
+    import torch
+    W, H = 640, 480
+    L, R = jn.node.synth_pair(W, H, 64, 4242)
+    flat = np.full((H, W), 128, np.uint8)
+    _, D1o, D2o = oracle.process(oracle.params(0, disp_max=63, postprocess_only_left=0), L, R)
+    dev = torch.device("cuda", 0)
+    for gate in ("1", "0"):
+        monkeypatch.setenv("JN_GATE_STAGE_B", gate)
+        with jn.Elas(jn.Elas.parameters(0, disp_max=63, postprocess_only_left=0), W, H, max_batch=1, host_threads=4) as e:
+            for rep in range(3):
+                for (a, b, few) in ((L, R, False), (flat, flat, True), (L, R, False)):
+                    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+                    o1 = torch.full((H, W), -7.0, dtype=torch.float32, device=dev); o2 = torch.full((H, W), -7.0, dtype=torch.float32, device=dev)
+                    torch.cuda.synchronize()
+                    st = e.process_batch(1, ta.data_ptr(), tb.data_ptr(), W, H * W, o1.data_ptr(), o2.data_ptr())
+                    if few:
+                        assert list(st) == [1] and float(o1.min()) == -7.0 and float(o1.max()) == -7.0, (gate, rep)
+                    else:
+                        assert list(st) == [0] and same(o1.cpu().numpy(), D1o) and same(o2.cpu().numpy(), D2o), (gate, rep)
+                D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+                assert e.process(L, R, D1, D2, (W, H, W)) == 0 and same(D1, D1o) and same(D2, D2o), (gate, rep, "host pointers")
