@@ -2895,7 +2895,9 @@ bool gap_mean_fusable(const DevParams& dp, int n) {
   return enabled && !dp.add_corners && dp.gap_width <= 3 && dp.W >= 16 && dp.H >= 16 && (long long)n * dp.W * dp.H >= min_pixels;
 }
 void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* in, float* out, bool mean) {
-  static const int band_rows = getenv("JN_POST_BAND") ? atoi(getenv("JN_POST_BAND")) : 48;   // short bands: the pass is bound by parallelism, not by the 14 halo rows
+  // rows per band: flat between 40 and 120 (0.209 / 0.206 / 0.205 / 0.202 / 0.197 / 0.205 / 0.214 ms at 40 / 48 / 60 / 72 / 80 / 90 / 120 rows, 720p batch 32,
+  // scripts/post_band_sweep.sh): fewer halo rows against fewer workgroups
+  static const int band_rows = getenv("JN_POST_BAND") ? atoi(getenv("JN_POST_BAND")) : 80;
   const int bands = (dp.H + band_rows - 1) / band_rows, rows = (dp.H + bands - 1) / bands;
   hipLaunchKernelGGL(k_gap_mean_fused, dim3((dp.W + kPostCols - 1) / kPostCols, bands, n), dim3(256), 0, st, dp, info, in, out, rows, mean ? 1 : 0);
 }
