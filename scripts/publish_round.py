@@ -61,7 +61,7 @@ for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.
                   ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None),
                   ("bm_ssd_bench_line.json", None), ("bm_ssd_1080p_bench_line.json", None), ("bm_sad_1080p_bench_line.json", None), ("bm_ssd_pmc_mfma.txt", None),
                   ("host_threads.txt", None), ("pk3_probe.txt", None), ("dep_chain_probe.txt", None), ("lds_unaligned_probe.txt", None), ("op_rate_probe.txt", None),
-                  ("dense_dbg_switches.txt", None), ("hw_queues_ab.txt", None), ("gpu_tests.txt", None)):
+                  ("dense_dbg_switches.txt", None), ("hw_queues_ab.txt", None), ("gate_ab.txt", None), ("lone_timeline.txt", None), ("gpu_tests.txt", None)):
     put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
 sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
 if sq:

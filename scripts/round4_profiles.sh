@@ -63,6 +63,7 @@ for pr in pk3 dep_chain lds_unaligned op_rate; do /opt/rocm/bin/hipcc --offload-
 # k_dense2's phases by its JN_DENSE_DBG switches (results wrong, timing only): the kernel alone, ms per launch by HIP events
 { for d in 0 1 2 3 4 12 20 28 64 0; do echo "JN_DENSE_DBG=$d: $(JN_DENSE_DBG=$d python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); r=j["roofline"]; print(r.get("ms_per_launch"), "ms alone,", r.get("ms_per_launch_pipelined"), "ms pipelined,", j["value"], "pairs/s")')"; done; } > $out/${tag}_dense_dbg_switches.txt
 bash scripts/hwq_ab.sh > $out/${tag}_hw_queues_ab.txt 2>&1
+bash scripts/lone_evidence.sh $tag
 bash scripts/host_threads_sweep.sh "2 4 8 12 16" > $out/${tag}_host_threads.txt 2>&1
 for v in 0 1; do echo "JN_STAGE_A_PRIORITY=$v $(JN_STAGE_A_PRIORITY=$v python3 bench.py --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_stage_a_priority_ab.txt
 for v in 1 0 1 0; do echo "JN_PACE=$v, the driver's command (--gpus 1 --steps 20 --warmup 5): $(JN_PACE=$v python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-latency-config 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["ms_per_step"], "ms/step")')"; done > $out/${tag}_pace_ab.txt
