@@ -27,7 +27,7 @@ class Elas {
   explicit Elas(parameters param) : param_(param) {}
   ~Elas() {}
 
-  // dims = {width, height, bytes per line}; D1/D2 caller-allocated width*height floats (elas.h:154-162)
+  // dims = {width, height, bytes per line}; D1/D2 caller-allocated width*height floats, (width/2)*(height/2) with param.subsampling (elas.h:154-162)
   void process(uint8_t* I1, uint8_t* I2, float* D1, float* D2, const int32_t* dims) {
     jn_elas* h = handle(dims[0], dims[1]);
     if (!h) { std::cout << "ERROR: jn_elas_create failed (no MI355X / unsupported parameters)" << std::endl; return; }

@@ -76,9 +76,13 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  *                 filters only where no kernel takes the lattice); 0 = one per CPU the process may use (affinity
  *                 mask, cut down to the container's cgroup CPU quota); 16 feed one MI355X at 20 k 720p pairs/s
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
- * Unsupported (JN_ERR_UNSUPPORTED): subsampling, disp_max > 255 or < 10, disp_min > disp_max,
+ * Unsupported (JN_ERR_UNSUPPORTED): subsampling with an odd width or height, disp_max > 255 or < 10, disp_min > disp_max,
  * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported; disp_min is honoured as the
  * reference does (elas.cpp:323-333: the first disparity the support matching tries; negative values act as 0; nothing else reads it).
+ * subsampling = 1 (elas.h:82, :160-162): D1 / D2 are (W/2) x (H/2) maps — per frame (W/2)*(H/2) floats, frames back to back — holding the
+ * disparities of the even pixels of the even rows, post-processed at that size as the reference does (elas.cpp:914-941, :987-992,
+ * :1107-1112, :1323-1391); the scan tail (jn_elas_submit_scan) is refused for such a handle (the node never subsamples: its Q matrix
+ * and LUT are the full image's).  Odd sizes are refused because the reference's (u/2, v/2, width/2) addressing runs over its rows there.
  * UNINITIALISED BYTES, both presets: the reference never writes descriptor columns 0..2 and W-3..W-1 (descriptor.cpp:29,
  * :84-88) but reads column W-3 in the right-image support match (elas.cpp:326, :340-349) and columns 2 and W-3 in
  * findMatch (elas.cpp:744-746, :752-754, :763-765, :770-772), so its D1/D2 depend on what malloc returned — with the node's

@@ -123,6 +123,8 @@ struct jn_elas {
   // through four host stages.  A batch's stage A therefore waits (on the device) until the batch submitted before it has finished its two
   // heavy kernels — the phase the pipeline settles into by itself.  In steady state that event is long complete: the wait is a no-op.
   std::mutex pace_m; hipEvent_t pace_prev = nullptr; bool pace = false;
+  bool sub = false;                 // param.subsampling: half-size maps (elas.h:82, :160-162); dph = the post-processing's parameters at that size
+  DevParams dph = {};
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
   bool gate_stage_b = false;        // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
@@ -299,6 +301,28 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       // Post-processing.  When gap interpolation and adaptive mean can run as one pass (gap_mean_fusable), the left image
       // travels raw -> tmp (L/R check) -> tmp (speckle, run lists in the still idle output image) -> D1 (fused pass), so that
       // every stage reads and writes the image once; otherwise the stages run in place on D1 with tmp as scratch.
+      if (h->sub) {
+        // subsampling: the matcher ran on every pixel (findMatch is per pixel, so the reference's half-size map is the full one at even
+        // (u, v)); the L/R check picks those out, everything behind it works on (W/2) x (H/2) maps with dph
+        const DevParams& dph = h->dph;
+        launch_lr_sub(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
+        HIP_TRY(mark(EV_LR));
+        launch_speckle(st, dph, n, s.info, j.dD1, s.label, s.size, s.tmp);
+        if (!h->p.postprocess_only_left) launch_speckle(st, dph, n, s.info, j.dD2, s.label, s.size, s.tmp);
+        HIP_TRY(mark(EV_SPECKLE));
+        launch_gap(st, dph, n, s.info, j.dD1, s.tmp);
+        if (!h->p.postprocess_only_left) launch_gap(st, dph, n, s.info, j.dD2, s.tmp);
+        HIP_TRY(mark(EV_GAP));
+        if (h->p.filter_adaptive_mean) {
+          launch_adaptive_mean_sub(st, dph, n, s.info, j.dD1, s.tmp);
+          if (!h->p.postprocess_only_left) launch_adaptive_mean_sub(st, dph, n, s.info, j.dD2, s.tmp);
+        }
+        if (h->p.filter_median) {
+          launch_median(st, dph, n, s.info, j.dD1, s.tmp);
+          if (!h->p.postprocess_only_left) launch_median(st, dph, n, s.info, j.dD2, s.tmp);
+        }
+        HIP_TRY(mark(EV_AM));
+      } else {
       launch_lr(st, dp, n, s.info, s.raw, fused ? s.tmp : j.dD1, j.dD2);
       HIP_TRY(mark(EV_LR));
       if (fused) {
@@ -328,6 +352,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
         if (!h->p.postprocess_only_left) launch_median(st, dp, n, s.info, j.dD2, s.tmp);
       }
       HIP_TRY(mark(EV_AM));
+      }
     } else {
       for (int e = EV_RASTER; e <= EV_AM; e++) HIP_TRY(mark(e));
     }
@@ -505,6 +530,7 @@ jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
   std::vector<int32_t> local(j.n, JN_OK);
   Job d = j;
   d.host = false; d.staged = true; d.dI1 = s.st_img; d.dI2 = s.st_img + B * px; d.pitch = h->W; d.stride = (int64_t)px;
+  const size_t opx = h->sub ? (size_t)(h->W / 2) * (h->H / 2) : px;          // pixels of an output map
   d.dD1 = s.st_D; d.dD2 = s.st_D + B * px; d.status = local.data();
   const jn_status r = run_batch(h, s, d);                 // stream-ordered behind the copies; synchronises at its end
   if (r != JN_OK) return r;
@@ -512,8 +538,8 @@ jn_status run_batch_host(jn_elas* h, Slot& s, const Job& j) {
     if (local[b] != JN_OK) { b++; continue; }
     int e = b;
     while (e < j.n && local[e] == JN_OK) e++;
-    HIP_TRY(hipMemcpyAsync(j.hD1 + b * px, s.st_D + b * px, (size_t)(e - b) * px * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(j.hD2 + b * px, s.st_D + (B + b) * px, (size_t)(e - b) * px * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(j.hD1 + b * opx, s.st_D + b * opx, (size_t)(e - b) * opx * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(j.hD2 + b * opx, s.st_D + B * px + b * opx, (size_t)(e - b) * opx * sizeof(float), hipMemcpyDeviceToHost, st));
     b = e;
   }
   HIP_TRY(hipEventRecord(s.ev[EV_END], st));
@@ -587,7 +613,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (!p || !out || W < 32 || H < 32 || W > 8192 || H > 8192 || max_batch < 1 || slots < 1) return JN_ERR_INVALID;
   *out = nullptr;
   const int radius = (int)std::max((float)std::ceil(p->sigma * p->sradius), 2.0f);        // elas.cpp:806
-  if (p->subsampling || p->disp_max > 255 || p->disp_max < 10 ||
+  if ((p->subsampling && ((W | H) & 1)) || p->disp_max > 255 || p->disp_max < 10 ||      // odd sizes with subsampling: the reference's half-size addressing runs over its rows
       p->disp_min > p->disp_max || p->ipol_gap_width < 0 || p->candidate_stepsize < 1 ||
       p->grid_size < 1 || radius > 7 || p->incon_window_size < 0)
     return JN_ERR_UNSUPPORTED;
@@ -613,6 +639,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   memset(&dp, 0, sizeof(dp));
   dp.W = W; dp.H = H; dp.pitch = (W + 63) / 64 * 64;
   dp.disp_max = p->disp_max; dp.disp_min = std::max(p->disp_min, 0); dp.support_texture = p->support_texture; dp.step = p->candidate_stepsize;
+  h->sub = p->subsampling != 0;
+  if (h->sub) dp.step += dp.step % 2;                                                    // elas.cpp:379-381: only even lines hold descriptors at half resolution
   dp.lr_threshold = p->lr_threshold; dp.support_threshold = p->support_threshold;
   dp.cw = (W + dp.step - 1) / dp.step; dp.ch = (H + dp.step - 1) / dp.step;            // elas.cpp:384-387
   dp.grid_size = p->grid_size;
@@ -626,6 +654,12 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     if (dp.P[dd] <= -(1 << 19) || dp.P[dd] >= (1 << 19)) return JN_ERR_UNSUPPORTED;
   dp.speckle_sim = p->speckle_sim_threshold; dp.speckle_size = p->speckle_size; dp.gap_width = p->ipol_gap_width;
   dp.add_corners = p->add_corners ? 1 : 0;
+  if (h->sub) {                                         // the half-size maps' post-processing (elas.cpp:987-992, :1107-1112, :1292-1297, :1499-1504)
+    h->dph = dp;
+    h->dph.W = W / 2; h->dph.H = H / 2; h->dph.pitch = (W / 2 + 63) / 64 * 64;
+    h->dph.speckle_size = (int32_t)(std::sqrt((float)p->speckle_size) * 2);
+    h->dph.gap_width = p->ipol_gap_width / 2 + 1;
+  }
 
   HostParams& hp = h->hp;
   hp.W = W; hp.H = H; hp.disp_max = p->disp_max; hp.step = dp.step; hp.incon_window_size = p->incon_window_size;
@@ -799,6 +833,7 @@ jn_status jn_elas_submit_scan(jn_elas* h, int32_t slot, int32_t n, const uint8_t
   if (!h || slot < 0 || slot >= (int)h->slots.size() || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dD1 || !dD2 ||
       pitch < h->W || !stride_ok(h, n, pitch, image_stride) || !sp || !dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024)
     return JN_ERR_INVALID;
+  if (h->sub) return JN_ERR_UNSUPPORTED;                  // the node's tail works on full-size maps (its Q matrix and LUT are the image's)
   Slot& s = *h->slots[slot];
   {
     std::unique_lock<std::mutex> l(s.m);
@@ -872,8 +907,9 @@ jn_status jn_elas_process(jn_elas* h, const uint8_t* I1, const uint8_t* I2, floa
     printf("ERROR: Need at least 3 support points!\n");
     return (jn_status)st;
   }
-  HIP_TRY(hipMemcpy(D1, h->s_D, px * sizeof(float), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(D2, h->s_D + px, px * sizeof(float), hipMemcpyDeviceToHost));
+  const size_t opx = h->sub ? (size_t)(h->W / 2) * (h->H / 2) : px;          // elas.h:160-162: half-size maps with subsampling
+  HIP_TRY(hipMemcpy(D1, h->s_D, opx * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(D2, h->s_D + px, opx * sizeof(float), hipMemcpyDeviceToHost));
   return JN_OK;
 }
 

@@ -67,6 +67,9 @@ void launch_adaptive_mean(hipStream_t st, const DevParams& dp, int n, const Fram
 bool gap_mean_fusable(const DevParams& dp, int n);
 void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* in, float* out, bool mean);
 void launch_copy_ok(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* src, float* dst);   // frames with info.ok only
+// subsampling = 1: L/R check of the half-size maps picked out of the full-size matcher output (dp = full size); 4-pixel adaptive mean (dph = half size)
+void launch_lr_sub(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2);
+void launch_adaptive_mean_sub(hipStream_t st, const DevParams& dph, int n, const FrameInfo* info, float* D, float* tmp);
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
 
 // Node side (point_cloud.cpp) -------------------------------------------------------------------

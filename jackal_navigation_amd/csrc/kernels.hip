@@ -1632,11 +1632,6 @@ __global__ void __launch_bounds__(256) k_lr(DevParams dp, const FrameInfo* __res
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Speckle removal (elas.cpp:981-1099) as union-find connected components: 4-connected valid
-// pixels whose disparities differ by <= speckle_sim_threshold; components smaller than
-// speckle_size (and every invalid pixel, a "segment" of one) are set to -10.  The reference's
-// flood fill visits the same components, so the result is order-free.
 DEV int uf_find(int32_t* __restrict__ lab, int x) {
   // path halving: every visited node is re-pointed at its grandparent.  Parents only ever move towards the
   // root (smaller index), so the unsynchronised stores are benign; without them a tall region builds a
@@ -1955,6 +1950,83 @@ DEV void am_pair(float x0, float x1, float c, float& pw, float& pf) {
   const jn_f2 p = X * w;
   pw = w.x + w.y; pf = p.x + p.y;
 }
+// ---- subsampling = 1 (elas.h:82): half-size maps ------------------------------------------------------------------------
+// The dense matching is per pixel (elas.cpp:683-780), so the reference's half-size map is the full one at even (u, v)
+// (:693, :877-896): the matcher runs unchanged and this pass picks every second pixel of every second row while it applies
+// the left/right check of the half-size maps, whose warps are by d / 2 (:914-941).  One workgroup per half-size row.
+__global__ void __launch_bounds__(256) k_lr_sub(DevParams dp, const FrameInfo* __restrict__ info, const int16_t* __restrict__ raw,
+                                                float* __restrict__ D1, float* __restrict__ D2) {
+  extern __shared__ int16_t s_raw[];                     // [2][W / 2]
+  const int v = blockIdx.x, frame = blockIdx.y;
+  if (!info[frame].ok) return;
+  const int W = dp.W, Wh = dp.W / 2, Hh = dp.H / 2;
+  const size_t plane = (size_t)dp.H * W, hplane = (size_t)Hh * Wh;
+  const int16_t* r1 = raw + (size_t)(frame * 2) * plane + (size_t)(2 * v) * W;
+  const int16_t* r2 = r1 + plane;
+  int16_t* s1 = s_raw; int16_t* s2 = s_raw + Wh;
+  for (int u = threadIdx.x; u < Wh; u += 256) { s1[u] = r1[2 * u]; s2[u] = r2[2 * u]; }
+  __syncthreads();
+  const float thr = (float)dp.lr_threshold;
+  float* o1row = D1 + (size_t)frame * hplane + (size_t)v * Wh;
+  float* o2row = D2 + (size_t)frame * hplane + (size_t)v * Wh;
+  for (int u = threadIdx.x; u < Wh; u += 256) {
+    const float d1 = (float)s1[u], d2 = (float)s2[u];
+    float o1 = d1, o2 = d2;
+    const float w1 = __fsub_rn((float)u, d1 / 2), w2 = __fadd_rn((float)u, d2 / 2);
+    if (d1 >= 0 && w1 >= 0 && w1 < (float)Wh) { if (fabsf((float)s2[(int)w1] - d1) > thr) o1 = -10.0f; } else o1 = -10.0f;
+    if (d2 >= 0 && w2 >= 0 && w2 < (float)Wh) { if (fabsf((float)s1[(int)w2] - d2) > thr) o2 = -10.0f; } else o2 = -10.0f;
+    o1row[u] = o1;
+    o2row[u] = o2;
+  }
+}
+// The 4-pixel adaptive mean of the half-size map (elas.cpp:1323-1391): the window of output pixel c is {c-2, c-1, c, c+1}, kept by the
+// reference in a ring of four (slot = position mod 4) and summed in SLOT order ((s0 + s1) + s2) + s3.  kRows = false: along the row,
+// in -> out for every pixel (pixels the pass leaves alone are copied: the reference's D_tmp is -10 where D is invalid, :1304-1309, and
+// heap memory elsewhere — a copy of D here, as in the full-size form).  kRows = true: down the column, in = the first pass's output,
+// D is written only where a mean forms (:1383-1386).
+template <bool kCols>
+__global__ void __launch_bounds__(256) k_adaptive_mean_sub(DevParams dp, const FrameInfo* __restrict__ info,
+                                                           const float* __restrict__ in, float* __restrict__ out) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y, frame = blockIdx.z;
+  if (u >= dp.W || !info[frame].ok) return;
+  const int W = dp.W, H = dp.H;
+  const size_t plane = (size_t)H * W;
+  const float* I = in + frame * plane;
+  const size_t p = (size_t)v * W + u;
+  const float c = I[p];
+  const bool inside = kCols ? (u >= 3 && u < W - 3 && v >= 2 && v <= H - 2) : (v >= 3 && v < H - 3 && u >= 2 && u <= W - 2);
+  float res = c; bool formed = false;
+  if (inside) {
+    const int stride = kCols ? W : 1, pos = kCols ? v : u;
+    float w[4], f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {                          // tap k = pixel pos - 2 + k, ring slot (pos - 2 + k) & 3
+      const float x = I[p + (long long)(k - 2) * stride];
+      w[k] = am_weight(x, c); f[k] = __fmul_rn(x, w[k]);
+    }
+    const int r = (pos - 2) & 3;                            // slot j holds tap (j - r) & 3: rotate the taps right by r
+    if (r & 1) {
+      const float tw = w[3], tf = f[3];
+      w[3] = w[2]; w[2] = w[1]; w[1] = w[0]; w[0] = tw;
+      f[3] = f[2]; f[2] = f[1]; f[1] = f[0]; f[0] = tf;
+    }
+    if (r & 2) {
+      float t = w[0]; w[0] = w[2]; w[2] = t; t = w[1]; w[1] = w[3]; w[3] = t;
+      t = f[0]; f[0] = f[2]; f[2] = t; t = f[1]; f[1] = f[3]; f[3] = t;
+    }
+    const float ws = __fadd_rn(__fadd_rn(__fadd_rn(w[0], w[1]), w[2]), w[3]);
+    const float fs = __fadd_rn(__fadd_rn(__fadd_rn(f[0], f[1]), f[2]), f[3]);
+    if (ws > 0) { const float d = fs / ws; if (d >= 0) { res = d; formed = true; } }
+  }
+  if (!kCols) out[frame * plane + p] = res;
+  else if (formed) out[frame * plane + p] = res;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Speckle removal (elas.cpp:981-1099) as union-find connected components: 4-connected valid
+// pixels whose disparities differ by <= speckle_sim_threshold; components smaller than
+// speckle_size (and every invalid pixel, a "segment" of one) are set to -10.  The reference's
+// flood fill visits the same components, so the result is order-free.
 // Horizontal pass: in = D, out = tmp; rows 3..H-4, centres 4..W-4.
 __global__ void __launch_bounds__(256) k_adaptive_mean_h(DevParams dp, const FrameInfo* __restrict__ info,
                                                          const float* __restrict__ in, float* __restrict__ out) {
@@ -2900,6 +2972,14 @@ void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const Fra
   static const int band_rows = getenv("JN_POST_BAND") ? atoi(getenv("JN_POST_BAND")) : 80;
   const int bands = (dp.H + band_rows - 1) / band_rows, rows = (dp.H + bands - 1) / bands;
   hipLaunchKernelGGL(k_gap_mean_fused, dim3((dp.W + kPostCols - 1) / kPostCols, bands, n), dim3(256), 0, st, dp, info, in, out, rows, mean ? 1 : 0);
+}
+void launch_lr_sub(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2) {
+  hipLaunchKernelGGL(k_lr_sub, dim3(dp.H / 2, n), dim3(256), (size_t)2 * (dp.W / 2) * sizeof(int16_t), st, dp, info, raw, D1, D2);
+}
+void launch_adaptive_mean_sub(hipStream_t st, const DevParams& dph, int n, const FrameInfo* info, float* D, float* tmp) {
+  const dim3 g = grid2d(dph.W, dph.H, n);
+  hipLaunchKernelGGL(k_adaptive_mean_sub<false>, g, dim3(256), 0, st, dph, info, D, tmp);
+  hipLaunchKernelGGL(k_adaptive_mean_sub<true>, g, dim3(256), 0, st, dph, info, tmp, D);
 }
 void launch_median(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp) {
   const dim3 g = grid2d(dp.W, dp.H, n);

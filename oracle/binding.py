@@ -198,6 +198,9 @@ class Oracle:
         D1 = np.full((H, W), fill, np.float32); D2 = np.full((H, W), fill, np.float32)
         I1 = np.ascontiguousarray(I1); I2 = np.ascontiguousarray(I2)
         st = self.lib.orc_elas_process(C.byref(p), _p(I1), _p(I2), _p(D1), _p(D2), W, H, W)
+        if p.subsampling:                        # elas.h:160-162: the maps are (W/2) x (H/2), at the start of the buffers
+            n = (W // 2) * (H // 2)
+            return st, D1.reshape(-1)[:n].reshape(H // 2, W // 2).copy(), D2.reshape(-1)[:n].reshape(H // 2, W // 2).copy()
         return st, D1, D2
 
     # ---- node side ----
@@ -392,6 +395,9 @@ class LocalReference:
         D1 = np.full((H, W), fill, np.float32); D2 = np.full((H, W), fill, np.float32)
         I1 = np.ascontiguousarray(I1); I2 = np.ascontiguousarray(I2)
         self.lib.ref_elas_process(C.byref(p), _p(I1), _p(I2), _p(D1), _p(D2), W, H, W)
+        if p.subsampling:
+            n = (W // 2) * (H // 2)
+            return D1.reshape(-1)[:n].reshape(H // 2, W // 2).copy(), D2.reshape(-1)[:n].reshape(H // 2, W // 2).copy()
         return D1, D2
 
     def sobel(self, I):

@@ -8,7 +8,7 @@
 // (tests/test_oracle_vs_reference.py) and against the survey's known-answer hashes.
 //
 // Build with -ffp-contract=off: the reference's results depend on the absence of FMA contraction.
-// Not supported (returns status 2): subsampling=1 (unused by the reference node).
+// subsampling=1 is restated for even image sizes (odd ones return status 2: the reference's half-size addressing runs over its rows there).
 #include "oracle.h"
 #include <cmath>
 #include <cstdlib>
@@ -563,10 +563,101 @@ extern "C" void orc_median(float* D, int32_t W, int32_t H) {
     }
 }
 
+// ---- subsampling = 1 (elas.h:82: "only computing disparities for each 2nd pixel"); outputs are (W/2) x (H/2) ----
+// elas.cpp:909-979 with D_width = width / 2 and the warps by d / 2 (:937-940)
+extern "C" void orc_lr_check_sub(const orc_params* p, float* D1, float* D2, int32_t W, int32_t H) {
+  std::vector<float> c1(D1, D1 + (size_t)W * H), c2(D2, D2 + (size_t)W * H);
+  for (int u = 0; u < W; u++)
+    for (int v = 0; v < H; v++) {
+      size_t a = (size_t)v * W + u;
+      float d1 = c1[a], d2 = c2[a];
+      float w1 = (float)u - d1 / 2, w2 = (float)u + d2 / 2;
+      if (d1 >= 0 && w1 >= 0 && w1 < W) {
+        if (std::fabs(c2[(size_t)v * W + (int32_t)w1] - d1) > p->lr_threshold) D1[a] = -10;
+      } else D1[a] = -10;
+      if (d2 >= 0 && w2 >= 0 && w2 < W) {
+        if (std::fabs(c1[(size_t)v * W + (int32_t)w2] - d2) > p->lr_threshold) D2[a] = -10;
+      } else D2[a] = -10;
+    }
+}
+// elas.cpp:1323-1391: the 4-pixel filter of the subsampled map.  A ring of four values (slot = index mod 4) holds pixels i-3 .. i, the
+// centre is pixel i-1, sums in SLOT order ((s0 + s1) + s2) + s3.  D_tmp is malloc'ed and only partially written by the horizontal pass;
+// as in the full-resolution form above it starts here as a copy of D_copy (the cells in question are the three border rows / columns).
+extern "C" void orc_adaptive_mean_sub(float* D, int32_t W, int32_t H) {
+  std::vector<float> cp(D, D + (size_t)W * H), tmp(D, D + (size_t)W * H);
+  float val[4] = {0, 0, 0, 0};                                   // (the reference's `val` is 8 floats of aligned heap; slots 0..3 are used here)
+  auto eval = [&](float centre, float& out) {
+    float w[4], f[4];
+    for (int i = 0; i < 4; i++) { w[i] = am_weight(val[i], centre); f[i] = val[i] * w[i]; }
+    const float wsum = w[0] + w[1] + w[2] + w[3], fsum = f[0] + f[1] + f[2] + f[3];
+    if (wsum > 0) { const float d = fsum / wsum; if (d >= 0) { out = d; return true; } }
+    return false;
+  };
+  for (int v = 3; v < H - 3; v++) {
+    const float* row = &cp[(size_t)v * W];
+    for (int u = 0; u < 3 && u < W; u++) val[u] = row[u];
+    for (int u = 3; u < W; u++) {
+      const float centre = row[u - 1];
+      val[u % 4] = row[u];
+      float d; if (eval(centre, d)) tmp[(size_t)v * W + u - 1] = d;
+    }
+  }
+  for (int u = 3; u < W - 3; u++) {
+    for (int v = 0; v < 3 && v < H; v++) val[v] = tmp[(size_t)v * W + u];
+    for (int v = 3; v < H; v++) {
+      const float centre = tmp[(size_t)(v - 1) * W + u];
+      val[v % 4] = tmp[(size_t)v * W + u];
+      float d; if (eval(centre, d)) D[(size_t)(v - 1) * W + u] = d;
+    }
+  }
+}
+
 // elas.cpp:32-151
 extern "C" int32_t orc_elas_process(const orc_params* p, const uint8_t* I1, const uint8_t* I2, float* D1, float* D2,
                                     int32_t W, int32_t H, int32_t pitch) {
-  if (p->subsampling) return 2;
+  if (p->subsampling) {
+    if ((W & 1) || (H & 1)) return 2;         // odd sizes: the reference's (u/2, v/2, width/2) addressing runs over its rows; not restated
+    // Descriptors: the reference computes only the even rows 4 .. H-4 (descriptor.cpp:47-78); every row the matching reads under
+    // subsampling is one of those or a row that neither form computes (2, H-3), so the full set serves.  Candidates: step rounded up to
+    // even (:379-381).  Dense matching: findMatch is per pixel (:683-780), so the half-size map is the full one at even (u, v) (:693, :877-896).
+    orc_params q = *p;
+    q.subsampling = 0;
+    q.candidate_stepsize = p->candidate_stepsize + p->candidate_stepsize % 2;
+    std::vector<uint8_t> desc1((size_t)16 * W * H), desc2((size_t)16 * W * H);
+    orc_descriptor(I1, W, H, pitch, desc1.data());
+    orc_descriptor(I2, W, H, pitch, desc2.data());
+    std::vector<SupportPt> sup = support_points(&q, desc1.data(), desc2.data(), W, H);
+    if (sup.size() < 3) return 1;
+    const int32_t n = (int32_t)sup.size();
+    const int32_t* uvd = &sup[0].u;
+    const int32_t cap = 2 * n + 16;
+    std::vector<int32_t> c1((size_t)3 * cap), c2((size_t)3 * cap);
+    std::vector<float> pl1((size_t)6 * cap), pl2((size_t)6 * cap);
+    int32_t n1 = orc_triangles(uvd, n, 0, c1.data(), pl1.data(), cap);
+    int32_t n2 = orc_triangles(uvd, n, 1, c2.data(), pl2.data(), cap);
+    if (n1 < 0 || n2 < 0) return 3;
+    int32_t gd[3];
+    const int gw = (int)std::ceil((float)W / (float)p->grid_size), gh = (int)std::ceil((float)H / (float)p->grid_size);
+    std::vector<int32_t> g1((size_t)gw * gh * (p->disp_max + 2)), g2(g1.size());
+    orc_grid(&q, uvd, n, W, H, 0, g1.data(), gd);
+    orc_grid(&q, uvd, n, W, H, 1, g2.data(), gd);
+    std::vector<float> F1((size_t)W * H), F2((size_t)W * H);
+    orc_dense(&q, uvd, n, c1.data(), pl1.data(), n1, g1.data(), gd, desc1.data(), desc2.data(), W, H, 0, F1.data());
+    orc_dense(&q, uvd, n, c2.data(), pl2.data(), n2, g2.data(), gd, desc1.data(), desc2.data(), W, H, 1, F2.data());
+    const int Wh = W / 2, Hh = H / 2;
+    for (int v = 0; v < Hh; v++)
+      for (int u = 0; u < Wh; u++) { D1[(size_t)v * Wh + u] = F1[(size_t)2 * v * W + 2 * u]; D2[(size_t)v * Wh + u] = F2[(size_t)2 * v * W + 2 * u]; }
+    orc_lr_check_sub(&q, D1, D2, Wh, Hh);
+    q.speckle_size = (int32_t)(std::sqrt((float)p->speckle_size) * 2);          // :991
+    q.ipol_gap_width = p->ipol_gap_width / 2 + 1;                                // :1111
+    orc_speckle(&q, D1, Wh, Hh);
+    if (!p->postprocess_only_left) orc_speckle(&q, D2, Wh, Hh);
+    orc_gap(&q, D1, Wh, Hh);
+    if (!p->postprocess_only_left) orc_gap(&q, D2, Wh, Hh);
+    if (p->filter_adaptive_mean) { orc_adaptive_mean_sub(D1, Wh, Hh); if (!p->postprocess_only_left) orc_adaptive_mean_sub(D2, Wh, Hh); }
+    if (p->filter_median) { orc_median(D1, Wh, Hh); if (!p->postprocess_only_left) orc_median(D2, Wh, Hh); }
+    return 0;
+  }
   std::vector<uint8_t> desc1((size_t)16 * W * H), desc2((size_t)16 * W * H);
   orc_descriptor(I1, W, H, pitch, desc1.data());
   orc_descriptor(I2, W, H, pitch, desc2.data());

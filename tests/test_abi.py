@@ -44,11 +44,13 @@ def test_struct_sizes(jn):
 def test_unsupported_parameter_combinations_are_refused(jn):
     from jackal_navigation_amd import _lib
     L = jn.load()
-    for kw in ({"subsampling": 1}, {"disp_max": 300}, {"disp_min": 300}, {"ipol_gap_width": -1}):      # (disp_min is honoured since round 4; beyond disp_max it is refused)
+    # (disp_min and subsampling are honoured since round 4: disp_min beyond disp_max and subsampling of odd-sized images are refused)
+    for kw, (W, H) in (({"subsampling": 1}, (321, 180)), ({"subsampling": 1}, (320, 181)), ({"disp_max": 300}, (320, 180)), ({"disp_min": 300}, (320, 180)),
+                       ({"ipol_gap_width": -1}, (320, 180))):
         p = jn.Elas.parameters(0, **kw)
         h = C.c_void_p()
-        st = L.jn_elas_create(C.byref(p), 320, 180, 1, 0, 1, 1, C.byref(h))
-        assert st == _lib.JN_ERR_UNSUPPORTED and not h.value, kw
+        st = L.jn_elas_create(C.byref(p), W, H, 1, 0, 1, 1, C.byref(h))
+        assert st == _lib.JN_ERR_UNSUPPORTED and not h.value, (kw, W, H)
     p = jn.Elas.parameters(0)
     h = C.c_void_p()
     assert L.jn_elas_create(C.byref(p), 8, 8, 1, 0, 1, 1, C.byref(h)) == _lib.JN_ERR_INVALID

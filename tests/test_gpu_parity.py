@@ -449,3 +449,34 @@ def test_scan_with_empty_and_saturated_maps(jn, oracle):
         bo, mo, used = oracle.scan(spo, disp[0], luto)
         assert np.allclose(bins.numpy()[0], bo, rtol=0, atol=SCAN_TOL), fillv
         assert np.allclose(meta.numpy()[0], mo, rtol=0, atol=SCAN_TOL), fillv
+
+
+@pytest.mark.parametrize("W,H,sd,dmax,seed,kw", [
+    (320, 240, 40, 79, 21, {}), (640, 480, 64, 63, 12345, {"postprocess_only_left": 0}),
+    (256, 200, 40, 63, 1, {"filter_median": 1, "postprocess_only_left": 0}),
+    (400, 304, 60, 127, 6, {"candidate_stepsize": 4, "ipol_gap_width": 7, "speckle_size": 50, "postprocess_only_left": 0}),
+    (322, 182, 48, 255, 12345, {"filter_adaptive_mean": 0}), (1280, 720, 128, 127, 12345, {"postprocess_only_left": 0}),
+])
+def test_subsampling_gives_the_reference_half_size_maps(jn, oracle, same, W, H, sd, dmax, seed, kw):
+    """param.subsampling = 1 (elas.h:82): (W/2) x (H/2) maps, bit-identical to the oracle (which tests/test_oracle_vs_reference.py pins
+    against the compiled reference for the same cases).  Through host pointers (jn_elas_process) and through device pointers in a batch
+    of two frames of which the second has too few support points (outputs untouched)."""
+    import torch
+    L, R = jn.node.synth_pair(W, H, sd, seed)
+    p = jn.Elas.parameters(0, disp_max=dmax, subsampling=1, **kw)
+    st_o, D1o, D2o = oracle.process(oracle.params(0, disp_max=dmax, subsampling=1, **kw), L, R)
+    Hh, Wh = H // 2, W // 2
+    assert st_o == 0 and D1o.shape == (Hh, Wh)
+    D1 = np.full((Hh, Wh), 7.0, np.float32); D2 = np.full((Hh, Wh), 7.0, np.float32)
+    with jn.Elas(p, W, H) as e:
+        assert e.process(L, R, D1, D2, (W, H, W)) == 0
+    assert same(D1, D1o) and same(D2, D2o), (int((D1 != D1o).sum()), int((D2 != D2o).sum()))
+    dev = torch.device("cuda", 0)
+    flat = np.full((H, W), 128, np.uint8)
+    tl = torch.from_numpy(np.stack([L, flat])).to(dev); tr = torch.from_numpy(np.stack([R, flat])).to(dev)
+    o1 = torch.full((2, Hh, Wh), -3.0, dtype=torch.float32, device=dev); o2 = torch.full((2, Hh, Wh), -3.0, dtype=torch.float32, device=dev)
+    with jn.Elas(p, W, H, max_batch=2, host_threads=4) as e:
+        st = e.process_batch(2, tl.data_ptr(), tr.data_ptr(), W, H * W, o1.data_ptr(), o2.data_ptr())
+    assert list(st) == [0, 1]
+    assert same(o1[0].cpu().numpy(), D1o) and same(o2[0].cpu().numpy(), D2o)
+    assert float(o1[1].min()) == -3.0 == float(o1[1].max()) and float(o2[1].min()) == -3.0 == float(o2[1].max())

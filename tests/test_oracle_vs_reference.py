@@ -217,3 +217,20 @@ def test_oracle_reproduces_the_committed_middlebury_hashes(oracle):
         L, R = oracle.synth_pair(W, H, sd, seed) if kind == "synth" else make_scene(kind, W, H, dmax, seed)
         st, D1, D2 = oracle.process(oracle.params(1, disp_max=dmax), L, R)
         assert st == 0 and oracle.fnv(D1) == int(h1, 16) and oracle.fnv(D2) == int(h2, 16), (kind, W, H)
+
+
+@pytest.mark.parametrize("W,H,sd,dmax,seed,kw", [
+    (320, 240, 40, 79, 21, {}), (320, 240, 40, 79, 21, {"postprocess_only_left": 0}),
+    (640, 480, 64, 63, 12345, {"postprocess_only_left": 0}), (256, 200, 40, 63, 1, {"filter_median": 1, "postprocess_only_left": 0}),
+    (400, 304, 60, 127, 6, {"candidate_stepsize": 4, "ipol_gap_width": 7, "speckle_size": 50, "postprocess_only_left": 0}),
+    (322, 182, 48, 255, 12345, {"filter_adaptive_mean": 0}),
+])
+def test_process_bit_exact_with_subsampling(oracle, reference, same, W, H, sd, dmax, seed, kw):
+    """subsampling = 1 (elas.h:82; elas.cpp:380, 693, 793, 877-896, 914-941, 987-992, 1107-1112, 1292-1297, 1323-1391, 1499-1504;
+    descriptor.cpp:47-78): half-size maps.  The node never sets it; the oracle restates it for even image sizes."""
+    L, R = oracle.synth_pair(W, H, sd, seed)
+    p = oracle.params(0, disp_max=dmax, subsampling=1, **kw)
+    st, D1, D2 = oracle.process(p, L, R)
+    D1r, D2r = reference.process(p, L, R)
+    assert D1.shape == (H // 2, W // 2) == D1r.shape
+    assert st == 0 and same(D1, D1r) and same(D2, D2r), (W, H, kw, int((D1 != D1r).sum()), int((D2 != D2r).sum()))
