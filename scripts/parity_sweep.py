@@ -71,6 +71,12 @@ def main():
         (1280, 720, 128, 127, {"host_threads": 32, "lone": 1}), (1920, 1080, 200, 255, {"host_threads": 32, "lone": 1}),
         (640, 480, "patches", 63, {"filter_adaptive_mean": 0}), (640, 480, "photometric", 63, {"ipol_gap_width": 2}),
     ]
+    # round 4: the two options the node never sets — disp_min, and subsampling (half-size maps)
+    configs += [
+        (640, 480, 64, 63, {"disp_min": 8}), (1280, 720, 128, 127, {"disp_min": 30, "postprocess_only_left": 0}),
+        (640, 480, 64, 63, {"subsampling": 1}), (1280, 720, "strips", 127, {"subsampling": 1, "postprocess_only_left": 0}),
+        (800, 600, 90, 127, {"subsampling": 1, "filter_median": 1}), (1920, 1080, 200, 255, {"subsampling": 1}),
+    ]
     sgm_configs = [(640, 480, 64, 64, {}), (1280, 720, 128, 128, {"subpixel": 1}), (320, 240, "strips", 64, {"subpixel": 1}),
                    (448, 333, "blobs", 128, {"P1": 5, "P2": 40, "prefilter_cap": 20}), (500, 200, 200, 256, {"lr_max_diff": 2})]
     bm_configs = [(640, 480, 64, 64, {}), (1280, 720, 128, 128, {"subpixel": 1}), (320, 240, "strips", 64, {"subpixel": 1, "block_radius": 3}),
@@ -93,14 +99,15 @@ def main():
             pairs = [make_pair(W, H, sd, dmax, 31000 + 100 * ci + b) for b in range(n)]
             Ls = np.stack([p[0] for p in pairs]); Rs = np.stack([p[1] for p in pairs])
             dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
-            d1 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32)); d2 = DeviceArray.from_numpy(np.full((n, H, W), 7.0, np.float32))
+            Ho, Wo = (H // 2, W // 2) if kw.get("subsampling") else (H, W)      # elas.h:160-162: half-size maps with subsampling
+            d1 = DeviceArray.from_numpy(np.full((n, Ho, Wo), 7.0, np.float32)); d2 = DeviceArray.from_numpy(np.full((n, Ho, Wo), 7.0, np.float32))
             t0 = time.time()
             pkw = {k: v for k, v in kw.items() if k not in ("setting", "host_threads", "lone")}
             with jn.Elas(jn.Elas.parameters(kw.get("setting", 0), disp_max=dmax, **pkw), W, H, max_batch=n, host_threads=kw.get("host_threads", 8)) as e:
                 if kw.get("lone"):                                   # one pair per call: the pool has idle threads, Delaunay runs in parts
                     status = []
                     for b in range(n):
-                        status += e.process_batch(1, dL.ptr + b * H * W, dR.ptr + b * H * W, W, H * W, d1.ptr + 4 * b * H * W, d2.ptr + 4 * b * H * W)
+                        status += e.process_batch(1, dL.ptr + b * H * W, dR.ptr + b * H * W, W, H * W, d1.ptr + 4 * b * Ho * Wo, d2.ptr + 4 * b * Ho * Wo)
                 else:
                     status = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
             t_gpu = time.time() - t0
