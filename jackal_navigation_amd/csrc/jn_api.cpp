@@ -259,13 +259,14 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     launch_support(sa, dp, n, s.desc, s.d_can);
     if (h->pace) { HIP_TRY(hipEventRecord(s.ev_head, sa)); h->pace_prev = s.ev_head; }
   }
-  const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
-      launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp);
-  HIP_TRY(mark_a(EV_SUPPORT));
   const int list_cap = dp.cw * dp.ch;
+  bool listed = false;                                   // k_filter_resolve wrote the support list too
+  const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
+      launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp, s.h_list, s.h_cnt, list_cap, &listed);
+  HIP_TRY(mark_a(EV_SUPPORT));
   bool arranged = false;
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
-    launch_support_list(sa, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
+    if (!listed) launch_support_list(sa, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
     // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
     // Sized by what this slot's previous batch held (+25 %): a 720p frame has 3.2 k support points and needs 52 KB of LDS, not
     // the 104 KB of the 8192-vertex maximum — a workgroup that asks for less finds room among the other slots' kernels sooner.
@@ -286,13 +287,18 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   // ---- stage B, as a function of what the host stage yields: the largest support / triangle counts (launch sizes), whether any frame
   // has a triangulation, where the payload is read from, and whether the two clears were queued ahead ----
   const bool fused = gap_mean_fusable(dp, n) && ((dp.W * dp.H) & 3) == 0;
+  // The candidate grid (elas.cpp:582-680) needs the support points, not the triangulation: without corner points they are the list the
+  // GPU has just written, so the grid is queued HERE, behind stage A, and is built while the host triangulates (JN_GRID_EARLY=0: in stage B).
+  static const bool grid_early_env = !(getenv("JN_GRID_EARLY") && atoi(getenv("JN_GRID_EARLY")) == 0);
+  const bool grid_early = grid_early_env && filtered && !dp.add_corners && sa == st;
+  if (grid_early) launch_grid_from_list(st, dp, n, s.h_list, s.h_cnt, list_cap, s.mark, s.gridbits);
   auto queue_stage_b = [&](int max_sup, int max_tri, bool any_ok, const uint8_t* payload, size_t payload_bytes, bool cleared) -> jn_status {
     HIP_TRY(mark(EV_H2D0));
     HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
     if (payload_bytes && payload == s.payload) HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(mark(EV_H2D));
     if (any_ok) {
-      launch_grid(st, dp, n, s.info, payload, 0, max_sup, s.mark, s.gridbits, !cleared);      // offsets in FrameInfo are batch-absolute
+      if (!grid_early) launch_grid(st, dp, n, s.info, payload, 0, max_sup, s.mark, s.gridbits, !cleared);      // offsets in FrameInfo are batch-absolute
       launch_tri_setup(st, dp, n, s.info, payload, 0, max_tri, h->tri_cap, s.recs);
       launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list, !cleared);
       HIP_TRY(mark(EV_RASTER));
@@ -375,7 +381,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   } gate;
   const bool gated = h->gate_stage_b && s.gate && filtered && h->zero_copy_payload && sa == st;
   if (gated) {
-    launch_grid_clear(st, dp, n, s.mark);
+    if (!grid_early) launch_grid_clear(st, dp, n, s.mark);
     launch_bin_clear(st, dp, n, s.bin_count);
     const uint32_t v = ++s.gate_seq;
     HIP_TRY(hipStreamWaitValue32(st, s.gate, v, hipStreamWaitValueEq, 0xFFFFFFFFu));

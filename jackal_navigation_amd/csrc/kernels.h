@@ -36,14 +36,18 @@ void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* c
                     int32_t* arr_ok, void* gbuf, int g_cap);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
+// list / count / list_cap / listed (optional): where the classification + resolution route takes the lattice, k_filter_resolve also writes
+// the support list (launch_support_list's output) and sets *listed
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,
-                            void* scratch);
+                            void* scratch, int16_t* list = nullptr, int32_t* count = nullptr, int list_cap = 0, bool* listed = nullptr);
 
 // GPU stage B -------------------------------------------------------------------------------
 // Grid prior (elas.cpp:579-659) from the support points: mark/gridbits [n][2][gh*gw][8] uint32.
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                  int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits, bool clear = true);
-void launch_grid_clear(hipStream_t st, const DevParams& dp, int n, uint32_t* mark);      // the clear alone (queued ahead by a latency-mode handle)
+void launch_grid_clear(hipStream_t st, const DevParams& dp, int n, uint32_t* mark);
+// the whole grid (clear, mark, dilate) from the GPU's own support list: for parameter sets without corner points, queued behind stage A
+void launch_grid_from_list(hipStream_t st, const DevParams& dp, int n, const int16_t* list, const int32_t* count, int cap, uint32_t* mark, uint32_t* gridbits);      // the clear alone (queued ahead by a latency-mode handle)
 // Plane fits + edge lines per triangle (elas.cpp:507-577, :847-872): recs [n][2][tri_cap].
 void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                       int64_t payload_stride, int max_tri, int tri_cap, TriRec* recs);

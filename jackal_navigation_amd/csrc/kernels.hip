@@ -554,7 +554,8 @@ __global__ void __launch_bounds__(256) k_filter_classify(DevParams dp, int tol, 
 constexpr int kFilterTodo = 2048;                                   // undecided points listed per frame (more: in-order scan)
 template <int WIN>
 __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp, int tol, int min_support, int16_t* __restrict__ d_can,
-                                                                   const uint8_t* __restrict__ code) {
+                                                                   const uint8_t* __restrict__ code, int16_t* __restrict__ list,
+                                                                   int32_t* __restrict__ count, int list_cap, int rounds) {
   extern __shared__ int16_t s_lat[];                      // lattice with a border of WIN cells, then the codes
   static_assert(WIN == 5, "redundant_line's window is the reference's fixed max_dist 5");
   const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x, N = cw * ch;
@@ -605,31 +606,63 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
     for (int i = i_lo; i < i_hi; i++) { const int c = s_code[i]; if (c != 0 && c != 255) s_todo[at++] = (uint16_t)i; }
   }
   __syncthreads();
-  if (tid < 64) {
+  {
     // lane -> one of the 60 window cells that precede the point in sweep order: 5 columns to the left (11 rows each),
     // then the 5 cells above in its own column
     constexpr int ROWS = 2 * WIN + 1, LEFT = WIN * ROWS;
-    const int du = tid < LEFT ? tid / ROWS - WIN : 0;
-    const int dv = tid < LEFT ? tid % ROWS - WIN : tid - LEFT - WIN;
-    const bool cell = tid < LEFT + WIN;
-    auto resolve = [&](int pidx) {
-      const int u = pidx / ch, v = pidx - u * ch;
-      const int d = base[v * pw + u], sure = s_code[pidx];
-      bool hit = false;
-      if (cell) {
-        const int e = base[(v + dv) * pw + (u + du)];        // the border reads as invalid
-        if (e >= 0 && abs(d - e) <= tol) hit = s_code[(u + du) * ch + (v + dv)] == 255;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int du = lane < LEFT ? lane / ROWS - WIN : 0;
+    const int dv = lane < LEFT ? lane % ROWS - WIN : lane - LEFT - WIN;
+    const bool cell = lane < LEFT + WIN;
+    if (total <= kFilterTodo && rounds) {
+      // The walk in sweep order, without the walk: in every round each wave takes every 8th listed point that is still undecided; a point
+      // whose earlier agreeing neighbours are ALL decided gets its verdict now (its fate depends on nothing else, and theirs is final), the
+      // others wait for the next round.  The earliest undecided point of the sweep order is never blocked, so every round makes progress;
+      // the undecided points sit at the rims of sparse regions, a few per cent of the lattice, and chains among them are short: two or
+      // three rounds instead of one dependent step per point.  Reading a neighbour while another wave decides it is harmless: old code =
+      // wait, new code = the final answer, and a dead point's value (-1) never agrees.
+      for (;;) {
+        int waiting = 0;
+        for (int k = wv; k < total; k += kFilterThreads / 64) {
+          const int pidx = s_todo[k];
+          const int sure = s_code[pidx];
+          if (sure == 0 || sure == 255) continue;              // decided in an earlier round (wave-uniform)
+          const int u = pidx / ch, v = pidx - u * ch;
+          const int d = base[v * pw + u];
+          bool hit = false, blocked = false;
+          if (cell) {
+            const int e = base[(v + dv) * pw + (u + du)];      // the border reads as invalid
+            if (e >= 0 && abs(d - e) <= tol) {
+              const int nc = s_code[(u + du) * ch + (v + dv)];
+              hit = nc == 255; blocked = nc != 0 && nc != 255;
+            }
+          }
+          if (__ballot(blocked) != 0ull) { waiting = 1; continue; }
+          const int count = sure + __popcll(__ballot(hit));
+          if (lane == 0) {
+            const bool lives = count >= min_support;
+            s_code[pidx] = lives ? 255 : 0;
+            if (!lives) base[v * pw + u] = -1;
+          }
+        }
+        if (!__syncthreads_or(waiting)) break;
       }
-      const int count = sure + __popcll(__ballot(hit));
-      if (tid == 0) {
-        const bool lives = count >= min_support;
-        s_code[pidx] = lives ? 255 : 0;
-        if (!lives) base[v * pw + u] = -1;
-      }
-    };
-    if (total <= kFilterTodo) {
-      for (int k = 0; k < total; k++) resolve(s_todo[k]);
-    } else {                                                 // more undecided points than the list holds: scan the codes in order
+    } else if (tid < 64) {                                   // more undecided points than the list holds (or JN_FILTER_ROUNDS=0): scan the codes in order, one wave
+      auto resolve = [&](int pidx) {
+        const int u = pidx / ch, v = pidx - u * ch;
+        const int d = base[v * pw + u], sure = s_code[pidx];
+        bool hit = false;
+        if (cell) {
+          const int e = base[(v + dv) * pw + (u + du)];
+          if (e >= 0 && abs(d - e) <= tol) hit = s_code[(u + du) * ch + (v + dv)] == 255;
+        }
+        const int count = sure + __popcll(__ballot(hit));
+        if (tid == 0) {
+          const bool lives = count >= min_support;
+          s_code[pidx] = lives ? 255 : 0;
+          if (!lives) base[v * pw + u] = -1;
+        }
+      };
       for (int i0 = 0; i0 < N; i0 += 64) {
         const int c = i0 + tid < N ? (int)s_code[i0 + tid] : 0;
         unsigned long long todo = __ballot(c != 0 && c != 255);
@@ -643,6 +676,40 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
   for (int v = tid; v < ch; v += kFilterThreads) redundant_line(base + v * pw, 1, cw);    // horizontal pass (elas.cpp:422)
   __syncthreads();
   lattice_store_all(s_lat, g, cw, ch, WIN, pw);
+  if (list) {
+    // The support list (k_support_list's job: the surviving points in the reference's order, elas.cpp:424-431) straight from the lattice
+    // in LDS — one launch and one trip through memory less on a lone pair's critical path.
+    int mine2 = 0;
+    {
+      int u = i_lo / ch, v = i_lo - u * ch;
+      for (int i = i_lo; i < i_hi; i++) {
+        mine2 += (u >= 1 && v >= 1 && base[v * pw + u] >= 0) ? 1 : 0;
+        if (++v == ch) { v = 0; u++; }
+      }
+    }
+    __syncthreads();                                         // s_off is reused
+    s_off[tid + 1] = mine2;
+    if (tid == 0) s_off[0] = 0;
+    __syncthreads();
+    for (int step = 1; step < kFilterThreads; step <<= 1) {
+      const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
+      __syncthreads();
+      s_off[tid + 1] += add;
+      __syncthreads();
+    }
+    int16_t* out = list + (size_t)blockIdx.x * list_cap * 3;
+    int at = s_off[tid];
+    int u = i_lo / ch, v = i_lo - u * ch;
+    for (int i = i_lo; i < i_hi; i++) {
+      const int d = base[v * pw + u];
+      if (u >= 1 && v >= 1 && d >= 0) {
+        if (at < list_cap) { out[3 * at] = (int16_t)u; out[3 * at + 1] = (int16_t)v; out[3 * at + 2] = (int16_t)d; }
+        at++;
+      }
+      if (++v == ch) { v = 0; u++; }
+    }
+    if (tid == 0) count[blockIdx.x] = s_off[kFilterThreads];
+  }
 }
 
 // The same resolution for lattices too large to sit in LDS next to their codes (1920x1080: 166 KB + 83 KB): only the
@@ -826,13 +893,27 @@ __global__ void __launch_bounds__(kFilterThreads) k_support_filters(DevParams dp
 // ------------------------------------------------------------------------------------------------
 // Grid prior (createGrid, elas.cpp:579-659) as 256-bit candidate sets per 20x20 cell.
 // mark: every support point sets d-1..d+1 in its cell (left: column u, right: column u-d).
+DEV void grid_mark_point(const DevParams& dp, int frame, int u, int v, int d, uint32_t* __restrict__ mark);
 __global__ void __launch_bounds__(256) k_grid_mark(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
                                                    long long payload_stride, uint32_t* __restrict__ mark) {
   const int i = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
   const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
   if (!fi.ok || i >= fi.nsup) return;
   const int32_t* s = reinterpret_cast<const int32_t*>(payload + (long long)frame * payload_stride + fi.sup_offset) + 3 * i;
-  const int u = s[0], v = s[1], d = s[2];
+  grid_mark_point(dp, frame, s[0], s[1], s[2], mark);
+}
+// The same from the support list the GPU wrote itself (k_support_list: lattice coordinates and disparity, in the reference's order):
+// without corner points (elas.cpp:435 add_corners = 0) the support points ARE that list, so the grid does not have to wait for the host
+// stage — it is queued behind stage A and runs while the host triangulates.  A frame is ok when it has at least three points (:66-71).
+__global__ void __launch_bounds__(256) k_grid_mark_list(DevParams dp, const int16_t* __restrict__ list, const int32_t* __restrict__ count, int cap,
+                                                        uint32_t* __restrict__ mark) {
+  const int i = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y;
+  const int nsup = min(count[frame], cap);
+  if (nsup < 3 || i >= nsup) return;
+  const int16_t* s = list + ((size_t)frame * cap + i) * 3;
+  grid_mark_point(dp, frame, (int)s[0] * dp.step, (int)s[1] * dp.step, (int)s[2], mark);
+}
+DEV void grid_mark_point(const DevParams& dp, int frame, int u, int v, int d, uint32_t* __restrict__ mark) {
   const size_t cells = (size_t)dp.gw * dp.gh;
   const int y = (int)floorf(__fdiv_rn((float)v, (float)dp.grid_size));                         // :606
   const int lo = max(d - 1, 0), hi = min(d + 1, dp.disp_max);                                  // :596-597
@@ -851,7 +932,7 @@ __global__ void __launch_bounds__(256) k_grid_dilate(DevParams dp, const FrameIn
                                                      uint32_t* __restrict__ bits) {
   const int cells = dp.gw * dp.gh;
   const int i = blockIdx.x * 256 + threadIdx.x, fs = blockIdx.y;     // fs = frame*2 + side
-  if (i >= cells * kGridWords || !info[fs >> 1].ok) return;
+  if (i >= cells * kGridWords || (info && !info[fs >> 1].ok)) return;   // info == nullptr: queued before the host stage (a failing frame's grid is never read)
   const int c = i / kGridWords, w = i % kGridWords;
   uint32_t acc = 0;
   if (c >= dp.gw + 1 && c < cells - dp.gw - 1) {
@@ -2644,7 +2725,8 @@ static int support_filters_form(const DevParams& dp, int win, int min_support) {
 }
 bool support_filters_fast(const DevParams& dp, int win, int min_support) { return support_filters_form(dp, win, min_support) != 0; }
 bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win, int tol, int min_support, int16_t* d_can,
-                            void* scratch) {
+                            void* scratch, int16_t* list, int32_t* count, int list_cap, bool* listed) {
+  if (listed) *listed = false;
   constexpr int WIN = 5, K = WIN + 1;                               // the reference's incon_window_size (elas.h:97)
   if (win != WIN) return false;                                     // other window sizes: the host stage filters
   const int form = scratch ? support_filters_form(dp, win, min_support) : 0;
@@ -2653,7 +2735,12 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
     if (form == 2) {
       uint8_t* code = reinterpret_cast<uint8_t*>(scratch);          // [n][cw*ch], column-major
       hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
-      hipLaunchKernelGGL(k_filter_resolve<WIN>, dim3(n), dim3(kFilterThreads), need, st, dp, tol, min_support, d_can, code);
+      static const bool fuse_list = !(getenv("JN_FUSE_LIST") && atoi(getenv("JN_FUSE_LIST")) == 0);
+      const bool with_list = fuse_list && list && count && listed;
+      const int rounds = getenv("JN_FILTER_ROUNDS") ? atoi(getenv("JN_FILTER_ROUNDS")) : 1;      // read per launch (A/B, tests)
+      hipLaunchKernelGGL(k_filter_resolve<WIN>, dim3(n), dim3(kFilterThreads), need, st, dp, tol, min_support, d_can, code,
+                         with_list ? list : static_cast<int16_t*>(nullptr), count, list_cap, rounds);
+      if (with_list) *listed = true;
       return true;
     }
   }
@@ -2850,6 +2937,11 @@ void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16
 }
 void launch_grid_clear(hipStream_t st, const DevParams& dp, int n, uint32_t* mark) {
   hipMemsetAsync(mark, 0, (size_t)n * 2 * dp.gw * dp.gh * kGridWords * sizeof(uint32_t), st);
+}
+void launch_grid_from_list(hipStream_t st, const DevParams& dp, int n, const int16_t* list, const int32_t* count, int cap, uint32_t* mark, uint32_t* gridbits) {
+  launch_grid_clear(st, dp, n, mark);
+  hipLaunchKernelGGL(k_grid_mark_list, dim3((cap + 255) / 256, n), dim3(256), 0, st, dp, list, count, cap, mark);
+  hipLaunchKernelGGL(k_grid_dilate, dim3((dp.gw * dp.gh * kGridWords + 255) / 256, 2 * n), dim3(256), 0, st, dp, static_cast<const FrameInfo*>(nullptr), mark, gridbits);
 }
 void launch_grid(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                  int64_t payload_stride, int max_sup, uint32_t* mark, uint32_t* gridbits, bool clear) {
