@@ -138,6 +138,7 @@ def parse_args():
     ap.add_argument("--no-pin", action="store_true", help="do not pin ranks to their GPU's NUMA node")
     ap.add_argument("--subpixel", type=int, default=0, help="sgm / bm mode: 1/16-pixel refinement")
     ap.add_argument("--block-radius", type=int, default=4, help="bm mode: block radius r (2, 3, 4)")
+    ap.add_argument("--bm-slots", type=int, default=4, help="bm mode: batches in flight (jn_bm_submit_scan / jn_bm_wait), as --sgm-slots for the SGM mode")
     ap.add_argument("--sgm-slots", type=int, default=4,
                     help="sgm mode: batches in flight (jn_sgm_submit_scan / jn_sgm_wait; 1 = one synchronous batch at a time as in rounds 2-3; each further "
                          "slot holds its own three W*H*D byte volumes per pair of the batch)")
@@ -340,7 +341,7 @@ def run_sgm(a):
     u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
     bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
     # SGM: batches pipelined over --sgm-slots slots (jn_sgm_submit_scan / jn_sgm_wait), each with its own outputs and its own copy of the inputs
-    SS = 1 if (bm or os.environ.get("JN_SGM_IMPL") == "0") else max(1, min(6, a.sgm_slots))     # (round 2's kernels, JN_SGM_IMPL=0, have no pipelined form)
+    SS = 1 if os.environ.get("JN_SGM_IMPL") == "0" else max(1, min(6, a.bm_slots if bm else a.sgm_slots))     # (round 2's kernels, JN_SGM_IMPL=0, have no pipelined form; the block matcher pipelines the same way: jn_bm_submit_scan / jn_bm_wait)
     slot_in = [(dL, dR)] + [(dL.clone(), dR.clone()) for _ in range(SS - 1)]
     slot_out = [(disp, u8, bins, meta)] + [(torch.zeros_like(disp), torch.zeros_like(u8), torch.zeros_like(bins), torch.zeros_like(meta)) for _ in range(SS - 1)]
     if bm:
@@ -354,7 +355,7 @@ def run_sgm(a):
     acc = {}
 
     def step():
-        if bm:                                               # matcher + u8 map + scan on one stream (jn_bm_process_scan)
+        if bm and SS == 1:                                   # matcher + u8 map + scan on one stream (jn_bm_process_scan), one batch at a time
             sgm.process_scan(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp.data_ptr(), sp, lut.ptr, u8.data_ptr(), bins.data_ptr(), meta.data_ptr())
             for k, v in sgm.last_times().items():
                 acc.setdefault(k, []).append(v)
@@ -411,6 +412,13 @@ def run_sgm(a):
         regions.append(region())
     elapsed = float(np.median(regions))
     value = world * B * a.steps / elapsed
+    if bm and SS > 1:                                        # the kernels' own durations for the roofline: a few batches alone, outside the timed regions
+        acc.clear()
+        for i in range(10):
+            sgm.process_scan(B, dL.data_ptr(), dR.data_ptr(), W, H * W, disp.data_ptr(), sp, lut.ptr, u8.data_ptr(), bins.data_ptr(), meta.data_ptr())
+            if i >= 2:
+                for k, v in sgm.last_times().items():
+                    acc.setdefault(k, []).append(v)
     ms = {k: float(np.mean(v)) for k, v in acc.items()}
     check = None
     if rank == 0:
@@ -871,7 +879,7 @@ def run_rank(a):
                     m = jn.Sgm(jn.Sgm.parameters(num_disparities=a.disp), W, H, max_batch=B, device=local_rank)
                 else:
                     m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4, cost_function=1 if kind == "bm_ssd" else 0), W, H, max_batch=B, device=local_rank)
-                reps_m = 120 if kind == "sgm" else 8   # the pipelined leg needs enough batches (0.8 s) for its fill and drain not to weigh
+                reps_m = 120 if kind == "sgm" else 160   # the pipelined legs need enough batches (0.8 / 0.25 s) for their fill and drain not to weigh
                 if kind == "sgm":                            # four batches in flight (jn_sgm_submit_scan / jn_sgm_wait), as `--mode sgm` runs it
                     nsl = 4
                     outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
@@ -883,11 +891,18 @@ def run_rank(a):
                             m.submit_scan(i % nsl, B, dLs[(i % nsl) % len(dLs)].data_ptr(), dRs[(i % nsl) % len(dRs)].data_ptr(), W, H * W, outs_m[i % nsl].data_ptr())
                         for sl in range(nsl):
                             m.wait(sl)
-                else:
+                else:                                        # the block matcher the same way (jn_bm_submit_scan / jn_bm_wait)
+                    nsl = 4
+                    outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
+
                     def run_m(k):
-                        for _ in range(k):
-                            m.process_batch(B, dLs[0].data_ptr(), dRs[0].data_ptr(), W, H * W, disp16.data_ptr())
-                run_m(16 if kind == "sgm" else 4)
+                        for i in range(k):
+                            if i >= nsl:
+                                m.wait(i % nsl)
+                            m.submit_scan(i % nsl, B, dLs[(i % nsl) % len(dLs)].data_ptr(), dRs[(i % nsl) % len(dRs)].data_ptr(), W, H * W, outs_m[i % nsl].data_ptr())
+                        for sl in range(nsl):
+                            m.wait(sl)
+                run_m(16 if kind == "sgm" else 8)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 run_m(reps_m)
@@ -903,7 +918,7 @@ def run_rank(a):
                     if kind in ("bm", "bm_ssd") and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
                         want_m = f[7]
                 other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_process_batch), same inputs as the ELAS regions" %
-                                                 (W, H, a.disp, {"sgm": "SGM 8 paths (four batches in flight)", "bm": "9x9 block matching (SAD, v_qsad)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8)"}[kind], B,
+                                                 (W, H, a.disp, {"sgm": "SGM 8 paths (four batches in flight)", "bm": "9x9 block matching (SAD, v_qsad; four batches in flight)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8; four batches in flight)"}[kind], B,
                                                   "bm" if kind == "bm_ssd" else kind),
                                      "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},
                                      "check": {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None,

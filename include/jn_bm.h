@@ -65,6 +65,14 @@ jn_status jn_bm_process_scan(jn_bm* h, int32_t n, const uint8_t* dI1, const uint
 /* Milliseconds of the last batch: prefilter, the left- and right-referenced matching launches, check + output (+ the scan
  * tail after jn_bm_process_scan). */
 typedef struct jn_bm_times { float prefilter, match, finish, total; } jn_bm_times;
+/* Several batches in flight (as jn_sgm_submit_scan / jn_sgm_wait): slot in [0, 6); each slot has its own stream, events and scratch,
+ * allocated when the slot is first used (slot 0 is the synchronous calls').  jn_bm_submit_scan queues the matcher and — when sp is not
+ * NULL — the mono8 map and the LUT scan on the slot's stream and returns; jn_bm_wait(slot) must precede reading the slot's outputs or
+ * submitting to it again.  With sp == NULL the u8 / bins / meta pointers may be NULL (disparities only).  A process that keeps more than
+ * eight streams busy should export GPU_MAX_HW_QUEUES=16. */
+jn_status jn_bm_submit_scan(jn_bm* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride,
+                            int16_t* dDisp, const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dDispU8, double* dBins, double* dMeta);
+jn_status jn_bm_wait(jn_bm* h, int32_t slot);
 jn_status jn_bm_last_times(jn_bm* h, jn_bm_times* out);
 
 #ifdef __cplusplus

@@ -30,13 +30,16 @@ def _bind():
         L.jn_bm_destroy.restype = None
         L.jn_bm_process_batch.argtypes = [vp, i32, vp, vp, i32, i64, vp]
         L.jn_bm_process_scan.argtypes = [vp, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp]
+        L.jn_bm_submit_scan.argtypes = [vp, i32, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp]
+        L.jn_bm_wait.argtypes = [vp, i32]
         L.jn_bm_last_times.argtypes = [vp, C.POINTER(BmTimes)]
         L.jn_sgm_disparity_to_u8.argtypes = [i32, vp, i32, vp, i64]
         L._bm_bound = True
     return L
 
 
-BM_EXPORTS = ["jn_bm_params_default", "jn_bm_create", "jn_bm_destroy", "jn_bm_process_batch", "jn_bm_process_scan", "jn_bm_last_times"]
+BM_EXPORTS = ["jn_bm_params_default", "jn_bm_create", "jn_bm_destroy", "jn_bm_process_batch", "jn_bm_process_scan", "jn_bm_submit_scan", "jn_bm_wait",
+              "jn_bm_last_times"]
 
 
 class Bm:
@@ -64,6 +67,14 @@ class Bm:
         """Matcher + u8 map + LUT scan on one stream with one synchronisation (jn_bm_process_scan)."""
         _lib.check(self._L.jn_bm_process_scan(self._h, n, dI1, dI2, pitch, image_stride, dDisp, C.byref(scan_params), dLut, dU8, dBins, dMeta),
                    "jn_bm_process_scan")
+
+    def submit_scan(self, slot, n, dI1, dI2, pitch, image_stride, dDisp, scan_params=None, dLut=None, dU8=None, dBins=None, dMeta=None):
+        """jn_bm_submit_scan: queue a batch on `slot` (0..5) and return; without scan_params only the disparities are produced."""
+        _lib.check(self._L.jn_bm_submit_scan(self._h, slot, n, dI1, dI2, pitch, image_stride, dDisp,
+                                             C.byref(scan_params) if scan_params is not None else None, dLut, dU8, dBins, dMeta), "jn_bm_submit_scan")
+
+    def wait(self, slot):
+        _lib.check(self._L.jn_bm_wait(self._h, slot), "jn_bm_wait")
 
     def last_times(self):
         t = BmTimes()

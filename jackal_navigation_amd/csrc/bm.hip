@@ -274,18 +274,28 @@ __global__ void __launch_bounds__(256) k_bm_finish_sub(BmDev s, int n, int band,
 
 }  // namespace
 
+// One slot = one batch in flight: its stream, events and scratch.  Slot 0 exists from jn_bm_create and serves the synchronous calls;
+// slots 1 .. kBmSlots-1 (jn_bm_submit_scan / jn_bm_wait) are allocated when first used.  Batches on different slots overlap on the GPU:
+// the memory-bound prefilter / finish / scan kernels of one run next to the issue-bound matching of another.
+struct BmSlot {
+  uint8_t* g = nullptr;        // prefiltered rows [2 * max_batch][H][Wp]
+  uint32_t* keys = nullptr;    // winners [2][max_batch][H][W]: cost << 8 | d
+  unsigned long long* scan_scratch = nullptr;   // [max_batch][4], the scan tail's extrema
+  int32_t* q = nullptr;        // JN_BM_COST_SSD: key halves / squared patch norms [2 * max_batch][H][Wp]
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {};
+  jn_bm_times times = {};
+  bool ready = false, pending = false;
+};
 struct jn_bm {
   jn_bm_params p;
   BmDev dev;
   int W = 0, H = 0, max_batch = 0, device = 0;
-  uint8_t* g = nullptr;        // prefiltered rows [2 * max_batch][H][Wp]
-  uint32_t* keys = nullptr;    // winners [2][max_batch][H][W]: cost << 8 | d
-  unsigned long long* scan_scratch = nullptr;   // [max_batch][4], the scan tail's extrema
   jnav_bmq::QDev qdev = {};    // JN_BM_COST_SSD: geometry of the matrix-core path (g then holds its plain prefiltered rows)
-  int32_t* q = nullptr;        //                  key halves / squared patch norms [2 * max_batch][H][Wp]
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {};
-  jn_bm_times times = {};
+  size_t g_bytes = 0, q_bytes = 0;
+  enum { kBmSlots = 6 };
+  BmSlot slot[kBmSlots];
+  jn_bm_times times = {};      // of the batch waited for last
 };
 
 #define BM_TRY(expr)                                                                        \
@@ -339,6 +349,19 @@ hipError_t launch_bm_finish(hipStream_t st, const BmDev& s, int n, const uint8_t
 
 }  // namespace
 
+static jn_status bm_ensure_slot(jn_bm* h, int k) {
+  BmSlot& x = h->slot[k];
+  if (x.ready) return JN_OK;
+  if (h->q_bytes) BM_TRY(hipMalloc(reinterpret_cast<void**>(&x.q), h->q_bytes));
+  BM_TRY(hipMalloc(reinterpret_cast<void**>(&x.g), h->g_bytes));
+  BM_TRY(hipMalloc(reinterpret_cast<void**>(&x.keys), (size_t)2 * h->max_batch * h->H * h->W * sizeof(uint32_t)));
+  BM_TRY(hipMalloc(reinterpret_cast<void**>(&x.scan_scratch), sizeof(unsigned long long) * 4 * h->max_batch));
+  BM_TRY(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking));
+  for (auto& e : x.ev) BM_TRY(hipEventCreate(&e));
+  x.ready = true;
+  return JN_OK;
+}
+
 extern "C" {
 
 void jn_bm_params_default(jn_bm_params* p) {
@@ -348,10 +371,12 @@ void jn_bm_params_default(jn_bm_params* p) {
 void jn_bm_destroy(jn_bm* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
-  hipFree(h->g); hipFree(h->keys); hipFree(h->scan_scratch); hipFree(h->q);
-  for (auto& e : h->ev) if (e) hipEventDestroy(e);
-  if (h->stream) hipStreamDestroy(h->stream);
+  for (auto& x : h->slot) {
+    if (x.stream) hipStreamSynchronize(x.stream);
+    hipFree(x.g); hipFree(x.keys); hipFree(x.scan_scratch); hipFree(x.q);
+    for (auto& e : x.ev) if (e) hipEventDestroy(e);
+    if (x.stream) hipStreamDestroy(x.stream);
+  }
   delete h;
 }
 
@@ -373,79 +398,90 @@ jn_status jn_bm_create(const jn_bm_params* p, int32_t W, int32_t H, int32_t max_
   s.W = W; s.H = H; s.D = D; s.r = p->block_radius; s.cap = p->prefilter_cap; s.lr = p->lr_max_diff; s.subpixel = p->subpixel ? 1 : 0;
   s.padx = D + kBmPad; s.Wp = (W + 2 * s.padx + 3) & ~3;
 #define BM_CREATE_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { fprintf(stderr, "libjn_stereo: %s failed: %s\n", #expr, hipGetErrorString(e__)); jn_bm_destroy(h); return JN_ERR_NO_DEVICE; } } while (0)
-  size_t g_bytes = (size_t)2 * max_batch * H * s.Wp + 64;
+  h->g_bytes = (size_t)2 * max_batch * H * s.Wp + 64;
   if (ssd) {
     jnav_bmq::Sizes z;
     jnav_bmq::geometry(W, H, D, p->block_radius, p->prefilter_cap, p->lr_max_diff, p->subpixel, &h->qdev, &z, max_batch);
-    g_bytes = z.g;
-    BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->q), z.q));
+    h->g_bytes = z.g; h->q_bytes = z.q;
   }
-  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->g), g_bytes));
-  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->keys), (size_t)2 * max_batch * H * W * sizeof(uint32_t)));
-  BM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->scan_scratch), sizeof(unsigned long long) * 4 * max_batch));
-  BM_CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  for (auto& e : h->ev) BM_CREATE_TRY(hipEventCreate(&e));
 #undef BM_CREATE_TRY
+  const jn_status es = bm_ensure_slot(h, 0);
+  if (es != JN_OK) { jn_bm_destroy(h); return es; }
   *out = h;
   return JN_OK;
 }
 
-static jn_status bm_run(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
-                        const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dU8, double* dBins, double* dMeta) {
-  if (!h || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dDisp || pitch < h->W) return JN_ERR_INVALID;
+static jn_status bm_submit(jn_bm* h, int k, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
+                           const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dU8, double* dBins, double* dMeta) {
+  if (!h || k < 0 || k >= jn_bm::kBmSlots || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dDisp || pitch < h->W) return JN_ERR_INVALID;
+  if (h->slot[k].pending) return JN_ERR_INVALID;               // one batch per slot: jn_bm_wait first
   BM_TRY(hipSetDevice(h->device));
+  const jn_status es = bm_ensure_slot(h, k);
+  if (es != JN_OK) return es;
+  BmSlot& x = h->slot[k];
   const BmDev& s = h->dev;
-  hipStream_t st = h->stream;
-  BM_TRY(hipEventRecord(h->ev[0], st));
+  hipStream_t st = x.stream;
+  BM_TRY(hipEventRecord(x.ev[0], st));
+  uint32_t* keysL = x.keys;
+  uint32_t* keysR = x.keys + (size_t)h->max_batch * s.H * s.W;
   if (h->p.cost_function == JN_BM_COST_SSD) {                  // squared differences: the banded int8 contraction on the matrix cores (bm_mfma.hip)
-    uint32_t* kL = h->keys;
-    uint32_t* kR = h->keys + (size_t)h->max_batch * s.H * s.W;
-    BM_TRY(jnav_bmq::run(h->qdev, n, dI1, dI2, pitch, (long long)image_stride, h->g, h->q, kL, kR, dDisp, dU8, st, h->ev));
-    if (sp) jnav::launch_scan(st, *sp, n, nullptr, dU8, dLut, s.W, s.H, dBins, dMeta, h->scan_scratch);
-    BM_TRY(hipEventRecord(h->ev[3], st));
-    BM_TRY(hipStreamSynchronize(st));
-    BM_TRY(hipGetLastError());
-    hipEventElapsedTime(&h->times.prefilter, h->ev[0], h->ev[1]);
-    hipEventElapsedTime(&h->times.match, h->ev[1], h->ev[2]);
-    hipEventElapsedTime(&h->times.finish, h->ev[2], h->ev[3]);
-    hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
-    return JN_OK;
+    BM_TRY(jnav_bmq::run(h->qdev, n, dI1, dI2, pitch, (long long)image_stride, x.g, x.q, keysL, keysR, dDisp, dU8, st, x.ev));
+  } else {
+    hipLaunchKernelGGL(k_bm_prefilter, dim3((s.Wp / 4 + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, x.g);
+    BM_TRY(hipEventRecord(x.ev[1], st));
+    // Rows per band: whole turns of the kernel's ring (band + 2r = k (2r+1)) so that no staged row is wasted, as many as
+    // fit 64 rows (halo overhead 2r / band), fewer turns while the launch would leave most of the 256 CUs idle (a lone pair).
+    const int ring = 2 * s.r + 1;
+    int turns = (kBmMaxBand + 2 * s.r) / ring;
+    while (turns > 2 && (long long)((s.W + 63) / 64) * ((s.H + turns * ring - 2 * s.r - 1) / (turns * ring - 2 * s.r)) * n < 1024) turns--;
+    int band = turns * ring - 2 * s.r;
+    if (const char* e = getenv("JN_BM_BAND")) band = std::min(std::max(atoi(e), 1), kBmMaxBand);
+    BM_TRY(launch_bm<0>(st, s, n, band, x.g, keysL));
+    if (s.lr >= 0) BM_TRY(launch_bm<1>(st, s, n, band, x.g, keysR));
+    BM_TRY(hipEventRecord(x.ev[2], st));
+    BM_TRY(launch_bm_finish(st, s, n, x.g, keysL, keysR, dDisp, dU8));
   }
-  hipLaunchKernelGGL(k_bm_prefilter, dim3((s.Wp / 4 + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, (long long)image_stride, n, h->g);
-  BM_TRY(hipEventRecord(h->ev[1], st));
-  // Rows per band: whole turns of the kernel's ring (band + 2r = k (2r+1)) so that no staged row is wasted, as many as
-  // fit 64 rows (halo overhead 2r / band), fewer turns while the launch would leave most of the 256 CUs idle (a lone pair).
-  const int ring = 2 * s.r + 1;
-  int turns = (kBmMaxBand + 2 * s.r) / ring;
-  while (turns > 2 && (long long)((s.W + 63) / 64) * ((s.H + turns * ring - 2 * s.r - 1) / (turns * ring - 2 * s.r)) * n < 1024) turns--;
-  int band = turns * ring - 2 * s.r;
-  if (const char* e = getenv("JN_BM_BAND")) band = std::min(std::max(atoi(e), 1), kBmMaxBand);
-  uint32_t* keysL = h->keys;
-  uint32_t* keysR = h->keys + (size_t)h->max_batch * s.H * s.W;
-  BM_TRY(launch_bm<0>(st, s, n, band, h->g, keysL));
-  if (s.lr >= 0) BM_TRY(launch_bm<1>(st, s, n, band, h->g, keysR));
-  BM_TRY(hipEventRecord(h->ev[2], st));
-  BM_TRY(launch_bm_finish(st, s, n, h->g, keysL, keysR, dDisp, dU8));
-  if (sp) jnav::launch_scan(st, *sp, n, nullptr, dU8, dLut, s.W, s.H, dBins, dMeta, h->scan_scratch);   // the node's tail, same stream
-  BM_TRY(hipEventRecord(h->ev[3], st));
-  BM_TRY(hipStreamSynchronize(st));
+  if (sp) jnav::launch_scan(st, *sp, n, nullptr, dU8, dLut, s.W, s.H, dBins, dMeta, x.scan_scratch);   // the node's tail, same stream
+  BM_TRY(hipEventRecord(x.ev[3], st));
   BM_TRY(hipGetLastError());
-  hipEventElapsedTime(&h->times.prefilter, h->ev[0], h->ev[1]);
-  hipEventElapsedTime(&h->times.match, h->ev[1], h->ev[2]);
-  hipEventElapsedTime(&h->times.finish, h->ev[2], h->ev[3]);
-  hipEventElapsedTime(&h->times.total, h->ev[0], h->ev[3]);
+  x.pending = true;
+  return JN_OK;
+}
+static jn_status bm_wait(jn_bm* h, int k) {
+  if (!h || k < 0 || k >= jn_bm::kBmSlots) return JN_ERR_INVALID;
+  BmSlot& x = h->slot[k];
+  if (!x.pending) return JN_OK;
+  BM_TRY(hipSetDevice(h->device));
+  x.pending = false;
+  BM_TRY(hipStreamSynchronize(x.stream));
+  BM_TRY(hipGetLastError());
+  hipEventElapsedTime(&x.times.prefilter, x.ev[0], x.ev[1]);
+  hipEventElapsedTime(&x.times.match, x.ev[1], x.ev[2]);
+  hipEventElapsedTime(&x.times.finish, x.ev[2], x.ev[3]);
+  hipEventElapsedTime(&x.times.total, x.ev[0], x.ev[3]);
+  h->times = x.times;
   return JN_OK;
 }
 
 jn_status jn_bm_process_batch(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp) {
-  return bm_run(h, n, dI1, dI2, pitch, image_stride, dDisp, nullptr, nullptr, nullptr, nullptr, nullptr);
+  const jn_status r = bm_submit(h, 0, n, dI1, dI2, pitch, image_stride, dDisp, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return r != JN_OK ? r : bm_wait(h, 0);
 }
 
 jn_status jn_bm_process_scan(jn_bm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
                              const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dDispU8, double* dBins, double* dMeta) {
   if (!sp || !dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024) return JN_ERR_INVALID;
-  return bm_run(h, n, dI1, dI2, pitch, image_stride, dDisp, sp, dLut, dDispU8, dBins, dMeta);
+  const jn_status r = bm_submit(h, 0, n, dI1, dI2, pitch, image_stride, dDisp, sp, dLut, dDispU8, dBins, dMeta);
+  return r != JN_OK ? r : bm_wait(h, 0);
 }
+
+jn_status jn_bm_submit_scan(jn_bm* h, int32_t slot, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp,
+                            const jn_scan_params* sp, const uint8_t* dLut, uint8_t* dDispU8, double* dBins, double* dMeta) {
+  if (sp && (!dLut || !dDispU8 || !dBins || !dMeta || sp->bins < 1 || sp->bins > 1024)) return JN_ERR_INVALID;
+  return bm_submit(h, slot, n, dI1, dI2, pitch, image_stride, dDisp, sp, dLut, dDispU8, dBins, dMeta);
+}
+
+jn_status jn_bm_wait(jn_bm* h, int32_t slot) { return bm_wait(h, slot); }
 
 jn_status jn_bm_last_times(jn_bm* h, jn_bm_times* out) {
   if (!h || !out) return JN_ERR_INVALID;

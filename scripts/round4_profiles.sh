@@ -30,20 +30,21 @@ JN_SGM_IMPL=0 python3 bench.py --mode sgm --sgm-slots 1 --steps 5 --warmup 2 --n
 for ns in 2 4 8; do echo "JN_SGM_FLOW=1 JN_SGM_NS=$ns $(JN_SGM_NS=$ns python3 bench.py --mode sgm --sgm-slots 1 --steps 4 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s", j["stage_ms_per_batch"])')"; done; } > $out/${tag}_sgm_strips_ab.txt
 # ---- block-matching mode ----
 cd /tmp
-fresh ${tag}_bm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm -- python3 $R/bench.py --mode bm --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm.log 2>&1
+fresh ${tag}_bm; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm -- python3 $R/bench.py --mode bm --bm-slots 1 --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm.log 2>&1
 cd $R
 python3 scripts/kstats.py $(ls $out/${tag}_bm/*/*kernel_stats.csv | tail -1) 8 > $out/${tag}_bm_summary.txt
 python3 bench.py --mode bm --steps 20 --warmup 3 > $out/${tag}_bm_bench_line.json 2> $out/${tag}_bm_bench.err
-python3 bench.py --mode bm --width 640 --height 480 --disp 64 --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/${tag}_bm_config2_bench_line.json 2>> $out/${tag}_bm_bench.err
+python3 bench.py --mode bm --bm-slots 1 --width 640 --height 480 --disp 64 --batch 1 --steps 200 --warmup 20 --no-cpu-baseline > $out/${tag}_bm_config2_bench_line.json 2>> $out/${tag}_bm_bench.err
 # ---- block matching with the squared-difference cost on the matrix cores (csrc/bm_mfma.hip), next to the v_qsad kernel ----
 cd /tmp
-fresh ${tag}_bm_ssd; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm_ssd -- python3 $R/bench.py --mode bm --bm-cost ssd --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm_ssd.log 2>&1
+fresh ${tag}_bm_ssd; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_bm_ssd -- python3 $R/bench.py --mode bm --bm-cost ssd --bm-slots 1 --steps 10 --warmup 2 --no-cpu-baseline > $R/$out/${tag}_bm_ssd.log 2>&1
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*" | sort -u > $R/$out/${tag}_mfma_counters_available.txt
-fresh ${tag}_bm_ssd_pmc; timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $R/$out/${tag}_bm_ssd_pmc -- python3 $R/bench.py --mode bm --bm-cost ssd --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_bm_ssd_pmc.log 2>&1
+fresh ${tag}_bm_ssd_pmc; timeout 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA --output-format csv -d $R/$out/${tag}_bm_ssd_pmc -- python3 $R/bench.py --mode bm --bm-cost ssd --bm-slots 1 --steps 2 --warmup 1 --no-cpu-baseline > $R/$out/${tag}_bm_ssd_pmc.log 2>&1
 cd $R
 python3 scripts/kstats.py $(ls $out/${tag}_bm_ssd/*/*kernel_stats.csv | tail -1) 8 > $out/${tag}_bm_ssd_summary.txt
 { echo "# counters with MFMA in their name on this box: $(tr '\n' ' ' < $out/${tag}_mfma_counters_available.txt)"; python3 scripts/pmc.py $(ls $out/${tag}_bm_ssd_pmc/*/*counter_collection.csv | tail -1) "k_bmq_"; } > $out/${tag}_bm_ssd_pmc_mfma.txt 2>&1
 python3 bench.py --mode bm --bm-cost ssd --steps 20 --warmup 3 > $out/${tag}_bm_ssd_bench_line.json 2>> $out/${tag}_bm_bench.err
+{ for c in sad ssd; do for ss in 1 2 4 6 1 4; do echo "--mode bm --bm-cost $c --bm-slots $ss: $(python3 bench.py --mode bm --bm-cost $c --bm-slots $ss --steps 40 --warmup 8 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch")')"; done; done; } > $out/${tag}_bm_slots_ab.txt
 python3 bench.py --mode bm --bm-cost ssd --width 1920 --height 1080 --disp 256 --batch 8 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bm_ssd_1080p_bench_line.json 2>> $out/${tag}_bm_bench.err
 python3 bench.py --mode bm --bm-cost sad --width 1920 --height 1080 --disp 256 --batch 8 --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bm_sad_1080p_bench_line.json 2>> $out/${tag}_bm_bench.err
 # ---- the north star's other frame sizes, one JSON line each ----

@@ -219,3 +219,46 @@ def test_bm_ssd_refuses_ranges_it_does_not_tile(jn):
     assert e.value.status == _lib.JN_ERR_UNSUPPORTED
     with pytest.raises(_lib.JnError):
         jn.Bm(jn.Bm.parameters(num_disparities=64, cost_function=7), 320, 240)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cost", [0, 1])
+def test_bm_pipelined_slots_equal_the_synchronous_call(jn, oracle, cost):
+    """jn_bm_submit_scan / jn_bm_wait: four batches of different frames in flight on four slots (slots 1-3 allocate their own scratch), with the
+    node's tail on the slot's stream — disparities, u8 maps and scans must equal what jn_bm_process_scan gives for the same frames, twice over
+    (the slots are reused); both cost functions; a second submit on a busy slot is refused."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node, _lib
+    W, H, D, n, S = 320, 180, 64, 2, 4
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    frames = [[oracle.synth_pair(W, H, 48, 700 + 10 * k + t) for t in range(n)] for k in range(2 * S)]
+    dL = [DeviceArray.from_numpy(np.stack([f[0] for f in fs])) for fs in frames]
+    dR = [DeviceArray.from_numpy(np.stack([f[1] for f in fs])) for fs in frames]
+    with jn.Bm(jn.Bm.parameters(num_disparities=D, subpixel=1, cost_function=cost), W, H, max_batch=n) as m:
+        want = []
+        for k in range(2 * S):
+            dd = DeviceArray((n, H, W), np.int16); du = DeviceArray((n, H, W), np.uint8)
+            bins = DeviceArray((n, sp.bins), np.float64); meta = DeviceArray((n, 4), np.float64)
+            m.process_scan(n, dL[k].ptr, dR[k].ptr, W, H * W, dd.ptr, sp, lut.ptr, du.ptr, bins.ptr, meta.ptr)
+            want.append((dd.numpy().copy(), du.numpy().copy(), bins.numpy().copy(), meta.numpy().copy()))
+        outs = [dict(dd=DeviceArray((n, H, W), np.int16), du=DeviceArray((n, H, W), np.uint8), bins=DeviceArray((n, sp.bins), np.float64),
+                     meta=DeviceArray((n, 4), np.float64)) for _ in range(S)]
+        got = [None] * (2 * S)
+        for k in range(2 * S):
+            s = k % S
+            if k >= S:
+                m.wait(s)
+                got[k - S] = tuple(outs[s][x].numpy().copy() for x in ("dd", "du", "bins", "meta"))
+            o = outs[s]
+            m.submit_scan(s, n, dL[k].ptr, dR[k].ptr, W, H * W, o["dd"].ptr, sp, lut.ptr, o["du"].ptr, o["bins"].ptr, o["meta"].ptr)
+            if k == 0:
+                with pytest.raises(_lib.JnError):               # one batch per slot
+                    m.submit_scan(s, n, dL[k].ptr, dR[k].ptr, W, H * W, o["dd"].ptr, sp, lut.ptr, o["du"].ptr, o["bins"].ptr, o["meta"].ptr)
+        for k in range(S, 2 * S):
+            s = k % S
+            m.wait(s)
+            got[k] = tuple(outs[s][x].numpy().copy() for x in ("dd", "du", "bins", "meta"))
+        for k in range(2 * S):
+            for a, b in zip(got[k], want[k]):
+                assert np.array_equal(a, b), (cost, k)
