@@ -8,9 +8,10 @@ compute lives in csrc/.  Importing the compute API requires the built library; t
 import os as _os
 
 # One hardware queue per slot stream: the HIP runtime multiplexes streams onto 4 hardware queues by default, so with
-# 4 slots + the caller's stream two slots share a queue and serialise (measured: -10 % pairs/s).  Must be in the
-# environment before the HIP runtime initialises; an explicit setting by the user wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# 4 slots + the caller's stream two slots share a queue and serialise (measured: -10 % pairs/s).  16 since round 4: a process
+# that holds an ELAS handle AND the SGM or block-matching mode's slots needs more than 8 (profiles/r04_hw_queues_ab.txt).  Must be
+# in the environment before the HIP runtime initialises; an explicit setting by the user wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # noqa: F401
 from .elas import Elas  # noqa: F401

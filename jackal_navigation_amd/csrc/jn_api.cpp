@@ -150,9 +150,11 @@ int comm_device(const jn_comm* c);
 namespace {
 
 // Runs when the library is loaded.  The HIP runtime multiplexes streams onto 4 hardware queues by default; with one
-// stream per slot plus the caller's, two slots then share a queue and serialise.  Ask for 8 unless the user chose a
-// value; it only takes effect if the HIP runtime has not initialised yet (load this library first, or export it).
-__attribute__((constructor)) void prefer_one_queue_per_slot() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// stream per slot plus the caller's, two slots then share a queue and serialise.  Ask for 16 unless the user chose a
+// value (8 until round 4: enough for one four-slot handle, but a process that also runs the SGM or block-matching mode
+// with its own slots lost 10 % there, profiles/r04_hw_queues_ab.txt; 16 measured neutral for a single handle); it only
+// takes effect if the HIP runtime has not initialised yet (load this library first, or export it).
+__attribute__((constructor)) void prefer_one_queue_per_slot() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 // Waiting for the GPU without burning the host's cores.  hipEventSynchronize spins on this runtime even for events created
 // with hipEventBlockingSync: the four slot workers then cost 2.5 cores of pure waiting (measured: 4.2 ms of CPU per 32-pair
