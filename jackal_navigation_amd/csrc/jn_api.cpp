@@ -381,15 +381,21 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     void open() { if (word) { std::atomic_thread_fence(std::memory_order_seq_cst); *word = value; word = nullptr; } }
     ~GateGuard() { open(); }
   } gate;
-  const bool gated = h->gate_stage_b && s.gate && filtered && h->zero_copy_payload && sa == st;
+  bool gated = h->gate_stage_b && s.gate && filtered && h->zero_copy_payload && sa == st;
+  bool cleared = false;                                  // the two clears are on the stream already
   if (gated) {
     if (!grid_early) launch_grid_clear(st, dp, n, s.mark);
     launch_bin_clear(st, dp, n, s.bin_count);
+    cleared = true;
     const uint32_t v = ++s.gate_seq;
-    HIP_TRY(hipStreamWaitValue32(st, s.gate, v, hipStreamWaitValueEq, 0xFFFFFFFFu));
-    gate.word = s.gate; gate.value = v;
-    const jn_status qs = queue_stage_b(list_cap + HostWorker::kCornerPoints, h->tri_cap, true, s.h_payload, 0, true);
-    if (qs != JN_OK) return qs;
+    if (hipStreamWaitValue32(st, s.gate, v, hipStreamWaitValueEq, 0xFFFFFFFFu) != hipSuccess) {
+      (void)hipGetLastError();                           // a runtime that reports the capability but refuses the call: this handle goes on without the gate
+      h->gate_stage_b = false; gated = false;
+    } else {
+      gate.word = s.gate; gate.value = v;
+      const jn_status qs = queue_stage_b(list_cap + HostWorker::kCornerPoints, h->tri_cap, true, s.h_payload, 0, true);
+      if (qs != JN_OK) return qs;
+    }
   }
   HIP_TRY(wait_event(s.ev[EV_D2H], h->wait_spin_us));
 
@@ -453,7 +459,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   else {
     // A latency-mode handle lets the two kernels that consume the payload read it where the host wrote it (pinned memory is visible to
     // the device): a lone pair's payload is ~50 KB read once, and the copy plus the pause behind it cost more than that (JN_ZERO_COPY=0/1).
-    const jn_status qs = queue_stage_b(max_sup, max_tri, any_ok != 0, h->zero_copy_payload ? s.h_payload : s.payload, payload_bytes, false);
+    const jn_status qs = queue_stage_b(max_sup, max_tri, any_ok != 0, h->zero_copy_payload ? s.h_payload : s.payload, payload_bytes, cleared);
     if (qs != JN_OK) return qs;
   }
   HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
