@@ -39,7 +39,8 @@ typedef struct jn_bm_params {
   int32_t lr_max_diff;       /* L/R check tolerance; < 0 disables the check (and the right-referenced pass) */
   int32_t subpixel;          /* 0: integer disparities, 1: 1/16 pixel */
   int32_t cost_function;     /* JN_BM_COST_SAD (default) or JN_BM_COST_SSD (then D must be a multiple of 32 in [32, 256]) */
-} jn_bm_params;
+} jn_bm_params;   /* ABI: six int32 since jn_version() "jn_stereo 0.3" (0.2 had five, without cost_function); the struct carries no size
+                   * field, so a caller checks jn_version() — or simply fills the struct through jn_bm_params_default() — before jn_bm_create */
 #define JN_BM_COST_SAD 0
 #define JN_BM_COST_SSD 1
 

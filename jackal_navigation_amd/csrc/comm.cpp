@@ -189,14 +189,9 @@ static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins
   return JN_OK;
 }
 
-jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta) {
-  if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
-  if (c->dead.load()) return JN_ERR_COMM;
-  Rccl* R = rccl();
-  if (!R) return JN_ERR_COMM;
-  const jn_status st = queue_merge(c, R, n, bins, dBins, dMeta, nullptr, nullptr);
-  if (st != JN_OK) return st;
-  // bounded (JN_COMM_TIMEOUT_MS, default 30 s, 0 = for ever): a peer that never joins must not hang this rank
+// Wait for everything queued on the communicator's stream, at most JN_COMM_TIMEOUT_MS (default 30 s, 0 = for ever): a peer that never
+// joins must not hang this rank — the communicator is aborted instead and the call reports JN_ERR_COMM.  Called WITHOUT c->m.
+static jn_status bounded_stream_wait(jn_comm* c) {
   int timeout_ms = 30000;
   if (const char* e = getenv("JN_COMM_TIMEOUT_MS")) timeout_ms = atoi(e);
   if (timeout_ms <= 0) { HIP_TRY_C(hipStreamSynchronize(c->stream)); }
@@ -210,6 +205,19 @@ jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, 
       std::this_thread::sleep_for(std::chrono::microseconds(50));
     }
   }
+  if (c->dead.load()) return JN_ERR_COMM;                    // another thread aborted meanwhile: what completed was the aborted kernels, not a reduction
+  return JN_OK;
+}
+
+jn_status jn_scan_allreduce(jn_comm* c, int32_t n, int32_t bins, double* dBins, double* dMeta) {
+  if (!c || n < 1 || bins < 1 || !dBins || !dMeta) return JN_ERR_INVALID;
+  if (c->dead.load()) return JN_ERR_COMM;
+  Rccl* R = rccl();
+  if (!R) return JN_ERR_COMM;
+  const jn_status st = queue_merge(c, R, n, bins, dBins, dMeta, nullptr, nullptr);
+  if (st != JN_OK) return st;
+  const jn_status ws = bounded_stream_wait(c);
+  if (ws != JN_OK) return ws;
   HIP_TRY_C(hipGetLastError());
   return JN_OK;
 }
@@ -231,22 +239,25 @@ jn_status comm_merge_identity(jn_comm* c, int n, int bins) {
   if (!c || n < 1 || bins < 1) return JN_ERR_INVALID;
   Rccl* R = rccl();
   if (!R) return JN_ERR_COMM;
-  std::lock_guard<std::mutex> guard(c->m);
-  if (c->dead.load()) return JN_ERR_COMM;
-  HIP_TRY_C(hipSetDevice(c->device));
   const size_t count = (size_t)n * (bins + 4);
-  if (count > c->cap) {
-    HIP_TRY_C(hipStreamSynchronize(c->stream));
-    if (c->flat) hipFree(c->flat);
-    c->flat = nullptr; c->cap = 0;
-    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
-    c->cap = count;
-  }
   const std::vector<double> ident(count, INFINITY);
-  HIP_TRY_C(hipMemcpyAsync(c->flat, ident.data(), count * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
-  HIP_TRY_C(hipStreamSynchronize(c->stream));
-  return JN_OK;
+  {
+    std::lock_guard<std::mutex> guard(c->m);
+    if (c->dead.load()) return JN_ERR_COMM;
+    HIP_TRY_C(hipSetDevice(c->device));
+    if (count > c->cap) {
+      HIP_TRY_C(hipStreamSynchronize(c->stream));
+      if (c->flat) hipFree(c->flat);
+      c->flat = nullptr; c->cap = 0;
+      HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
+      c->cap = count;
+    }
+    HIP_TRY_C(hipMemcpy(c->flat, ident.data(), count * sizeof(double), hipMemcpyHostToDevice));   // synchronous: `ident` is pageable and dies with this call
+    RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
+  }
+  // bounded like every other wait on the communicator (the peer this rank is feeding may itself be gone), and outside c->m so that an
+  // abort from another slot's worker is not locked out
+  return bounded_stream_wait(c);
 }
 // A collective that does not complete (a peer died or never joined): ncclCommAbort ends the kernel this rank is stuck in and
 // releases the communicator's resources; the handle stays allocated (jn_comm_destroy frees it) but is dead from here on.
@@ -254,6 +265,9 @@ void comm_abort(jn_comm* c) {
   if (!c || c->dead.exchange(true)) return;
   Rccl* R = rccl();
   fprintf(stderr, "libjn_stereo: cross-rig merge on rank %d of %d did not complete in time: aborting the communicator\n", c->rank, c->world);
+  // under c->m: queue_merge / comm_merge_identity check `dead` and use c->comm under the same mutex, so none of them can be between
+  // its check and its ncclAllReduce while the communicator goes away (enqueueing a collective does not block, the lock is short)
+  std::lock_guard<std::mutex> guard(c->m);
   if (R && R->CommAbort && c->comm) { R->CommAbort(c->comm); c->comm = nullptr; }
 }
 bool comm_dead(const jn_comm* c) { return c && c->dead.load(); }

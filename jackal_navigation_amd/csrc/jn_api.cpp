@@ -126,7 +126,7 @@ struct jn_elas {
   bool sub = false;                 // param.subsampling: half-size maps (elas.h:82, :160-162); dph = the post-processing's parameters at that size
   DevParams dph = {};
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
-  bool gate_stage_b = false;        // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
+  std::atomic<bool> gate_stage_b{false};   // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
   std::vector<uint64_t> merge_log;                            // submission numbers in the order their merges were queued (the last 4096; jn_elas_merge_order)
   int comm_timeout_ms = 30000;                                // JN_COMM_TIMEOUT_MS: a merge not complete by then is aborted (0: wait for ever)
@@ -378,8 +378,18 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   // stream left waiting would hang the handle.
   struct GateGuard {
     volatile uint32_t* word = nullptr; uint32_t value = 0;
+    FrameInfo* info = nullptr; int n = 0; hipStream_t st = nullptr;
     void open() { if (word) { std::atomic_thread_fence(std::memory_order_seq_cst); *word = value; word = nullptr; } }
-    ~GateGuard() { open(); }
+    // An early return with the gate still shut: stage B is on the stream and WILL run once the gate opens, on whatever FrameInfo holds —
+    // the previous batch's, if the host stage never ran.  Every frame is therefore marked as failed first (the matching and the
+    // post-processing return on !ok; the scan tail still scans whatever D1 holds into the caller's buffers), and the stream is drained
+    // before the error goes back: the caller may free its buffers as soon as it has it.
+    ~GateGuard() {
+      if (!word) return;
+      for (int i = 0; i < n; i++) info[i].ok = 0;
+      open();
+      hipStreamSynchronize(st);
+    }
   } gate;
   bool gated = h->gate_stage_b && s.gate && filtered && h->zero_copy_payload && sa == st;
   bool cleared = false;                                  // the two clears are on the stream already
@@ -392,7 +402,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       (void)hipGetLastError();                           // a runtime that reports the capability but refuses the call: this handle goes on without the gate
       h->gate_stage_b = false; gated = false;
     } else {
-      gate.word = s.gate; gate.value = v;
+      gate.word = s.gate; gate.value = v; gate.info = s.h_info; gate.n = n; gate.st = st;
       const jn_status qs = queue_stage_b(list_cap + HostWorker::kCornerPoints, h->tri_cap, true, s.h_payload, 0, true);
       if (qs != JN_OK) return qs;
     }
@@ -499,6 +509,9 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       const hipError_t we = wait_event_bounded(s.ev_merged, std::max(h->wait_spin_us, 400), h->comm_timeout_ms);
       if (we == hipErrorNotReady) { comm_abort(h->comm); return JN_ERR_COMM; }
       HIP_TRY(we);
+      // another slot's merge timed out and aborted the communicator meanwhile: this merge's event completed because the aborted kernels
+      // exited, its bins were never reduced
+      if (comm_dead(h->comm)) return JN_ERR_COMM;
     }
     merge_host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_m0).count();
     merged = true;
@@ -592,7 +605,7 @@ extern "C" void jn_elas_destroy(jn_elas* h);
 
 extern "C" {
 
-const char* jn_version(void) { return "jn_stereo 0.2 (gfx950)"; }
+const char* jn_version(void) { return "jn_stereo 0.3 (gfx950)"; }
 
 uint64_t jn_fnv1a64_u32(const uint32_t* words, int64_t n) {
   uint64_t h = 1469598103934665603ull;

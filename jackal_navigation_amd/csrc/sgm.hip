@@ -271,6 +271,7 @@ struct jn_sgm {
   jnav_sgm::SweepBuffers sb = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
+  hipEvent_t ev_end[6] = {};   // per slot: recorded behind EVERYTHING a submit queued (sweeps + the scan tail); what jn_sgm_wait waits for
   jn_sgm_times times = {};
   // Pipelined form (jn_sgm_submit_scan / jn_sgm_wait): slot 0 is the set above, slots 1 .. kSgmSlots-1 get their own stream, events and
   // buffers the first time they are used.  Batches on different slots overlap on the GPU: the upward sweep's tail (the last blocks of
@@ -280,6 +281,7 @@ struct jn_sgm {
   Extra extra[kSgmSlots - 1];
   unsigned long long* scan_scratch[kSgmSlots] = {};   // [max_batch][4] per slot, the scan tail's extrema
   bool pending[kSgmSlots] = {};
+  static_assert(kSgmSlots == sizeof(ev_end) / sizeof(ev_end[0]), "one end event per slot");
 };
 
 #define SGM_TRY(expr)                                                                       \
@@ -313,6 +315,7 @@ void jn_sgm_destroy(jn_sgm* h) {
   jnav_sgm::sweep_release(h->sb);
   hipFree(h->sb.gm); hipFree(h->sb.volF); hipFree(h->sb.volH0); hipFree(h->sb.volH1); hipFree(h->sb.gx); hipFree(h->sb.flags); hipFree(h->sb.minr); hipFree(h->sb.dl);
   for (auto& e : h->ev) if (e) hipEventDestroy(e);
+  for (auto& e : h->ev_end) if (e) hipEventDestroy(e);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -363,6 +366,7 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
 
 jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride, int16_t* dDisp) {
   if (!h || n < 1 || n > h->max_batch || !dI1 || !dI2 || !dDisp || pitch < h->W) return JN_ERR_INVALID;
+  if (h->pending[0]) return JN_ERR_INVALID;                     // slot 0's buffers carry a submitted batch: jn_sgm_wait(h, 0) first
   SGM_TRY(hipSetDevice(h->device));
   const SgmDev& s = h->dev;
   hipStream_t st = h->stream;
@@ -451,6 +455,9 @@ jn_status jn_sgm_submit_scan(jn_sgm* h, int32_t slot, int32_t n, const uint8_t* 
     hipLaunchKernelGGL(k_sgm_to_u8, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, dDisp, h->p.subpixel ? 1 : 0, dDispU8, px);
     jnav::launch_scan(st, *sp, n, nullptr, dDispU8, dLut, h->W, h->H, dBins, dMeta, h->scan_scratch[slot]);
   }
+  // the batch's end: behind the scan tail, not behind the sweeps (ev[3] stays the end of the winner-takes-all timing)
+  if (!h->ev_end[slot]) SGM_TRY(hipEventCreateWithFlags(&h->ev_end[slot], hipEventDisableTiming));
+  SGM_TRY(hipEventRecord(h->ev_end[slot], st));
   SGM_TRY(hipGetLastError());
   h->pending[slot] = true;
   return JN_OK;
@@ -460,11 +467,10 @@ jn_status jn_sgm_wait(jn_sgm* h, int32_t slot) {
   if (!h || slot < 0 || slot >= jn_sgm::kSgmSlots) return JN_ERR_INVALID;
   if (!h->pending[slot]) return JN_OK;
   SGM_TRY(hipSetDevice(h->device));
-  hipStream_t st = slot == 0 ? h->stream : h->extra[slot - 1].stream;
   hipEvent_t* ev = slot == 0 ? h->ev : h->extra[slot - 1].ev;
   jn_sgm_times& t = slot == 0 ? h->times : h->extra[slot - 1].times;
   h->pending[slot] = false;
-  SGM_TRY(hipEventSynchronize(ev[3]));                          // the slot's own end (its stream may carry a later slot's batch)
+  SGM_TRY(hipEventSynchronize(h->ev_end[slot]));                // the slot's own end, scan tail included (its stream may carry a later slot's batch)
   SGM_TRY(hipGetLastError());
   hipEventElapsedTime(&t.prefilter, ev[0], ev[1]);
   hipEventElapsedTime(&t.paths, ev[1], ev[2]);

@@ -230,3 +230,37 @@ def test_sgm_pipelined_slots_equal_the_synchronous_call(jn, oracle):
         for a, b in zip(want[k], got[k]):
             assert np.array_equal(a, b), k
         assert (want[k][0] >= 0).mean() > 0.5
+
+
+def test_sgm_wait_covers_the_scan_tail_at_full_size(jn, oracle):
+    """jn_sgm_wait returns when the WHOLE batch is complete — the u8 map and the LUT scan queued behind the sweeps included (ADVICE r04:
+    it used to wait for the event behind the L/R kernel only, and the slot streams are non-blocking, so a copy right after the wait could
+    read bins that were still being written).  1280x720, batch 8: the tail is long enough to lose that race; the outputs are read straight
+    after the wait and must equal the synchronous route's.  Also: the synchronous call refuses to run on slot 0 while it carries a batch."""
+    from jackal_navigation_amd.device import DeviceArray
+    from jackal_navigation_amd import node, _lib
+    W, H, D, n = 1280, 720, 128, 8
+    sp = node.scan_params(W, H)
+    lut = node.build_valid_disp_lut(sp, W, H)
+    pairs = [oracle.synth_pair(W, H, 100, 4000 + b) for b in range(n)]
+    dL = DeviceArray.from_numpy(np.stack([p[0] for p in pairs])); dR = DeviceArray.from_numpy(np.stack([p[1] for p in pairs]))
+    with jn.Sgm(jn.Sgm.parameters(num_disparities=D), W, H, max_batch=n) as m:
+        dd = DeviceArray((n, H, W), np.int16); du = DeviceArray((n, H, W), np.uint8)
+        bins = DeviceArray((n, sp.bins), np.float64); meta = DeviceArray((n, 4), np.float64)
+        m.process_batch(n, dL.ptr, dR.ptr, W, H * W, dd.ptr)
+        m.to_u8(dd.ptr, du.ptr, n * H * W)
+        node.obstacle_scan(sp, n, du.ptr, lut.ptr, W, H, bins.ptr, meta.ptr)
+        want = (du.numpy().copy(), bins.numpy().copy(), meta.numpy().copy())
+        for slot in (0, 1, 0, 1, 0):
+            du2 = DeviceArray((n, H, W), np.uint8); bins2 = DeviceArray((n, sp.bins), np.float64); meta2 = DeviceArray((n, 4), np.float64)
+            bins2.fill(0) if hasattr(bins2, "fill") else None
+            m.submit_scan(slot, n, dL.ptr, dR.ptr, W, H * W, dd.ptr, sp, lut.ptr, du2.ptr, bins2.ptr, meta2.ptr)
+            if slot == 0:
+                with pytest.raises(_lib.JnError):
+                    m.process_batch(n, dL.ptr, dR.ptr, W, H * W, dd.ptr)
+            m.wait(slot)
+            got = (du2.numpy(), bins2.numpy(), meta2.numpy())       # plain hipMemcpy: not ordered behind the slot's non-blocking stream
+            for a, b in zip(want, got):
+                assert np.array_equal(a, b), slot
+            for a in (du2, bins2, meta2):
+                a.free()
