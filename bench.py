@@ -126,7 +126,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency-config", action="store_true",
                     help="skip the informational 640x480 batch-1 leg (profiles then hold the headline workload's launches only)")
-    ap.add_argument("--no-alone-leg", action="store_true", help="skip the un-pipelined leg that times k_dense running alone")
+    ap.add_argument("--no-alone-leg", action="store_true", help="skip the un-pipelined leg that times k_dense_row running alone")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (=RCCL, default) or gloo; gloo + --share-gpu lets two ranks dry-run the N>1 path on one GPU")
     ap.add_argument("--merge", default="cabi", choices=["cabi", "torch"],
@@ -644,6 +644,7 @@ def run_rank(a):
 
     stage_acc = {}
     dense_ms = []
+    owner_ms = []
     merge_ms = []
     merge_state = {"attached": comm is not None}
 
@@ -653,6 +654,7 @@ def run_rank(a):
         for k, v in elas.last_times(slot).items():
             stage_acc.setdefault(k, []).append(v)
         dense_ms.append(elas.kernel_time(slot)[0])
+        owner_ms.append(elas.kernel_time(slot, b"k_owner")[0])
         if merge_state["attached"]:               # merged already: the batch ended with the all-reduce (jn_elas_set_comm)
             merge_ms.append(elas.merge_time(slot))
             return
@@ -735,12 +737,13 @@ def run_rank(a):
             stage_acc.clear(); run(a.warmup)           # stage times of the un-merged pipeline again, as in a plain run
             stage_ms = {k: float(np.mean(v)) for k, v in stage_acc.items()}
 
-    # k_dense running ALONE (one batch in flight, kernels back to back): what the roofline fraction is computed from
-    k_ms_alone = None
+    # k_dense_row running ALONE (one batch in flight, kernels back to back): what the roofline fraction is computed from
+    k_ms_alone = owner_ms_alone = None
     if not a.no_alone_leg:
-        del dense_ms[:]
+        del dense_ms[:]; del owner_ms[:]
         run(6, depth=1)
         k_ms_alone = float(np.mean(dense_ms[1:]))
+        owner_ms_alone = float(np.mean(owner_ms[1:]))
     sync()
 
     # what was timed is what the reference computes: EVERY frame of EVERY slot after the timed region against what the compiled reference
@@ -782,7 +785,7 @@ def run_rank(a):
                            "(OpenCV / ROS side by definition)",
                  "ok": (len(bad) == 0) if n_d1 else None}
 
-    # roofline of the dominant kernel, k_dense: algorithmic bytes per launch (dense L+R = 16 B per pixel per
+    # roofline of the dominant kernel, k_dense_row: algorithmic bytes per launch (dense L+R = 16 B per pixel per
     # pair, one launch = the whole batch, both sides) over its average duration, measured with HIP events the library
     # records around the kernel on the stream it runs on.
     alg_bytes = STAGE_BYTES_PER_PX["gpu_matching"] * W * H * B
@@ -800,15 +803,16 @@ def run_rank(a):
                 traffic_note = "PMC passes in %s were taken with a different kernels.hip (sha256 differs): not reported" % os.path.basename(PMC_FILE)
     except Exception:
         traffic_note = "no PMC file for this round yet"
-    roofline = {"bound": "hbm", "kernel": "k_dense", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_dense_row", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "ms_per_launch": round(k_ms, 4), "ms_per_launch_is": "alone (one batch in flight)" if k_ms_alone else "pipelined",
                 "ms_per_launch_pipelined": round(k_ms_pipelined, 4),
                 "frac_pipelined": round(alg_bytes / (k_ms_pipelined * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "whole_path_frac": round(value / world * 97.0 * W * H / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "k_dense is bound by vector-instruction issue, not by HBM; pipelined, its launches stretch because "
-                        "kernels of the other slots share the GPU"}
+                "ms_owner_pass": round(owner_ms_alone, 4) if owner_ms_alone else None,
+                "note": "k_dense_row (the dense matcher; k_owner in front of it resolves which triangle owns a pixel: ms_owner_pass, same stage) is bound by "
+                        "vector-instruction issue, not by HBM; pipelined, its launches stretch because kernels of the other slots share the GPU"}
     if traffic_note:
         roofline["traffic_note"] = traffic_note
     roofline.update(extra_roof)

@@ -325,8 +325,9 @@ jn_status jn_memcpy_d2h(int32_t device, void* dst, const void* src, int64_t byte
 jn_status jn_device_synchronize(int32_t device);
 
 /* Timing of one kernel class with HIP events on the library's own stream, for bench.py's
- * roofline block: average milliseconds per launch of the dense-matching kernel during the last
- * batch of `slot` (both sides), and launches counted. */
+ * roofline block: average milliseconds per launch during the last batch of `slot` (both sides), and
+ * launches counted.  kernel: "k_dense_row" (or "k_dense": the dense matcher of the handle's data
+ * flow), "k_owner" (the ownership pass in front of k_dense_row; 0 for a handle on materialised descriptors). */
 jn_status jn_elas_kernel_time(jn_elas* h, int32_t slot, const char* kernel, float* avg_ms, int32_t* launches);
 
 const char* jn_version(void);

@@ -68,7 +68,7 @@ struct Slot {
   uint32_t* gate = nullptr; uint32_t gate_seq = 0;            // latency mode: the word stage B's queued launches wait on (hipMallocSignalMemory), see run_batch
   hipEvent_t ev[EV_COUNT] = {};
   // device
-  uint4* desc = nullptr; int16_t* d_can = nullptr;
+  uint4* desc = nullptr; uint8_t* planes = nullptr; int16_t* d_can = nullptr;   // descriptors: materialised (the old flow) OR the two Sobel planes (h->plane_flow)
   FrameInfo* info = nullptr; uint8_t* payload = nullptr; int32_t* bin_count = nullptr; BinEntry* bin_list = nullptr; int16_t* raw = nullptr;
   float* tmp = nullptr; int32_t* label = nullptr; int32_t* size = nullptr;
   uint32_t* mark = nullptr; uint32_t* gridbits = nullptr; TriRec* recs = nullptr;
@@ -89,7 +89,8 @@ struct Slot {
   bool has_job = false, busy = false, quit = false;
   Job job; jn_status result = JN_OK;
   jn_stage_times times = {};
-  float dense_ms = 0; int dense_launches = 0;
+  float dense_ms = 0, owner_ms = 0; int dense_launches = 0;
+  hipEvent_t ev_owner = nullptr;                               // between k_owner and k_dense_row (plane flow, stage events on)
 };
 
 }  // namespace
@@ -126,6 +127,7 @@ struct jn_elas {
   bool sub = false;                 // param.subsampling: half-size maps (elas.h:82, :160-162); dph = the post-processing's parameters at that size
   DevParams dph = {};
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
+  bool plane_flow = true;           // descriptors assembled from the Sobel planes inside the matching kernels (JN_DESC_FLOW=desc: materialised, the old flow)
   std::atomic<bool> gate_stage_b{false};   // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
   std::vector<uint64_t> merge_log;                            // submission numbers in the order their merges were queued (the last 4096; jn_elas_merge_order)
@@ -248,6 +250,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   // overlap within a slot (the worker waits for stage A, and for the batch's end before the next stage A), so no events tie
   // them together.  Host-pointer jobs stage their images on the ordinary stream and keep everything there.
   hipStream_t sa = (s.stream_a && !j.staged) ? s.stream_a : st;
+  const DescSrc dsrc = h->plane_flow ? DescSrc{s.planes, plane_pitch(dp.W), true} : DescSrc{s.desc, 0, false};
   auto mark_a = [&](int e) { return stage_events ? hipEventRecord(s.ev[e], sa) : hipSuccess; };
   {
     std::unique_lock<std::mutex> pl(h->pace_m, std::defer_lock);
@@ -256,9 +259,10 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       if (h->pace_prev && h->pace_prev != s.ev_head) HIP_TRY(hipStreamWaitEvent(sa, h->pace_prev, 0));
     }
     HIP_TRY(mark_a(EV_BEGIN));
-    launch_descriptor(sa, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
+    if (h->plane_flow) launch_sobel_planes(sa, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.planes);
+    else launch_descriptor(sa, dp, j.dI1, j.dI2, j.pitch, j.stride, n, s.desc);
     HIP_TRY(mark_a(EV_DESC));
-    launch_support(sa, dp, n, s.desc, s.d_can);
+    launch_support(sa, dp, n, dsrc, s.d_can);
     if (h->pace) { HIP_TRY(hipEventRecord(s.ev_head, sa)); h->pace_prev = s.ev_head; }
   }
   const int list_cap = dp.cw * dp.ch;
@@ -304,7 +308,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       launch_tri_setup(st, dp, n, s.info, payload, 0, max_tri, h->tri_cap, s.recs);
       launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list, !cleared);
       HIP_TRY(mark(EV_RASTER));
-      launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, s.desc, s.raw);
+      launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, dsrc, s.raw, false, (stage_events && h->plane_flow) ? s.ev_owner : nullptr);
       HIP_TRY(mark(EV_DENSE));
       // Post-processing.  When gap interpolation and adaptive mean can run as one pass (gap_mean_fusable), the left image
       // travels raw -> tmp (L/R check) -> tmp (speckle, run lists in the still idle output image) -> D1 (fused pass), so that
@@ -526,7 +530,12 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   t.gpu_matching = ms(EV_H2D, EV_DENSE); t.gpu_lr = ms(EV_DENSE, EV_LR); t.gpu_speckle = ms(EV_LR, EV_SPECKLE);
   t.gpu_gap = ms(EV_SPECKLE, EV_GAP); t.gpu_adaptive_mean = ms(EV_GAP, EV_AM);
   t.total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
-  s.dense_ms = ms(EV_RASTER, EV_DENSE); s.dense_launches = any_ok && stage_events ? 1 : 0;
+  s.dense_launches = any_ok && stage_events ? 1 : 0;
+  if (s.dense_launches && h->plane_flow) {                   // k_bin | k_owner | k_dense_row: the matcher proper is timed from behind k_owner
+    float a = 0, b = 0;
+    hipEventElapsedTime(&a, s.ev[EV_RASTER], s.ev_owner); hipEventElapsedTime(&b, s.ev_owner, s.ev[EV_DENSE]);
+    s.owner_ms = a; s.dense_ms = b;
+  } else { s.dense_ms = ms(EV_RASTER, EV_DENSE); s.owner_ms = 0; }
   s.merge_ms = merged ? merge_host_ms : 0.f;               // scan complete -> merged bins in place, on the worker's clock (its turn in the order included)
   return JN_OK;
 }
@@ -706,6 +715,14 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->pool.reset(new Pool(nthreads, hp, pool_spin));
   h->filter_min_batch = nthreads + 1;
   h->filters_fast = support_filters_fast(h->dp, p->incon_window_size, p->incon_min_support);
+  // The plane data flow needs the LDS-staged forms of the two matching kernels; the parameter sets those do not take (support windows
+  // beyond 2560 columns, grids below 8 pixels, priors beyond the keys' cost field) keep materialised descriptors and the kernels that read them.
+  {
+    const DescSrc probe{nullptr, 0, true};
+    h->plane_flow = launch_support(nullptr, h->dp, max_batch, probe, nullptr, true) &&
+                    launch_dense(nullptr, h->dp, max_batch, nullptr, nullptr, 0, nullptr, nullptr, nullptr, probe, nullptr, true);
+    if (const char* e = getenv("JN_DESC_FLOW")) h->plane_flow = h->plane_flow && strcmp(e, "desc") != 0;
+  }
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
   h->arr_cap = std::min(dp.cw * dp.ch, 8192);
@@ -753,11 +770,13 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     for (int e = 0; e < EV_COUNT; e++) CREATE_TRY(hipEventCreateWithFlags(&s->ev[e], hipEventBlockingSync));
     CREATE_TRY(hipEventCreate(&s->ev_scan)); CREATE_TRY(hipEventCreate(&s->ev_merged));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreate(&s->ev_owner));
     if (h->gate_stage_b) {                                   // no signal memory: the handle simply queues stage B after the host stage
       if (hipExtMallocWithFlags((void**)&s->gate, 8, hipMallocSignalMemory) == hipSuccess) { s->gate[0] = 0; s->gate[1] = 0; }
       else { (void)hipGetLastError(); s->gate = nullptr; }
     }
-    CREATE_TRY(dmalloc(&s->desc, 2 * B * px));
+    if (h->plane_flow) CREATE_TRY(dmalloc(&s->planes, plane_bytes(W, H, 2 * (int)B) + 64));
+    else CREATE_TRY(dmalloc(&s->desc, 2 * B * px));
     CREATE_TRY(dmalloc(&s->d_can, B * dp.cw * dp.ch));
     CREATE_TRY(dmalloc(&s->info, B)); CREATE_TRY(dmalloc(&s->payload, B * h->payload_cap));
     const size_t tiles = (size_t)((W + kTileW - 1) / kTileW) * ((H + kTileH - 1) / kTileH);
@@ -799,7 +818,7 @@ void jn_elas_destroy(jn_elas* h) {
   }
   hipSetDevice(h->device);
   for (auto& s : h->slots) {
-    hipFree(s->desc); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
+    hipFree(s->desc); hipFree(s->planes); hipFree(s->d_can); hipFree(s->info); hipFree(s->payload);
     hipFree(s->bin_count); hipFree(s->bin_list); hipFree(s->raw); hipFree(s->tmp); hipFree(s->label); hipFree(s->size); hipFree(s->scan_scratch); hipFree(s->d_flat); hipFree(s->st_img); hipFree(s->st_D); hipFree(s->arr_scratch);
     hipFree(s->mark); hipFree(s->gridbits); hipFree(s->recs);
     hipHostFree(s->h_can); hipHostFree(s->h_info); hipHostFree(s->h_payload); hipHostFree(s->h_list); hipHostFree(s->h_cnt); hipHostFree(s->h_arr); hipHostFree(s->h_arr_ok);
@@ -807,6 +826,7 @@ void jn_elas_destroy(jn_elas* h) {
     if (s->ev_scan) hipEventDestroy(s->ev_scan);
     if (s->ev_merged) hipEventDestroy(s->ev_merged);
     if (s->ev_head) hipEventDestroy(s->ev_head);
+    if (s->ev_owner) hipEventDestroy(s->ev_owner);
     if (s->gate) hipFree(s->gate);
     if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -948,8 +968,11 @@ jn_status jn_elas_last_times(jn_elas* h, int32_t slot, jn_stage_times* out) {
 
 jn_status jn_elas_kernel_time(jn_elas* h, int32_t slot, const char* kernel, float* avg_ms, int32_t* launches) {
   if (!h || !kernel || !avg_ms || !launches || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
-  if (std::string(kernel) != "k_dense") return JN_ERR_INVALID;
-  *avg_ms = h->slots[slot]->dense_ms; *launches = h->slots[slot]->dense_launches;
+  const std::string k(kernel);
+  if (k == "k_dense" || k == "k_dense_row") *avg_ms = h->slots[slot]->dense_ms;      // the dense matcher of this handle's data flow
+  else if (k == "k_owner") *avg_ms = h->slots[slot]->owner_ms;
+  else return JN_ERR_INVALID;
+  *launches = h->slots[slot]->dense_launches;
   return JN_OK;
 }
 

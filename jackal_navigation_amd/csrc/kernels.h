@@ -18,8 +18,16 @@ hipError_t configure_device_kernels();
 // image order L0..L(n-1), R0..R(n-1).
 void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch,
                        int64_t in_stride, int n, uint4* desc);
-// Support matching with back-check (elas.cpp:269-413): D_can [n][ch][cw] int16.
-void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can);
+// The plane data flow (default): the two Sobel responses as byte planes [2n][du | dv][H][plane_pitch(W)], 2 bytes per pixel instead of the
+// 16 of a materialised descriptor; the matching kernels assemble the descriptors they stage in LDS from them (kernels.hip).
+int plane_pitch(int W);
+size_t plane_bytes(int W, int H, int images);
+void launch_sobel_planes(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch, int64_t in_stride, int n, uint8_t* planes);
+// What the matching kernels read descriptors from: the planes (planes = true, Wp = plane_pitch(W)) or the materialised image.
+struct DescSrc { const void* ptr; int Wp; bool planes; };
+// Support matching with back-check (elas.cpp:269-413): D_can [n][ch][cw] int16.  dry = true launches nothing and returns whether an
+// LDS-staged kernel takes these parameters (the only form the plane flow has); otherwise the return value says the same of what ran.
+bool launch_support(hipStream_t st, const DevParams& dp, int n, const DescSrc& desc, int16_t* d_can, bool dry = false);
 
 // In-place support-point filters (elas.cpp:153-235 as called at :416-422) on d_can.  Returns false (nothing
 // launched) when the lattice does not fit the LDS; the host stage then runs them.
@@ -56,8 +64,11 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
                 int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear = true);
 void launch_bin_clear(hipStream_t st, const DevParams& dp, int n, int32_t* bin_count);
 // Dense MAP matching with in-kernel triangle lookup (elas.cpp:683-907): raw [n][2][H][W] float.
-void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, int16_t* raw);
+// Planes: k_owner (which triangle owns a pixel, its plane's disparity: one 16-bit word per pixel, left in `raw`) + k_dense_row; materialised
+// descriptors: k_dense.  dry = true launches nothing and returns whether the plane form takes these parameters.
+bool launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const DescSrc& desc, int16_t* raw, bool dry = false,
+                  hipEvent_t ev_owner = nullptr);   // ev_owner: recorded between k_owner and k_dense_row (timing)
 // Left/right consistency (elas.cpp:909-979): raw -> D1, D2 (user buffers).
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2);
 // Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.

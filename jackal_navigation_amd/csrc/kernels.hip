@@ -181,6 +181,116 @@ __global__ void __launch_bounds__(256) k_descriptor_fused(DevParams dp, const ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// The plane data flow (round 5).  A descriptor is 16 bytes PICKED from the two Sobel responses (descriptor.cpp:84-111: twelve taps of
+// du on a five-row diamond, four of dv), so materialising it costs 32 bytes per pixel and pair in HBM to write and as much again for
+// every kernel that reads it back — the path's largest traffic term.  Instead the two responses are stored as byte planes (2 bytes per
+// pixel and image) and the kernels that match descriptors assemble the ones they need, where they stage them in LDS anyway.
+//
+// Plane layout, per image [du | dv][H][Wp] bytes (Wp a multiple of 64, >= W + 8), images L0..L(n-1), R0..R(n-1):
+//   P_du[v][x] = du(v, x - 2),   P_dv[v][x] = dv(v, x - 1)
+// so that the descriptors of the four columns 4g .. 4g+3 of row v tap bytes 4g .. 4g+7 of du rows v-2 .. v+2 and of dv rows
+// v-1 .. v+1: one aligned 8-byte load per plane row, eight per four descriptors.  Descriptors exist for u in [3, W-4], v in [3, H-4]
+// (descriptor.cpp:84-88); outside they are ZERO (uninitialised in the reference) — the assembling kernels apply that rule,
+// the plane bytes those taps would touch are never looked at.
+struct PlaneRows { uint32_t al[5], ah[5], bl[3], bh[3]; };   // lo / hi dword of the 8-byte load: du rows v-2..v+2, dv rows v-1..v+1
+// descriptor of column 4g + C (C a compile-time 0..3) from the rows loaded at plane byte 4g: eight v_perm_b32
+template <int C>
+DEV uint4 desc_from_rows(const PlaneRows& p) {
+  constexpr uint32_t c = C, X = 0x0cu;                       // selector 0x0c = constant zero byte; 0-3 pick from the second operand, 4-7 from the first
+  uint4 d;
+  // d.x = du(v-2,u) | du(v-1,u-2) | du(v-1,u) | du(v-1,u+2): row 0 byte c+2; row 1 bytes c, c+2, c+4
+  uint32_t t = __builtin_amdgcn_perm(p.ah[1], p.al[1], ((c + 4) << 24) | ((c + 2) << 16) | (c << 8) | X);
+  d.x = __builtin_amdgcn_perm(t, c + 2 < 4 ? p.al[0] : p.ah[0], (7u << 24) | (6u << 16) | (5u << 8) | ((c + 2) & 3));
+  // d.y = du(v,u-1) | du(v,u) | du(v,u) | du(v,u+1)
+  d.y = __builtin_amdgcn_perm(p.ah[2], p.al[2], ((c + 3) << 24) | ((c + 2) << 16) | ((c + 2) << 8) | (c + 1));
+  // d.z = du(v+1,u-2) | du(v+1,u) | du(v+1,u+2) | du(v+2,u)
+  t = __builtin_amdgcn_perm(p.ah[3], p.al[3], (X << 24) | ((c + 4) << 16) | ((c + 2) << 8) | c);
+  d.z = __builtin_amdgcn_perm(c + 2 < 4 ? p.al[4] : p.ah[4], t, ((4 + ((c + 2) & 3)) << 24) | (2u << 16) | (1u << 8) | 0u);
+  // d.w = dv(v-1,u) | dv(v,u-1) | dv(v,u+1) | dv(v+1,u): dv row 0 byte c+1; row 1 bytes c, c+2; row 2 byte c+1
+  t = __builtin_amdgcn_perm(p.bh[1], p.bl[1], (X << 24) | ((c + 2) << 16) | (c << 8) | X);
+  t = __builtin_amdgcn_perm(t, c + 1 < 4 ? p.bl[0] : p.bh[0], (7u << 24) | (6u << 16) | (5u << 8) | ((c + 1) & 3));
+  d.w = __builtin_amdgcn_perm(c + 1 < 4 ? p.bl[2] : p.bh[2], t, ((4 + ((c + 1) & 3)) << 24) | (2u << 16) | (1u << 8) | 0u);
+  return d;
+}
+// The eight plane rows of descriptor row v at plane byte x (a multiple of 4, 0 <= x <= Wp - 8), v in [2, H-3].  The buffer resources span
+// the image's du / dv plane, x rides in the vector offset, the row in the scalar one: no address arithmetic per load.
+DEV PlaneRows load_plane_rows(__amdgpu_buffer_rsrc_t rdu, __amdgpu_buffer_rsrc_t rdv, int x, int v, int Wp) {
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+  PlaneRows p;
+  const int o = x + (v - 2) * Wp;                            // first du row; the rows below it ride in the scalar offset
+#pragma unroll
+  for (int k = 0; k < 5; k++) { const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rdu, o, k * Wp, 0); p.al[k] = t.x; p.ah[k] = t.y; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rdv, o, (k + 1) * Wp, 0); p.bl[k] = t.x; p.bh[k] = t.y; }
+  return p;
+}
+DEV __amdgpu_buffer_rsrc_t plane_rsrc(const uint8_t* planes, int img, int kind, int H, int Wp) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(planes + (size_t)(img * 2 + kind) * H * Wp), 0, H * Wp, 0x00020000);
+}
+// One descriptor at a per-lane column: the rows at the aligned byte below it, shifted down by the lane's u & 3 (v_alignbit), then
+// the C = 0 pick.  Zero outside the descriptor image.  v in [2, H-3], u in [0, W-1].
+DEV uint4 descriptor_at(__amdgpu_buffer_rsrc_t rdu, __amdgpu_buffer_rsrc_t rdv, int u, int v, int W, int H, int Wp) {
+  PlaneRows p = load_plane_rows(rdu, rdv, u & ~3, v, Wp);
+  const uint32_t sh = 8u * (uint32_t)(u & 3);
+#pragma unroll
+  for (int k = 0; k < 5; k++) { p.al[k] = __builtin_amdgcn_alignbit(p.ah[k], p.al[k], sh); p.ah[k] >>= sh; }   // (ah of rows 0, 2, 4 is not used: dropped by the compiler)
+#pragma unroll
+  for (int k = 0; k < 3; k++) p.bl[k] = __builtin_amdgcn_alignbit(p.bh[k], p.bl[k], sh);
+  const uint4 d = desc_from_rows<0>(p);
+  const bool in = u >= 3 && u <= W - 4 && v >= 3 && v <= H - 4;
+  return in ? d : make_uint4(0, 0, 0, 0);
+}
+
+// Sobel responses as byte planes (filter.cpp:372-416, :227-267, :176-222 — the arithmetic of k_descriptor_fused above, whose tile of
+// finished descriptors this replaces).  A thread owns four plane bytes of du and of dv (image columns x-4 .. x+3 of three rows feed them)
+// and walks down kPlaneRows rows with a sliding window of three image rows: one 8-byte load and two 4-byte stores per row.
+enum { kPlaneRows = 16 };
+__global__ void __launch_bounds__(256) k_sobel_planes(DevParams dp, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2,
+                                                      int in_pitch, long long in_stride, int n, uint8_t* __restrict__ planes, int Wp) {
+  const int img = blockIdx.z, W = dp.W, H = dp.H;
+  const uint8_t* I = (img < n ? I1 + (long long)img * in_stride : I2 + (long long)(img - n) * in_stride);
+  const int x = 4 * (blockIdx.x * 64 + (threadIdx.x & 63));                  // plane byte; image columns x-4 .. x+3
+  const int v_begin = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPlaneRows;
+  if (x >= Wp || v_begin >= H) return;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(I) | (uintptr_t)in_pitch) & 3) == 0;
+  auto word = [&](int v, int u) -> uint32_t {                                  // image bytes u .. u+3 of row v, zero outside the image
+    if (v < 0 || v >= H || u + 3 < 0 || u >= W) return 0u;
+    const uint8_t* src = I + (size_t)v * in_pitch + u;
+    if (aligned && u >= 0 && u + 3 < W) return *reinterpret_cast<const uint32_t*>(src);
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) if (u + b >= 0 && u + b < W) w |= (uint32_t)src[b] << (8 * b);
+    return w;
+  };
+  uint8_t* pdu = planes + (size_t)(img * 2) * H * Wp;
+  uint8_t* pdv = pdu + (size_t)H * Wp;
+  uint32_t lo0 = word(v_begin - 1, x - 4), hi0 = word(v_begin - 1, x), lo1 = word(v_begin, x - 4), hi1 = word(v_begin, x);
+#define JN_PAIR(hi, lo, j) __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | (uint32_t)(j) | ((uint32_t)((j) + 1) << 16))
+  const int v_end = min(v_begin + kPlaneRows, H);
+  for (int v = v_begin; v < v_end; v++) {
+    const uint32_t lo2 = word(v + 1, x - 4), hi2 = word(v + 1, x);
+    // bytes b0..b7 = image columns x-4 .. x+3; pair(j) = (b_j, b_j+1) as two 16-bit halves
+    uint32_t S[3];                                                           // S = I[v-1] + 2 I[v] + I[v+1] at bytes (1,2), (3,4), (5,6)
+    pk16 T[3];                                                               // T = I[v-1] - I[v+1] at bytes (2,3), (4,5), (6,7)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      S[j] = JN_PAIR(hi0, lo0, 2 * j + 1) + 2 * JN_PAIR(hi1, lo1, 2 * j + 1) + JN_PAIR(hi2, lo2, 2 * j + 1);   // <= 1020 per half: no carry
+      T[j] = as_pk(JN_PAIR(hi0, lo0, 2 * j + 2)) - as_pk(JN_PAIR(hi2, lo2, 2 * j + 2));
+    }
+    // du(c) = sat(((S(c-1) - S(c+1)) >> 2) + 128) at columns x-2 .. x+1 = plane bytes x .. x+3
+    const pk16 d01 = sobel_norm(as_pk(S[0]) - as_pk(S[1])), d23 = sobel_norm(as_pk(S[1]) - as_pk(S[2]));
+    *reinterpret_cast<uint32_t*>(pdu + (size_t)v * Wp + x) = __builtin_amdgcn_perm(as_u32(d23), as_u32(d01), 0x06040200u);
+    // dv(c) = sat(((T(c-1) + 2 T(c) + T(c+1)) >> 2) + 128) at columns x-1 .. x+2 = plane bytes x .. x+3
+    const pk16 m01 = as_pk(__builtin_amdgcn_perm(as_u32(T[1]), as_u32(T[0]), 0x05040302u));   // (T3, T4)
+    const pk16 m23 = as_pk(__builtin_amdgcn_perm(as_u32(T[2]), as_u32(T[1]), 0x05040302u));   // (T5, T6)
+    const pk16 e01 = sobel_norm(T[0] + m01 + m01 + T[1]), e23 = sobel_norm(T[1] + m23 + m23 + T[2]);
+    *reinterpret_cast<uint32_t*>(pdv + (size_t)v * Wp + x) = __builtin_amdgcn_perm(as_u32(e23), as_u32(e01), 0x06040200u);
+    lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2;
+  }
+#undef JN_PAIR
+}
+
+// ------------------------------------------------------------------------------------------------
 // Support matching (elas.cpp:269-373 per candidate, :395-413 forward + backward check).
 // One wave64 per lattice candidate; lanes stride the disparity range, keep (best, first d of best,
 // second best) privately, then a 6-step butterfly merges them.  The reference's sequential
@@ -263,13 +373,13 @@ enum { kSupportLanes = 4 };
 // The running best / second best (reference: strict `<`, first d wins, elas.cpp:354-362) are kept as packed keys
 // energy << 16 | d: E1 = smallest key's energy with the smallest d attaining it, E2 = second smallest key's energy =
 // second smallest energy of the multiset (two disparities sharing the minimum give E2 = E1, as in the reference).
-template <int LANES, int PITCH>
+template <int LANES, int PITCH, typename TEX>
 DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint4* __restrict__ Bt,
-                   const uint4* __restrict__ Arow_v, int u, bool right, bool active, int j) {
+                   TEX&& texture_at, int u, bool right, bool active, int j) {
   static_assert(LANES == 4, "lane j walks the disparities j, j+4, j+8, ...");
   const int W = dp.W;
   bool ok = active && u >= 5 && u <= W - 6;                                   // :283 (rows checked by the caller)
-  if (ok) ok = texture16(Arow_v[u]) >= dp.support_texture;                    // :301-305
+  if (ok) ok = texture_at(u) >= dp.support_texture;                           // :301-305 (the descriptor at (u, v) itself)
   const int dmax = right ? min(dp.disp_max, W - u - 5) : min(dp.disp_max, u - 5);   // :325-326
   const int dmin = dp.disp_min;                                               // :323
   ok = ok && dmax - dmin >= 10;                                               // :329
@@ -325,8 +435,11 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
 // (the backward match of the right-image candidate u - d walks up to dmax to the right again) and the right rows over
 // [u_lo - dmax - 2, u_hi + 2]; the row pointers are shifted by the window start so that quad_match keeps indexing by column.
 // Read-aheads past a window's end stay inside the four staged rows (the right rows follow the left ones).
-template <int LANES, int PITCH>
-__global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const uint4* __restrict__ desc, int16_t* __restrict__ d_can, int nseg) {
+// PL = true: `src` holds the Sobel planes (pitch Wp) and the four rows are ASSEMBLED here (the plane data flow above): wave-sized passes of
+// 64 x 4 columns, eight 8-byte loads and 32 v_perm per lane and pass; the texture test assembles the candidate's own descriptor.
+// PL = false: `src` holds materialised descriptors (the route kept for what the plane flow does not take, launch_support()).
+template <int LANES, int PITCH, bool PL>
+__global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const void* __restrict__ src, int Wp, int16_t* __restrict__ d_can, int nseg) {
   extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], PITCH each
   const int vc = blockIdx.x, frame = blockIdx.y, seg = blockIdx.z, W = dp.W;
   const int v = vc * dp.step, nthr = blockDim.x;           // 1024 threads, fewer when a segment has fewer than 256 candidates
@@ -337,17 +450,40 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
     for (int uc = uc_lo + threadIdx.x; uc < uc_hi; uc += nthr) out_row[uc] = (vc == 0 || uc == 0) ? 0 : -1;
     return;
   }
-  const uint4* L = desc + (size_t)frame * dp.H * W;
-  const uint4* R = desc + (size_t)(n + frame) * dp.H * W;
   const int u_lo = uc_lo * dp.step, u_hi = (uc_hi - 1) * dp.step;
   const int c0 = nseg == 1 ? 0 : max(u_lo - dp.disp_max - 2, 0);                        // window start, both images
   const int c1L = nseg == 1 ? W : min(u_hi + dp.disp_max + 3, W), c1R = nseg == 1 ? W : min(u_hi + 3, W);
   uint4* Lt = rows - c0; uint4* Rt = rows + 2 * PITCH - c0;                             // indexed by image column
-  for (int i = c0 + threadIdx.x; i < c1L; i += nthr) { Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i]; }
-  for (int i = c0 + threadIdx.x; i < c1R; i += nthr) { Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i]; }
+  const uint4* L = nullptr; const uint4* R = nullptr;
+  __amdgpu_buffer_rsrc_t rduL, rdvL, rduR, rdvR;
+  if constexpr (PL) {
+    const uint8_t* planes = static_cast<const uint8_t*>(src);
+    rduL = plane_rsrc(planes, frame, 0, dp.H, Wp); rdvL = plane_rsrc(planes, frame, 1, dp.H, Wp);
+    rduR = plane_rsrc(planes, n + frame, 0, dp.H, Wp); rdvR = plane_rsrc(planes, n + frame, 1, dp.H, Wp);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = nthr >> 6, lane = threadIdx.x & 63;
+    const int g0 = c0 >> 2, npass = (((c1L - 1) >> 2) - g0) / 64 + 1;                  // passes of 64 four-column groups per row (c1L >= c1R)
+    for (int it = wave; it < 4 * npass; it += nwaves) {
+      const int rr = it & 3, pass = it >> 2;                                          // which of the four rows (wave-uniform)
+      const int g = g0 + pass * 64 + lane, c1 = rr < 2 ? c1L : c1R;
+      const PlaneRows p = load_plane_rows(rr < 2 ? rduL : rduR, rr < 2 ? rdvL : rdvR, min(4 * g, Wp - 8), (rr & 1) ? v + 2 : v - 2, Wp);
+      uint4* dst = rows + rr * PITCH - c0;
+      const uint4 zero = make_uint4(0, 0, 0, 0);
+      const int col = 4 * g;                                                          // descriptors exist for columns [3, W-4]
+      if (col + 0 >= c0 && col + 0 < c1) dst[col + 0] = (col + 0 >= 3 && col + 0 <= W - 4) ? desc_from_rows<0>(p) : zero;
+      if (col + 1 >= c0 && col + 1 < c1) dst[col + 1] = (col + 1 >= 3 && col + 1 <= W - 4) ? desc_from_rows<1>(p) : zero;
+      if (col + 2 >= c0 && col + 2 < c1) dst[col + 2] = (col + 2 >= 3 && col + 2 <= W - 4) ? desc_from_rows<2>(p) : zero;
+      if (col + 3 >= c0 && col + 3 < c1) dst[col + 3] = (col + 3 >= 3 && col + 3 <= W - 4) ? desc_from_rows<3>(p) : zero;
+    }
+  } else {
+    L = static_cast<const uint4*>(src) + (size_t)frame * dp.H * W;
+    R = static_cast<const uint4*>(src) + (size_t)(n + frame) * dp.H * W;
+    for (int i = c0 + threadIdx.x; i < c1L; i += nthr) { Lt[i] = L[(size_t)(v - 2) * W + i]; Lt[PITCH + i] = L[(size_t)(v + 2) * W + i]; }
+    for (int i = c0 + threadIdx.x; i < c1R; i += nthr) { Rt[i] = R[(size_t)(v - 2) * W + i]; Rt[PITCH + i] = R[(size_t)(v + 2) * W + i]; }
+  }
   __syncthreads();
-  const uint4* Lv = L + (size_t)v * W;                  // row v itself is only read for the texture test
-  const uint4* Rv = R + (size_t)v * W;
+  // row v itself is only read for the texture test
+  auto texL = [&](int u) -> int { if constexpr (PL) return texture16(descriptor_at(rduL, rdvL, u, v, W, dp.H, Wp)); else return texture16(L[(size_t)v * W + u]); };
+  auto texR = [&](int u) -> int { if constexpr (PL) return texture16(descriptor_at(rduR, rdvR, u, v, W, dp.H, Wp)); else return texture16(R[(size_t)v * W + u]); };
   const int j = threadIdx.x & (LANES - 1);
   // Which candidate a quad of lanes takes.  A wave's 16-byte LDS reads are served in four groups of 16 lanes — quads
   // {0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15} (MI355X_MICROARCH.md, LDS: ds_read_b128) — and a descriptor column
@@ -364,8 +500,8 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
     const bool active = uc >= 1 && uc < uc_hi;
     const int u = uc * dp.step;
     int res = -1;
-    const int d = quad_match<LANES, PITCH>(dp, Lt, Rt, Lv, u, false, active, j);
-    const int d2 = quad_match<LANES, PITCH>(dp, Rt, Lt, Rv, u - d, true, active && d >= 0, j);
+    const int d = quad_match<LANES, PITCH>(dp, Lt, Rt, texL, u, false, active, j);
+    const int d2 = quad_match<LANES, PITCH>(dp, Rt, Lt, texR, u - d, true, active && d >= 0, j);
     if (d >= 0 && d2 >= 0 && abs(d - d2) <= dp.lr_threshold) res = d;         // :404-411
     if (j == 0 && uc < uc_hi) out_row[uc] = (int16_t)(uc == 0 ? 0 : res);
   }
@@ -1376,26 +1512,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense MAP matching, second form (same reference lines, strip and LDS layout as k_dense above, which stays as the
-// route for parameter sets this one does not take).  k_dense is bound by vector-instruction issue (PMC: its VALU pipes
-// are active 86 % of the kernel's duration; 395 vector instructions per wave and 64 pixels, of which only ~60 are the
-// SADs), so this form removes instructions, not bytes.  Measured attribution of k_dense's instructions (debug builds
-// that skip a phase): staging + lists + own loads 40 %, range masks 16 %, grid candidates 13 %, plane neighbourhood
-// 15 %, ownership / plane / store 16 %.
-//  * Staging: one wave per strip row, raw buffer loads whose bounds are the image row (columns outside the image
-//    read as zero without compares), addresses advanced by constants: ~5 instead of ~18 instructions per descriptor.
-//  * Lists: rank and cover words are built with v_readlane on loop-uniform indices instead of ds_bpermute shuffles; the
-//    planes are stored by rank, so the owning triangle's plane is one 16-byte LDS read.
-//  * Keys.  v_sad_hi_u8 adds the 4-byte SAD shifted left by 16 to its accumulator operand, so four of them on
-//    (bias + prior) << 16 | d give (cost << 16) | d without shift / or; the minimum of the keys is the reference's
-//    "strict <, candidates in ascending d" choice.
-//  * Grid candidates (elas.cpp:742-750) keep k_dense's per-lane bit scan — every lane evaluates a DIFFERENT disparity
-//    per round, which beats walking the wave's union of candidates with a uniform d (tried: 411 M instead of 364 M
-//    instructions, lanes want different small subsets) — but the border mask is only applied in strips that can reach
-//    the image border.
-//  * Plane neighbourhood (elas.cpp:751-756) = 2r+1 consecutive descriptors in LDS: one address, reads at immediate
-//    offsets, all in flight together; when every lane of the wave has its whole neighbourhood inside the valid range
-//    and a valid prior (the common case) no per-candidate test is left.
+// Helpers of the LDS-window matchers (k_dense_row)
 enum { kDense2Slack = 16, kCellBias = 8192, kCellPriorMax = 8000, kCellInvalid = 0x60000000 };
 typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
 // w |= bit if bit `pos` of m is set: the sign-extended single bit as an and-mask.  Two plain VALU instructions; written as
@@ -1410,20 +1527,248 @@ typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const jn_u32x4 jn_lds_u4;
 DEV uint32_t lds_addr(const uint4* p) { return (uint32_t)(uintptr_t)(jn_lds_u4*)p; }
 DEV uint4 lds_read16(uint32_t a) { const jn_u32x4 t = *(jn_lds_u4*)a; return make_uint4(t.x, t.y, t.z, t.w); }
+// One pixel of the dense matching behind the ownership lookup (elas.cpp:722-779), used by k_dense_row: `a` the pixel's own
+// descriptor, Bu[d] the descriptor of the column matched at disparity d in the LDS window (u + d in the right image's window, u - d in the
+// mirrored left one), cw the candidate set of the pixel's grid cell.  Every lane of the wave must call it (one ballot inside).
 template <int NW>
-__global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, const FrameInfo* __restrict__ info,
-                                               const TriRec* __restrict__ recs, int tri_cap, const int32_t* __restrict__ bin_count,
-                                               const BinEntry* __restrict__ bin_list, const uint32_t* __restrict__ gridbits,
-                                               const uint4* __restrict__ desc, int16_t* __restrict__ raw, int nbx, int nby, int xcd_order, int dbg, uint32_t nbx_magic, uint32_t nby_magic) {
-  static_assert(kDenseThreads / 64 == kTileH, "one wave stages one strip row");
-  __shared__ uint32_t s_list[kStripTiles][kBinLds * kBinWords];   // candidate lists of the strip's four tiles
-  __shared__ uint4 s_plane[kStripTiles][kBinLds];                 // (pa, pb, pc, flags) of a tile's listed triangles, by rank
-  __shared__ int s_cnt[kStripTiles];
-  __shared__ uint16_t s_cover[kStripTiles][kTileW][kTileH];       // per pixel (column, row): bit k set <=> the k-th smallest listed triangle covers it
+DEV int match_pixel(const DevParams& dp, const uint4& a, bool elig, int d_plane, bool valid, int u, int side, const uint4* Bu,
+                    const uint32_t (&cw)[NW], bool border, int dbg) {
+  constexpr unsigned kNoKey = 0xFFFFFFFFu;
+  const int radius = dp.radius, W = dp.W;
+  const int lo = max(d_plane - radius, 0), hi = min(d_plane + radius, dp.disp_max);                      // :723-724
+  // disparities whose warped column stays inside [2, W-2) (:746, :753, :764, :771)
+  const int dmax_ok = side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
+  const int dlow = d_plane - radius;
+  const int phi = min(hi, dmax_ok);
+
+  // ---- grid candidates outside the plane range (:742-750): per-lane bit scan, one (different) disparity per lane and round ----
+  // Keys here are (SAD << 16) + LDS byte address of the candidate's descriptor: the address is what the read needs anyway, it orders
+  // like d, and d = (address - address of Bu[0]) / 16 is recovered once at the end (the bias the plane keys carry is added there too).
+  unsigned best1 = kNoKey;
+  const uint32_t bu_a = lds_addr(Bu);
+  if (elig && !(dbg & 1)) {
+    // The plane range [lo, hi] (at most 15 wide) sits as ones in bits 16.. of T; word w of the exclusion mask is the HIGH half of
+    // T << (lo + 16 - 32 w) with the shift clamped to [0, 63]: below 0 and from 48 up nothing of T lands in bits 32..63, in between it
+    // is M << (lo - 32 w) or the spill M >> (32 w - lo) of a range that starts in the word below.  (hi < lo: T = 0.)
+    const unsigned long long T = (unsigned long long)(((1u << max(hi - lo + 1, 0)) - 1u) << 16);
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      const uint32_t excl = (uint32_t)((T << min(max(lo + 16 - 32 * w, 0), 63)) >> 32);
+      uint32_t bits = cw[w] & ~excl;
+      if (border) bits &= range_mask(0, dmax_ok, w);
+      while (bits) {
+        const uint32_t ad = bu_a + (uint32_t)((w << 5) + __builtin_ctz(bits)) * 16u;
+        bits &= bits - 1;
+        best1 = min(best1, sadhi16(a, lds_read16(ad), ad));
+      }
+    }
+  }
+
+  // ---- plane neighbourhood with prior (:751-756): d = dlow + k, k = 0 .. 2r ----
+  unsigned best2 = kNoKey;
+  if (dbg & 2) {} else
+  if (radius == 2) {
+    // address window clamped so that it stays inside the LDS block (+- kDense2Slack); a clamped window holds no valid d
+    const uint4* Bw = Bu + max(min(dlow, dp.disp_max), -2 * radius);
+    uint4 nb[5];
+#pragma unroll
+    for (int kk = 0; kk < 5; kk++) nb[kk] = Bw[kk];
+    const bool all_in = dlow >= 0 && dlow + 4 <= phi && valid;          // whole neighbourhood valid, prior on
+    if (__ballot(elig && !all_in) == 0ull) {
+      // every lane of the wave: five valid candidates with the prior — no per-candidate tests (scalar key bases)
+      const unsigned i0 = ((unsigned)(kCellBias + dp.P[2]) << 16), i1 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 1u,
+                     i2 = ((unsigned)(kCellBias + dp.P[0]) << 16) + 2u, i3 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 3u,
+                     i4 = ((unsigned)(kCellBias + dp.P[2]) << 16) + 4u;
+      // keys relative to dlow (scalar bases), dlow added to the minimum: 0 <= dlow and dlow + 4 <= 255, no carry into the cost
+      const unsigned k0 = sadhi16(a, nb[0], i0), k1 = sadhi16(a, nb[1], i1), k2 = sadhi16(a, nb[2], i2),
+                     k3 = sadhi16(a, nb[3], i3), k4 = sadhi16(a, nb[4], i4);
+      best2 = min(min(min(k0, k1), min(k2, k3)), k4) + (unsigned)dlow;
+    } else {
+      const unsigned prior_on = valid ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int kk = 0; kk < 5; kk++) {
+        const int d = dlow + kk;
+        const unsigned init = (d >= 0 && d <= phi) ? (((unsigned)kCellBias << 16) + (((unsigned)dp.P[kk < 2 ? 2 - kk : kk - 2] << 16) & prior_on) + (unsigned)d)
+                                                   : (unsigned)kCellInvalid;
+        best2 = min(best2, sadhi16(a, nb[kk], init));
+      }
+      if (best2 >= (unsigned)kCellInvalid) best2 = kNoKey;
+    }
+  } else if (elig) {                                                     // other radii: one read per candidate
+#pragma unroll
+    for (int off = -7; off <= 7; off++) {
+      if ((off < 0 ? -off : off) > radius) continue;                     // uniform
+      const int d = d_plane + off;
+      if (d >= lo && d <= phi) {
+        const unsigned init = (valid ? (unsigned)(kCellBias + dp.P[off < 0 ? -off : off]) << 16 : (unsigned)kCellBias << 16) + (unsigned)d;
+        best2 = min(best2, sadhi16(a, Bu[d], init));
+      }
+    }
+  }
+  // the plane phase wins only with a strictly smaller cost; a missing grid key (0xFFFF + bias) loses to every plane key, a missing plane
+  // key (cost field 0xFFFF) to every grid key (SAD <= 4080); both missing: the plane branch answers -1
+  const bool plane_wins = (best2 >> 16) < (best1 >> 16) + (unsigned)kCellBias;
+  int result = -10;                                                      // :797-798
+  if (elig) result = plane_wins ? (best2 == kNoKey ? -1 : (int)(best2 & 255u)) : (int)(((best1 & 0xFFFFu) - bu_a) >> 4);   // :778-779
+  return result;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The dense matching of the plane data flow (round 5): k_owner + k_dense_row replace k_dense2's list handling and its barrier.
+//
+// k_dense2's workgroup spends half its life in a prologue: four of its eight waves rank a tile's triangle list and fold the row masks into cover
+// words through a chain of LDS round trips while the others wait at the barrier.  None of that needs the descriptors.  k_owner does it
+// ahead, one wave per 32x8 tile at full occupancy, and leaves ONE 16-bit word per pixel (in the matcher's own output image, which the
+// matcher overwrites):  bit 15 = a triangle covers the pixel (the LAST covering one in list order counts, as in k_dense2), bit 14 = its
+// plane prior is valid (elas.cpp:872), bits 0..13 = d_plane + 32 (elas.cpp:722), clamped to [-32, 8000] — every use of d_plane is a
+// comparison against a range inside [-radius - 1, disp_max + radius + 1], so the clamp changes nothing.
+enum { kOwnerBias = 32, kOwnerMax = 8000 };
+__global__ void __launch_bounds__(256) k_owner(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs, int tri_cap,
+                                               const int32_t* __restrict__ bin_count, const BinEntry* __restrict__ bin_list, uint16_t* __restrict__ owner, int dbg, int fast_max, int scan_from) {
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
+  const int tx = blockIdx.x * 4 + wave, ty = blockIdx.y, fs = blockIdx.z, frame = fs >> 1, side = fs & 1;
+  if (tx >= tiles_x) return;
+  if (dbg & 4) return;
+  const FrameInfo& fi = info[frame];
+  const size_t bin = ((size_t)fs * tiles_y + ty) * tiles_x + tx;
+  // What this kernel costs is its vector-memory INSTRUCTIONS (a CU issues one per ~8 cycles whatever it moves; 230 k tiles), so a tile is
+  // seven of them: frame flag, list length, the list's first 16 entries as four coalesced dword loads (lane l holds words l, l+64, l+128,
+  // l+192 — they always exist: kBinCap entries per tile), one 8-byte store per lane.  An entry's wave-uniform words (triangle, plane, flag)
+  // are v_readlane'd out of those registers, its row-mask word for the lane's columns comes by ds_bpermute.
+  // Lane (r, g) = (lane >> 3, lane & 7): row r of the tile, columns 4g .. 4g+3 — byte j of mask word 1 + g holds column 4g + j's row bits.
+  const int r = lane >> 3, g = lane & 7;
+  const int u = tx * kTileW + 4 * g, v = ty * kTileH + r;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
+  __shared__ uint32_t s_list[4][kBinLds * kBinWords];        // the list's first 16 entries, per wave
+  __shared__ uint4 s_plane[4][kBinLds];                      // their planes by rank
+  int vzero = 0;
+  asm volatile("" : "+v"(vzero));
+  const int ok_v = (&fi.ok)[vzero], cnt_v = bin_count[bin + vzero];
+  uint32_t lw[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) lw[i] = (dbg & 1) ? (uint32_t)(lane * 77 + i) : src[lane + 64 * i];
+  int best_t[4] = {-1, -1, -1, -1};
+  float pa[4], pb[4], pc[4]; bool valid[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { pa[j] = pb[j] = pc[j] = 0.f; valid[j] = false; }
+  // (the frame flag is looked at last: an early return on it would make the compiler sink every load above behind that wait.  A frame
+  // that failed has stale but addressable lists; its overflow scan is skipped.)
+  const int cnt = __builtin_amdgcn_readfirstlane(cnt_v);
+  const int cnt_l = min(cnt, (int)kBinCap);
+  if (cnt_l <= fast_max) {                                   // (fast_max = kBinLds; tests lower it to send ordinary lists through the general form)
+    // The usual case (mean 7 entries, 17 the most seen at 720p): what the kernel costs here is its VECTOR instructions (230 k waves x ~400
+    // in the general form below = the 0.17 ms it took), so ownership is resolved k_dense2's way — the entries are RANKED by triangle number,
+    // an entry's hits on the lane's four pixels ((mask word >> row) & 0x01010101: bit 0 of byte j = column 4g + j) are or-ed into the
+    // pixels' cover words at the entry's rank (three instructions per entry for four pixels), and a pixel's owner is its highest set bit.
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_list[wave][lane + 64 * i] = lw[i];
+    const int myt = lane < cnt_l ? (int)s_list[wave][(lane & (kBinLds - 1)) * kBinWords] : 0x7FFFFFFF;
+    int rank = 0;
+    for (int jj = 0; jj < cnt_l; jj++) rank += __builtin_amdgcn_readlane(myt, jj) < myt ? 1 : 0;
+    if (lane < cnt_l) {
+      const uint32_t* e = &s_list[wave][lane * kBinWords];
+      s_plane[wave][rank] = make_uint4(e[9], e[10], e[11], e[12]);
+    }
+    unsigned acc_lo = 0, acc_hi = 0;                         // byte j: ranks 0..7 / 8..15 that cover pixel (4g + j, r)
+    const uint32_t* mrow = &s_list[wave][1 + g];
+    for (int c0 = 0; c0 < cnt_l; c0 += 4) {                  // four mask reads in flight (c0 + 3 <= 15: inside the 16 entries)
+      unsigned mk[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) mk[k] = mrow[(c0 + k) * kBinWords];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (c0 + k >= cnt_l) break;                          // uniform
+        const unsigned hit = (mk[k] >> r) & 0x01010101u;
+        const int rk = __builtin_amdgcn_readlane(rank, c0 + k);
+        if (rk < 8) acc_lo |= hit << rk; else acc_hi |= hit << (rk - 8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned cover = ((acc_lo >> (8 * j)) & 0xFFu) | (((acc_hi >> (8 * j)) & 0xFFu) << 8);
+      if (cover) {
+        const uint4 pl = s_plane[wave][31 - __clz(cover)];
+        best_t[j] = 0; pa[j] = __uint_as_float(pl.x); pb[j] = __uint_as_float(pl.y); pc[j] = __uint_as_float(pl.z); valid[j] = pl.w & 1u;
+      }
+    }
+  } else
+  for (int c0 = 0;;) {                                       // longer lists: the largest covering triangle number entry by entry, sixteen entries a round
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (c0 + k >= cnt_l) break;                            // uniform
+      const uint32_t w = lw[k >> 2];
+      const int base_lane = 16 * (k & 3);
+      const int tc = __builtin_amdgcn_readlane((int)w, base_lane);
+      const float epa = __uint_as_float(__builtin_amdgcn_readlane((int)w, base_lane + 9)), epb = __uint_as_float(__builtin_amdgcn_readlane((int)w, base_lane + 10)),
+                  epc = __uint_as_float(__builtin_amdgcn_readlane((int)w, base_lane + 11));
+      const bool ev = __builtin_amdgcn_readlane((int)w, base_lane + 12) & 1;
+      const uint32_t mw = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * (base_lane + 1 + g), (int)w);
+      const uint32_t hit = (mw >> r) & 0x01010101u;          // byte j: the triangle covers (column 4g + j, row r)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool take = ((hit >> (8 * j)) & 1u) && tc > best_t[j];               // the covering triangle with the LARGEST index
+        best_t[j] = take ? tc : best_t[j]; pa[j] = take ? epa : pa[j]; pb[j] = take ? epb : pb[j]; pc[j] = take ? epc : pc[j]; valid[j] = take ? ev : valid[j];
+      }
+    }
+    c0 += 16;
+    if (c0 >= cnt_l) break;
+#pragma unroll
+    for (int i = 0; i < 4; i++) lw[i] = src[c0 * kBinWords + lane + 64 * i];       // the next 16 entries (c0 + 16 <= kBinCap)
+  }
+  const bool ok = __builtin_amdgcn_readfirstlane(ok_v);
+  if (cnt > scan_from && ok) {                               // (scan_from = kBinCap; tests lower it)  overflowing tile: scan every triangle of this side, last one first (overrides the list's answer)
+    const TriRec* R = recs + (size_t)fs * tri_cap;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      best_t[j] = -1; pa[j] = pb[j] = pc[j] = 0.f; valid[j] = false;
+      for (int c = fi.ntri[side] - 1; c >= 0; c--) {
+        const TriRec* q = R + c;
+        if (tri_covers(q->Au, q->Bu, q->Cu, q->ACa, q->ACb, q->ABa, q->ABb, q->BCa, q->BCb, u + j, v)) { best_t[j] = c; break; }
+      }
+      if (best_t[j] >= 0) { const TriRec* tr = R + best_t[j]; pa[j] = tr->pa; pb[j] = tr->pb; pc[j] = tr->pc; valid[j] = tr->flags & 1; }
+    }
+  }
+  if (!ok || v >= dp.H || u >= dp.W) return;
+  if ((dbg & 2) && best_t[0] != 12345678) return;
+  unsigned code[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa[j], (float)(u + j)), __fmul_rn(pb[j], (float)v)), pc[j]);   // :722
+    code[j] = (best_t[j] >= 0 ? 0x8000u : 0u) | (valid[j] ? 0x4000u : 0u) | (unsigned)(min(max(d_plane, -kOwnerBias), (int)kOwnerMax) + kOwnerBias);
+  }
+  uint16_t* o = owner + ((size_t)fs * dp.H + v) * dp.W + u;
+  if ((dp.W & 3) == 0) *reinterpret_cast<uint2*>(o) = make_uint2(code[0] | (code[1] << 16), code[2] | (code[3] << 16));   // u + 3 < W, 8-byte aligned
+  else
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (u + j < dp.W) o[j] = (uint16_t)code[j];
+}
+
+// k_dense_row: one WAVE per strip row of 128 pixels, a lane owns two neighbouring pixels; a workgroup is eight such rows (the 128 x 8 strip
+// of one side in the XCD-aware order k_dense describes) only because they share plane rows in the CU's cache — there is NO barrier and
+// no LDS shared between waves: wave w assembles window row w and is the only one that reads it.  A wave's life: pull its arguments, issue every
+// load (the eight plane rows of its own 128 pixels, the eight of its window, the two ownership words, the grid cell), assemble (v_perm), store
+// the window row, match.  Waves of a CU are at different points of that, so the memory round trips of one hide behind the matching of
+// the others without software pipelining.
+//  * Every plane dword is fetched by ONE lane (4-byte loads) and the second dword a lane needs comes from its neighbour by DPP.  [Measured
+//    against 8-byte loads per lane, every dword fetched twice: the same kernel time — what the loads cost is their number, 16 a wave, ~8
+//    cycles of the CU's vector-memory path each = 0.1 ms of the kernel — but fewer registers and half the bytes through the cache.]
+//  * own descriptors: the two pixels 2l, 2l+1 of lane l lie in the aligned group 4 (l >> 1): even lanes fetch the group's first dword, odd
+//    lanes the one behind it, a quad_perm swap hands each the other, and one v_perm with a per-lane selector shifts the odd lanes' view
+//    down by two columns; then the C = 0 and C = 1 picks of desc_from_rows.
+//  * window: lane l assembles the image-aligned group of columns 4 (g0 + l) .. + 3: its dword, the next lane's (wave_shl:1; behind the last
+//    lane: a scalar load), 32 v_perm, four 16-byte LDS stores 64 bytes apart (4-way bank conflicts; slots without them were timed: -2 %).
+// Tried and dropped (profiles/r05_dense_forms.txt): k_dense2 reading the planes (own descriptors per thread: 0.61 ms; through a wave-private
+// corner of the window block: 0.63 ms — the barrier and the list waves stay); the strip's plane rows fetched once per workgroup into LDS
+// behind one barrier (12 loads a workgroup instead of 16 a wave: 0.57 ms — the barrier is back, and the LDS round trip costs what the loads did).
+template <int NW>
+__global__ void __launch_bounds__(kDenseThreads) k_dense_row(DevParams dp, int n, const FrameInfo* __restrict__ info, const uint32_t* __restrict__ gridbits,
+                                                             const uint8_t* __restrict__ planes, int Wp, int16_t* __restrict__ raw, int nbx, int nby,
+                                                             int xcd_order, int dbg, uint32_t nbx_magic, uint32_t nby_magic) {
   extern __shared__ uint4 s_Bx[];                            // kDense2Slack + [kTileH][kStripW + disp_max] + kDense2Slack
-  // Every kernel argument the block will need is pulled into scalar registers HERE, behind one wait: left alone the compiler fetches
+  // Every kernel argument the wave will need is pulled into scalar registers HERE, behind one wait: left alone the compiler fetches
   // them one basic block at a time, each fetch a scalar-cache round trip in series with the loads below.
-  asm volatile("" :: "s"(info), "s"(bin_count), "s"(bin_list), "s"(gridbits), "s"(desc), "s"(raw),
+  asm volatile("" :: "s"(info), "s"(gridbits), "s"(planes), "s"(Wp), "s"(raw),
                "s"(dp.W), "s"(dp.H), "s"(dp.disp_max), "s"(dp.gw), "s"(dp.gh), "s"(dp.grid_magic), "s"(dp.radius), "s"(dp.match_texture),
                "s"(dp.P[0]), "s"(dp.P[1]), "s"(dp.P[2]), "s"(n), "s"(nbx), "s"(nby), "s"(dbg), "s"(nbx_magic), "s"(nby_magic));
   const int total = nbx * nby * 2 * n;
@@ -1431,255 +1776,156 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense2(DevParams dp, int n, c
   if (xcd_order) { const int per_xcd = (total + 7) / 8; item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); }   // see k_dense
   if (item >= total) return;
   if (dbg & 64) return;                                     // JN_DENSE_DBG profiling switches (results are then WRONG): 64 = empty blocks,
-                                                            // 8 / 16 = no window / own descriptor loads, 4 = stop after the prologue, 1 / 2 = no grid / plane candidates
+                                                            // 8 / 16 = no window / own plane loads, 4 = stop after the prologue, 1 / 2 = no grid / plane candidates
   // item -> (side, bx, by, frame): the two divisions by multiply-high with the host's ceil(2^32 / n) (exact while x n < 2^32, which
-  // launch_dense() checks) — the compiler's division sequence is ~28 dependent instructions each, in front of the block's first load
+  // launch_dense() checks) — the compiler's division sequence is ~28 dependent instructions each, in front of the wave's first load
   const int side = item & 1;
   const unsigned rest = (unsigned)item >> 1;
   const unsigned rest2 = nbx == 1 ? rest : __umulhi(rest, nbx_magic);     // ceil(2^32 / 1) does not fit
   const int bx = (int)(rest - rest2 * (unsigned)nbx);
   const int frame = (int)(nby == 1 ? rest2 : __umulhi(rest2, nby_magic));
   const int by = (int)(rest2 - (unsigned)frame * (unsigned)nby);
-  const FrameInfo& fi = info[frame];
   const int W = dp.W, H = dp.H;
-  const int tid = threadIdx.x;
-  const int u0 = bx * kStripW, v0 = by * kTileH;
-  uint4* s_B = s_Bx + kDense2Slack;
-  const uint4* A = desc + (size_t)((side ? n : 0) + frame) * H * W;      // image being filled
-  const uint4* B = desc + (size_t)((side ? 0 : n) + frame) * H * W;      // image searched
-  const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
-  const int tiles_x = (W + kTileW - 1) / kTileW;
-  const size_t bin_row = ((size_t)(frame * 2 + side) * nby + by) * tiles_x;
-  const int x = tid & (kTileW - 1), r = (tid / kTileW) & (kTileH - 1), grp = tid / (kTileW * kTileH);   // grp 0: tiles 0,2; grp 1: tiles 1,3
-  const int v = v0 + r;
-  const int vr = max(min(v, H - 3), 2);                                    // :701
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int u0 = bx * kStripW, v = by * kTileH + wave;
+  if (v >= H) return;                                        // (no barrier below: a wave may leave)
+  const int fs = frame * 2 + side;
+  const int imgA = (side ? n : 0) + frame, imgB = (side ? 0 : n) + frame;                // image being filled, image searched
+  const int vr = max(min(v, H - 3), 2);                      // :701
+  const int ok = info[frame].ok;                             // (scalar load; looked at after the window row has been stored)
 
-  // ---- issue every global read of this thread up front, consume afterwards ----
-  const int lw = tid >> 6, lane = tid & 63;                  // waves 4..7 (second pixel pair) have no list duty
-  const int wave = __builtin_amdgcn_readfirstlane(lw);
-  const bool list_wave = wave < kStripTiles && bx * kStripTiles + wave < tiles_x;
-  // The prologue is a chain of memory round trips with the vector pipes idle, and a block's lifetime is what bounds the kernel (the CU's
-  // LDS and wave slots are full at four blocks): nothing here waits for an earlier load.  The list's first kBinLds entries are read whole
-  // (kBinCap >= kBinLds of them always exist) instead of `count` entries after the count has arrived.
-  static_assert(kBinCap >= kBinLds && kBinLds * kBinWords == 256, "four loads of 64 words cover the LDS-resident part of a list");
-  // The two wave-uniform words (frame ok, list length) are read with VECTOR loads (an index the compiler cannot prove uniform): a scalar
-  // load would have to be waited for before the next scalar load, vector loads return in order behind everything issued here.
-  int vzero = 0;
-  asm volatile("" : "+v"(vzero));
-  const int ok_v = (&fi.ok)[vzero];
-  int cnt_v = 0;
-  uint32_t lw0 = 0, lw1 = 0, lw2 = 0, lw3 = 0;
-  if (list_wave) {
-    const size_t bin = bin_row + bx * kStripTiles + wave;
-    cnt_v = bin_count[bin + vzero];
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(bin_list + bin * kBinCap);
-    lw0 = src[lane]; lw1 = src[lane + 64]; lw2 = src[lane + 128]; lw3 = src[lane + 192];
-  }
-  // own descriptors and grid-cell candidate sets of the thread's two pixels
-  uint4 a4[kPxPerThread];
-  uint32_t cellw[kPxPerThread][NW];
-  // x / G as one multiply-high (dense2_applies() guarantees G >= 8, so the magic constant is exact for any pixel index)
-  const uint32_t* cells = gridbits + ((size_t)(frame * 2 + side) * dp.gw * dp.gh + (size_t)__umulhi((unsigned)min(v, H - 1), dp.grid_magic) * dp.gw) * kGridWords;
-#pragma unroll
-  for (int q = 0; q < kPxPerThread; q++) {
-    const int u = min(u0 + (grp + 2 * q) * kTileW + x, W - 1);
-    a4[q] = (dbg & 16) ? make_uint4(u, u, u, u) : A[(size_t)vr * W + u];
-    const uint32_t* cell = cells + (size_t)__umulhi((unsigned)u, dp.grid_magic) * kGridWords;
-#pragma unroll
-    for (int w = 0; w < NW; w++) cellw[q][w] = cell[w];
-  }
-  // the other image's descriptors the strip can reach: wave w stages strip row w.  The buffer resource spans exactly the
-  // image row, so columns outside [0, W) come back as zeros (a negative byte offset is a huge unsigned one).  The left
-  // image's window is stored mirrored, so that on both sides the descriptor matched at disparity d sits d slots after
-  // the one matched at d = 0.
+  // ---- every load of the wave, up front ----
+  const int up = u0 + 2 * lane;                              // the lane's pixels: up, up + 1
   const int span = kStripW + dp.disp_max;
-  const int base = side ? u0 : u0 - dp.disp_max;
-  {
-    const uint4* rowp = B + (size_t)max(min(v0 + wave, H - 3), 2) * W;    // :701 row clamp
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(rowp), 0, W * 16, 0x00020000);
-    uint4* dst = s_B + wave * span;
-    const int goff = (base + lane) * 16;                     // byte offset inside the row
-    const int li = side ? lane : span - 1 - lane;            // LDS slot
-    // span <= 128 + 32 NW - 1: all the row's loads are issued together (a load past the window is harmless: it stays inside the row or
-    // reads as zero), then stored — one memory round trip per wave instead of one per 64 columns
-    constexpr int kLoads = (kStripW + 32 * NW + 62) / 64;
-    jn_u32x4 t[kLoads];
+  const int base = side ? u0 : u0 - dp.disp_max;             // left image looks left (u - d), right image looks right (u + d)
+  const int g0 = base >> 2;                                  // arithmetic shift: floor for the negative bases of the left image's first strips
+  constexpr int kPasses = NW == 4 ? 1 : 2;                   // 128 + roundup4(disp_max) <= 256 columns are at most 64 groups for NW = 4 (u0 is a multiple of 128), 96 for NW = 8
+  const uint8_t* duA = planes + (size_t)(imgA * 2) * H * Wp;
+  const uint8_t* duB = planes + (size_t)(imgB * 2) * H * Wp;
+  const int dv_off = H * Wp;                                 // the dv plane follows the du plane
+  // (buffer loads: the lane's byte offset in the vector operand, the row in the scalar one — no 64-bit address arithmetic per load)
+  uint32_t oL[8];
+  if (!(dbg & 16)) {
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(duA), 0, 2 * H * Wp, 0x00020000);
+    const int o = (vr - 2) * Wp + min((up & ~3) + 4 * (lane & 1), Wp - 4);
 #pragma unroll
-    for (int i = 0; i < kLoads; i++) t[i] = (dbg & 8) ? jn_u32x4{0, 0, 0, 0} : __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff + i * 1024, 0, 0);
+    for (int k = 0; k < 5; k++) oL[k] = __builtin_amdgcn_raw_buffer_load_b32(rA, o, k * Wp, 0);
 #pragma unroll
-    for (int i = 0; i < kLoads; i++)
-      if (lane + 64 * i < span) dst[li + (side ? 64 * i : -64 * i)] = make_uint4(t[i].x, t[i].y, t[i].z, t[i].w);
+    for (int k = 0; k < 3; k++) oL[5 + k] = __builtin_amdgcn_raw_buffer_load_b32(rA, o, dv_off + (k + 1) * Wp, 0);
   }
-  if (!__builtin_amdgcn_readfirstlane(ok_v)) return;         // uniform over the block
-  const int cnt = __builtin_amdgcn_readfirstlane(cnt_v);
-  if (list_wave) {
-    s_list[wave][lane] = lw0; s_list[wave][lane + 64] = lw1; s_list[wave][lane + 128] = lw2; s_list[wave][lane + 192] = lw3;
-    // rank among the listed triangles (indices are distinct): a pixel's owner is the covering triangle with the
-    // LARGEST index = the highest set bit of its cover word; the planes are stored by rank so that the owner's plane is
-    // one read.  v_readlane on compile-time / loop-uniform lanes instead of shuffles.
-    const int c16u = __builtin_amdgcn_readfirstlane(min(cnt, (int)kBinLds));
-    const int myt = lane < c16u ? (int)s_list[wave][(lane & (kBinLds - 1)) * kBinWords] : 0x7FFFFFFF;
-    int rank = 0;
-    for (int jj = 0; jj < c16u; jj++) rank += __builtin_amdgcn_readlane(myt, jj) < myt ? 1 : 0;
-    if (lane < c16u) {
-      const uint32_t* e = &s_list[wave][lane * kBinWords];
-      s_plane[wave][rank] = make_uint4(e[9], e[10], e[11], e[12]);
-    }
-    // lane (xx, half) accumulates rows half*4 .. half*4+3 of column xx over all listed candidates.  The candidate's four row bits n are
-    // spread to bit 0 of four bytes ((n * 0x204081) & 0x01010101: bit j lands on bit 8 j, no two products collide there) and shifted to
-    // the triangle's rank inside the byte — ranks 0..7 in one word, 8..15 in the other (the rank is wave-uniform: a scalar branch).
-    const int xx = lane & (kTileW - 1), half = lane >> 5;
-    const uint32_t* mrow = &s_list[wave][1 + (xx >> 2)];
-    const int sh = (xx & 3) * 8 + half * 4;
-    unsigned acc_lo = 0, acc_hi = 0;
-    for (int c0 = 0; c0 < c16u; c0 += 4) {                   // four mask reads in flight (c0 + 3 <= 15: inside the tile's 16 entries)
-      unsigned m[4];
+  uint32_t wL[kPasses][8], wS[8];
+  if (!(dbg & 8)) {
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(duB), 0, 2 * H * Wp, 0x00020000);
 #pragma unroll
-      for (int k = 0; k < 4; k++) m[k] = mrow[(c0 + k) * kBinWords];
+    for (int i = 0; i < kPasses; i++) {
+      // groups outside the image: any in-range address — their descriptors are zeroed below, and every dword a VALID descriptor taps lies in [0, W + 4)
+      const int o = (vr - 2) * Wp + max(min(4 * (g0 + lane + 64 * i), Wp - 4), 0);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (c0 + k >= c16u) break;                           // uniform
-        const unsigned spread = (((m[k] >> sh) & 15u) * 0x204081u) & 0x01010101u;
-        const int rk = __builtin_amdgcn_readlane(rank, c0 + k);
-        if (rk < 8) acc_lo |= spread << rk; else acc_hi |= spread << (rk - 8);
-      }
+      for (int k = 0; k < 5; k++) wL[i][k] = __builtin_amdgcn_raw_buffer_load_b32(rB, o, k * Wp, 0);
+#pragma unroll
+      for (int k = 0; k < 3; k++) wL[i][5 + k] = __builtin_amdgcn_raw_buffer_load_b32(rB, o, dv_off + (k + 1) * Wp, 0);
     }
-    // row j's word = byte j of acc_lo | byte j of acc_hi << 8; the four rows of a column are adjacent: one 8-byte store
-    uint2 cw;
-    cw.x = __builtin_amdgcn_perm(acc_hi, acc_lo, 0x05010400u);
-    cw.y = __builtin_amdgcn_perm(acc_hi, acc_lo, 0x07030602u);
-    *reinterpret_cast<uint2*>(&s_cover[wave][xx][half * 4]) = cw;
+    const uint8_t* ps = duB + (size_t)(vr - 2) * Wp + max(min(4 * (g0 + 64 * kPasses), Wp - 4), 0);       // wave-uniform address: scalar loads
+#pragma unroll
+    for (int k = 0; k < 5; k++) wS[k] = *reinterpret_cast<const uint32_t*>(ps + (size_t)k * Wp);
+#pragma unroll
+    for (int k = 0; k < 3; k++) wS[5 + k] = *reinterpret_cast<const uint32_t*>(ps + dv_off + (size_t)(k + 1) * Wp);
   }
-  if (lw < kStripTiles && lane == 0) s_cnt[lw] = cnt;
-  __syncthreads();
-  if (dbg & 4) return;
-  if (v >= H) return;
+  // ownership words of the two pixels (k_owner left them in the output image), one aligned dword when the rows are dword-aligned
+  uint16_t* orow = reinterpret_cast<uint16_t*>(raw) + ((size_t)fs * H + v) * W;
+  const bool pair_io = (W & 1) == 0;                         // uniform
+  unsigned ow;
+  if (pair_io) ow = up < W ? *reinterpret_cast<const uint32_t*>(orow + up) : 0u;
+  else ow = (up < W ? (unsigned)orow[up] : 0u) | (up + 1 < W ? (unsigned)orow[up + 1] << 16 : 0u);
+  // grid cells of the two pixels: the same one unless a cell boundary falls between them (never for an even grid size).  x / G as one
+  // multiply-high (dense_row_applies() guarantees G >= 8, so the magic constant is exact for any pixel index)
+  uint32_t cellw[2][NW];
+  const uint32_t* cells = gridbits + ((size_t)fs * dp.gw * dp.gh + (size_t)__umulhi((unsigned)v, dp.grid_magic) * dp.gw) * kGridWords;
+  const unsigned c0 = __umulhi((unsigned)min(up, W - 1), dp.grid_magic), c1 = __umulhi((unsigned)min(up + 1, W - 1), dp.grid_magic);
+#pragma unroll
+  for (int w = 0; w < NW; w++) cellw[0][w] = cells[(size_t)c0 * kGridWords + w];
+  const bool two_cells = __any(c1 != c0);
+  if (two_cells) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) cellw[1][w] = cells[(size_t)c1 * kGridWords + w];
+  } else {
+#pragma unroll
+    for (int w = 0; w < NW; w++) cellw[1][w] = cellw[0][w];
+  }
 
-  constexpr unsigned kNoKey = 0xFFFFFFFFu;
-  const int radius = dp.radius;
-  int16_t* out = raw + ((size_t)(frame * 2 + side) * H + v) * W;   // integer disparity, -1 no match, -10 not visited (:797-798)
+  // ---- own descriptors ----
+  uint4 a4[2];
+  if (dbg & 16) { a4[0] = make_uint4(up, up, up, up); a4[1] = a4[0]; }
+  else {
+    // L = the dword this lane fetched, P = its pair partner's (quad_perm [1,0,3,2]).  Even lanes hold (lo, hi) = (L, P) and want the bytes from
+    // 0 on; odd lanes hold (P, L) and want them from byte 2 on (columns 2, 3 of the group): one v_perm with a per-lane selector each for
+    // the first four bytes (W) and the ones behind them (W2).
+    const bool odd = lane & 1;
+    const uint32_t selW = odd ? 0x05040302u : 0x07060504u, selW2 = odd ? 0x0c0c0706u : 0x03020100u;
+    PlaneRows po;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t L = oL[k], P = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)L, 0xB1, 0xF, 0xF, false);
+      const uint32_t Wd = __builtin_amdgcn_perm(L, P, selW), W2 = __builtin_amdgcn_perm(L, P, selW2);
+      if (k < 5) { po.al[k] = Wd; po.ah[k] = W2; } else { po.bl[k - 5] = Wd; po.bh[k - 5] = W2; }
+    }
+    a4[0] = desc_from_rows<0>(po); a4[1] = desc_from_rows<1>(po);
+    const bool rz = vr < 3 || vr > H - 4;
+    if (rz || up < 3 || up + 1 > W - 4) {                    // (only the image's rim: zeros outside the descriptor image)
+      if (rz || up < 3 || up > W - 4) a4[0] = make_uint4(0, 0, 0, 0);
+      if (rz || up + 1 < 3 || up + 1 > W - 4) a4[1] = make_uint4(0, 0, 0, 0);
+    }
+  }
+  // ---- the window row.  The left image's window is stored mirrored, so that on both sides the descriptor matched at disparity d sits d slots
+  // after the one matched at d = 0 ----
+  uint4* s_B = s_Bx + kDense2Slack;
+  uint4* dst = s_B + wave * span;
+  {
+    const bool row_zero = vr < 3 || vr > H - 4;              // rows 2 and H-3 hold no descriptors: zeros
+    const bool rim = row_zero || base < 3 || base + span - 1 > W - 4;      // only strips at the image's rim hold columns outside [3, W-4]
+#pragma unroll
+    for (int i = 0; i < kPasses; i++) {
+      const int col = 4 * (g0 + lane + 64 * i), c = col - base;             // window slot of the group's first column
+      PlaneRows pw;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        // the dword behind this lane's: the next lane's (wave_shl:1); the last lane keeps `old` = the next pass's first lane or the scalar load
+        uint32_t lo = wL[i][k], behind = (i + 1 < kPasses) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wL[kPasses - 1][k]) : wS[k];
+        if (dbg & 8) { lo = col + k; behind = col; }
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)behind, (int)lo, 0x130, 0xF, 0xF, false);
+        if (k < 5) { pw.al[k] = lo; pw.ah[k] = hi; } else { pw.bl[k - 5] = lo; pw.bh[k - 5] = hi; }
+      }
+      auto put = [&](int k, uint4 d) {
+        if (rim && (row_zero || col + k < 3 || col + k > W - 4)) d = make_uint4(0, 0, 0, 0);
+        if ((unsigned)(c + k) < (unsigned)span) dst[side ? c + k : span - 1 - (c + k)] = d;
+      };
+      put(0, desc_from_rows<0>(pw)); put(1, desc_from_rows<1>(pw)); put(2, desc_from_rows<2>(pw)); put(3, desc_from_rows<3>(pw));
+    }
+  }
+  if (!ok) return;                                           // uniform over the wave (and the block)
+  __builtin_amdgcn_wave_barrier();                           // LDS operations of one wave execute in order: the stores above precede the reads below
+  if (dbg & 4) return;
+
+  // ---- matching ----
   // the strip needs the image-border mask only if some pixel's disparity range can leave [2, W-2)
   const bool border = side ? (u0 + kStripW - 1 + dp.disp_max > W - 3) : (u0 - dp.disp_max < 2);
-  const int grp_u = wave >> 2;                               // = grp, wave-uniform for the compiler
-
+  int res[2];
 #pragma unroll
-  for (int q = 0; q < kPxPerThread; q++) {
-    const int k = grp_u + 2 * q;
-    const int ut0 = u0 + k * kTileW;                                     // first column of the tile (wave-uniform)
-    if (ut0 >= W) break;
-    const int u = ut0 + x;
+  for (int q = 0; q < 2; q++) {
+    const int u = up + q;
     const bool inw = u < W;
-    // ---- which triangle owns this pixel: the last covering one in list order ----
-    const int cntk = s_cnt[k];
-    int t = -1; float pa = 0, pb = 0, pc = 0; bool valid = false;
-    if (inw) {
-      if (cntk <= kBinLds) {
-        const unsigned cover = s_cover[k][x][r];
-        if (cover) {
-          const uint4 pl = s_plane[k][31 - __clz(cover)];
-          t = 0;
-          pa = __uint_as_float(pl.x); pb = __uint_as_float(pl.y); pc = __uint_as_float(pl.z); valid = pl.w & 1u;
-        }
-      } else {
-        if (cntk <= kBinCap) {                               // long list: read it from global memory
-          const BinEntry* list = bin_list + (bin_row + bx * kStripTiles + k) * kBinCap;
-          for (int c = 0; c < cntk; c++) {
-            const unsigned m = reinterpret_cast<const uint8_t*>(list[c].rows)[x];
-            const int tc = list[c].t;
-            if (((m >> r) & 1u) && tc > t) t = tc;
-          }
-        } else {                                             // overflowing tile: scan every triangle of this side
-          for (int c = fi.ntri[side] - 1; c >= 0; c--) {
-            const TriRec* qq = R + c;
-            if (tri_covers(qq->Au, qq->Bu, qq->Cu, qq->ACa, qq->ACb, qq->ABa, qq->ABb, qq->BCa, qq->BCb, u, v)) { t = c; break; }
-          }
-        }
-        if (t >= 0) { const TriRec* tr = R + t; pa = tr->pa; pb = tr->pb; pc = tr->pc; valid = tr->flags & 1; }
-      }
-    }
+    const unsigned code = (ow >> (16 * q)) & 0xFFFFu;
+    const bool valid = (code >> 14) & 1u;
+    const int d_plane = (int)(code & 0x3FFFu) - kOwnerBias;
     const uint4 a = a4[q];
-    const bool elig = inw && t >= 0 && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture;   // :697, :715-719
-    const int d_plane = (int)__fadd_rn(__fadd_rn(__fmul_rn(pa, (float)u), __fmul_rn(pb, (float)v)), pc);   // :722
-    const int lo = max(d_plane - radius, 0), hi = min(d_plane + radius, dp.disp_max);                      // :723-724
-    // disparities whose warped column stays inside [2, W-2) (:746, :753, :764, :771)
-    const int dmax_ok = side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
-    // Bu[d] = descriptor of the column matched at disparity d (u + d in the right image's window, u - d in the mirrored left one)
+    const bool elig = inw && (code >> 15) && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture;   // :697, :715-719
     const int uc = min(u, W - 1);
-    const uint4* Bu = s_B + r * span + (side ? (uc - base) : (span - 1 + base - uc));
-    const int dlow = d_plane - radius;
-    const int phi = min(hi, dmax_ok);
-
-    // ---- grid candidates outside the plane range (:742-750): per-lane bit scan, one (different) disparity per lane and round ----
-    // Keys here are (SAD << 16) + LDS byte address of the candidate's descriptor: the address is what the read needs anyway, it orders
-    // like d, and d = (address - address of Bu[0]) / 16 is recovered once at the end (the bias the plane keys carry is added there too).
-    unsigned best1 = kNoKey;
-    const uint32_t bu_a = lds_addr(Bu);
-    if (elig && !(dbg & 1)) {
-      // The plane range [lo, hi] (at most 15 wide) sits as ones in bits 16.. of T; word w of the exclusion mask is the HIGH half of
-      // T << (lo + 16 - 32 w) with the shift clamped to [0, 63]: below 0 and from 48 up nothing of T lands in bits 32..63, in between it
-      // is M << (lo - 32 w) or the spill M >> (32 w - lo) of a range that starts in the word below.  (hi < lo: T = 0.)
-      const unsigned long long T = (unsigned long long)(((1u << max(hi - lo + 1, 0)) - 1u) << 16);
-#pragma unroll
-      for (int w = 0; w < NW; w++) {
-        const uint32_t excl = (uint32_t)((T << min(max(lo + 16 - 32 * w, 0), 63)) >> 32);
-        uint32_t bits = cellw[q][w] & ~excl;
-        if (border) bits &= range_mask(0, dmax_ok, w);
-        while (bits) {
-          const uint32_t ad = bu_a + (uint32_t)((w << 5) + __builtin_ctz(bits)) * 16u;
-          bits &= bits - 1;
-          best1 = min(best1, sadhi16(a, lds_read16(ad), ad));
-        }
-      }
-    }
-
-    // ---- plane neighbourhood with prior (:751-756): d = dlow + k, k = 0 .. 2r ----
-    unsigned best2 = kNoKey;
-    if (dbg & 2) {} else
-    if (radius == 2) {
-      // address window clamped so that it stays inside the LDS block (+- kDense2Slack); a clamped window holds no valid d
-      const uint4* Bw = Bu + max(min(dlow, dp.disp_max), -2 * radius);
-      uint4 nb[5];
-#pragma unroll
-      for (int kk = 0; kk < 5; kk++) nb[kk] = Bw[kk];
-      const bool all_in = dlow >= 0 && dlow + 4 <= phi && valid;          // whole neighbourhood valid, prior on
-      if (__ballot(elig && !all_in) == 0ull) {
-        // every lane of the wave: five valid candidates with the prior — no per-candidate tests (scalar key bases)
-        const unsigned i0 = ((unsigned)(kCellBias + dp.P[2]) << 16), i1 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 1u,
-                       i2 = ((unsigned)(kCellBias + dp.P[0]) << 16) + 2u, i3 = ((unsigned)(kCellBias + dp.P[1]) << 16) + 3u,
-                       i4 = ((unsigned)(kCellBias + dp.P[2]) << 16) + 4u;
-        // keys relative to dlow (scalar bases), dlow added to the minimum: 0 <= dlow and dlow + 4 <= 255, no carry into the cost
-        const unsigned k0 = sadhi16(a, nb[0], i0), k1 = sadhi16(a, nb[1], i1), k2 = sadhi16(a, nb[2], i2),
-                       k3 = sadhi16(a, nb[3], i3), k4 = sadhi16(a, nb[4], i4);
-        best2 = min(min(min(k0, k1), min(k2, k3)), k4) + (unsigned)dlow;
-      } else {
-        const unsigned prior_on = valid ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-        for (int kk = 0; kk < 5; kk++) {
-          const int d = dlow + kk;
-          const unsigned init = (d >= 0 && d <= phi) ? (((unsigned)kCellBias << 16) + (((unsigned)dp.P[kk < 2 ? 2 - kk : kk - 2] << 16) & prior_on) + (unsigned)d)
-                                                     : (unsigned)kCellInvalid;
-          best2 = min(best2, sadhi16(a, nb[kk], init));
-        }
-        if (best2 >= (unsigned)kCellInvalid) best2 = kNoKey;
-      }
-    } else if (elig) {                                                     // other radii: one read per candidate
-#pragma unroll
-      for (int off = -7; off <= 7; off++) {
-        if ((off < 0 ? -off : off) > radius) continue;                     // uniform
-        const int d = d_plane + off;
-        if (d >= lo && d <= phi) {
-          const unsigned init = (valid ? (unsigned)(kCellBias + dp.P[off < 0 ? -off : off]) << 16 : (unsigned)kCellBias << 16) + (unsigned)d;
-          best2 = min(best2, sadhi16(a, Bu[d], init));
-        }
-      }
-    }
-    // the plane phase wins only with a strictly smaller cost; a missing grid key (0xFFFF + bias) loses to every plane key, a missing plane
-    // key (cost field 0xFFFF) to every grid key (SAD <= 4080); both missing: the plane branch answers -1
-    const bool plane_wins = (best2 >> 16) < (best1 >> 16) + (unsigned)kCellBias;
-    int result = -10;                                                      // :797-798
-    if (elig) result = plane_wins ? (best2 == kNoKey ? -1 : (int)(best2 & 255u)) : (int)(((best1 & 0xFFFFu) - bu_a) >> 4);   // :778-779
-    if (inw) out[u] = (int16_t)result;
+    const uint4* Bu = dst + (side ? (uc - base) : (span - 1 + base - uc));
+    res[q] = match_pixel<NW>(dp, a, elig, d_plane, valid, u, side, Bu, cellw[q], border, dbg);
   }
+  int16_t* out = raw + ((size_t)fs * H + v) * W;             // integer disparity, -1 no match, -10 not visited (:797-798)
+  if (pair_io) { if (up < W) *reinterpret_cast<uint32_t*>(out + up) = ((unsigned)res[0] & 0xFFFFu) | ((unsigned)res[1] << 16); }
+  else { if (up < W) out[up] = (int16_t)res[0]; if (up + 1 < W) out[up + 1] = (int16_t)res[1]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2630,7 +2876,9 @@ static inline dim3 grid2d(int W, int H, int z) { return dim3((W + 255) / 256, H,
 // anything can launch, so the launchers themselves carry no lazy-initialisation state (four slot workers reaching a
 // launcher together during warm-up used to race on it).
 template <int PITCH> static hipError_t configure_support_pitch() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <bool IN_LDS>
 __global__ void k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step, int arr_cap,
@@ -2677,26 +2925,39 @@ void launch_descriptor(hipStream_t st, const DevParams& dp, const uint8_t* I1, c
   const dim3 grid((tiles_x + kDescTiles - 1) / kDescTiles, (dp.H + kDescTH - 1) / kDescTH, 2 * n);
   hipLaunchKernelGGL(k_descriptor_fused, grid, dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, desc);
 }
+int plane_pitch(int W) { return (W + 8 + 63) / 64 * 64; }
+size_t plane_bytes(int W, int H, int images) { return (size_t)images * 2 * H * plane_pitch(W); }
+void launch_sobel_planes(hipStream_t st, const DevParams& dp, const uint8_t* I1, const uint8_t* I2, int32_t in_pitch, int64_t in_stride, int n, uint8_t* planes) {
+  const int Wp = plane_pitch(dp.W);
+  const dim3 grid((Wp / 4 + 63) / 64, (dp.H + 4 * kPlaneRows - 1) / (4 * kPlaneRows), 2 * n);
+  hipLaunchKernelGGL(k_sobel_planes, grid, dim3(256), 0, st, dp, I1, I2, in_pitch, (long long)in_stride, n, planes, Wp);
+}
 template <int PITCH>
-static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can, int nseg) {
+static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const DescSrc& src, int16_t* d_can, int nseg) {
   const int per_seg = (dp.cw + nseg - 1) / nseg;
   const int threads = std::min(1024, (per_seg * kSupportLanes + 63) / 64 * 64);           // one pass over the segment's candidates when they fit
-  hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH>), dim3(dp.ch, n, nseg), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, desc, d_can, nseg);
+  if (src.planes)
+    hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH, true>), dim3(dp.ch, n, nseg), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, src.ptr, src.Wp, d_can, nseg);
+  else
+    hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH, false>), dim3(dp.ch, n, nseg), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, src.ptr, 0, d_can, nseg);
 }
 // columns of both images a workgroup stages for one of nseg segments of a lattice row
 static int support_window(const DevParams& dp, int nseg) {
   return nseg == 1 ? dp.W : ((dp.cw + nseg - 1) / nseg) * dp.step + 2 * dp.disp_max + 8;
 }
-static bool launch_support_bucket(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can, int nseg) {
+static bool launch_support_bucket(hipStream_t st, const DevParams& dp, int n, const DescSrc& desc, int16_t* d_can, int nseg, bool dry = false) {
   const int win = support_window(dp, nseg);
+  if (win > 2560) return false;
+  if (dry) return true;
   if (win <= 320) launch_support_pitch<320>(st, dp, n, desc, d_can, nseg);
   else if (win <= 640) launch_support_pitch<640>(st, dp, n, desc, d_can, nseg);
   else if (win <= 1280) launch_support_pitch<1280>(st, dp, n, desc, d_can, nseg);
-  else if (win <= 2560) launch_support_pitch<2560>(st, dp, n, desc, d_can, nseg);
-  else return false;
+  else launch_support_pitch<2560>(st, dp, n, desc, d_can, nseg);
   return true;
 }
-void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* desc, int16_t* d_can) {
+// dry: nothing is launched; the return value says whether an LDS bucket takes these parameters (false: the global-memory kernel would run,
+// which reads materialised descriptors only)
+bool launch_support(hipStream_t st, const DevParams& dp, int n, const DescSrc& desc, int16_t* d_can, bool dry) {
   // The LDS row pitch is a template constant (immediate tap offsets): the smallest bucket that holds the staged window;
   // 1280 columns = 80 KB, 2560 = the whole 160 KB.  A lattice row is cut into column segments, one workgroup each (windows
   // overlap by 2 disp_max): segments of 64 candidates (256 threads, a 320 / 640-column bucket) while the overlap stays below
@@ -2704,13 +2965,14 @@ void launch_support(hipStream_t st, const DevParams& dp, int n, const uint4* des
   // among the other slots' kernels the small workgroups find room at once instead of queueing for 80 KB of LDS, and the
   // pipelined rate gains 1.5 % (profiles/r02_d_support_split_ab.txt).  JN_SUPPORT_SPLIT=k forces k segments (1 = one per row).
   const int split = getenv("JN_SUPPORT_SPLIT") ? atoi(getenv("JN_SUPPORT_SPLIT")) : 0;
-  if (split >= 1 && launch_support_bucket(st, dp, n, desc, d_can, split)) return;
+  if (split >= 1 && launch_support_bucket(st, dp, n, desc, d_can, split, dry)) return true;
   const int per = 2 * dp.disp_max + 8 <= 64 * dp.step ? 64 : 128;
   static const int max_seg = getenv("JN_SUPPORT_SEGMENTS") ? atoi(getenv("JN_SUPPORT_SEGMENTS")) : 8;
   for (int nseg = std::min(std::max(1, (dp.cw + per - 1) / per), std::max(1, max_seg)); nseg <= std::max(1, max_seg); nseg++)
-    if (launch_support_bucket(st, dp, n, desc, d_can, nseg)) return;       // more segments until the window fits a bucket
-  if (launch_support_bucket(st, dp, n, desc, d_can, 1)) return;
-  hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, desc, d_can);
+    if (launch_support_bucket(st, dp, n, desc, d_can, nseg, dry)) return true;       // more segments until the window fits a bucket
+  if (launch_support_bucket(st, dp, n, desc, d_can, 1, dry)) return true;
+  if (!dry && !desc.planes) hipLaunchKernelGGL(k_support, dim3((dp.cw * dp.ch + 3) / 4, n), dim3(256), 0, st, dp, n, static_cast<const uint4*>(desc.ptr), d_can);
+  return false;
 }
 // classify + resolve applies when lattice (with border) and codes fit the LDS together; JN_FILTER_WAVEFRONT=1 keeps the
 // skewed-wavefront kernel (A/B and test hook), which also serves lattices that need streaming
@@ -2965,34 +3227,46 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
   if (max_tri <= 0) return;
   hipLaunchKernelGGL(k_bin, dim3((max_tri + kBinTris - 1) / kBinTris, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
 }
-bool dense2_applies(const DevParams& dp) {
-  static const int enabled = getenv("JN_DENSE2") ? atoi(getenv("JN_DENSE2")) : 1;
-  if (!enabled || dp.grid_size < 8) return false;                 // tiny grids: a wave would touch many cells
+bool dense_row_applies(const DevParams& dp) {
+  if (dp.grid_size < 8) return false;                 // tiny grids: a wave would touch many cells
   for (int k = 0; k <= dp.radius; k++) if (dp.P[k] < -kCellPriorMax || dp.P[k] > kCellPriorMax) return false;   // 16-bit cost field of the keys
   return true;
 }
-void launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const uint4* desc, int16_t* raw) {
+// Planes: k_owner + k_dense_row (false when they do not take these parameters: nothing is launched then).  Materialised descriptors: k_dense.
+// dry: nothing is launched; the return value says whether the plane form takes these parameters.
+bool launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
+                  const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const DescSrc& desc, int16_t* raw, bool dry, hipEvent_t ev_owner) {
   static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
   const int nbx = (dp.W + kStripW - 1) / kStripW, nby = (dp.H + kTileH - 1) / kTileH;
   const int total = nbx * nby * 2 * n;
   const int blocks = xcd_order ? (total + 7) / 8 * 8 : total;
   const size_t lds = (size_t)kTileH * (kStripW + dp.disp_max) * sizeof(uint4);   // 32.6 KB at disp_max 127, 49 KB at 255
-  const unsigned long long items_half = (unsigned long long)nbx * nby * n;          // the largest dividend of k_dense2's item decode
+  const unsigned long long items_half = (unsigned long long)nbx * nby * n;          // the largest dividend of k_dense_row's item decode
   const bool magic_ok = items_half * (unsigned long long)max(nbx, nby) < (1ull << 32);
-  if (dense2_applies(dp) && magic_ok) {
+  if (desc.planes) {
+    if (!(dense_row_applies(dp) && magic_ok)) return false;
+    if (dry) return true;
     const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + nbx - 1) / nbx), nby_magic = (uint32_t)(((1ull << 32) + nby - 1) / nby);
     static const int dbg = getenv("JN_DENSE_DBG") ? atoi(getenv("JN_DENSE_DBG")) : 0;
+    const size_t lds2 = lds + 2 * kDense2Slack * sizeof(uint4);
+    const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
+    static const int odbg = getenv("JN_OWNER_DBG") ? atoi(getenv("JN_OWNER_DBG")) : 0;          // profiling switches (results wrong): 1 no list loads, 2 no stores, 4 empty
+    // test hooks (read per launch; results stay right): lists longer than JN_OWNER_FAST_MAX take the general loop, longer than JN_OWNER_SCAN_FROM the all-triangles scan
+    const char* e1 = getenv("JN_OWNER_FAST_MAX"); const char* e2 = getenv("JN_OWNER_SCAN_FROM");
+    const int fast_max = e1 ? std::min(atoi(e1), (int)kBinLds) : (int)kBinLds, scan_from = e2 ? std::min(atoi(e2), (int)kBinCap) : (int)kBinCap;
+    hipLaunchKernelGGL(k_owner, dim3((tiles_x + 3) / 4, tiles_y, 2 * n), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list, reinterpret_cast<uint16_t*>(raw), odbg, fast_max, scan_from);
+    if (ev_owner) hipEventRecord(ev_owner, st);                // (timing of the matcher proper, jn_elas_kernel_time)
+    const uint8_t* pl = static_cast<const uint8_t*>(desc.ptr);
     if (dp.disp_max < 128)
-      hipLaunchKernelGGL(k_dense2<4>, dim3(blocks), dim3(kDenseThreads), lds + 2 * kDense2Slack * sizeof(uint4), st, dp, n, info, recs, tri_cap, bin_count,
-                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
+      hipLaunchKernelGGL(k_dense_row<4>, dim3(blocks), dim3(kDenseThreads), lds2, st, dp, n, info, gridbits, pl, desc.Wp, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
     else
-      hipLaunchKernelGGL(k_dense2<8>, dim3(blocks), dim3(kDenseThreads), lds + 2 * kDense2Slack * sizeof(uint4), st, dp, n, info, recs, tri_cap, bin_count,
-                         bin_list, gridbits, desc, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
-    return;
+      hipLaunchKernelGGL(k_dense_row<8>, dim3(blocks), dim3(kDenseThreads), lds2, st, dp, n, info, gridbits, pl, desc.Wp, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
+    return true;
   }
-  hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(kDenseThreads), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits, desc, raw,
-                     nbx, nby, xcd_order);
+  if (!dry && !desc.planes)
+    hipLaunchKernelGGL(k_dense, dim3(blocks), dim3(kDenseThreads), lds, st, dp, n, info, recs, tri_cap, bin_count, bin_list, gridbits,
+                       static_cast<const uint4*>(desc.ptr), raw, nbx, nby, xcd_order);
+  return false;
 }
 void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2) {
   hipLaunchKernelGGL(k_lr, dim3(dp.H, n), dim3(256), (size_t)2 * dp.W * sizeof(int16_t), st, dp, info, raw, D1, D2);

@@ -480,3 +480,21 @@ def test_subsampling_gives_the_reference_half_size_maps(jn, oracle, same, W, H, 
     assert list(st) == [0, 1]
     assert same(o1[0].cpu().numpy(), D1o) and same(o2[0].cpu().numpy(), D2o)
     assert float(o1[1].min()) == -3.0 == float(o1[1].max()) and float(o2[1].min()) == -3.0 == float(o2[1].max())
+
+
+@pytest.mark.parametrize("fast_max,scan_from", [(16, 64), (3, 64), (0, 64), (3, 6), (0, 0)])
+def test_every_ownership_route_gives_the_same_maps(jn, oracle, same, monkeypatch, fast_max, scan_from):
+    """k_owner resolves which triangle owns a pixel three ways: ranked cover words for lists of up to 16 triangles per 32x8 tile (every
+    list at 720p so far), the largest covering triangle number entry by entry for longer lists, and a scan over all of a side's triangles
+    for tiles whose list overflowed its 64 entries.  The two test hooks lower the thresholds so that ORDINARY lists take the other routes:
+    (3, 64) mixes ranked and entry-by-entry, (0, 64) is entry-by-entry only, (3, 6) adds the scan for the longer lists, (0, 0) scans every
+    tile.  All of them must give the oracle's maps bit for bit."""
+    monkeypatch.setenv("JN_OWNER_FAST_MAX", str(fast_max))
+    monkeypatch.setenv("JN_OWNER_SCAN_FROM", str(scan_from))
+    from scenes import make_scene
+    for kind, W, H, dmax in (("blobs", 320, 240, 79), ("slanted", 333, 201, 63)):
+        L, R = make_scene(kind, W, H, dmax, 77)
+        p = dict(disp_max=dmax, postprocess_only_left=0)
+        st, D1, D2 = run_elas(jn, jn.Elas.parameters(0, **p), L, R)
+        st_o, D1o, D2o = oracle.process(oracle.params(0, **p), L, R)
+        assert st == st_o == 0 and same(D1, D1o) and same(D2, D2o), (kind, fast_max, scan_from)
