@@ -867,6 +867,55 @@ def run_rank(a):
         except Exception as exc:                     # informational leg: never let it take the headline line down
             extra["block_matching"] = {"error": repr(exc)}
 
+    # north_star asks for the rate at 640x480 too: the same pipelined path (ELAS -> u8 map -> scan, inputs resident, four batches of 32 in
+    # flight) on 640x480 D=64 Appendix-A pairs, informational, outside `value`; frame 0 of every slot against the compiled reference's hash
+    vga = None
+    if rank == 0 and world == 1 and not a.no_latency_config and (W, H) != (640, 480):
+        try:
+            w3, h3, d3, b3 = 640, 480, 64, 32
+            L3 = np.empty((b3, h3, w3), np.uint8); R3 = np.empty((b3, h3, w3), np.uint8)
+            for b in range(b3):
+                L3[b], R3[b] = node.synth_pair(w3, h3, d3, 12345 + b)
+            tL3, tR3 = torch.from_numpy(L3).to(dev), torch.from_numpy(R3).to(dev)
+            e3 = jn.Elas(jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=d3 - 1), w3, h3, max_batch=b3, device=local_rank, host_threads=host_threads, slots=S)
+            sp3 = node.scan_params(w3, h3); lut3 = node.build_valid_disp_lut(sp3, w3, h3, device=local_rank)
+            o1 = [torch.zeros((b3, h3, w3), dtype=torch.float32, device=dev) for _ in range(S)]; o2 = [torch.zeros_like(x) for x in o1]
+            u3 = [torch.zeros((b3, h3, w3), dtype=torch.uint8, device=dev) for _ in range(S)]
+            sc3 = [parallel.ScanBuffer(b3, 90, dev) for _ in range(S)]
+            st3 = [(C.c_int32 * b3)() for _ in range(S)]
+
+            def run3(steps):
+                fl = []
+                for i in range(steps):
+                    sl = i % S
+                    if len(fl) == S:
+                        e3.wait(fl.pop(0))
+                    e3.submit_scan(sl, b3, tL3.data_ptr(), tR3.data_ptr(), w3, h3 * w3, o1[sl].data_ptr(), o2[sl].data_ptr(), sp3, lut3.ptr,
+                                   u3[sl].data_ptr(), sc3[sl].bins.data_ptr(), sc3[sl].meta.data_ptr(), st3[sl])
+                    fl.append(sl)
+                while fl:
+                    e3.wait(fl.pop(0))
+            run3(12)
+            torch.cuda.synchronize()
+            regs3 = []
+            for _ in range(5):
+                t1 = time.perf_counter(); run3(80); torch.cuda.synchronize(); regs3.append(time.perf_counter() - t1)
+            el3 = float(np.median(regs3)) / 80
+            want3 = golden_hash(w3, h3, d3, d3 - 1)
+            got3 = []
+            for sl in range(S):
+                h_ = o1[sl][0].cpu().numpy()                 # (kept alive while its pointer is used)
+                got3.append("%016x" % jn.load().jn_fnv1a64_u32(h_.ctypes.data, h3 * w3))
+            vga = {"workload": "640x480 D=64, ELAS -> u8 map -> 90-bin scan, batch=32, %d batches in flight, inputs resident in HBM" % S,
+                   "pairs_per_sec": round(b3 / el3, 1), "ms_per_step": round(el3 * 1e3, 3), "steps_per_region": 80, "regions": 5,
+                   "whole_path_frac": round(b3 / el3 * 97.0 * w3 * h3 / 1e9 / HBM_PEAK_GBS, 4),
+                   "check": {"what": "frame 0 (seed 12345) of every slot: FNV-1a-64 of D1 against the compiled reference's", "expected": want3, "got": got3,
+                             "ok": all(g == want3 for g in got3) if want3 else None}}
+            e3.close()
+            del o1, o2, u3, tL3, tR3
+        except Exception as exc:                             # informational leg: never let it take the headline line down
+            vga = {"error": repr(exc)}
+
     # the non-reference matchers on the SAME batch, after the timed ELAS regions and outside `value`: BASELINE config 3 names
     # "SGM 8-path", the reference has only ELAS; these keys let the driver's line record what include/jn_sgm.h / jn_bm.h run at
     other_modes = None
@@ -912,21 +961,46 @@ def run_rank(a):
                 run_m(reps_m)
                 torch.cuda.synchronize()
                 el_m = (time.perf_counter() - t1) / reps_m
-                host = disp16[0].cpu().numpy()
-                got_m = "%016x" % jn.load().jn_fnv1a64_u32(host.ctypes.data, host.size // 2)
-                want_m = None
-                for line in open(os.path.join(ROOT, "tests", "golden", "%s_hashes.txt" % kind)):
-                    f = line.split()
-                    if kind == "sgm" and f[:6] == [str(W), str(H), str(scene), str(a.disp), "0", "12345"]:
-                        want_m = f[6]
-                    if kind in ("bm", "bm_ssd") and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
-                        want_m = f[7]
-                other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_process_batch), same inputs as the ELAS regions" %
+                # every frame of every slot against the mode's scalar definition (tests/golden/bench_modes_golden.json: all 32 pairs of the
+                # headline batch); other configurations: frame 0 of slot 0 against the recorded hash of seed 12345
+                got_m = want_m = None
+                n_checked, bad_m = 0, []
+                modes_gold = None
+                try:
+                    mg = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_modes_golden.json")))
+                    if (mg["W"], mg["H"], mg["scene_disp"], mg["D"]) == (W, H, scene, a.disp):
+                        modes_gold = mg["frames"]
+                except (OSError, ValueError, KeyError):
+                    pass
+                if modes_gold is not None:
+                    for s_ in range(nsl):
+                        hm = outs_m[s_].cpu().numpy()
+                        for i in range(B):
+                            g = modes_gold.get(str(seed_of(s_ % S, i)))
+                            if g is None:
+                                continue
+                            gh = "%016x" % jn.load().jn_fnv1a64_u32(hm[i].ctypes.data, hm[i].size // 2)
+                            n_checked += 1
+                            if gh != g[kind]:
+                                bad_m.append({"slot": s_, "frame": i, "seed": seed_of(s_ % S, i), "got": gh, "expected": g[kind]})
+                    check_m = {"frames_checked": n_checked, "slots": nsl, "n_mismatches": len(bad_m), "mismatches": bad_m[:4], "ok": (len(bad_m) == 0) if n_checked else None,
+                               "source": "tests/golden/bench_modes_golden.json (the mode's scalar definition on every pair of the batch; the reference has no such matcher)"}
+                else:
+                    host = disp16[0].cpu().numpy()
+                    got_m = "%016x" % jn.load().jn_fnv1a64_u32(host.ctypes.data, host.size // 2)
+                    for line in open(os.path.join(ROOT, "tests", "golden", "%s_hashes.txt" % kind)):
+                        f = line.split()
+                        if kind == "sgm" and f[:6] == [str(W), str(H), str(scene), str(a.disp), "0", "12345"]:
+                            want_m = f[6]
+                        if kind in ("bm", "bm_ssd") and len(f) >= 8 and f[:7] == [str(W), str(H), str(scene), str(a.disp), "4", "0", "12345"]:
+                            want_m = f[7]
+                    check_m = {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None, "frames_checked": 1 if want_m else 0,
+                               "source": "tests/golden/%s_hashes.txt (the mode's scalar definition; the reference has no such matcher)" % kind}
+                other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_submit_scan / wait), a distinct input batch per slot, same pairs as the ELAS regions" %
                                                  (W, H, a.disp, {"sgm": "SGM 8 paths (four batches in flight)", "bm": "9x9 block matching (SAD, v_qsad; four batches in flight)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8; four batches in flight)"}[kind], B,
                                                   "bm" if kind == "bm_ssd" else kind),
                                      "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},
-                                     "check": {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None,
-                                               "source": "tests/golden/%s_hashes.txt (the mode's scalar definition; the reference has no such matcher)" % kind}}
+                                     "check": check_m}
                 m.close()
                 del disp16
             except Exception as exc:                 # informational legs: never let them take the headline line down
@@ -960,6 +1034,7 @@ def run_rank(a):
             "cpu_baseline": cpu,
             "check": check,
             "latency_config": extra,
+            "vga_config": vga,
             "other_modes": other_modes,
             "host_cpu": host_cpu,
         }

@@ -308,6 +308,11 @@ jn_status jn_elas_set_comm(jn_elas* h, jn_comm* c);
  * oldest first; returns how many were written).  In a correct run this is 0, 1, 2, ... whatever order the batches' host
  * stages finished in. */
 int32_t jn_elas_merge_order(jn_elas* h, uint64_t* out, int32_t cap);
+/* Testing aid: triangle lists of the 32x8 tiles of `slot`'s last batch (call with no batch in flight on it; frames that failed count with
+ * whatever their tiles held): out[0] = the longest list, out[1] = tiles whose list is longer than the 16 entries the ownership pass
+ * resolves by ranked cover words (they take its entry-by-entry form), out[2] = tiles whose list overflowed its 64 entries (scan over all
+ * of the side's triangles).  Tests use it to show that a scene really took those routes. */
+jn_status jn_elas_bin_stats(jn_elas* h, int32_t slot, int32_t out[3]);
 jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms);
 void jn_comm_destroy(jn_comm* c);
 

@@ -90,6 +90,7 @@ struct Slot {
   Job job; jn_status result = JN_OK;
   jn_stage_times times = {};
   float dense_ms = 0, owner_ms = 0; int dense_launches = 0;
+  int last_n = 0;                                              // frames of the slot's last batch (jn_elas_bin_stats)
   hipEvent_t ev_owner = nullptr;                               // between k_owner and k_dense_row (plane flow, stage events on)
 };
 
@@ -530,6 +531,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   t.gpu_matching = ms(EV_H2D, EV_DENSE); t.gpu_lr = ms(EV_DENSE, EV_LR); t.gpu_speckle = ms(EV_LR, EV_SPECKLE);
   t.gpu_gap = ms(EV_SPECKLE, EV_GAP); t.gpu_adaptive_mean = ms(EV_GAP, EV_AM);
   t.total = std::chrono::duration<float, std::milli>(t_end - t_begin).count();
+  s.last_n = n;
   s.dense_launches = any_ok && stage_events ? 1 : 0;
   if (s.dense_launches && h->plane_flow) {                   // k_bin | k_owner | k_dense_row: the matcher proper is timed from behind k_owner
     float a = 0, b = 0;
@@ -916,6 +918,19 @@ int32_t jn_elas_merge_order(jn_elas* h, uint64_t* out, int32_t cap) {
   const size_t k = std::min<size_t>(h->merge_log.size(), (size_t)cap);
   std::copy(h->merge_log.end() - k, h->merge_log.end(), out);
   return (int32_t)k;
+}
+
+jn_status jn_elas_bin_stats(jn_elas* h, int32_t slot, int32_t out[3]) {
+  if (!h || !out || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
+  Slot& s = *h->slots[slot];
+  out[0] = out[1] = out[2] = 0;
+  if (s.last_n < 1) return JN_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t tiles = (size_t)((h->W + kTileW - 1) / kTileW) * ((h->H + kTileH - 1) / kTileH), count = (size_t)s.last_n * 2 * tiles;
+  std::vector<int32_t> c(count);
+  HIP_TRY(hipMemcpy(c.data(), s.bin_count, count * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int32_t x : c) { out[0] = std::max(out[0], x); out[1] += x > (int32_t)kBinLds; out[2] += x > (int32_t)kBinCap; }
+  return JN_OK;
 }
 
 jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms) {

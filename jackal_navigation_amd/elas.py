@@ -123,6 +123,12 @@ class Elas:
         _lib.check(self._L.jn_elas_last_times(self._h, slot, C.byref(t)), "jn_elas_last_times")
         return t.as_dict()
 
+    def bin_stats(self, slot=0):
+        """(longest triangle list of a 32x8 tile, tiles with more than 16 entries, tiles beyond 64) of the slot's last batch (jn_elas_bin_stats; a testing aid)."""
+        out = (C.c_int32 * 3)()
+        _lib.check(self._L.jn_elas_bin_stats(self._h, slot, C.byref(out)), "jn_elas_bin_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def kernel_time(self, slot=0, kernel=b"k_dense"):
         ms, cnt = C.c_float(), C.c_int32()
         _lib.check(self._L.jn_elas_kernel_time(self._h, slot, kernel, C.byref(ms), C.byref(cnt)), "jn_elas_kernel_time")

@@ -40,7 +40,7 @@ def test_process_bit_exact_with_other_parameters(oracle, reference, same, kw):
     assert st == 0 and same(D1, D1r) and same(D2, D2r), kw
 
 
-@pytest.mark.parametrize("kind", ["strips", "patches", "slanted", "photometric", "blobs", "shallow"])
+@pytest.mark.parametrize("kind", ["strips", "patches", "slanted", "photometric", "blobs", "shallow", "grain", "periodic"])
 def test_process_bit_exact_on_other_scenes(oracle, reference, same, kind):
     """Scenes unlike the survey's plane-and-box generator (tests/scenes.py): depth jumps and occlusions, textureless
     patches, slanted surfaces, gain / offset / noise between the images, random blobs."""
