@@ -24,10 +24,31 @@ def _worker(rank, world, port, out_dir):
     lut = o.valid_lut(sp, W, H)
     bins = np.full((1, sp.bins), 1e9)
     meta = np.array([[400., -400., 1e9, -500.]])
-    for rig in range(lo, hi):                       # each rank scans its own rigs (checker as stand-in for the GPU path)
+    use_hip = torch.cuda.is_available()             # on a GPU box the rigs go through the product (HIP path, C-ABI); here (no GPU) the checker stands in
+    if use_hip:
+        import jackal_navigation_amd as jn
+        from jackal_navigation_amd import node
+        from jackal_navigation_amd.device import DeviceArray
+        spj = node.scan_params(W, H)
+        lutj = node.build_valid_disp_lut(spj, W, H)
+        elas = jn.Elas(jn.Elas.parameters(0, disp_max=63), W, H)
+    for rig in range(lo, hi):                       # each rank scans its own rigs
         L, R = o.synth_pair(W, H, 24, 100 + rig)
-        _, D1, _ = o.process(o.params(0, disp_max=63), L, R)
-        b, m, _ = o.scan(sp, o.to_u8(D1), lut)
+        if use_hip:
+            D1 = np.zeros((H, W), np.float32); D2 = np.zeros((H, W), np.float32)
+            assert elas.process(L, R, D1, D2, (W, H, W)) == 0
+            dD = DeviceArray.from_numpy(D1); du8 = DeviceArray((H, W), np.uint8)
+            db = DeviceArray((1, spj.bins), np.float64); dm = DeviceArray((1, 4), np.float64)
+            node.disparity_scan(spj, 1, dD.ptr, lutj.ptr, W, H, du8.ptr, db.ptr, dm.ptr)
+            b, m = db.numpy()[0], dm.numpy()[0]
+            for x in (dD, du8, db, dm):
+                x.free()
+            _, D1o, _ = o.process(o.params(0, disp_max=63), L, R)          # ... and the checker beside it
+            bo, mo, _ = o.scan(sp, o.to_u8(D1o), lut)
+            assert np.array_equal(D1.view(np.uint32), D1o.view(np.uint32)) and np.allclose(b, bo, rtol=0, atol=1e-4) and np.allclose(m, mo, rtol=0, atol=1e-4)
+        else:
+            _, D1, _ = o.process(o.params(0, disp_max=63), L, R)
+            b, m, _ = o.scan(sp, o.to_u8(D1), lut)
         bins[0] = np.minimum(bins[0], b)
         meta[0] = [min(meta[0, 0], m[0]), max(meta[0, 1], m[1]), min(meta[0, 2], m[2]), max(meta[0, 3], m[3])]
     tb, tm = torch.from_numpy(bins.copy()), torch.from_numpy(meta.copy())
@@ -39,6 +60,8 @@ def _worker(rank, world, port, out_dir):
     sb.bins.copy_(torch.from_numpy(bins)); sb.meta.copy_(torch.from_numpy(meta))
     sb.merge()
     assert torch.equal(sb.bins, tb) and torch.equal(sb.meta, tm)
+    if use_hip:
+        elas.close()
     torch.distributed.destroy_process_group()
 
 
@@ -65,6 +88,14 @@ def test_two_rank_scan_merge(tmp_path):
     assert np.array_equal(b0, np.minimum(l0, l1))                             # element-wise MIN over rigs
     assert (b0 < 1e9 - 1).sum() >= max((l0 < 1e9 - 1).sum(), (l1 < 1e9 - 1).sum())
     assert m0[0, 0] <= m0[0, 1] and m0[0, 2] <= m0[0, 3]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_rank_scan_merge_with_the_hip_path(tmp_path):
+    """The same two-process run on a GPU box: _worker sends its rigs through the HIP path (both ranks on device 0, gloo for the merge) and
+    checks every rig against the oracle beside it."""
+    test_two_rank_scan_merge(tmp_path)
 
 
 def test_cpulist_round_trip():
