@@ -374,6 +374,12 @@ int64_t jn_host_stage(const jn_elas_params* p, int32_t width, int32_t height, in
 int32_t jn_host_arrangement(const int32_t* x, const int32_t* y, int32_t n, uint16_t* out);
 jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t n, int32_t step, uint16_t* left, uint16_t* right,
                                 int32_t ok[2]);
+/* The whole triangulation on the GPU (k_arrange + k_delaunay, delaunay_gpu.hip: what a batch handle runs instead of the host stage) for one
+ * frame's support list: the triangles of the left side (vertices (uc*step, vc*step)) and of the right side ((uc*step - d, vc*step)), (org,
+ * dest, apex) per triangle in Triangle's output order, capacity 6*n ints each; ntri[side] = how many; *need_host = bit mask of the sides
+ * the GPU handed back (too many vertices for the LDS, coinciding vertices).  Exposed so that it can be compared with jn_host_triangulate. */
+jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t n, int32_t step, int32_t* tri_left, int32_t* tri_right, int32_t ntri[2],
+                                int32_t* need_host);
 
 /* The GPU's support filters on their own (elas.cpp:416-422 on n candidate lattices [n][ch][cw], host memory, filtered in
  * place), exposed so that the kernels can be verified on arbitrary lattices.  form: 0 = whatever jn_elas would use,

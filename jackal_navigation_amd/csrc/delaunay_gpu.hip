@@ -1,0 +1,390 @@
+// delaunay_gpu.hip — the hull recursion of the support points' Delaunay triangulation on the GPU (round 5).  Product code.
+//
+// What it replaces: csrc/delaunay.cpp's conquer() / zip() on the host — the last per-frame serial code of the path, one pool task per frame
+// side (0.66 ms of a core each at 720p; ~10 busy cores at 20 k pairs/s, the part of the path that does not shard with the GPUs).  The
+// reference is Shewchuk's Triangle (src/elas/triangle.cpp, called by src/elas/elas.cpp:445-505 as triangulate("zQB")): divide and conquer
+// with alternating cuts; support points sit on a lattice, so the triangulation is not unique and every tie-break of that recursion
+// shows in the output.  delaunay.cpp is an exact integer replay of it (decision sequence: triangle.cpp:5638-5947 base cases and hull
+// zipping, :5953-6103 recursion, :6105-6148 / :7832-7843 output order; predicates exact in int64 = the sign of :2706-2745, :3334-3379).
+// This file runs the SAME functions — zip() and the base cases below are delaunay.cpp's, statement for statement — one workgroup per
+// frame side, with the whole triangle structure in LDS:
+//   * k_arrange (kernels.hip) has already left Triangle's alternating-cut arrangement of the vertices; what remains is the recursion
+//     conquer(a, n, axis): a binary tree whose node (depth k, index j) owns the range the repeated halving gives it.  The tree is walked
+//     LEVEL BY LEVEL from the leaves up, every node of a level on its own thread (they touch disjoint triangles), a barrier between levels.
+//   * Triangle NUMBERS are part of the result (creation order decides which triangle owns a doubly covered pixel downstream).  A merge
+//     creates exactly two triangles (base and cap), a leaf two (n = 2) or four (n = 3), so the slot a node's triangles get in the sequential
+//     recursion is a function of the sizes alone: count(m) = count(m >> 1) + count(m - (m >> 1)) + 2; a node finds its first slot by
+//     walking down from the root.  Output = non-ghost triangles in slot order (a block-wide compaction).
+//   * 16-bit everything: handles (triangle << 2 | edge, < 4 x 2n), vertices (ghost = -1), coordinates: 34 bytes per vertex, 4 600
+//     vertices per side in 160 KB (a 720p frame has 3 100 - 3 400).  Sides that do not fit, or whose vertices coincide (k_arrange hands
+//     those back: which duplicate survives depends on Triangle's randomised quicksort), set the frame's need_host flag and the slot's
+//     worker sends the batch through the host stage instead (jn_api.cpp).
+// Time: the top merges are one thread each walking a seam of ~sqrt(n) steps through LDS; ~0.3 ms per 720p side, all sides of a batch
+// side by side on 64 CUs, no host round trip, no host cores.
+#include "kernels.h"
+#include <algorithm>
+#include <mutex>
+
+namespace jnav {
+
+namespace {
+
+#define DEV static __device__ __forceinline__
+
+struct DT {
+  const int16_t* X; const int16_t* Y;       // vertex coordinates
+  // volatile: every access is the 16-bit LDS operation it says.  Left to itself the compiler merges neighbouring halfword stores (the three
+  // of fresh(), org / dest pairs) into 4-, 8- and 16-byte ones at 2-byte alignment, and the triangles of the two-vertex leaves came out wrong
+  // on the device (a record is 6 bytes: odd slots start in the middle of a dword); nothing here would gain from wider accesses anyway.
+  volatile uint16_t* LINK;                  // [3 T]: handle across that edge
+  volatile int16_t* VERT;                   // [3 T]: vertex or -1 (ghost corner)
+  int budget;                               // loop iterations left before the node gives up (a corrupt structure must not spin for ever on the GPU; the frame then goes to the host)
+  typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge
+  struct Ctx { int next; };
+
+  __device__ __forceinline__ static uint32_t at(H h) { return h - (h >> 2); }              // 3 t + e
+  __device__ __forceinline__ static unsigned up(unsigned e) { return e == 2 ? 0u : e + 1u; }
+  __device__ __forceinline__ static unsigned down(unsigned e) { return e == 0 ? 2u : e - 1u; }
+  __device__ __forceinline__ static H ccw_edge(H h) { return (h & ~3u) | up(h & 3); }
+  __device__ __forceinline__ static H cw_edge(H h) { return (h & ~3u) | down(h & 3); }
+  __device__ __forceinline__ H across(H h) const { return (H)LINK[at(h)]; }
+  __device__ __forceinline__ int org(H h) const { return VERT[at(ccw_edge(h))]; }
+  __device__ __forceinline__ int dest(H h) const { return VERT[at(cw_edge(h))]; }
+  __device__ __forceinline__ int apex(H h) const { return VERT[at(h)]; }
+  __device__ __forceinline__ void set_org(H h, int v) { VERT[at(ccw_edge(h))] = (int16_t)v; }
+  __device__ __forceinline__ void set_dest(H h, int v) { VERT[at(cw_edge(h))] = (int16_t)v; }
+  __device__ __forceinline__ void set_apex(H h, int v) { VERT[at(h)] = (int16_t)v; }
+  __device__ __forceinline__ void glue(H a, H b) { LINK[at(a)] = (uint16_t)b; LINK[at(b)] = (uint16_t)a; }
+  __device__ __forceinline__ H fresh(Ctx& c) {
+    const int t = c.next++;
+    LINK[3 * t] = LINK[3 * t + 1] = LINK[3 * t + 2] = 0xFFFFu;
+    VERT[3 * t] = VERT[3 * t + 1] = VERT[3 * t + 2] = -1;
+    return (H)t << 2;
+  }
+  __device__ __forceinline__ int orient(int a, int b, int c) const {
+    const long long acx = X[a] - X[c], acy = Y[a] - Y[c], bcx = X[b] - X[c], bcy = Y[b] - Y[c];
+    const long long det = acx * bcy - acy * bcx;
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+  }
+  __device__ __forceinline__ int in_circle(int a, int b, int c, int d) const {
+    const long long ax = X[a] - X[d], ay = Y[a] - Y[d];
+    const long long bx = X[b] - X[d], by = Y[b] - Y[d];
+    const long long cx = X[c] - X[d], cy = Y[c] - Y[d];
+    const long long det = (ax * ax + ay * ay) * (bx * cy - by * cx) + (bx * bx + by * by) * (cx * ay - cy * ax) +
+                          (cx * cx + cy * cy) * (ax * by - ay * bx);
+    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+  }
+
+  // the 2- and 3-vertex base cases (delaunay.cpp conquer(), triangle.cpp:5964-6060)
+  __device__ void leaf(const uint16_t* a, int n, H& farleft, H& farright, Ctx& c) {
+    if (n == 2) {   // a lone edge: two ghosts glued on all three sides
+      farleft = fresh(c);  set_org(farleft, a[0]);  set_dest(farleft, a[1]);
+      farright = fresh(c); set_org(farright, a[1]); set_dest(farright, a[0]);
+      glue(farleft, farright);
+      farleft = cw_edge(farleft); farright = ccw_edge(farright); glue(farleft, farright);
+      farleft = cw_edge(farleft); farright = ccw_edge(farright); glue(farleft, farright);
+      farleft = cw_edge(farright);
+      return;
+    }
+    H mid = fresh(c), g1 = fresh(c), g2 = fresh(c), g3 = fresh(c);
+    const int turn = orient(a[0], a[1], a[2]);
+    if (turn == 0) {   // collinear triple: two edges, four ghosts
+      set_org(mid, a[0]); set_dest(mid, a[1]);
+      set_org(g1, a[1]);  set_dest(g1, a[0]);
+      set_org(g2, a[2]);  set_dest(g2, a[1]);
+      set_org(g3, a[1]);  set_dest(g3, a[2]);
+      glue(mid, g1); glue(g2, g3);
+      mid = ccw_edge(mid); g1 = cw_edge(g1); g2 = ccw_edge(g2); g3 = cw_edge(g3);
+      glue(mid, g3); glue(g1, g2);
+      mid = ccw_edge(mid); g1 = cw_edge(g1); g2 = ccw_edge(g2); g3 = cw_edge(g3);
+      glue(mid, g1); glue(g2, g3);
+      farleft = g1; farright = g2;
+    } else {           // one real triangle ringed by three ghosts
+      const int second = turn > 0 ? a[1] : a[2], third = turn > 0 ? a[2] : a[1];
+      set_org(mid, a[0]);    set_dest(g1, a[0]);   set_org(g3, a[0]);
+      set_dest(mid, second); set_org(g1, second);  set_dest(g2, second);
+      set_apex(mid, third);  set_org(g2, third);   set_dest(g3, third);
+      glue(mid, g1); mid = ccw_edge(mid);
+      glue(mid, g2); mid = ccw_edge(mid);
+      glue(mid, g3);
+      g1 = cw_edge(g1); g2 = ccw_edge(g2); glue(g1, g2);
+      g1 = cw_edge(g1); g3 = cw_edge(g3);  glue(g1, g3);
+      g2 = ccw_edge(g2); g3 = cw_edge(g3); glue(g2, g3);
+      farleft = g1;
+      farright = turn > 0 ? g2 : ccw_edge(farleft);
+    }
+  }
+
+  // Merge two triangulated halves by walking up the seam between their hulls (delaunay.cpp zip(), triangle.cpp:5638-5947).
+  __device__ void zip(H& farleft, H& innerleft, H& innerright, H& farright, int axis, Ctx& c) {
+    int il_dest = dest(innerleft), il_apex = apex(innerleft);
+    int ir_org = org(innerright), ir_apex = apex(innerright);
+
+    if (axis == 1) {   // horizontal cut: hull handles must point at the extreme-y vertices
+      int fl_pt = org(farleft), fl_apex = apex(farleft);
+      int fr_pt = dest(farright);
+      while (Y[fl_apex] < Y[fl_pt] && --budget > 0) {
+        farleft = across(ccw_edge(farleft));
+        fl_pt = fl_apex; fl_apex = apex(farleft);
+      }
+      H probe = across(innerleft); int pv = apex(probe);
+      while (Y[pv] > Y[il_dest] && --budget > 0) {
+        innerleft = ccw_edge(probe);
+        il_apex = il_dest; il_dest = pv;
+        probe = across(innerleft); pv = apex(probe);
+      }
+      while (Y[ir_apex] < Y[ir_org] && --budget > 0) {
+        innerright = across(ccw_edge(innerright));
+        ir_org = ir_apex; ir_apex = apex(innerright);
+      }
+      probe = across(farright); pv = apex(probe);
+      while (Y[pv] > Y[fr_pt] && --budget > 0) {
+        farright = ccw_edge(probe);
+        fr_pt = pv;
+        probe = across(farright); pv = apex(probe);
+      }
+    }
+
+    for (bool again = true; again && --budget > 0;) {   // slide down to the lower common tangent
+      again = false;
+      if (orient(il_dest, il_apex, ir_org) > 0) {
+        innerleft = across(cw_edge(innerleft));
+        il_dest = il_apex; il_apex = apex(innerleft); again = true;
+      }
+      if (orient(ir_apex, ir_org, il_dest) > 0) {
+        innerright = across(ccw_edge(innerright));
+        ir_org = ir_apex; ir_apex = apex(innerright); again = true;
+      }
+    }
+
+    H lcand = across(innerleft), rcand = across(innerright);
+    H base = fresh(c);
+    glue(base, innerleft);  base = ccw_edge(base);
+    glue(base, innerright); base = ccw_edge(base);
+    set_org(base, ir_org); set_dest(base, il_dest);
+    if (il_dest == org(farleft)) farleft = ccw_edge(base);
+    if (ir_org == dest(farright)) farright = cw_edge(base);
+
+    int lo_l = il_dest, lo_r = ir_org;
+    int up_l = apex(lcand), up_r = apex(rcand);
+
+    for (;;) {
+      if (--budget <= 0) return;
+      const bool l_done = orient(up_l, lo_l, lo_r) <= 0;
+      const bool r_done = orient(up_r, lo_l, lo_r) <= 0;
+      if (l_done && r_done) {
+        H cap = fresh(c);
+        set_org(cap, lo_l); set_dest(cap, lo_r);
+        glue(cap, base);  cap = ccw_edge(cap);
+        glue(cap, rcand); cap = ccw_edge(cap);
+        glue(cap, lcand);
+        if (axis == 1) {   // back to extreme-x handles
+          int fl_pt = org(farleft);
+          int fr_pt = dest(farright), fr_apex = apex(farright);
+          H probe = across(farleft); int pv = apex(probe);
+          while (X[pv] < X[fl_pt] && --budget > 0) {
+            farleft = cw_edge(probe);
+            fl_pt = pv;
+            probe = across(farleft); pv = apex(probe);
+          }
+          while (X[fr_apex] > X[fr_pt] && --budget > 0) {
+            farright = across(cw_edge(farright));
+            fr_pt = fr_apex; fr_apex = apex(farright);
+          }
+        }
+        return;
+      }
+      if (!l_done) {   // flip away left-hull edges that the new cross edge invalidates
+        H e = across(cw_edge(lcand));
+        int w = apex(e);
+        if (w >= 0) {
+          bool bad = in_circle(lo_l, lo_r, up_l, w) > 0;
+          while (bad && --budget > 0) {
+            e = ccw_edge(e); const H top = across(e);
+            e = ccw_edge(e); const H side = across(e);
+            glue(e, top);
+            glue(lcand, side);
+            lcand = ccw_edge(lcand); const H outer = across(lcand);
+            e = cw_edge(e);
+            glue(e, outer);
+            set_org(lcand, lo_l); set_dest(lcand, -1); set_apex(lcand, w);
+            set_org(e, -1); set_dest(e, up_l); set_apex(e, w);
+            up_l = w;
+            e = side; w = apex(e);
+            bad = w >= 0 && in_circle(lo_l, lo_r, up_l, w) > 0;
+          }
+        }
+      }
+      if (!r_done) {   // same on the right hull, mirrored
+        H e = across(ccw_edge(rcand));
+        int w = apex(e);
+        if (w >= 0) {
+          bool bad = in_circle(lo_l, lo_r, up_r, w) > 0;
+          while (bad && --budget > 0) {
+            e = cw_edge(e); const H top = across(e);
+            e = cw_edge(e); const H side = across(e);
+            glue(e, top);
+            glue(rcand, side);
+            rcand = cw_edge(rcand); const H outer = across(rcand);
+            e = ccw_edge(e);
+            glue(e, outer);
+            set_org(rcand, -1); set_dest(rcand, lo_r); set_apex(rcand, w);
+            set_org(e, up_r); set_dest(e, -1); set_apex(e, w);
+            up_r = w;
+            e = side; w = apex(e);
+            bad = w >= 0 && in_circle(lo_l, lo_r, up_r, w) > 0;
+          }
+        }
+      }
+      if (l_done || (!r_done && in_circle(up_l, lo_l, lo_r, up_r) > 0)) {
+        glue(base, rcand);
+        base = cw_edge(rcand);
+        set_dest(base, lo_l);
+        lo_r = up_r;
+        rcand = across(base);
+        up_r = apex(rcand);
+      } else {
+        glue(base, lcand);
+        base = ccw_edge(lcand);
+        set_org(base, lo_r);
+        lo_l = up_l;
+        lcand = across(base);
+        up_l = apex(lcand);
+      }
+    }
+  }
+};
+
+enum { kDtThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 34 };
+
+// One workgroup per frame side.  list: (uc, vc, d) int16 triples of the frame's support points in the reference's order; count: how many;
+// arr / arr_ok: k_arrange's alternating-cut arrangement of this side's vertices.  Writes FrameInfo (side 0: ok, nsup, the payload
+// offsets HostWorker::place() would give the frame at payload_stride * frame; both sides: their ntri), the support points (side 0) and the
+// triangles' corner indices into the batch payload.  cap_pts: vertices this launch's LDS holds.
+__global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
+                                                         const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int cap_pts,
+                                                         uint8_t* __restrict__ payload, long long payload_stride, FrameInfo* __restrict__ info,
+                                                         int32_t* __restrict__ need_host) {
+  extern __shared__ uint8_t s_dt[];
+  __shared__ int s_f[kDtMaxDepth + 2], s_c[kDtMaxDepth + 2][2], s_K;
+  __shared__ int s_scan[kDtThreads + 1];
+  const int frame = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+  const int n = count[frame];
+  const int nlist = min(n, list_cap);
+  FrameInfo* fi = info + frame;
+  // the frame's place in the payload (HostWorker::place): [nsup x (u, v, d)][<= 2 nsup + 8 triangles of the left side][... of the right side]
+  const long long base = (long long)frame * payload_stride;
+  const long long sup_bytes = (long long)nlist * 12, side_bytes = (2ll * nlist + 8) * 12;
+  if (side == 0 && tid == 0) {
+    fi->nsup = nlist; fi->ok = nlist >= 3 ? 1 : 0;                         // elas.cpp:66-71
+    fi->sup_offset = base; fi->corner_offset[0] = base + sup_bytes; fi->corner_offset[1] = base + sup_bytes + side_bytes; fi->reserved = 0;
+  }
+  if (nlist < 3) { if (tid == 0) fi->ntri[side] = 0; return; }
+  if (n > list_cap || n > cap_pts || !arr_ok[frame * 2 + side]) {          // not for this kernel: the host stage takes the batch
+    if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
+    return;
+  }
+  const int16_t* t = list + (size_t)frame * list_cap * 3;
+  // LDS: X, Y, A, HL, HR [n] 16-bit each | LINK, VERT [3 T], T = 2 n (count(n) <= 2 n - 2)
+  const int np = (n + 3) & ~3, T = 2 * n;
+  int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
+  uint16_t* A = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HL = A + np; uint16_t* HR = HL + np;
+  uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 3 * T);
+  const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
+  int32_t* sup_out = reinterpret_cast<int32_t*>(payload + base);
+  for (int i = tid; i < n; i += kDtThreads) {
+    const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
+    X[i] = (int16_t)(side ? u - d : u); Y[i] = (int16_t)v;                  // right image: (u - d, v), elas.cpp:466-467
+    A[i] = a_in[i];
+    if (side == 0) { sup_out[3 * i] = u; sup_out[3 * i + 1] = v; sup_out[3 * i + 2] = d; }
+  }
+  // sizes at depth k are f_k = n >> k or f_k + 1; c[k][b] = count(f_k + b) triangles a subtree of that size creates
+  if (tid == 0) {
+    int K = 0;
+    while ((n >> K) > 2) K++;                                              // at depth K every node has at most 3 vertices
+    for (int k = 0; k <= K + 1; k++) s_f[k] = n >> k;
+    for (int k = K + 1; k >= 0; k--)
+      for (int b = 0; b < 2; b++) {
+        const int m = s_f[k] + b;
+        int cnt = 0;
+        if (m == 2) cnt = 2; else if (m == 3) cnt = 4;
+        else if (m >= 4 && k <= K) { const int h = m >> 1; cnt = s_c[k + 1][h - s_f[k + 1]] + s_c[k + 1][(m - h) - s_f[k + 1]] + 2; }
+        s_c[k][b] = cnt;
+      }
+    s_K = K;
+  }
+  __syncthreads();
+  DT dt{X, Y, LINK, VERT, 0};
+  bool gave_up = false;
+  const int K = s_K;
+  for (int k = K; k >= 0; k--) {
+    for (int j = tid; j < (1 << k); j += kDtThreads) {
+      // node (k, j): walk down from the root
+      int lo = 0, size = n, slot = 0;
+      bool exists = true;
+      for (int d = 0; d < k; d++) {
+        if (size <= 3) { exists = false; break; }
+        const int half = size >> 1;
+        if ((j >> (k - 1 - d)) & 1) { slot += s_c[d + 1][half - s_f[d + 1]]; lo += half; size -= half; } else size = half;
+      }
+      if (!exists) continue;
+      DT::H fl, fr;
+      if (size <= 3) {
+        DT::Ctx c{slot};
+        dt.leaf(A + lo, size, fl, fr, c);
+      } else {
+        const int half = size >> 1;
+        DT::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
+        fl = HL[lo]; fr = HR[lo + half];
+        DT::H il = HR[lo], ir = HL[lo + half];
+        dt.budget = 16 * size + 256;                                       // (a merge of `size` vertices takes a few steps per seam vertex)
+        dt.zip(fl, il, ir, fr, k & 1, c);                                  // the root is cut on axis 0, its children on axis 1, ...
+        gave_up |= dt.budget <= 0;
+      }
+      HL[lo] = (uint16_t)fl; HR[lo] = (uint16_t)fr;
+    }
+    __syncthreads();
+  }
+  if (__syncthreads_or(gave_up)) {                                        // never seen; a structure that does not close must not hang the GPU
+    if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
+    return;
+  }
+  // output: non-ghost triangles in slot (= creation) order, (org, dest, apex) of edge 0 (delaunay.cpp finish())
+  const int total = s_c[0][0];
+  const int per = (total + kDtThreads - 1) / kDtThreads, t0 = tid * per, t1 = min(t0 + per, total);
+  int mine = 0;
+  for (int s = t0; s < t1; s++) mine += (VERT[3 * s] | VERT[3 * s + 1] | VERT[3 * s + 2]) >= 0 ? 1 : 0;
+  s_scan[tid + 1] = mine;
+  if (tid == 0) s_scan[0] = 0;
+  __syncthreads();
+  if (tid == 0) for (int i = 1; i <= kDtThreads; i++) s_scan[i] += s_scan[i - 1];
+  __syncthreads();
+  int32_t* tri = reinterpret_cast<int32_t*>(payload + base + sup_bytes + (side ? side_bytes : 0));
+  int out = s_scan[tid];
+  for (int s = t0; s < t1; s++) {
+    const int c0 = VERT[3 * s], c1 = VERT[3 * s + 1], c2 = VERT[3 * s + 2];
+    if ((c0 | c1 | c2) < 0) continue;
+    tri[3 * out] = c1; tri[3 * out + 1] = c2; tri[3 * out + 2] = c0;
+    out++;
+  }
+  if (tid == 0) fi->ntri[side] = s_scan[kDtThreads];
+}
+
+}  // namespace
+
+int delaunay_gpu_capacity(size_t lds_bytes) { return (int)((lds_bytes > 64 ? lds_bytes - 64 : 0) / kDtBytesPerVertex); }
+size_t delaunay_gpu_lds_bytes(int points) { return (size_t)((points + 3) & ~3) * kDtBytesPerVertex + 64; }
+
+hipError_t configure_delaunay_kernel() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+}
+
+void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
+                     int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host) {
+  cap_pts = std::min(cap_pts, delaunay_gpu_capacity(156 * 1024));
+  hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st);
+  hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
+                     payload, payload_stride, info, need_host);
+}
+
+}  // namespace jnav

@@ -1172,6 +1172,45 @@ jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t 
   return JN_OK;
 }
 
+jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t n, int32_t step, int32_t* tri_left, int32_t* tri_right, int32_t ntri[2],
+                                int32_t* need_host) {
+  if (!triples || !tri_left || !tri_right || !ntri || !need_host || n < 0 || step < 1) return JN_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(configure_device_kernels());
+  const int cap = std::max(n, 1), arr_cap = std::min(cap, 8192);
+  const size_t pay = (size_t)cap * 12 + 2 * (2 * (size_t)cap + 8) * 12 + 256;
+  int16_t* d_list = nullptr; int32_t* d_cnt = nullptr; uint16_t* d_arr = nullptr; int32_t* d_ok = nullptr; uint8_t* d_pay = nullptr; FrameInfo* d_info = nullptr; int32_t* d_need = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_list), (size_t)cap * 3 * sizeof(int16_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_arr), (size_t)2 * arr_cap * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_pay), pay);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_info), sizeof(FrameInfo));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_need), sizeof(int32_t));
+  if (e == hipSuccess && n) e = hipMemcpy(d_list, triples, (size_t)n * 3 * sizeof(int16_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_cnt, &n, sizeof(int32_t), hipMemcpyHostToDevice);
+  FrameInfo fi;
+  memset(&fi, 0, sizeof(fi));
+  if (e == hipSuccess) {
+    launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, arr_cap, d_arr, d_ok, nullptr, 0);
+    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, arr_cap, delaunay_gpu_capacity(156 * 1024), d_pay, (long long)pay, d_info, d_need);
+    e = hipStreamSynchronize(nullptr);
+  }
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(&fi, d_info, sizeof(fi), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(need_host, d_need, sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) {
+    ntri[0] = fi.ntri[0]; ntri[1] = fi.ntri[1];
+    if (fi.ntri[0] > 0) e = hipMemcpy(tri_left, d_pay + fi.corner_offset[0], (size_t)fi.ntri[0] * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && fi.ntri[1] > 0) e = hipMemcpy(tri_right, d_pay + fi.corner_offset[1], (size_t)fi.ntri[1] * 12, hipMemcpyDeviceToHost);
+  }
+  hipFree(d_list); hipFree(d_cnt); hipFree(d_arr); hipFree(d_ok); hipFree(d_pay); hipFree(d_info); hipFree(d_need);
+  HIP_TRY(e);
+  return JN_OK;
+}
+
 jn_status jn_device_support_filters(int32_t device, const jn_elas_params* p, int32_t W, int32_t H, int32_t n, int16_t* d_can,
                                     int32_t form) {
   if (!p || !d_can || n < 1 || W < 1 || H < 1 || p->candidate_stepsize < 1 || form < 0 || form > 2) return JN_ERR_INVALID;

@@ -42,6 +42,14 @@ size_t arrange_lds_bytes(int arr_cap);
 size_t arrange_scratch_bytes(int n, int g_cap);
 void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
                     int32_t* arr_ok, void* gbuf, int g_cap);
+// The hull recursion of the Delaunay triangulation on the GPU (delaunay_gpu.hip): one workgroup per frame side, behind k_arrange.  Writes
+// FrameInfo (device), the support points and the triangles' corner indices into the batch payload (frame i at payload_stride * i, laid out
+// as HostWorker::place() does); sides it cannot take (too many vertices for cap_pts, coinciding vertices) set need_host[frame].
+int delaunay_gpu_capacity(size_t lds_bytes);          // vertices per side that fit
+size_t delaunay_gpu_lds_bytes(int points);
+hipError_t configure_delaunay_kernel();
+void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
+                     int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 // list / count / list_cap / listed (optional): where the classification + resolution route takes the lattice, k_filter_resolve also writes

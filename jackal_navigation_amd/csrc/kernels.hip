@@ -2904,6 +2904,7 @@ hipError_t configure_device_kernels() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gap_rows_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+  if ((e = configure_delaunay_kernel()) != hipSuccess) return e;
   done |= bit;
   return hipSuccess;
 }
