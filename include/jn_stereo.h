@@ -313,6 +313,11 @@ int32_t jn_elas_merge_order(jn_elas* h, uint64_t* out, int32_t cap);
  * resolves by ranked cover words (they take its entry-by-entry form), out[2] = tiles whose list overflowed its 64 entries (scan over all
  * of the side's triangles).  Tests use it to show that a scene really took those routes. */
 jn_status jn_elas_bin_stats(jn_elas* h, int32_t slot, int32_t out[3]);
+/* Testing aid: which routes the handle takes.  out[0] = 1 when its batches triangulate on the GPU (delaunay_gpu.hip: batch handles of
+ * processes with fewer than 14 cores of their own, or JN_GPU_DELAUNAY=1; no host stage then), out[1] = batches of `slot` that went through the
+ * host stage after all because the GPU handed a side back (coinciding vertices, too many vertices for the LDS), out[2] = 1 when descriptors
+ * are assembled from the Sobel planes (the default) rather than materialised. */
+jn_status jn_elas_route_stats(jn_elas* h, int32_t slot, int32_t out[3]);
 jn_status jn_elas_merge_time(jn_elas* h, int32_t slot, float* ms);
 void jn_comm_destroy(jn_comm* c);
 

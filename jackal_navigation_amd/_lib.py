@@ -89,7 +89,7 @@ EXPORTS = [
     "jn_device_synchronize", "jn_elas_kernel_time", "jn_version", "jn_host_triangulate", "jn_host_stage",
     "jn_stereo_calib_default", "jn_stereo_rectify", "jn_init_undistort_rectify_map", "jn_remap_bilinear",
     "jn_nav_params_default", "jn_nav_state_reset", "jn_scan_to_points", "jn_nav_vote", "jn_device_support_filters", "jn_host_arrangement", "jn_device_arrangement", "jn_elas_submit_scan", "jn_elas_submit_host",
-    "jn_host_triangulate_parts", "jn_jpeg_info", "jn_jpeg_decode_gray", "jn_host_jpeg_coefficients", "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32", "jn_elas_set_comm", "jn_elas_merge_time", "jn_elas_merge_order", "jn_jpeg_decode_gray_pair", "jn_elas_bin_stats", "jn_device_triangulate",
+    "jn_host_triangulate_parts", "jn_jpeg_info", "jn_jpeg_decode_gray", "jn_host_jpeg_coefficients", "jn_comm_unique_id", "jn_comm_create", "jn_comm_info", "jn_scan_allreduce", "jn_comm_destroy", "jn_fnv1a64_u32", "jn_elas_set_comm", "jn_elas_merge_time", "jn_elas_merge_order", "jn_jpeg_decode_gray_pair", "jn_elas_bin_stats", "jn_device_triangulate", "jn_elas_route_stats",
 ]
 
 _lib = None
@@ -124,6 +124,7 @@ def load():
     L.jn_elas_wait.argtypes = [vp, i32]
     L.jn_elas_last_times.argtypes = [vp, i32, C.POINTER(StageTimes)]
     L.jn_elas_bin_stats.argtypes = [vp, i32, C.POINTER(i32 * 3)]
+    L.jn_elas_route_stats.argtypes = [vp, i32, C.POINTER(i32 * 3)]
     L.jn_elas_kernel_time.argtypes = [vp, i32, C.c_char_p, C.POINTER(C.c_float), C.POINTER(i32)]
     L.jn_disparity_to_u8.argtypes = [i32, vp, vp, i64]
     L.jn_build_valid_disp_lut.argtypes = [i32, C.POINTER(ScanParams), i32, i32, vp]

@@ -15,8 +15,8 @@
 //     creates exactly two triangles (base and cap), a leaf two (n = 2) or four (n = 3), so the slot a node's triangles get in the sequential
 //     recursion is a function of the sizes alone: count(m) = count(m >> 1) + count(m - (m >> 1)) + 2; a node finds its first slot by
 //     walking down from the root.  Output = non-ghost triangles in slot order (a block-wide compaction).
-//   * 16-bit everything: handles (triangle << 2 | edge, < 4 x 2n), vertices (ghost = -1), coordinates: 34 bytes per vertex, 4 600
-//     vertices per side in 160 KB (a 720p frame has 3 100 - 3 400).  Sides that do not fit, or whose vertices coincide (k_arrange hands
+//   * 16-bit everything: handles (triangle << 2 | edge, < 4 x 2n), vertices (ghost = -1), coordinates: 42 bytes per vertex, 3 700
+//     vertices per side in 152 KB (a 720p frame has 3 100 - 3 400).  Sides that do not fit, or whose vertices coincide (k_arrange hands
 //     those back: which duplicate survives depends on Triangle's randomised quicksort), set the frame's need_host flag and the slot's
 //     worker sends the batch through the host stage instead (jn_api.cpp).
 // Time: the top merges are one thread each walking a seam of ~sqrt(n) steps through LDS; ~0.3 ms per 720p side, all sides of a batch
@@ -31,18 +31,23 @@ namespace {
 
 #define DEV static __device__ __forceinline__
 
+// LDS pointers carry their address space: a plain (generic) pointer that is also volatile makes every access a FLAT instruction — through the
+// vector-memory path, several hundred nanoseconds each, which is what the first version of this kernel spent its 1.5 ms on.
+typedef __attribute__((address_space(3))) const int16_t lds_ci16;
+typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
+typedef __attribute__((address_space(3))) volatile int16_t lds_vi16;
 struct DT {
-  const int16_t* X; const int16_t* Y;       // vertex coordinates
+  lds_ci16* X; lds_ci16* Y;                 // vertex coordinates
   // volatile: every access is the 16-bit LDS operation it says.  Left to itself the compiler merges neighbouring halfword stores (the three
   // of fresh(), org / dest pairs) into 4-, 8- and 16-byte ones at 2-byte alignment, and the triangles of the two-vertex leaves came out wrong
   // on the device (a record is 6 bytes: odd slots start in the middle of a dword); nothing here would gain from wider accesses anyway.
-  volatile uint16_t* LINK;                  // [3 T]: handle across that edge
-  volatile int16_t* VERT;                   // [3 T]: vertex or -1 (ghost corner)
+  lds_vu16* LINK;                           // [3 T]: handle across that edge
+  lds_vi16* VERT;                           // [3 T]: vertex or -1 (ghost corner)
   int budget;                               // loop iterations left before the node gives up (a corrupt structure must not spin for ever on the GPU; the frame then goes to the host)
   typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge
   struct Ctx { int next; };
 
-  __device__ __forceinline__ static uint32_t at(H h) { return h - (h >> 2); }              // 3 t + e
+  __device__ __forceinline__ static uint32_t at(H h) { return h; }                          // records are [triangle][4] halfwords (the fourth unused): the handle IS the index — one address instruction per access (3 t + e cost three, in front of ~20 accesses per seam step)
   __device__ __forceinline__ static unsigned up(unsigned e) { return e == 2 ? 0u : e + 1u; }
   __device__ __forceinline__ static unsigned down(unsigned e) { return e == 0 ? 2u : e - 1u; }
   __device__ __forceinline__ static H ccw_edge(H h) { return (h & ~3u) | up(h & 3); }
@@ -57,26 +62,28 @@ struct DT {
   __device__ __forceinline__ void glue(H a, H b) { LINK[at(a)] = (uint16_t)b; LINK[at(b)] = (uint16_t)a; }
   __device__ __forceinline__ H fresh(Ctx& c) {
     const int t = c.next++;
-    LINK[3 * t] = LINK[3 * t + 1] = LINK[3 * t + 2] = 0xFFFFu;
-    VERT[3 * t] = VERT[3 * t + 1] = VERT[3 * t + 2] = -1;
+    LINK[4 * t] = 0xFFFFu; LINK[4 * t + 1] = 0xFFFFu; LINK[4 * t + 2] = 0xFFFFu;
+    VERT[4 * t] = -1; VERT[4 * t + 1] = -1; VERT[4 * t + 2] = -1;
     return (H)t << 2;
   }
-  __device__ __forceinline__ int orient(int a, int b, int c) const {
-    const long long acx = X[a] - X[c], acy = Y[a] - Y[c], bcx = X[b] - X[c], bcy = Y[b] - Y[c];
-    const long long det = acx * bcy - acy * bcx;
-    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+  // Predicates in FP64.  Coordinates lie in (-2048, 2048) (launch_delaunay's caller guarantees it: image widths below 2048), so differences
+  // are below 2^12, the 2x2 determinants and the squared lengths below 2^25, their products below 2^50 and the sum of three below 2^52:
+  // every intermediate is an integer a double holds exactly, i.e. the sign is delaunay.cpp's int64 sign — at a tenth of the instructions
+  // (a 64-bit integer multiply is a dozen 32-bit operations here; the top merges are ONE thread, which issues an instruction every ~8 cycles).
+  struct P { int v; double x, y; };
+  __device__ __forceinline__ P pt(int v) const { return P{v, (double)X[v], (double)Y[v]}; }
+  __device__ __forceinline__ static int sgn(double d) { return d > 0 ? 1 : (d < 0 ? -1 : 0); }
+  __device__ __forceinline__ static int orient(const P& a, const P& b, const P& c) {
+    return sgn((a.x - c.x) * (b.y - c.y) - (a.y - c.y) * (b.x - c.x));
   }
-  __device__ __forceinline__ int in_circle(int a, int b, int c, int d) const {
-    const long long ax = X[a] - X[d], ay = Y[a] - Y[d];
-    const long long bx = X[b] - X[d], by = Y[b] - Y[d];
-    const long long cx = X[c] - X[d], cy = Y[c] - Y[d];
-    const long long det = (ax * ax + ay * ay) * (bx * cy - by * cx) + (bx * bx + by * by) * (cx * ay - cy * ax) +
-                          (cx * cx + cy * cy) * (ax * by - ay * bx);
-    return det > 0 ? 1 : (det < 0 ? -1 : 0);
+  __device__ __forceinline__ int orient(int a, int b, int c) const { return orient(pt(a), pt(b), pt(c)); }
+  __device__ __forceinline__ static int in_circle(const P& a, const P& b, const P& c, const P& d) {
+    const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    return sgn((ax * ax + ay * ay) * (bx * cy - by * cx) + (bx * bx + by * by) * (cx * ay - cy * ax) + (cx * cx + cy * cy) * (ax * by - ay * bx));
   }
 
   // the 2- and 3-vertex base cases (delaunay.cpp conquer(), triangle.cpp:5964-6060)
-  __device__ void leaf(const uint16_t* a, int n, H& farleft, H& farright, Ctx& c) {
+  __device__ void leaf(__attribute__((address_space(3))) const uint16_t* a, int n, H& farleft, H& farright, Ctx& c) {
     if (n == 2) {   // a lone edge: two ghosts glued on all three sides
       farleft = fresh(c);  set_org(farleft, a[0]);  set_dest(farleft, a[1]);
       farright = fresh(c); set_org(farright, a[1]); set_dest(farright, a[0]);
@@ -165,8 +172,9 @@ struct DT {
     if (il_dest == org(farleft)) farleft = ccw_edge(base);
     if (ir_org == dest(farright)) farright = cw_edge(base);
 
-    int lo_l = il_dest, lo_r = ir_org;
-    int up_l = apex(lcand), up_r = apex(rcand);
+    // the seam walk, with the four vertices' coordinates carried in registers (lo_l, lo_r change once a step; only a flip candidate w is fetched)
+    P lo_l = pt(il_dest), lo_r = pt(ir_org);
+    P up_l = pt(apex(lcand)), up_r = pt(apex(rcand));
 
     for (;;) {
       if (--budget <= 0) return;
@@ -174,7 +182,7 @@ struct DT {
       const bool r_done = orient(up_r, lo_l, lo_r) <= 0;
       if (l_done && r_done) {
         H cap = fresh(c);
-        set_org(cap, lo_l); set_dest(cap, lo_r);
+        set_org(cap, lo_l.v); set_dest(cap, lo_r.v);
         glue(cap, base);  cap = ccw_edge(cap);
         glue(cap, rcand); cap = ccw_edge(cap);
         glue(cap, lcand);
@@ -198,7 +206,8 @@ struct DT {
         H e = across(cw_edge(lcand));
         int w = apex(e);
         if (w >= 0) {
-          bool bad = in_circle(lo_l, lo_r, up_l, w) > 0;
+          P pw = pt(w);
+          bool bad = in_circle(lo_l, lo_r, up_l, pw) > 0;
           while (bad && --budget > 0) {
             e = ccw_edge(e); const H top = across(e);
             e = ccw_edge(e); const H side = across(e);
@@ -207,11 +216,12 @@ struct DT {
             lcand = ccw_edge(lcand); const H outer = across(lcand);
             e = cw_edge(e);
             glue(e, outer);
-            set_org(lcand, lo_l); set_dest(lcand, -1); set_apex(lcand, w);
-            set_org(e, -1); set_dest(e, up_l); set_apex(e, w);
-            up_l = w;
+            set_org(lcand, lo_l.v); set_dest(lcand, -1); set_apex(lcand, w);
+            set_org(e, -1); set_dest(e, up_l.v); set_apex(e, w);
+            up_l = pw;
             e = side; w = apex(e);
-            bad = w >= 0 && in_circle(lo_l, lo_r, up_l, w) > 0;
+            bad = false;
+            if (w >= 0) { pw = pt(w); bad = in_circle(lo_l, lo_r, up_l, pw) > 0; }
           }
         }
       }
@@ -219,7 +229,8 @@ struct DT {
         H e = across(ccw_edge(rcand));
         int w = apex(e);
         if (w >= 0) {
-          bool bad = in_circle(lo_l, lo_r, up_r, w) > 0;
+          P pw = pt(w);
+          bool bad = in_circle(lo_l, lo_r, up_r, pw) > 0;
           while (bad && --budget > 0) {
             e = cw_edge(e); const H top = across(e);
             e = cw_edge(e); const H side = across(e);
@@ -228,34 +239,35 @@ struct DT {
             rcand = cw_edge(rcand); const H outer = across(rcand);
             e = ccw_edge(e);
             glue(e, outer);
-            set_org(rcand, -1); set_dest(rcand, lo_r); set_apex(rcand, w);
-            set_org(e, up_r); set_dest(e, -1); set_apex(e, w);
-            up_r = w;
+            set_org(rcand, -1); set_dest(rcand, lo_r.v); set_apex(rcand, w);
+            set_org(e, up_r.v); set_dest(e, -1); set_apex(e, w);
+            up_r = pw;
             e = side; w = apex(e);
-            bad = w >= 0 && in_circle(lo_l, lo_r, up_r, w) > 0;
+            bad = false;
+            if (w >= 0) { pw = pt(w); bad = in_circle(lo_l, lo_r, up_r, pw) > 0; }
           }
         }
       }
       if (l_done || (!r_done && in_circle(up_l, lo_l, lo_r, up_r) > 0)) {
         glue(base, rcand);
         base = cw_edge(rcand);
-        set_dest(base, lo_l);
+        set_dest(base, lo_l.v);
         lo_r = up_r;
         rcand = across(base);
-        up_r = apex(rcand);
+        up_r = pt(apex(rcand));
       } else {
         glue(base, lcand);
         base = ccw_edge(lcand);
-        set_org(base, lo_r);
+        set_org(base, lo_r.v);
         lo_l = up_l;
         lcand = across(base);
-        up_l = apex(lcand);
+        up_l = pt(apex(lcand));
       }
     }
   }
 };
 
-enum { kDtThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 34 };
+enum { kDtThreads = 1024, kDtMaxDepth = 16, kDtBytesPerVertex = 42 };   // 5 x 2 (X, Y, A, HL, HR) + 2 triangles x (4 + 4) x 2
 
 // One workgroup per frame side.  list: (uc, vc, d) int16 triples of the frame's support points in the reference's order; count: how many;
 // arr / arr_ok: k_arrange's alternating-cut arrangement of this side's vertices.  Writes FrameInfo (side 0: ok, nsup, the payload
@@ -264,7 +276,7 @@ enum { kDtThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 34 };
 __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
                                                          const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int cap_pts,
                                                          uint8_t* __restrict__ payload, long long payload_stride, FrameInfo* __restrict__ info,
-                                                         int32_t* __restrict__ need_host) {
+                                                         int32_t* __restrict__ need_host, long long* __restrict__ dbg_clock) {
   extern __shared__ uint8_t s_dt[];
   __shared__ int s_f[kDtMaxDepth + 2], s_c[kDtMaxDepth + 2][2], s_K;
   __shared__ int s_scan[kDtThreads + 1];
@@ -285,11 +297,11 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
     return;
   }
   const int16_t* t = list + (size_t)frame * list_cap * 3;
-  // LDS: X, Y, A, HL, HR [n] 16-bit each | LINK, VERT [3 T], T = 2 n (count(n) <= 2 n - 2)
+  // LDS: X, Y, A, HL, HR [n] 16-bit each | LINK, VERT [4 T], T = 2 n (count(n) <= 2 n - 2)
   const int np = (n + 3) & ~3, T = 2 * n;
   int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
   uint16_t* A = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HL = A + np; uint16_t* HR = HL + np;
-  uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 3 * T);
+  uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
   const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
   int32_t* sup_out = reinterpret_cast<int32_t*>(payload + base);
   for (int i = tid; i < n; i += kDtThreads) {
@@ -314,11 +326,17 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
     s_K = K;
   }
   __syncthreads();
-  DT dt{X, Y, LINK, VERT, 0};
+  DT dt{(lds_ci16*)X, (lds_ci16*)Y, (lds_vu16*)LINK, (lds_vi16*)VERT, 0};
   bool gave_up = false;
   const int K = s_K;
+  if (dbg_clock && tid == 0 && frame == 0) dbg_clock[side * 32 + 31] = wall_clock64();
   for (int k = K; k >= 0; k--) {
-    for (int j = tid; j < (1 << k); j += kDtThreads) {
+    // Which thread takes which node: neighbouring nodes go to DIFFERENT waves (node j of a round -> wave j % 16, lane j / 16).  The merges are
+    // data-dependent loops: lanes of one wave that sit in different merges are executed one after the other, so the levels with 2 .. 16 nodes
+    // — the long merges — took longer in one wave than the root's single merge (measured: 153 us for the two merges below the root against 135).
+    for (int j0 = 0; j0 < (1 << k); j0 += kDtThreads) {
+      const int j = j0 + (tid & 63) * (kDtThreads / 64) + (tid >> 6);
+      if (j >= (1 << k)) continue;
       // node (k, j): walk down from the root
       int lo = 0, size = n, slot = 0;
       bool exists = true;
@@ -331,7 +349,7 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
       DT::H fl, fr;
       if (size <= 3) {
         DT::Ctx c{slot};
-        dt.leaf(A + lo, size, fl, fr, c);
+        dt.leaf((__attribute__((address_space(3))) const uint16_t*)(A + lo), size, fl, fr, c);
       } else {
         const int half = size >> 1;
         DT::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
@@ -344,6 +362,7 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
       HL[lo] = (uint16_t)fl; HR[lo] = (uint16_t)fr;
     }
     __syncthreads();
+    if (dbg_clock && tid == 0 && frame == 0) dbg_clock[side * 32 + k] = wall_clock64();      // (profiling aid: when each level of the tree was done)
   }
   if (__syncthreads_or(gave_up)) {                                        // never seen; a structure that does not close must not hang the GPU
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
@@ -353,7 +372,7 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   const int total = s_c[0][0];
   const int per = (total + kDtThreads - 1) / kDtThreads, t0 = tid * per, t1 = min(t0 + per, total);
   int mine = 0;
-  for (int s = t0; s < t1; s++) mine += (VERT[3 * s] | VERT[3 * s + 1] | VERT[3 * s + 2]) >= 0 ? 1 : 0;
+  for (int s = t0; s < t1; s++) mine += (VERT[4 * s] | VERT[4 * s + 1] | VERT[4 * s + 2]) >= 0 ? 1 : 0;
   s_scan[tid + 1] = mine;
   if (tid == 0) s_scan[0] = 0;
   __syncthreads();
@@ -362,7 +381,7 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   int32_t* tri = reinterpret_cast<int32_t*>(payload + base + sup_bytes + (side ? side_bytes : 0));
   int out = s_scan[tid];
   for (int s = t0; s < t1; s++) {
-    const int c0 = VERT[3 * s], c1 = VERT[3 * s + 1], c2 = VERT[3 * s + 2];
+    const int c0 = VERT[4 * s], c1 = VERT[4 * s + 1], c2 = VERT[4 * s + 2];
     if ((c0 | c1 | c2) < 0) continue;
     tri[3 * out] = c1; tri[3 * out + 1] = c2; tri[3 * out + 2] = c0;
     out++;
@@ -376,15 +395,15 @@ int delaunay_gpu_capacity(size_t lds_bytes) { return (int)((lds_bytes > 64 ? lds
 size_t delaunay_gpu_lds_bytes(int points) { return (size_t)((points + 3) & ~3) * kDtBytesPerVertex + 64; }
 
 hipError_t configure_delaunay_kernel() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
 
 void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
-                     int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host) {
-  cap_pts = std::min(cap_pts, delaunay_gpu_capacity(156 * 1024));
+                     int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock) {
+  cap_pts = std::min(cap_pts, delaunay_gpu_capacity(152 * 1024));
   hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st);
   hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
-                     payload, payload_stride, info, need_host);
+                     payload, payload_stride, info, need_host, dbg_clock);
 }
 
 }  // namespace jnav

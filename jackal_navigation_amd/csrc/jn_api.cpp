@@ -91,6 +91,8 @@ struct Slot {
   jn_stage_times times = {};
   float dense_ms = 0, owner_ms = 0; int dense_launches = 0;
   int last_n = 0;                                              // frames of the slot's last batch (jn_elas_bin_stats)
+  int32_t* need_host = nullptr; int32_t* h_need = nullptr;     // per frame: sides k_delaunay handed back (device / pinned copy)
+  long long gpu_dt_fallbacks = 0;                              // batches that went through the host stage after all
   hipEvent_t ev_owner = nullptr;                               // between k_owner and k_dense_row (plane flow, stage events on)
 };
 
@@ -128,6 +130,7 @@ struct jn_elas {
   bool sub = false;                 // param.subsampling: half-size maps (elas.h:82, :160-162); dph = the post-processing's parameters at that size
   DevParams dph = {};
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
+  bool gpu_delaunay = false;        // batch handles: the triangulations' hull recursion on the GPU too (delaunay_gpu.hip; JN_GPU_DELAUNAY=0/1), no host stage
   bool plane_flow = true;           // descriptors assembled from the Sobel planes inside the matching kernels (JN_DESC_FLOW=desc: materialised, the old flow)
   std::atomic<bool> gate_stage_b{false};   // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
   uint64_t submit_seq = 0, merge_seq = 0;                     // next number handed to a scan batch / next batch allowed to queue its merge
@@ -233,11 +236,17 @@ struct MergeTurn {
   }
 };
 
+jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bool force_host);
 jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
-  const DevParams& dp = h->dp;
-  const int n = j.n;
   MergeTurn turn(h, j);
   if (j.merge && h->test_fail_seq >= 0 && (long long)j.seq == h->test_fail_seq) return JN_ERR_INTERNAL;
+  return run_batch_route(h, s, j, turn, false);
+}
+// force_host: the triangulations on the host (the route of latency-mode handles, of parameter sets with corner points, and the second pass
+// of a batch whose frames the GPU's triangulation handed back)
+jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bool force_host) {
+  const DevParams& dp = h->dp;
+  const int n = j.n;
   hipStream_t st = s.stream;
   HIP_TRY(hipSetDevice(h->device));
   auto t_begin = std::chrono::steady_clock::now();
@@ -271,19 +280,27 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
       launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp, s.h_list, s.h_cnt, list_cap, &listed);
   HIP_TRY(mark_a(EV_SUPPORT));
-  bool arranged = false;
+  bool arranged = false, gpu_dt = false;
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
     if (!listed) launch_support_list(sa, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
     // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
     // Sized by what this slot's previous batch held (+25 %): a 720p frame has 3.2 k support points and needs 52 KB of LDS, not
     // the 104 KB of the 8192-vertex maximum — a workgroup that asks for less finds room among the other slots' kernels sooner.
     // Frames beyond the maximum (1920x1080: 11 k points) skip the launch: it could only hand every side back.
-    arranged = h->gpu_arrange && delaunay_parts(h, n) == 1 && s.arr_hint <= h->arr_stride;
+    // The triangulation itself on the GPU (delaunay_gpu.hip) wherever it applies: batch handles, no corner points, lattices the LDS holds.
+    // Then there is NO host stage: k_delaunay writes FrameInfo and the payload on the device, stage B is queued right behind it with
+    // capacity-sized launches, and the worker only waits for the batch's end.
+    gpu_dt = h->gpu_delaunay && !force_host && listed && sa == st && s.arr_hint <= delaunay_gpu_capacity(152 * 1024);
+    arranged = h->gpu_arrange && (gpu_dt || delaunay_parts(h, n) == 1) && s.arr_hint <= h->arr_stride;
+    gpu_dt = gpu_dt && arranged;
     if (arranged) {
       const int want = s.arr_hint ? s.arr_hint + s.arr_hint / 4 + 64 : h->arr_cap;
       // more points than the LDS can order (1920x1080: 11 k): every side works in its slice of the global scratch, the launch asks for the minimum of LDS
       const int cap = s.arr_hint > h->arr_cap ? 1024 : std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
       launch_arrange(sa, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_stride, s.h_arr, s.h_arr_ok, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
+      if (gpu_dt)                                        // LDS for what the slot's last batches held (+25 %), as the arrangement; a side beyond it goes to the host
+        launch_delaunay(sa, n, s.h_list, s.h_cnt, list_cap, dp.step, s.h_arr, s.h_arr_ok, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
+                        (long long)h->payload_cap, s.info, s.need_host);
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -299,9 +316,9 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   static const bool grid_early_env = !(getenv("JN_GRID_EARLY") && atoi(getenv("JN_GRID_EARLY")) == 0);
   const bool grid_early = grid_early_env && filtered && !dp.add_corners && sa == st;
   if (grid_early) launch_grid_from_list(st, dp, n, s.h_list, s.h_cnt, list_cap, s.mark, s.gridbits);
-  auto queue_stage_b = [&](int max_sup, int max_tri, bool any_ok, const uint8_t* payload, size_t payload_bytes, bool cleared) -> jn_status {
+  auto queue_stage_b = [&](int max_sup, int max_tri, bool any_ok, const uint8_t* payload, size_t payload_bytes, bool cleared, bool device_info = false) -> jn_status {
     HIP_TRY(mark(EV_H2D0));
-    HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
+    if (!device_info) HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
     if (payload_bytes && payload == s.payload) HIP_TRY(hipMemcpyAsync(s.payload, s.h_payload, payload_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(mark(EV_H2D));
     if (any_ok) {
@@ -374,6 +391,29 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
     HIP_TRY(hipEventRecord(s.ev[EV_END], st));
     return JN_OK;
   };
+  auto t_host0 = std::chrono::steady_clock::now(), t_host1 = t_host0;
+  int any_ok = 0;
+  if (gpu_dt) {
+    any_ok = 1;
+    const jn_status qs = queue_stage_b(list_cap, h->tri_cap, true, s.payload, 0, false, true);
+    if (qs != JN_OK) return qs;
+    // what the host needs of the batch: which frames matched out (status), how many support points they held (the next launches' LDS),
+    // whether a side was handed back — copied behind everything else, read after the one wait
+    HIP_TRY(hipMemcpyAsync(s.h_info, s.info, sizeof(FrameInfo) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s.h_need, s.need_host, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(s.ev[EV_END], st));
+    HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
+    HIP_TRY(hipGetLastError());
+    int batch_most = 0, handed_back = 0;
+    for (int i = 0; i < n; i++) { batch_most = std::max(batch_most, (int)s.h_cnt[i]); handed_back |= s.h_need[i]; }
+    s.arr_hist[s.arr_pos] = batch_most; s.arr_pos = (s.arr_pos + 1) % Slot::kArrHist;
+    s.arr_hint = *std::max_element(s.arr_hist, s.arr_hist + Slot::kArrHist);
+    if (handed_back) {                                   // coinciding vertices or more of them than the launch's LDS held: the whole batch again, host stage and all
+      s.gpu_dt_fallbacks++;
+      return run_batch_route(h, s, j, turn, true);
+    }
+    for (int i = 0; i < n; i++) if (j.status) j.status[i] = s.h_info[i].ok ? JN_OK : JN_ERR_FEW_SUPPORT;
+  } else {
   // Latency mode (a handle of max_batch 1): a lone pair's stage B is two dozen launches of a few microseconds each, and queued after the
   // host stage they reach the GPU slower than it finishes them (~30 us of idle gaps at 640x480).  They are queued NOW instead, while the
   // GPU runs stage A, behind a wait on a word of signal memory that the host sets when its stage is done (hipStreamWaitValue32).  What
@@ -414,7 +454,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   }
   HIP_TRY(wait_event(s.ev[EV_D2H], h->wait_spin_us));
 
-  auto t_host0 = std::chrono::steady_clock::now();
+  t_host0 = std::chrono::steady_clock::now();
   size_t payload_bytes = 0;                              // frames packed back to back: one H2D copy per batch
   if (filtered) {
     // the counts are known, so the frames can be placed at once and the batch is one flat set of frame-side tasks
@@ -459,9 +499,9 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
       w.triangulate_side(k & 1, s.scratch[i], s.h_payload, &s.h_info[i]);
     });
   }
-  auto t_host1 = std::chrono::steady_clock::now();
+  t_host1 = std::chrono::steady_clock::now();
 
-  int max_tri = 0, max_sup = 0, any_ok = 0;
+  int max_tri = 0, max_sup = 0;
   for (int i = 0; i < n; i++) {
     const FrameInfo& fi = s.h_info[i];
     if (j.status) j.status[i] = fi.ok ? JN_OK : JN_ERR_FEW_SUPPORT;
@@ -479,6 +519,7 @@ jn_status run_batch(jn_elas* h, Slot& s, const Job& j) {
   }
   HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
   HIP_TRY(hipGetLastError());
+  }   // (host-stage route)
   bool merged = false;
   float merge_host_ms = 0.f;
   if (j.merge) {
@@ -734,6 +775,22 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->arr_stride = (getenv("JN_ARRANGE_GLOBAL") && atoi(getenv("JN_ARRANGE_GLOBAL"))) ? std::min(dp.cw * dp.ch, 16384) : h->arr_cap;
   h->gpu_arrange = !h->hp.add_corners;                     // the six corner points join the list on the host
   if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
+  // Batch handles triangulate on the GPU as well (a latency-mode handle keeps the host stage: two pool threads finish a 640x480 pair's
+  // two sides in 65 us, the kernel's serial top merges take longer than that); needs the device filters' list and the device arrangement.
+  // (the FP64 predicates of the kernel are exact for coordinates in (-2048, 2048))
+  const bool gpu_dt_possible = max_batch > 1 && h->gpu_arrange && h->filters_fast && W < 2048 && H < 2048;
+  // Which of the two is faster depends on the host cores this process has (profiles/r05_gpu_delaunay_ab.txt, one MI355X): the kernel's top
+  // merges are one thread each walking a seam through LDS (0.8-0.9 ms a batch, 42 bytes per vertex of every side held in LDS meanwhile):
+  // 19.6 k pairs/s whatever the cores (0.3 busy); the host stage gives 22.0 k with ~10 busy cores where the scheduler may spread 16
+  // threads over a whole socket, but 18.3 k pinned to 16 cores, 16.3 k to 12, 12.7 k to 8, 6.9 k to 4.  So: the GPU route for a process
+  // PINNED to 16 cores or fewer (what a rank of a multi-GPU job gets: parallel.pin_rank) or with a CPU quota below 14, the host route
+  // otherwise; JN_GPU_DELAUNAY=0/1 decides otherwise.
+  {
+    cpu_set_t set;
+    const int pinned = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+    h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14);
+  }
+  if (const char* e = getenv("JN_GPU_DELAUNAY")) h->gpu_delaunay = gpu_dt_possible && atoi(e) != 0;
   h->stage_events = max_batch > 1;
   h->wait_spin_us = max_batch > 1 ? 60 : 1000;
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
@@ -773,6 +830,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     CREATE_TRY(hipEventCreate(&s->ev_scan)); CREATE_TRY(hipEventCreate(&s->ev_merged));
     CREATE_TRY(hipEventCreateWithFlags(&s->ev_head, hipEventDisableTiming));
     CREATE_TRY(hipEventCreate(&s->ev_owner));
+    CREATE_TRY(dmalloc(&s->need_host, B));
+    CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_need), B * sizeof(int32_t), hipHostMallocDefault));
     if (h->gate_stage_b) {                                   // no signal memory: the handle simply queues stage B after the host stage
       if (hipExtMallocWithFlags((void**)&s->gate, 8, hipMallocSignalMemory) == hipSuccess) { s->gate[0] = 0; s->gate[1] = 0; }
       else { (void)hipGetLastError(); s->gate = nullptr; }
@@ -829,6 +888,7 @@ void jn_elas_destroy(jn_elas* h) {
     if (s->ev_merged) hipEventDestroy(s->ev_merged);
     if (s->ev_head) hipEventDestroy(s->ev_head);
     if (s->ev_owner) hipEventDestroy(s->ev_owner);
+    hipFree(s->need_host); if (s->h_need) hipHostFree(s->h_need);
     if (s->gate) hipFree(s->gate);
     if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -918,6 +978,12 @@ int32_t jn_elas_merge_order(jn_elas* h, uint64_t* out, int32_t cap) {
   const size_t k = std::min<size_t>(h->merge_log.size(), (size_t)cap);
   std::copy(h->merge_log.end() - k, h->merge_log.end(), out);
   return (int32_t)k;
+}
+
+jn_status jn_elas_route_stats(jn_elas* h, int32_t slot, int32_t out[3]) {
+  if (!h || !out || slot < 0 || slot >= (int)h->slots.size()) return JN_ERR_INVALID;
+  out[0] = h->gpu_delaunay ? 1 : 0; out[1] = (int32_t)h->slots[slot]->gpu_dt_fallbacks; out[2] = h->plane_flow ? 1 : 0;
+  return JN_OK;
 }
 
 jn_status jn_elas_bin_stats(jn_elas* h, int32_t slot, int32_t out[3]) {
@@ -1195,8 +1261,22 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
   memset(&fi, 0, sizeof(fi));
   if (e == hipSuccess) {
     launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, arr_cap, d_arr, d_ok, nullptr, 0);
-    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, arr_cap, delaunay_gpu_capacity(156 * 1024), d_pay, (long long)pay, d_info, d_need);
+    long long* d_clk = nullptr;
+    const bool want_clk = getenv("JN_DT_CLOCKS") != nullptr;
+    if (want_clk && hipMalloc(reinterpret_cast<void**>(&d_clk), 64 * sizeof(long long)) == hipSuccess) hipMemset(d_clk, 0, 64 * sizeof(long long));
+    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, arr_cap, delaunay_gpu_capacity(152 * 1024), d_pay, (long long)pay, d_info, d_need, d_clk);
     e = hipStreamSynchronize(nullptr);
+    if (d_clk) {                                             // JN_DT_CLOCKS: microseconds per tree level (leaves first) of both sides, to stderr
+      long long clk[64];
+      if (hipMemcpy(clk, d_clk, sizeof(clk), hipMemcpyDeviceToHost) == hipSuccess)
+        for (int sd = 0; sd < 2; sd++) {
+          fprintf(stderr, "k_delaunay n=%d side %d, us per level from the leaves up:", n, sd);
+          long long prev = clk[sd * 32 + 31];
+          for (int k = 30; k >= 0; k--) if (clk[sd * 32 + k]) { fprintf(stderr, " %.1f", (clk[sd * 32 + k] - prev) / 100.0); prev = clk[sd * 32 + k]; }
+          fprintf(stderr, "  total %.1f\n", (prev - clk[sd * 32 + 31]) / 100.0);
+        }
+      hipFree(d_clk);
+    }
   }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(&fi, d_info, sizeof(fi), hipMemcpyDeviceToHost);

@@ -129,6 +129,12 @@ class Elas:
         _lib.check(self._L.jn_elas_bin_stats(self._h, slot, C.byref(out)), "jn_elas_bin_stats")
         return int(out[0]), int(out[1]), int(out[2])
 
+    def route_stats(self, slot=0):
+        """(triangulates on the GPU, batches of the slot that fell back to the host stage, descriptors from the Sobel planes) — jn_elas_route_stats, a testing aid."""
+        out = (C.c_int32 * 3)()
+        _lib.check(self._L.jn_elas_route_stats(self._h, slot, C.byref(out)), "jn_elas_route_stats")
+        return int(out[0]), int(out[1]), int(out[2])
+
     def kernel_time(self, slot=0, kernel=b"k_dense"):
         ms, cnt = C.c_float(), C.c_int32()
         _lib.check(self._L.jn_elas_kernel_time(self._h, slot, kernel, C.byref(ms), C.byref(cnt)), "jn_elas_kernel_time")

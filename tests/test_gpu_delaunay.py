@@ -39,7 +39,7 @@ def test_gpu_triangulation_equals_the_hosts_on_lattices(jn):
     L = jn.load()
     rng = np.random.default_rng(7)
     sides_checked = 0
-    for n in (3, 4, 5, 6, 7, 8, 9, 12, 13, 31, 64, 100, 257, 819, 1024, 2047, 3232, 3350, 4200, 4600):
+    for n in (3, 4, 5, 6, 7, 8, 9, 12, 13, 31, 64, 100, 257, 819, 1024, 2047, 3232, 3350, 3600, 3690):
         for rep in range(3 if n < 2000 else 1):
             t = lattice_case(rng, n, 256, 144, 127, row_d=(rep == 1))
             (kl, tl), (kr, tr), need = device_tri(L, t, 5)
@@ -76,7 +76,7 @@ def test_gpu_triangulation_on_support_points_of_real_frames(jn, oracle):
 def test_sides_the_gpu_cannot_take_are_handed_back(jn):
     L = jn.load()
     rng = np.random.default_rng(3)
-    t = lattice_case(rng, 5200, 384, 216, 255, row_d=True)                 # more vertices than the LDS holds
+    t = lattice_case(rng, 4200, 384, 216, 255, row_d=True)                 # more vertices than the LDS holds
     _, _, need = device_tri(L, t, 5)
     assert need == 3
     t = lattice_case(rng, 300, 256, 144, 127)
@@ -90,3 +90,63 @@ def test_sides_the_gpu_cannot_take_are_handed_back(jn):
     for n in (0, 1, 2):                                                     # fewer than three support points: no triangles, nothing for the host either (elas.cpp:66-71)
         (kl, _), (kr, _), need = device_tri(L, lattice_case(rng, n, 256, 144, 127) if n else np.zeros((0, 3), np.int16), 5)
         assert (kl, kr, need) == (0, 0, 0)
+
+
+@pytest.mark.parametrize("gpu_dt", ["1", "0"])
+def test_batches_through_both_triangulation_routes(jn, oracle, monkeypatch, gpu_dt):
+    """A batch handle with the triangulations on the GPU (JN_GPU_DELAUNAY=1: no host stage at all) and on the host (=0) gives the oracle's maps
+    bit for bit: five frames one of which has too few support points (its outputs stay untouched, its status says so), two slots, device pointers."""
+    from jackal_navigation_amd.device import DeviceArray
+    monkeypatch.setenv("JN_GPU_DELAUNAY", gpu_dt)
+    W, H, n = 640, 360, 5
+    rng = np.random.default_rng(1)
+    Ls = np.zeros((n, H, W), np.uint8); Rs = np.zeros((n, H, W), np.uint8)
+    for b in range(n):
+        Ls[b], Rs[b] = jn.node.synth_pair(W, H, 60, 700 + b)
+    Ls[3] = rng.integers(0, 255, (H, W)); Rs[3] = rng.integers(0, 255, (H, W))    # frame 3: noise -> few support points
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    p = dict(disp_max=95, postprocess_only_left=0)
+    with jn.Elas(jn.Elas.parameters(0, **p), W, H, max_batch=n, host_threads=4, slots=2) as e:
+        assert e.route_stats(0)[0] == int(gpu_dt)
+        for slot in (0, 1, 0):
+            d1 = DeviceArray.from_numpy(np.full((n, H, W), 5.0, np.float32)); d2 = DeviceArray.from_numpy(np.full((n, H, W), 5.0, np.float32))
+            st = (C.c_int32 * n)()
+            e.submit(slot, n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr, st)
+            e.wait(slot)
+            D1, D2 = d1.numpy(), d2.numpy()
+            assert list(st) == [0, 0, 0, 1, 0]
+            assert (D1[3] == 5).all() and (D2[3] == 5).all()
+            for b in (0, 1, 2, 4):
+                _, D1o, D2o = oracle.process(oracle.params(0, **p), Ls[b], Rs[b])
+                assert np.array_equal(D1[b].view(np.uint32), D1o.view(np.uint32)) and np.array_equal(D2[b].view(np.uint32), D2o.view(np.uint32)), (slot, b)
+            d1.free(); d2.free()
+        assert e.route_stats(0)[1] == 0 and e.route_stats(1)[1] == 0          # nothing was handed back
+        assert e.last_times(0)["host_stage"] == 0 if gpu_dt == "1" else e.last_times(0)["host_stage"] > 0
+
+
+def test_a_side_the_gpu_hands_back_sends_the_batch_through_the_host_stage(jn, oracle, monkeypatch):
+    """With lr_threshold 6 two left-image support points 5 columns apart may map to ONE right-image vertex: k_arrange hands such a side back
+    (which of the two survives depends on Triangle's randomised quicksort, replayed on the host), k_delaunay flags the frame, and the worker
+    runs the batch through the host stage instead — same maps as the oracle, and the fallback is counted."""
+    from jackal_navigation_amd.device import DeviceArray
+    from scenes import make_scene
+    monkeypatch.setenv("JN_GPU_DELAUNAY", "1")
+    W, H, n = 640, 360, 3
+    fell_back = 0
+    for kind, kw in (("strips", dict(lr_threshold=6, support_threshold=0.98)), ("blobs", dict(lr_threshold=8, support_threshold=0.99, incon_min_support=2))):
+        pairs = [make_scene(kind, W, H, 95, 20 + b) for b in range(n)]
+        Ls = np.stack([q[0] for q in pairs]); Rs = np.stack([q[1] for q in pairs])
+        dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+        d1 = DeviceArray((n, H, W), np.float32); d2 = DeviceArray((n, H, W), np.float32)
+        p = dict(disp_max=95, postprocess_only_left=0, **kw)
+        with jn.Elas(jn.Elas.parameters(0, **p), W, H, max_batch=n, host_threads=4) as e:
+            st = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
+            fell_back += e.route_stats(0)[1]
+        D1, D2 = d1.numpy(), d2.numpy()
+        for b in range(n):
+            st_o, D1o, D2o = oracle.process(oracle.params(0, **p), Ls[b], Rs[b])
+            assert st[b] == st_o == 0
+            assert np.array_equal(D1[b].view(np.uint32), D1o.view(np.uint32)) and np.array_equal(D2[b].view(np.uint32), D2o.view(np.uint32)), (kind, b)
+        for a in (dL, dR, d1, d2):
+            a.free()
+    assert fell_back >= 1, "no side was handed back: the scenes no longer produce coinciding right-image vertices"

@@ -218,7 +218,7 @@ def test_batch_device_pointers_with_a_failing_frame(jn, oracle, same):
         e.wait(1)
         assert list(st_arr) == status and same(dE1.numpy(), D1) and same(dE2.numpy(), D2)
         times = e.last_times(1)
-        assert times["total"] > 0 and times["host_stage"] > 0
+        assert times["total"] > 0 and times["host_stage"] >= 0       # (0: a batch handle triangulates on the GPU, there is no host stage)
     assert status == [0, 0, 1, 0, 0]
     assert (D1[2] == 5).all() and (D2[2] == 5).all()
     po = oracle.params(0)
