@@ -353,10 +353,9 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
         }
         HIP_TRY(mark(EV_AM));
       } else {
-      launch_lr(st, dp, n, s.info, s.raw, fused ? s.tmp : j.dD1, j.dD2);
-      HIP_TRY(mark(EV_LR));
       if (fused) {
-        launch_speckle(st, dp, n, s.info, s.tmp, s.label, s.size, j.dD1);
+        launch_lr_speckle(st, dp, n, s.info, s.raw, s.tmp, j.dD2, s.label, s.size, j.dD1);   // (the L/R check and the speckle pass' row labelling are one kernel here)
+        HIP_TRY(mark(EV_LR));
         HIP_TRY(mark(EV_SPECKLE));
         launch_gap_mean_fused(st, dp, n, s.info, s.tmp, j.dD1, h->p.filter_adaptive_mean != 0);
         if (!h->p.postprocess_only_left) {                     // right image: in place, fused pass into tmp, copied back
@@ -366,6 +365,8 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
         }
         HIP_TRY(mark(EV_GAP));
       } else {
+        launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
+        HIP_TRY(mark(EV_LR));
         launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
         if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
         HIP_TRY(mark(EV_SPECKLE));

@@ -83,6 +83,9 @@ void launch_lr(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info
 // Speckle removal (elas.cpp:981-1099) in place on D [n][H][W]; label/size scratch [n][H][W] int32 each.
 void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, int32_t* label, int32_t* size,
                     void* scratch);
+// launch_lr(raw -> D, D2) + launch_speckle(D) with the L/R check and the speckle pass' row labelling as ONE kernel (the row stays in LDS between them)
+void launch_lr_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D, float* D2, int32_t* label, int32_t* size,
+                       void* scratch);
 // Gap interpolation (elas.cpp:1101-1284): rows D->tmp, columns tmp->D.
 void launch_gap(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, float* D, float* tmp);
 // Adaptive mean (elas.cpp:1287-1492): horizontal D->tmp, vertical tmp->D.

@@ -2037,6 +2037,73 @@ __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo*
   }
   if (lane == 0) runs.count(frame)[v] = carry_cnt;
 }
+// k_lr and k_ccl_rows in one pass over the row (the route where the left map travels raw -> tmp -> D1): the workgroup that has just formed the
+// row's L/R-checked values keeps the left ones in LDS, and its first wave labels their runs from there — the row is not read back from
+// memory (4 of the two kernels' 20 bytes per pixel) and one launch is gone.  Same outputs as k_lr (D1 = the checked left row, D2) followed
+// by k_ccl_rows on D1.
+__global__ void __launch_bounds__(256) k_lr_ccl_rows(DevParams dp, const FrameInfo* __restrict__ info, const int16_t* __restrict__ raw,
+                                                     float* __restrict__ D1, float* __restrict__ D2, int32_t* __restrict__ lab, int32_t* __restrict__ sz, RunLists runs) {
+  extern __shared__ int16_t s_raw[];                     // [2][W] raw rows, then [W] float: the checked left row
+  const int v = blockIdx.x, frame = blockIdx.y;
+  if (!info[frame].ok) return;
+  const int W = dp.W;
+  const size_t plane = (size_t)dp.H * W;
+  const int16_t* r1 = raw + (size_t)(frame * 2) * plane + (size_t)v * W;
+  const int16_t* r2 = r1 + plane;
+  int16_t* s1 = s_raw; int16_t* s2 = s_raw + W;
+  float* s_o1 = reinterpret_cast<float*>(s_raw + 2 * ((W + 1) & ~1));
+  for (int u = threadIdx.x; u < W; u += 256) { s1[u] = r1[u]; s2[u] = r2[u]; }
+  __syncthreads();
+  const float thr = (float)dp.lr_threshold;
+  float* o1row = D1 + (size_t)frame * plane + (size_t)v * W;
+  float* o2row = D2 + (size_t)frame * plane + (size_t)v * W;
+  for (int u = threadIdx.x; u < W; u += 256) {           // elas.cpp:909-979, as k_lr
+    const float d1 = (float)s1[u], d2 = (float)s2[u];
+    float o1 = d1, o2 = d2;
+    const float w1 = (float)u - d1, w2 = (float)u + d2;
+    if (d1 >= 0 && w1 >= 0 && w1 < (float)W) { if (fabsf((float)s2[(int)w1] - d1) > thr) o1 = -10.0f; } else o1 = -10.0f;
+    if (d2 >= 0 && w2 >= 0 && w2 < (float)W) { if (fabsf((float)s1[(int)w2] - d2) > thr) o2 = -10.0f; } else o2 = -10.0f;
+    o1row[u] = o1; s_o1[u] = o1;
+    o2row[u] = o2;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  // the row's runs, as k_ccl_rows (one wave, 64 pixels at a time, wave-uniform carries), reading the row from LDS
+  const int lane = threadIdx.x;
+  const size_t base = (size_t)frame * dp.H * W + (size_t)v * W;
+  const size_t rbase = (size_t)v * runs.pitch;
+  uint16_t* r_starts = runs.starts(frame); uint16_t* r_ends = runs.ends(frame);
+  const float sim = dp.speckle_sim;
+  int carry = -1, carry_cnt = 0;
+  float left = -10.0f;
+  float d = lane < W ? s_o1[lane] : -10.0f;
+  for (int u0 = 0; u0 < W; u0 += 64) {
+    const int u = u0 + lane;
+    const float nxt = u + 64 < W ? s_o1[u + 64] : -10.0f;
+    const float nxt0 = __shfl(nxt, 0);
+    float prev = __shfl_up(d, 1), foll = __shfl_down(d, 1);
+    if (lane == 0) prev = left;
+    if (lane == 63) foll = nxt0;
+    const bool valid = d >= 0;
+    const bool conn = valid && prev >= 0 && fabsf(d - prev) <= sim;
+    const bool conn_next = valid && foll >= 0 && fabsf(foll - d) <= sim;
+    const bool start = valid && !conn, last = valid && !conn_next;
+    int s = start ? u : -1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(s, off); if (lane >= off) s = max(s, o); }
+    s = max(s, carry);
+    const unsigned long long starts = __ballot(start);
+    const int k = carry_cnt + __popcll(starts & (~0ull >> (63 - lane))) - 1;
+    if (u < W) lab[base + u] = valid ? v * W + s : -1;
+    if (start) { sz[base + u] = 0; r_starts[rbase + k] = (uint16_t)u; }
+    if (last) r_ends[rbase + k] = (uint16_t)u;
+    carry = __shfl(s, 63);
+    carry_cnt += __popcll(starts);
+    left = __shfl(d, 63);
+    d = nxt;
+  }
+  if (lane == 0) runs.count(frame)[v] = carry_cnt;
+}
 // Column pass: unite vertically adjacent runs.  A pixel issues the union only if it is the first
 // column of the contact between its run and the run below (the pixel to its left belongs to the
 // same two runs otherwise), which removes almost all redundant atomics.
@@ -3283,6 +3350,25 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
   const dim3 gr((dp.H + 3) / 4, n);                          // one wave per image row
   hipLaunchKernelGGL(k_ccl_rows, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
   // enough waves to fill the GPU even for a lone small pair: split the rows of the merge pass into column segments
+  const int row_waves = dp.H * n, chunks = (dp.W + 63) / 64;
+  const int segs = row_waves >= 4096 ? 1 : max(1, min(chunks, 4096 / max(row_waves, 1)));
+  hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs);
+  hipLaunchKernelGGL(k_ccl_count, gr, dim3(256), 0, st, dp, info, label, size, runs);
+  hipLaunchKernelGGL(k_ccl_apply, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
+}
+// launch_lr(raw -> D, D2) followed by launch_speckle(D) with the first two kernels as one (k_lr_ccl_rows)
+void launch_lr_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D, float* D2, int32_t* label, int32_t* size,
+                       void* scratch) {
+  static const int fuse = getenv("JN_LR_CCL_FUSED") ? atoi(getenv("JN_LR_CCL_FUSED")) : 1;       // 0: the two kernels (A/B)
+  if (!fuse) { launch_lr(st, dp, n, info, raw, D, D2); launch_speckle(st, dp, n, info, D, label, size, scratch); return; }
+  RunLists runs;
+  runs.pitch = (dp.W / 2 + 2) & ~1;
+  runs.H = dp.H;
+  runs.base = reinterpret_cast<uint8_t*>(scratch);
+  runs.frame_bytes = (size_t)dp.H * dp.W * sizeof(float);
+  const size_t lds = (size_t)2 * ((dp.W + 1) & ~1) * sizeof(int16_t) + (size_t)dp.W * sizeof(float);
+  hipLaunchKernelGGL(k_lr_ccl_rows, dim3(dp.H, n), dim3(256), lds, st, dp, info, raw, D, D2, label, size, runs);
+  const dim3 gr((dp.H + 3) / 4, n);
   const int row_waves = dp.H * n, chunks = (dp.W + 63) / 64;
   const int segs = row_waves >= 4096 ? 1 : max(1, min(chunks, 4096 / max(row_waves, 1)));
   hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs);

@@ -3,7 +3,7 @@ the pair's first kernel, its duration and the idle gap before it.
 Usage: python3 scripts/lone_timeline.py <kernel_trace.csv> [first kernel name, default k_descriptor_fused] [which pair, default -3]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-first = sys.argv[2] if len(sys.argv) > 2 else "k_descriptor_fused"
+first = sys.argv[2] if len(sys.argv) > 2 else "k_sobel_planes"
 which = int(sys.argv[3]) if len(sys.argv) > 3 else -3
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("jnav::", "")) for r in rows)
 starts = [i for i, e in enumerate(ev) if first in e[2]]
