@@ -441,7 +441,17 @@ DEV int quad_match(const DevParams& dp, const uint4* __restrict__ At, const uint
 template <int LANES, int PITCH, bool PL>
 __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const void* __restrict__ src, int Wp, int16_t* __restrict__ d_can, int nseg) {
   extern __shared__ uint4 rows[];                       // [Ltop | Lbot | Rtop | Rbot], PITCH each
-  const int vc = blockIdx.x, frame = blockIdx.y, seg = blockIdx.z, W = dp.W;
+  // XCD-aware work order (as k_dense): consecutive workgroups go round-robin to the 8 XCDs, each with its own L2; workgroup b takes item
+  // (b % 8) * per_xcd + b / 8 of the list ordered (frame, lattice row, segment), so that one XCD walks a frame's lattice rows in order —
+  // neighbouring rows tap overlapping plane rows (v +- 4 around rows 5 apart) and a row's segments overlap by 2 disp_max columns.  [PMC: 0.43 GB
+  // fetched per batch in launch order, every workgroup's rows from memory]
+  int item = blockIdx.x;
+  {
+    const int total = dp.ch * nseg * n, per_xcd = (total + 7) / 8;
+    item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= total) return;
+  }
+  const int seg = item % nseg, vc = (item / nseg) % dp.ch, frame = item / (nseg * dp.ch), W = dp.W;
   const int v = vc * dp.step, nthr = blockDim.x;           // 1024 threads, fewer when a segment has fewer than 256 candidates
   int16_t* out_row = d_can + ((size_t)frame * dp.ch + vc) * dp.cw;
   const int per_seg = (dp.cw + nseg - 1) / nseg, uc_lo = seg * per_seg, uc_hi = min(uc_lo + per_seg, dp.cw);   // candidates [uc_lo, uc_hi)
@@ -3004,10 +3014,11 @@ template <int PITCH>
 static void launch_support_pitch(hipStream_t st, const DevParams& dp, int n, const DescSrc& src, int16_t* d_can, int nseg) {
   const int per_seg = (dp.cw + nseg - 1) / nseg;
   const int threads = std::min(1024, (per_seg * kSupportLanes + 63) / 64 * 64);           // one pass over the segment's candidates when they fit
+  const int blocks = (dp.ch * nseg * n + 7) / 8 * 8;      // (k_support_lds decodes its item from a flat index, XCD-aware)
   if (src.planes)
-    hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH, true>), dim3(dp.ch, n, nseg), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, src.ptr, src.Wp, d_can, nseg);
+    hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH, true>), dim3(blocks), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, src.ptr, src.Wp, d_can, nseg);
   else
-    hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH, false>), dim3(dp.ch, n, nseg), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, src.ptr, 0, d_can, nseg);
+    hipLaunchKernelGGL((k_support_lds<kSupportLanes, PITCH, false>), dim3(blocks), dim3(threads), (size_t)4 * PITCH * sizeof(uint4), st, dp, n, src.ptr, 0, d_can, nseg);
 }
 // columns of both images a workgroup stages for one of nseg segments of a lattice row
 static int support_window(const DevParams& dp, int nseg) {
