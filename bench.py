@@ -799,6 +799,10 @@ def run_rank(a):
                 traffic = pmc["k_dense"]["traffic_bytes"]
                 extra_roof = {"valu_issue_frac_alone": pmc["k_dense"].get("valu_issue_frac_alone"),
                               "SQ_INSTS_VALU": pmc["k_dense"].get("SQ_INSTS_VALU"), "pmc_commit": pmc.get("commit")}
+                wp = pmc.get("whole_path")
+                if wp:                                       # every kernel of a batch: counted HBM bytes against SURVEY 8d's 97 B per pixel and pair
+                    extra_roof.update({"whole_path_traffic": wp["traffic_bytes_per_batch"], "whole_path_traffic_ratio": wp["traffic_ratio"],
+                                       "whole_path_traffic_is": "PMC FETCH_SIZE x 2 + WRITE_SIZE summed over the %d kernels of one batch (profiles/%s)" % (len(wp["kernels"]), os.path.basename(PMC_FILE))})
             else:
                 traffic_note = "PMC passes in %s were taken with a different kernels.hip (sha256 differs): not reported" % os.path.basename(PMC_FILE)
     except Exception:
@@ -996,7 +1000,15 @@ def run_rank(a):
                             want_m = f[7]
                     check_m = {"got": got_m, "expected": want_m, "ok": (got_m == want_m) if want_m else None, "frames_checked": 1 if want_m else 0,
                                "source": "tests/golden/%s_hashes.txt (the mode's scalar definition; the reference has no such matcher)" % kind}
-                other_modes[kind] = {"workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_submit_scan / wait), a distinct input batch per slot, same pairs as the ELAS regions" %
+                roof_m = None
+                if kind == "sgm":                            # SURVEY 8d's B_sgm = one read + one write of the W x H x D byte volume and the images, per batch, against the step time
+                    b_sgm = float((4 * W * H * a.disp + 5 * W * H) * B)
+                    roof_m = {"bound": "hbm", "achieved": round(b_sgm / el_m / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_sgm / el_m / 1e9 / HBM_PEAK_GBS, 4),
+                              "algorithmic_bytes_per_batch": int(b_sgm), "traffic": None, "is": "B_sgm per batch / step time with four batches in flight"}
+                    pm_ = sgm_pmc_traffic(W, H, a.disp, B)
+                    if pm_:
+                        roof_m["traffic"] = pm_["bytes"]; roof_m["traffic_is"] = pm_["note"]
+                other_modes[kind] = {"roofline": roof_m, "workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_submit_scan / wait), a distinct input batch per slot, same pairs as the ELAS regions" %
                                                  (W, H, a.disp, {"sgm": "SGM 8 paths (four batches in flight)", "bm": "9x9 block matching (SAD, v_qsad; four batches in flight)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8; four batches in flight)"}[kind], B,
                                                   "bm" if kind == "bm_ssd" else kind),
                                      "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},

@@ -17,7 +17,9 @@ cd $root
 python3 scripts/kstats.py $(ls $out/${tag}_slots1/*/*kernel_stats.csv | tail -1) 30 > $out/${tag}_slots1_summary.txt
 python3 scripts/kstats.py $(ls $out/${tag}_default/*/*kernel_stats.csv | tail -1) 30 > $out/${tag}_default_summary.txt
 python3 scripts/busy.py $(ls $out/${tag}_default/*/*kernel_trace.csv | tail -1) > $out/${tag}_default_occupancy.txt
-for c in FETCH_SIZE WRITE_SIZE; do python3 scripts/pmc.py $(ls $out/${tag}_pmc_$c/*/*counter_collection.csv | tail -1) "k_dense|k_descriptor|k_support|k_lr$" > $out/${tag}_pmc_$c.txt; done
+# JN_PMC_ALL=1 (round 5 on): every kernel of the path, not only the heavy four
+pat="k_dense|k_descriptor|k_support|k_lr$"; [ -n "$JN_PMC_ALL" ] && pat="^(void )?k_"
+for c in FETCH_SIZE WRITE_SIZE; do python3 scripts/pmc.py $(ls $out/${tag}_pmc_$c/*/*counter_collection.csv | tail -1) "$pat" > $out/${tag}_pmc_$c.txt; done
 grep "^{\"metric\"" $out/${tag}_default.log | tail -1 > $out/${tag}_default_bench_line.json
 python3 bench.py > $out/${tag}_bench_line.json 2> $out/${tag}_bench.err
 cat $out/${tag}_slots1_summary.txt | head -8; cat $out/${tag}_default_occupancy.txt | head -3; cat $out/${tag}_pmc_FETCH_SIZE.txt $out/${tag}_pmc_WRITE_SIZE.txt; tail -1 $out/${tag}_bench_line.json | cut -c1-300

@@ -61,5 +61,14 @@ for name in sorted(set(fetch) | set(write)):
         doc["k_dense"] = e
     else:
         doc[key] = e
+# the whole path per batch: every kernel that runs once per batch (k_valid_lut runs once per handle: left out)
+per_batch = {k: v for k, v in doc.items() if isinstance(v, dict) and "traffic_bytes" in v and k != "k_valid_lut"}
+if len(per_batch) >= 10:
+    total = sum(v["traffic_bytes"] for v in per_batch.values())
+    alg = int(97 * 1280 * 720 * 32)
+    doc["whole_path"] = {"kernels": sorted(v["kernel"] for v in per_batch.values()), "traffic_bytes_per_batch": total, "algorithmic_bytes_per_batch": alg,
+                         "traffic_ratio": round(total / alg, 3),
+                         "alone_ms_sum": round(sum(v.get("alone_ms_per_launch", 0.0) for v in per_batch.values()), 4),
+                         "note": "FETCH_SIZE x 2 + WRITE_SIZE summed over the kernels of one batch (32 pairs 1280x720), one slot; 97 B per pixel and pair is SURVEY 8d's algorithmic figure"}
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps(doc.get("k_dense"), indent=1))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the evidence set scripts/round4_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
+"""Copy the evidence set scripts/round5_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
 profiles/<tag>_manifest.json: every published file, the sha256 of the kernel sources it was measured on, the commit.
     python3 scripts/publish_round.py <tag>
 Files are taken NEWEST FIRST (gpurun_out/ accumulates merged results of several calls; round 2 published stale ones)."""
@@ -61,7 +61,8 @@ for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.
                   ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None),
                   ("bm_ssd_bench_line.json", None), ("bm_ssd_1080p_bench_line.json", None), ("bm_sad_1080p_bench_line.json", None), ("bm_ssd_pmc_mfma.txt", None),
                   ("host_threads.txt", None), ("pk3_probe.txt", None), ("dep_chain_probe.txt", None), ("lds_unaligned_probe.txt", None), ("op_rate_probe.txt", None),
-                  ("dense_dbg_switches.txt", None), ("hw_queues_ab.txt", None), ("gate_ab.txt", None), ("lone_timeline.txt", None), ("gpu_tests.txt", None)):
+                  ("dense_dbg_switches.txt", None), ("hw_queues_ab.txt", None), ("gate_ab.txt", None), ("lone_timeline.txt", None), ("gpu_tests.txt", None),
+                  ("gpu_delaunay_ab.txt", None), ("lone_env_ab.txt", None)):
     put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
 sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
 if sq:
@@ -102,7 +103,7 @@ if os.path.exists(fs) and os.path.exists(ws):     # SGM traffic from its own PMC
     published["%s_sgm_pmc_traffic.json" % rnd] = "from %s_sgm_pmc_*.txt" % tag
 manifest = {"tag": tag, "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
             "sources_sha256": {f: sha(f) for f in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip", "jackal_navigation_amd/csrc/bm_mfma.hip", "jackal_navigation_amd/csrc/prefilter.h",
-                                                   "jackal_navigation_amd/csrc/jn_api.cpp", "bench.py")},
+                                                   "jackal_navigation_amd/csrc/delaunay_gpu.hip", "jackal_navigation_amd/csrc/jn_api.cpp", "bench.py")},
             "inputs_newest_mtime": _newest_in, "files": published}
 json.dump(manifest, open(os.path.join(p, "%s_manifest.json" % tag), "w"), indent=1)
 open(os.path.join(p, "CURRENT"), "w").write(tag + "\n")

@@ -39,6 +39,17 @@ def line(name):
     return json.loads([l for l in txt.splitlines() if l.startswith('{"metric"')][-1])
 
 
+def gpu_dt_row(tag):
+    try:
+        for l in open(os.path.join(P, "%s_gpu_delaunay_ab.txt" % tag)):
+            if l.startswith("all cores, JN_GPU_DELAUNAY=1:"):
+                m = re.search(r": ([0-9.]+) pairs/s.*host cores busy ([0-9.]+)", l)
+                return "%.1f k pairs/s, %.1f" % (float(m.group(1)) / 1e3, float(m.group(2)))
+    except OSError:
+        pass
+    return "n/a"
+
+
 def block():
     tag = open(os.path.join(P, "CURRENT")).read().strip()
     b = line("%s_bench_line.json" % tag)
@@ -60,7 +71,10 @@ def block():
     rows = [
         ("ELAS 1280x720, D=128, batch 32, one MI355X (`bench.py`, the headline)", "%.1f k pairs/s, %.3f ms per step" % (b["value"] / 1e3, b["ms_per_step"])),
         ("  the same with the driver's command (`--gpus 1 --steps 20 --warmup 5`: 20-step regions)", ("%.1f k pairs/s" % (sum(drv) / len(drv) / 1e3)) if drv else "n/a"),
-        ("  roofline of `k_dense2` alone / whole path (fraction of 8 TB/s)", "%.3f / %.3f" % (b["roofline"]["frac"], b["roofline"]["whole_path_frac"])),
+        ("  roofline of `k_dense_row` alone / whole path (fraction of 8 TB/s)", "%.3f / %.3f" % (b["roofline"]["frac"], b["roofline"]["whole_path_frac"])),
+        ("  HBM bytes counted over the whole path / SURVEY's 97 B per pixel and pair", ("%.2f GB per batch, ratio %.2f" % (b["roofline"]["whole_path_traffic"] / 1e9, b["roofline"]["whole_path_traffic_ratio"])) if b["roofline"].get("whole_path_traffic") else "n/a"),
+        ("  the same pipeline with NO host stage (`JN_GPU_DELAUNAY=1`: what a rank pinned to <= 16 cores runs), busy host cores", gpu_dt_row(tag)),
+        ("ELAS 640x480, D=64, batch 32, four batches in flight (the driver line's `vga_config`)", ("%.1f k pairs/s" % (b["vga_config"]["pairs_per_sec"] / 1e3)) if b.get("vga_config") and b["vga_config"].get("pairs_per_sec") else "n/a"),
         ("  reference CPU path on the same box (%d cores)" % b["cpu_baseline"]["cores"], "%.0f pairs/s" % b["cpu_baseline"]["value"]),
         ("ELAS 640x480, D=64, batch 64", "%.1f k pairs/s" % (find("640x480 rectified pairs (scene disparities <= 64), ELAS disp_max=63 (D=64), batch=64")["value"] / 1e3)),
         ("ELAS 320x180, disp_max 255, batch 128 (the reference's native size)", "%.0f k pairs/s" % (find("320x180")["value"] / 1e3)),
