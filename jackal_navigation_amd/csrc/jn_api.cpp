@@ -1,14 +1,16 @@
 // jn_api.cpp — C-ABI of libjn_stereo.so (include/jn_stereo.h).  Product code.
 //
 // Pipeline per batch (one "slot" = one HIP stream + its buffers + one worker thread):
-//   GPU stage A : sobel + descriptor -> support matching -> support filters -> support list   (kernels.hip)
+//   GPU stage A : Sobel planes -> support matching -> support filters -> support list -> alternating-cut arrangement   (kernels.hip)
 //                 the list (uc, vc, d) is written by the GPU straight into pinned host memory
-//   host stage  : Delaunay x2 per frame                                       (delaunay.cpp, thread pool)
+//   host stage  : Delaunay's hull recursion x2 per frame                       (delaunay.cpp, thread pool)
 //                 (+ the support filters when no kernel takes the lattice or JN_HOST_FILTERS=1: host_stage.cpp)
 //   H2D         : one copy per batch: support points + triangle corner indices
-//   GPU stage B : grid prior, plane fits, raster bins -> dense L/R -> L/R check -> speckle -> gaps -> adaptive mean
+//   GPU stage B : grid prior, plane fits, raster bins, ownership -> dense L/R -> L/R check -> speckle -> gaps -> adaptive mean
 //                 [-> u8 map + obstacle scan when submitted through jn_elas_submit_scan]
 // Several slots in flight overlap one batch's host stage with another batch's GPU stages.
+// Batch handles of processes with few cores of their own have NO host stage: the hull recursion runs on the GPU too (delaunay_gpu.hip),
+// FrameInfo and the payload are written on the device and stage B is queued right behind it (run_batch_route).
 #include "../../include/jn_stereo.h"
 #include "kernels.h"
 #include "host_stage.h"

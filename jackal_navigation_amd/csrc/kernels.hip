@@ -1525,14 +1525,6 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(DevParams dp, int n, co
 // Helpers of the LDS-window matchers (k_dense_row)
 enum { kDense2Slack = 16, kCellBias = 8192, kCellPriorMax = 8000, kCellInvalid = 0x60000000 };
 typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
-// w |= bit if bit `pos` of m is set: the sign-extended single bit as an and-mask.  Two plain VALU instructions; written as
-// asm because the compiler rewrites every C form of it into and / compare / select / or (4 instructions).
-#define or_bit_if(w, m, pos, bit)                                                                          \
-  do {                                                                                                    \
-    int sx__;                                                                                             \
-    asm("v_bfe_i32 %0, %1, " #pos ", 1" : "=v"(sx__) : "v"(m));                                             \
-    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(w) : "v"(sx__), "s"(bit));                                     \
-  } while (0)
 // LDS byte address of a pointer into __shared__ memory, and a 16-byte read at such an address
 typedef __attribute__((address_space(3))) const jn_u32x4 jn_lds_u4;
 DEV uint32_t lds_addr(const uint4* p) { return (uint32_t)(uintptr_t)(jn_lds_u4*)p; }
@@ -1624,9 +1616,10 @@ DEV int match_pixel(const DevParams& dp, const uint4& a, bool elig, int d_plane,
 }
 
 // ------------------------------------------------------------------------------------------------
-// The dense matching of the plane data flow (round 5): k_owner + k_dense_row replace k_dense2's list handling and its barrier.
+// The dense matching of the plane data flow (round 5): k_owner + k_dense_row.  They replace k_dense2 (rounds 2-4; git history, DESIGN_HISTORY.md):
+// a workgroup per 128 x 8 strip with a barrier, whose list handling they take out of the matcher.
 //
-// k_dense2's workgroup spends half its life in a prologue: four of its eight waves rank a tile's triangle list and fold the row masks into cover
+// k_dense2's workgroup spent half its life in a prologue: four of its eight waves rank a tile's triangle list and fold the row masks into cover
 // words through a chain of LDS round trips while the others wait at the barrier.  None of that needs the descriptors.  k_owner does it
 // ahead, one wave per 32x8 tile at full occupancy, and leaves ONE 16-bit word per pixel (in the matcher's own output image, which the
 // matcher overwrites):  bit 15 = a triangle covers the pixel (the LAST covering one in list order counts, as in k_dense2), bit 14 = its
@@ -1668,7 +1661,7 @@ __global__ void __launch_bounds__(256) k_owner(DevParams dp, const FrameInfo* __
   const int cnt_l = min(cnt, (int)kBinCap);
   if (cnt_l <= fast_max) {                                   // (fast_max = kBinLds; tests lower it to send ordinary lists through the general form)
     // The usual case (mean 7 entries, 17 the most seen at 720p): what the kernel costs here is its VECTOR instructions (230 k waves x ~400
-    // in the general form below = the 0.17 ms it took), so ownership is resolved k_dense2's way — the entries are RANKED by triangle number,
+    // in the general form below = the 0.17 ms it took), so ownership is resolved by cover words (k_dense2's scheme) — the entries are RANKED by triangle number,
     // an entry's hits on the lane's four pixels ((mask word >> row) & 0x01010101: bit 0 of byte j = column 4g + j) are or-ed into the
     // pixels' cover words at the entry's rank (three instructions per entry for four pixels), and a pixel's owner is its highest set bit.
 #pragma unroll
