@@ -74,7 +74,11 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  *   device        HIP device ordinal
  *   host_threads  worker threads for the host stage (the hull recursion of the Delaunay triangulations; the support
  *                 filters only where no kernel takes the lattice); 0 = one per CPU the process may use (affinity
- *                 mask, cut down to the container's cgroup CPU quota); 16 feed one MI355X at 20 k 720p pairs/s
+ *                 mask, cut down to the container's cgroup CPU quota); 16 feed one MI355X at 22 k 720p pairs/s.
+ *                 A batch handle (max_batch > 1) of a process pinned to 16 cores or fewer (or with a CPU quota below 14) has NO host
+ *                 stage: the hull recursion runs on the GPU as well (19.6 k pairs/s with 0.3 busy cores; JN_GPU_DELAUNAY=0/1 decides
+ *                 otherwise) and the pool idles; a batch the GPU cannot triangulate (coinciding right-image vertices, more than ~3 700
+ *                 support points a side) goes through the host stage after all.
  *   slots         pipeline depth for jn_elas_submit (>=1); each slot has its own stream/buffers
  * Unsupported (JN_ERR_UNSUPPORTED): subsampling with an odd width or height, disp_max > 255 or < 10, disp_min > disp_max,
  * candidate_stepsize < 1, grid_size < 1, plane radius > 7.  Both presets of elas.h:92-145 are supported; disp_min is honoured as the
