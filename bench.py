@@ -341,7 +341,7 @@ def run_sgm(a):
     u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
     bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
     # SGM: batches pipelined over --sgm-slots slots (jn_sgm_submit_scan / jn_sgm_wait), each with its own outputs and its own copy of the inputs
-    SS = 1 if os.environ.get("JN_SGM_IMPL") == "0" else max(1, min(6, a.bm_slots if bm else a.sgm_slots))     # (round 2's kernels, JN_SGM_IMPL=0, have no pipelined form; the block matcher pipelines the same way: jn_bm_submit_scan / jn_bm_wait)
+    SS = 1 if os.environ.get("JN_SGM_IMPL") == "0" else max(1, min(6 if bm else 8, a.bm_slots if bm else a.sgm_slots))     # (round 2's kernels, JN_SGM_IMPL=0, have no pipelined form; the block matcher pipelines the same way: jn_bm_submit_scan / jn_bm_wait)
     slot_in = [(dL, dR)] + [(dL.clone(), dR.clone()) for _ in range(SS - 1)]
     slot_out = [(disp, u8, bins, meta)] + [(torch.zeros_like(disp), torch.zeros_like(u8), torch.zeros_like(bins), torch.zeros_like(meta)) for _ in range(SS - 1)]
     if bm:

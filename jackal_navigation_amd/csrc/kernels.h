@@ -104,8 +104,12 @@ void launch_to_u8(hipStream_t st, const float* D, uint8_t* out, int64_t count);
 void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, uint8_t* lut);
 // scratch: [n][4] uint64.  If dD != nullptr the u8 map is produced from it first (fused), else dDisp is read.
 // lut == nullptr selects the -g flavour (points with d >= 2 minus the ground model, point_cloud.cpp:149-211).
+// sgm != nullptr (with lut): the disparities are the SGM mode's winners — left winners dl [n][H][W] (d | d16 << 16, x-mirrored columns) and the
+// right image's minr [n][H][W] (S << 16 | d, mirrored): the scan kernel applies the L/R check, writes the int16 map `disp` and the mono8 map
+// dDisp on the way (include/jn_sgm.h's definitions of both) and scans what it wrote.
+struct SgmWinners { const uint32_t* dl = nullptr; const uint32_t* minr = nullptr; int16_t* disp = nullptr; int lr = -1, subpixel = 0; };
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
-                 int W, int H, double* bins, double* meta, unsigned long long* scratch, double* flat = nullptr);
+                 int W, int H, double* bins, double* meta, unsigned long long* scratch, double* flat = nullptr, const SgmWinners* sgm = nullptr);
 // Cross-rig merge: pack (bins, meta with maxima negated) into `flat` [n*bins + n*4] or unpack it back.
 void launch_scan_pack(hipStream_t st, int n, int bins, double* dBins, double* dMeta, double* flat, bool pack);
 // Rectification front end (point_cloud.cpp:440, :481, :553-554).

@@ -2765,10 +2765,14 @@ __device__ __host__ inline double dec(unsigned long long k) {
 // point_cloud.cpp:321-352, :149-211): every pixel with d >= 2 becomes a point, points on the ground
 // model are dropped, the rest are binned — instead of the LUT test of the default path.
 constexpr int kScanRows = 16;
-template <bool kFromCloud>
+// kSgm: the disparities come from the SGM mode's winners (sgm_sweep.hip): the L/R check (k_sw_lr), the int16 map, its mono8 form
+// (jn_sgm_disparity_to_u8's rounding) and the scan in ONE pass — the three-kernel tail read the int16 map back twice and the mono8 map once.
+// The winners of a thread's 16 rows are requested together (a left winner, then the right image's winner it points at: two dependent
+// loads, which one row at a time would pay 16 times).
+template <bool kFromCloud, bool kSgm = false>
 __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict__ dD, uint8_t* __restrict__ dDisp,
                                               const uint8_t* __restrict__ lut, int W, int H, unsigned long long* __restrict__ gbins,
-                                              unsigned long long* __restrict__ gmeta) {
+                                              unsigned long long* __restrict__ gmeta, SgmWinners sw = SgmWinners()) {
   extern __shared__ unsigned long long lds[];      // [bins] + 4
   unsigned long long* lbins = lds;
   unsigned long long* lmeta = lds + s.bins;
@@ -2784,12 +2788,36 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
   int cur_bin = -1;
   unsigned long long cur_min = ~0ull;
   const int jend = min(j0 + kScanRows, H);
+  uint32_t u8pk[kScanRows / 4] = {};                              // kSgm: the mono8 values of this thread's rows
   // the next row's disparity and LUT entry are fetched before this row's double-precision work starts
   auto fetch = [&](int j, float& fd, int& ud, int& l0, int& l1) {
     const size_t p = ((size_t)frame * H + j) * W + i;
-    if (dD) fd = dD[p]; else ud = dDisp[p];
+    if constexpr (kSgm) { const int r = j - j0; const uint32_t w = r < 8 ? (r < 4 ? u8pk[0] : u8pk[1]) : (r < 12 ? u8pk[2] : u8pk[3]); ud = (int)((w >> (8 * (r & 3))) & 255u); }
+    else if (dD) fd = dD[p]; else ud = dDisp[p];
     if (!kFromCloud) { const uint16_t l = reinterpret_cast<const uint16_t*>(lut)[(size_t)j * W + i]; l0 = l & 0xFF; l1 = l >> 8; }   // :234
   };
+  if constexpr (kSgm) {
+    if (i < W) {
+      const int xk = W - 1 - i;                                   // the sweeps work on x-mirrored columns
+      uint32_t e[kScanRows], m[kScanRows];
+#pragma unroll
+      for (int r = 0; r < kScanRows; r++) e[r] = sw.dl[((size_t)frame * H + min(j0 + r, H - 1)) * W + xk];
+#pragma unroll
+      for (int r = 0; r < kScanRows; r++) m[r] = sw.minr[((size_t)frame * H + min(j0 + r, H - 1)) * W + min(xk + (int)(e[r] & 0xFFFFu), W - 1)];
+#pragma unroll
+      for (int r = 0; r < kScanRows; r++) {
+        const int d = (int)(e[r] & 0xFFFFu);
+        const bool ok = sw.lr < 0 || (xk + d < W && abs(d - (int)(m[r] & 0xFFFFu)) <= sw.lr);    // x - d >= 0 and the right image's winner there agrees
+        int v = ok ? (sw.subpixel ? (int)(int16_t)(e[r] >> 16) : d) : (sw.subpixel ? -16 : -1);
+        if (j0 + r < H) sw.disp[((size_t)frame * H + j0 + r) * W + i] = (int16_t)v;
+        if (v < 0) v = 0;
+        else if (sw.subpixel) { const int q = v >> 4, f = v & 15; v = q + ((f > 8 || (f == 8 && (q & 1))) ? 1 : 0); }   // half to even, as jn_sgm_disparity_to_u8
+        v = min(v, 255);
+        if (j0 + r < H) dDisp[((size_t)frame * H + j0 + r) * W + i] = (uint8_t)v;
+        u8pk[r >> 2] |= (uint32_t)v << (8 * (r & 3));
+      }
+    }
+  }
   float fd_n = 0; int ud_n = 0, l0_n = 0, l1_n = 0;
   if (i < W && j0 < jend) fetch(j0, fd_n, ud_n, l0_n, l1_n);
   if (i < W) for (int j = j0; j < jend; j++) {
@@ -2797,7 +2825,7 @@ __global__ void __launch_bounds__(256) k_scan(ScanDev s, const float* __restrict
     const float fd = fd_n; const int ud = ud_n, l0 = l0_n, l1 = l1_n;
     if (j + 1 < jend) fetch(j + 1, fd_n, ud_n, l0_n, l1_n);
     int d;
-    if (dD) { const uint8_t q = f32_to_u8(fd); dDisp[p] = q; d = q; } else d = ud;
+    if (!kSgm && dD) { const uint8_t q = f32_to_u8(fd); dDisp[p] = q; d = q; } else d = ud;
     bool take;
     double X = 0, Y = 0, Z = 0;
     if (kFromCloud) take = d >= 2 && reproject(s, i, j, d, X, Y, Z) && !is_ground(s, X, Z);      // :324, :166-172
@@ -3450,14 +3478,15 @@ void launch_valid_lut(hipStream_t st, const jn_scan_params& sp, int W, int H, ui
   hipLaunchKernelGGL(k_valid_lut, grid2d(W, H, 1), dim3(256), 0, st, to_dev(sp), W, H, lut);
 }
 void launch_scan(hipStream_t st, const jn_scan_params& sp, int n, const float* dD, uint8_t* dDisp, const uint8_t* lut,
-                 int W, int H, double* bins, double* meta, unsigned long long* scratch, double* flat) {
+                 int W, int H, double* bins, double* meta, unsigned long long* scratch, double* flat, const SgmWinners* sgm) {
   const ScanDev s = to_dev(sp);
   unsigned long long* gb = reinterpret_cast<unsigned long long*>(bins);
   const int total = n * s.bins, m = total > n * 4 ? total : n * 4;
   hipLaunchKernelGGL(k_scan_init, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch);
   const dim3 sg((W + 255) / 256, (H + kScanRows - 1) / kScanRows, n);
-  if (lut) hipLaunchKernelGGL(k_scan<false>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
-  else     hipLaunchKernelGGL(k_scan<true>, sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch);
+  if (sgm) hipLaunchKernelGGL((k_scan<false, true>), sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, nullptr, dDisp, lut, W, H, gb, scratch, *sgm);
+  else if (lut) hipLaunchKernelGGL((k_scan<false>), sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch, SgmWinners());
+  else     hipLaunchKernelGGL((k_scan<true>), sg, dim3(256), (s.bins + 4) * sizeof(unsigned long long), st, s, dD, dDisp, lut, W, H, gb, scratch, SgmWinners());
   hipLaunchKernelGGL(k_scan_finish, dim3((m + 255) / 256), dim3(256), 0, st, total, n, gb, scratch, meta, flat);
 }
 void launch_scan_pack(hipStream_t st, int n, int bins, double* dBins, double* dMeta, double* flat, bool pack) {

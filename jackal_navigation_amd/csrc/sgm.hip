@@ -271,13 +271,13 @@ struct jn_sgm {
   jnav_sgm::SweepBuffers sb = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {};
-  hipEvent_t ev_end[6] = {};   // per slot: recorded behind EVERYTHING a submit queued (sweeps + the scan tail); what jn_sgm_wait waits for
+  hipEvent_t ev_end[8] = {};   // per slot: recorded behind EVERYTHING a submit queued (sweeps + the scan tail); what jn_sgm_wait waits for
   jn_sgm_times times = {};
   // Pipelined form (jn_sgm_submit_scan / jn_sgm_wait): slot 0 is the set above, slots 1 .. kSgmSlots-1 get their own stream, events and
   // buffers the first time they are used.  Batches on different slots overlap on the GPU: the upward sweep's tail (the last blocks of
   // its parallelogram run alone) is filled by the next batch's horizontal and downward sweeps.
   struct Extra { jnav_sgm::SweepBuffers sb = {}; hipStream_t stream = nullptr; hipEvent_t ev[4] = {}; jn_sgm_times times = {}; bool ready = false, shared = false; };
-  enum { kSgmSlots = 6 };
+  enum { kSgmSlots = 8 };
   Extra extra[kSgmSlots - 1];
   unsigned long long* scan_scratch[kSgmSlots] = {};   // [max_batch][4] per slot, the scan tail's extrema
   bool pending[kSgmSlots] = {};
@@ -449,8 +449,16 @@ jn_status jn_sgm_submit_scan(jn_sgm* h, int32_t slot, int32_t n, const uint8_t* 
   jnav_sgm::SweepBuffers& sb = slot == 0 ? h->sb : h->extra[slot - 1].sb;
   hipStream_t st = slot == 0 ? h->stream : h->extra[slot - 1].stream;
   hipEvent_t* ev = slot == 0 ? h->ev : h->extra[slot - 1].ev;
-  SGM_TRY(jnav_sgm::sweep_run(h->sw, n, dI1, dI2, pitch, (long long)image_stride, dDisp, st, sb, ev, false));
-  if (sp) {                                                    // the node's tail on the same stream: mono8 map (point_cloud.cpp:422 semantics) + LUT scan
+  // With a scan: ONE tail kernel applies the L/R check, writes the int16 map and the mono8 map (point_cloud.cpp:422 semantics) and scans
+  // (JN_SGM_TAIL=3: the three kernels k_sw_lr, k_sgm_to_u8, k_scan one after the other, for A/B).
+  static const bool fused_tail = !(getenv("JN_SGM_TAIL") && atoi(getenv("JN_SGM_TAIL")) == 3);
+  const bool fuse = sp && fused_tail;
+  SGM_TRY(jnav_sgm::sweep_run(h->sw, n, dI1, dI2, pitch, (long long)image_stride, dDisp, st, sb, ev, false, !fuse));
+  if (fuse) {
+    jnav::SgmWinners w;
+    w.dl = sb.dl; w.minr = sb.minr; w.disp = dDisp; w.lr = h->sw.lr; w.subpixel = h->sw.subpixel;
+    jnav::launch_scan(st, *sp, n, nullptr, dDispU8, dLut, h->W, h->H, dBins, dMeta, h->scan_scratch[slot], nullptr, &w);
+  } else if (sp) {
     const long long px = (long long)n * h->W * h->H;
     hipLaunchKernelGGL(k_sgm_to_u8, dim3((unsigned)((px + 255) / 256)), dim3(256), 0, st, dDisp, h->p.subpixel ? 1 : 0, dDispU8, px);
     jnav::launch_scan(st, *sp, n, nullptr, dDispU8, dLut, h->W, h->H, dBins, dMeta, h->scan_scratch[slot]);

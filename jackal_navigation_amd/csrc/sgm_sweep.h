@@ -44,7 +44,9 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
 // Queues prefilter, the two horizontal paths, the downward sweep, the upward sweep + winners, the L/R check on `st`.
 // ev[0..3] are recorded before the prefilter, before the paths, before the final sweep and at the end.
 // side_overlap: run the horizontal sweep on the buffers' side stream next to the downward sweep (a lone batch); JN_SGM_OVERLAP=0/1 overrides.
+// lr_kernel = false leaves the L/R check (and the int16 map) to the caller's next kernel: jn_sgm_submit_scan's tail applies it while it scans
+// (kernels.h, launch_scan with SgmWinners); dDisp is then not written here.
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                     SweepBuffers& b, hipEvent_t* ev, bool side_overlap);
+                     SweepBuffers& b, hipEvent_t* ev, bool side_overlap, bool lr_kernel = true);
 
 }  // namespace jnav_sgm

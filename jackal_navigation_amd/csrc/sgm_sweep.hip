@@ -212,26 +212,51 @@ DEV void load_words(const uint8_t* pixel_base, int q, uint32_t (&f)[NR]) {
 // ---- prefilter: mirrored, padded, +1 ----
 // gm[img][y][padl + x_k] = clamp(Sobel_x(I, W-1-cl(x_k), y), -cap, cap) + cap + 1, cl = clamp to [0, W-1] (replicated borders:
 // the cost's coordinate clamps become plain reads).  +1 keeps every byte non-zero for v_mqsad's mask.
+// A thread owns four padded columns of kPreRows consecutive rows and walks down them: the horizontal differences h(y) = I(x+1, y) - I(x-1, y)
+// of a row are formed once and used by three output rows (Sobel_x = h(y-1) + 2 h(y) + h(y+1)), one 8-byte load per row instead of three
+// (round 4's form — one thread per four bytes of ONE row, 92 k workgroups a batch — took 0.12 ms, a quarter of the chip's copy rate).
+constexpr int kPreRows = 8;
 __global__ void __launch_bounds__(256) k_sw_prefilter(SwDev s, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2, int pitch,
                                                       long long stride, int n, uint8_t* __restrict__ gm) {
-  const int xp = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, img = blockIdx.z;      // four padded columns per thread (Wp is a multiple of 16)
-  if (xp >= s.Wp) return;
+  const int xp = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * kPreRows, img = blockIdx.z;
+  if (xp >= s.Wp || y0 >= s.H) return;                          // (Wp is a multiple of 16)
   const uint8_t* I = img < n ? I1 + (long long)img * stride : I2 + (long long)(img - n) * stride;
-  const int ym = max(y - 1, 0), yq = min(y + 1, s.H - 1);
-  const uint8_t* r0 = I + (size_t)ym * pitch; const uint8_t* r1 = I + (size_t)y * pitch; const uint8_t* r2 = I + (size_t)yq * pitch;
-  int g[4];
+  const int W = s.W, H = s.H;
   const int xk0 = xp - s.padl;                                  // mirrored column of the first of the four; the image column DEscends with it
-  if (xk0 >= 0 && xk0 + 3 <= s.W - 1) jnav_pre::sobel4<-1>(r0, r1, r2, s.W - 1 - xk0, s.W, s.cap, g);
-  else {
+  const int hi = W - 1 - xk0, lo = hi - 3;                      // image columns of the four outputs when none needs a clamp: output k is column hi - k
+  const bool fast = xk0 >= 0 && xk0 + 3 <= W - 1 && lo >= 1 && hi <= W - 2 && lo + 6 <= W - 1;    // the 8-byte window lo-1 .. lo+6 lies inside the row
+  int xq[4], xm[4];                                             // otherwise: per output the clamped columns x+1 / x-1 (the row's padding replicates the outermost columns)
 #pragma unroll
-    for (int k = 0; k < 4; k++) {                               // the row's padding: replicas of the outermost columns
-      const int x = s.W - 1 - min(max(xk0 + k, 0), s.W - 1);
-      g[k] = min(max(jnav_pre::sobel_x_clamped(r0, r1, r2, x, s.W), -s.cap), s.cap);
+  for (int k = 0; k < 4; k++) { const int x = W - 1 - min(max(xk0 + k, 0), W - 1); xq[k] = min(x + 1, W - 1); xm[k] = max(x - 1, 0); }
+  auto hrow = [&](int y, int (&h)[4]) __attribute__((always_inline)) {
+    const uint8_t* r = I + (size_t)min(max(y, 0), H - 1) * pitch;
+    if (fast) {
+      uint64_t a;
+      __builtin_memcpy(&a, r + lo - 1, 8);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const int i = 4 - k; h[k] = (int)((a >> (8 * (i + 1))) & 255u) - (int)((a >> (8 * (i - 1))) & 255u); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) h[k] = (int)r[xq[k]] - (int)r[xm[k]];
     }
-  }
+  };
+  int ha[4], hb[4], hc[4];
+  hrow(y0 - 1, ha); hrow(y0, hb);
   const uint32_t c1 = (uint32_t)(s.cap + 1);
-  *reinterpret_cast<uint32_t*>(gm + ((size_t)img * s.H + y) * s.Wp + xp) =
-      ((uint32_t)g[0] + c1) | (((uint32_t)g[1] + c1) << 8) | (((uint32_t)g[2] + c1) << 16) | (((uint32_t)g[3] + c1) << 24);
+  uint8_t* out = gm + ((size_t)img * H + y0) * s.Wp + xp;
+#pragma unroll
+  for (int r = 0; r < kPreRows; r++) {
+    if (y0 + r >= H) break;
+    hrow(y0 + r + 1, hc);
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int g = min(max(ha[k] + 2 * hb[k] + hc[k], -s.cap), s.cap);
+      w |= ((uint32_t)g + c1) << (8 * k);
+      ha[k] = hb[k]; hb[k] = hc[k];
+    }
+    *reinterpret_cast<uint32_t*>(out + (size_t)r * s.Wp) = w;
+  }
 }
 
 // ---- horizontal paths: lanes = 16 rows x 4 disparity quarters; blockIdx.z = 0 walks x_k upwards, 1 downwards ----
@@ -635,6 +660,23 @@ DEV int lds_load_relaxed(const int* p) { return __hip_atomic_load(p, __ATOMIC_RE
 DEV void lds_store_relaxed(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// a piece of a row of boundary columns as it crosses between blocks: 16 or 8 bytes, write-through (aux 16 = sc1)
+template <int PW> struct Piece;
+template <> struct Piece<4> {
+  typedef u32x4 T;
+  DEV T load(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16); }
+  DEV void store(T v, __amdgpu_buffer_rsrc_t r, int off) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 16); }
+  DEV bool all_tagged(T v, uint32_t tag) { return ((v.x & 0xFF00FF00u) == tag) & ((v.y & 0xFF00FF00u) == tag) & ((v.z & 0xFF00FF00u) == tag) & ((v.w & 0xFF00FF00u) == tag); }
+  DEV T zero() { return (T){0u, 0u, 0u, 0u}; }
+};
+template <> struct Piece<2> {
+  typedef u32x2 T;
+  DEV T load(__amdgpu_buffer_rsrc_t r, int off) { return __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 16); }
+  DEV void store(T v, __amdgpu_buffer_rsrc_t r, int off) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 16); }
+  DEV bool all_tagged(T v, uint32_t tag) { return ((v.x & 0xFF00FF00u) == tag) & ((v.y & 0xFF00FF00u) == tag); }
+  DEV T zero() { return (T){0u, 0u}; }
+};
 // Profiling switches of k_sw_w (results are then WRONG; attribution only): compiled in with -DJN_SGM_PROFILE (make ... EXTRA=-DJN_SGM_PROFILE),
 // absent from the product build — a switch that is only tested at run time still keeps registers alive across the code it guards.
 //   JN_SGM_DBG bits: 1 no wait for / load of the producer block's columns, 2 no right-image minima (LDS atomics + flush), 4 no volume loads /
@@ -682,10 +724,13 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
                                                   uint32_t* __restrict__ ctr, uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
   constexpr int NQ = LQ, PX = 64 / LQ;                         // lanes per pixel (4, or 8 for D = 256: 16 disparity pairs per lane either way), pixels per strip
   constexpr bool LATE_PROD = FINAL && LQ == 8;                 // where the last strip requests its producer block's columns (see there)
-  constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = PX + DPL, NG = (SLOT + 63) / 64;
+  constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = PX + DPL;
+  constexpr int PW = LQ == 4 ? 4 : 2, NP = SLOT / PW, NG = (NP + 63) / 64;       // dwords per piece of a row of columns between blocks, pieces per row, pieces per lane
+  typedef Piece<PW> Px;
+  typedef typename Px::T piece_t;
   static_assert((RING & (RING - 1)) == 0, "ring depth is a power of two");
-  __shared__ uint32_t ring[RING][NS][SLOT];                    // boundary columns [row mod RING][strip][V0 | M0 | M1][quarter][NR]
-  __shared__ uint32_t nextblk[SLOT];                           // the next block's columns for the last strip (written and read by that wave only)
+  __shared__ __attribute__((aligned(16))) uint32_t ring[RING][NS][SLOT];                    // boundary columns [row mod RING][strip][V0 | M0 | M1][quarter][NR]
+  __shared__ __attribute__((aligned(16))) uint32_t nextblk[SLOT];                           // the next block's columns for the last strip (written and read by that wave only)
   __shared__ uint32_t minR[FINAL ? NS : 1][FINAL ? 2 : 1][FINAL ? NQ : 1][FINAL ? MR : 1];   // right-image winners of one row of one strip, per disparity quarter (rows alternate)
   __shared__ uint32_t minR_trash[FINAL ? NS : 1][FINAL ? NQ : 1][FINAL ? MR : 1];              // where lanes outside the image send theirs
   __shared__ int prog[NS], cons[NS];                           // rows published by strip w / rows of strip w's columns consumed by strip w-1
@@ -715,15 +760,36 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
   const int ybsp = max(0, -(x0p + BLK - 1)), ybep = min(H - 1, W - 1 - x0p);
   const uint32_t* p_gx = gx + ((size_t)frame * NB + j + 1) * H * (size_t)SLOT;
   const bool last = wave == NS - 1;
-  uint32_t g[NG];                                              // last strip: the producer's row, loaded a row ahead of its use
+  // The columns cross between blocks in 16-BYTE pieces (round 5; they were single dwords): a write-through dword store is one fabric write
+  // of its own and costs ~6x a 16-byte store's time per byte, an 8-byte one 2.7x (MI355X_MICROARCH.md, stores of each flavour).  Every dword
+  // still carries its tag, so nothing is assumed about how a wider store becomes visible.  Lanes beyond the row's NP pieces: the buffer's range
+  // check drops their stores and returns zeros to their loads (they count as valid).  (Eight lanes per pixel: 8-byte pieces — as many
+  // registers as the dwords took; with 16-byte ones the final sweep spills a dozen more.)
+  piece_t g[NG];                                               // last strip: the producer's row, loaded a row ahead of its use
 #pragma unroll
-  for (int k = 0; k < NG; k++) g[k] = 0u;
-  auto load_prod = [&](int yr, uint32_t (&dst)[NG]) __attribute__((always_inline)) {
-    const uint32_t* src = p_gx + (size_t)yr * SLOT;             // wave-uniform
+  for (int k = 0; k < NG; k++) g[k] = Px::zero();
+  auto gx_rsrc = [&](const uint32_t* row) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), 0, SLOT * 4, 0x00020000);
+  };
+  auto load_prod = [&](int yr, piece_t (&dst)[NG]) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t r = gx_rsrc(p_gx + (size_t)yr * SLOT);     // wave-uniform
     int ln = lane;
     asm volatile("" : "+v"(ln));                                // scalar base + lane offset, formed here: a per-lane 64-bit pointer kept across the loop is two registers the final sweep lacks
 #pragma unroll
-    for (int k = 0; k < NG; k++) { const int o = ln + 64 * k; dst[k] = (SLOT % 64 == 0 || o < SLOT) ? ld_sc1(src + o) : tagpk; }
+    for (int k = 0; k < NG; k++) dst[k] = Px::load(r, 4 * PW * (ln + 64 * k));
+  };
+  auto tags_ok = [&](const piece_t (&v)[NG]) __attribute__((always_inline)) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NG; k++) ok = ok && (Px::all_tagged(v[k], tagpk) || (NP % 64 != 0 && lane + 64 * k >= NP));
+    return ok;
+  };
+  auto to_nextblk = [&](const piece_t (&v)[NG], uint32_t* nb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+      const int o = lane + 64 * k;
+      if (NP % 64 == 0 || o < NP) *reinterpret_cast<piece_t*>(nb + PW * o) = v[k] & 0x00FF00FFu;
+    }
   };
   const int q = lane / PX, p = lane & (PX - 1);
   const int xl = x0 + PX * wave + p;                           // this lane's sheared column
@@ -887,27 +953,19 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
         // g was loaded for exactly this row (before the loop or during the previous row).  The usual case — every tag is this launch's —
         // has its own code path, so that its wait counts only what is older than g; the retry loop (the producer has not written the
         // whole row yet) reloads into other registers.
-        bool ok = true;
-#pragma unroll
-        for (int k = 0; k < NG; k++) ok = ok && (g[k] & 0xFF00FF00u) == tagpk;
-        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) {
-#pragma unroll
-          for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = g[k] & 0x00FF00FFu; }
+        if (__builtin_amdgcn_ballot_w64(!tags_ok(g)) == 0ull) {
+          to_nextblk(g, nextblk);
         } else {
-          uint32_t v[NG];
+          piece_t v[NG];
           do {
             __builtin_amdgcn_s_sleep(8);
             load_prod(yr, v);
-            ok = true;
-#pragma unroll
-            for (int k = 0; k < NG; k++) ok = ok && (v[k] & 0xFF00FF00u) == tagpk;
-          } while (__builtin_amdgcn_ballot_w64(!ok) != 0ull);
-#pragma unroll
-          for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = v[k] & 0x00FF00FFu; }
+          } while (__builtin_amdgcn_ballot_w64(!tags_ok(v)) != 0ull);
+          to_nextblk(v, nextblk);
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < NG; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = P2pk; }
+        for (int k = 0; k < (SLOT + 63) / 64; k++) { const int o = lane + 64 * k; if (SLOT % 64 == 0 || o < SLOT) nextblk[o] = P2pk; }
       }
       if constexpr (!LATE_PROD) { if (has_prod && yb >= ybsp && yb <= ybep && yb < ybe && !SW_DBG(1)) load_prod(yb, g); }  // the next row's, speculatively: checked when it is needed
     }
@@ -996,7 +1054,7 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
       if (last && has_prod && yb >= ybsp && yb <= ybep && yb < ybe && !SW_DBG(1)) load_prod(yb, g);
       else {
 #pragma unroll
-        for (int k = 0; k < NG; k++) g[k] = 0u;
+        for (int k = 0; k < NG; k++) g[k] = Px::zero();
       }
     }
     // ---- publish this strip's first two columns of row yb ----
@@ -1022,11 +1080,15 @@ __global__ void __launch_bounds__(NS * 64, NR == 16 ? 3 : (NR == 32 && !FINAL) ?
         if (lane == 0) lds_store_relaxed(&prog[wave], yb + 1);
       } else {                                                 // strip 0: to the next block through memory, tagged
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
-        uint32_t* dst = my_gx + (size_t)yb * SLOT;
+        const __amdgpu_buffer_rsrc_t rG = gx_rsrc(my_gx + (size_t)yb * SLOT);
         int ln = lane;
         asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int k = 0; k < NG; k++) { const int oo = ln + 64 * k; if (SLOT % 64 == 0 || oo < SLOT) st_sc1(dst + oo, o[oo] | tagpk); }
+        for (int k = 0; k < NG; k++) {
+          const int oo = ln + 64 * k;                           // (lanes beyond the row read a valid piece again; their store is dropped)
+          const piece_t v = *reinterpret_cast<const piece_t*>(o + PW * min(oo, NP - 1)) | tagpk;
+          Px::store(v, rG, 4 * PW * oo);
+        }
       }
     }
     if (!last && yb < ybe) known_p = __builtin_amdgcn_readfirstlane(lds_load_relaxed(&prog[wave + 1]));   // for the next row: usually already far enough
@@ -1214,11 +1276,18 @@ static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuff
 
 template <int NR, int NS, bool FLOW, int LQ = 4>
 static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                          SweepBuffers& b, hipEvent_t* ev, bool side_overlap) {
+                          SweepBuffers& b, hipEvent_t* ev, bool side_overlap, bool lr_kernel) {
   hipError_t e;
   const size_t px = (size_t)s.W * s.H;
   if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp / 4 + 255) / 256, s.H, 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
+#ifdef JN_SGM_PROFILE
+  static const int exp_ = getenv("JN_SGM_EXP") ? atoi(getenv("JN_SGM_EXP")) : 0;   // attribution only (results WRONG): 1 no prefilter, 2 no L/R kernel, 8 no minima memset
+  if (!(exp_ & 1))
+#endif
+  hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp + 255) / 256, (s.H + 4 * kPreRows - 1) / (4 * kPreRows), 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
+#ifdef JN_SGM_PROFILE
+  if (!(exp_ & 8))
+#endif
   if ((e = hipMemsetAsync(b.minr, 0xFF, (size_t)n * px * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   constexpr int PXL = 64 / LQ;                                  // image rows per wave of the horizontal sweep = pixels per strip of the row sweeps
@@ -1249,7 +1318,10 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   if ((e = hipEventRecord(ev[2], st)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
   if ((e = sweep(true)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_sw_lr, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, n, b.dl, b.minr, dDisp);
+#ifdef JN_SGM_PROFILE
+  if (!(exp_ & 2))
+#endif
+  if (lr_kernel) hipLaunchKernelGGL(k_sw_lr, dim3((s.W + 255) / 256, s.H, n), dim3(256), 0, st, s, n, b.dl, b.minr, dDisp);
   if ((e = hipEventRecord(ev[3], st)) != hipSuccess) return e;
   return hipGetLastError();
 }
@@ -1261,14 +1333,14 @@ void sweep_release(SweepBuffers& b) {
 }
 
 hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
-                     SweepBuffers& b, hipEvent_t* ev, bool side_overlap) {
+                     SweepBuffers& b, hipEvent_t* ev, bool side_overlap, bool lr_kernel) {
   const int lq = lanes_per_pixel(s.D);
   const int ns = (s.padl - 32) / (64 / lq);                    // strips per block, as sweep_geometry() chose them (padl = BLK + 32)
-#define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap)
+#define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap, lr_kernel)
   if (s.flow) {
     if (s.D == 64) return ns == 2 ? JN_RUN(8, 2, true) : ns == 8 ? JN_RUN(8, 8, true) : JN_RUN(8, 4, true);
     if (s.D == 128) return ns == 2 ? JN_RUN(16, 2, true) : ns == 8 ? JN_RUN(16, 8, true) : JN_RUN(16, 4, true);
-    if (lq == 8) return run_all<16, 4, true, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap);     // D = 256: eight lanes per pixel, 16 pairs per lane
+    if (lq == 8) return run_all<16, 4, true, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap, lr_kernel);     // D = 256: eight lanes per pixel, 16 pairs per lane
     return JN_RUN(32, 4, true);
   }
   if (s.D == 64) return ns == 3 ? JN_RUN(8, 3, false) : ns == 5 ? JN_RUN(8, 5, false) : JN_RUN(8, 7, false);

@@ -189,19 +189,25 @@ def test_sgm_long_chain_of_blocks(jn, sgm, oracle):
         assert np.array_equal(out[b], exp), b
 
 
-def test_sgm_pipelined_slots_equal_the_synchronous_call(jn, oracle):
+@pytest.mark.parametrize("W,H,sub,lr", [(320, 180, 1, None), (333, 187, 0, -1), (270, 161, 0, 2)])
+def test_sgm_pipelined_slots_equal_the_synchronous_call(jn, oracle, W, H, sub, lr):
     """jn_sgm_submit_scan / jn_sgm_wait: four batches of different frames in flight on four slots (slots 1-3 allocate their own volumes), with
     the node's tail on the slot's stream — disparities, u8 maps and scans must equal what the synchronous calls give for the same frames,
-    twice over (the slots are reused), and a second submit on a busy slot is refused."""
+    twice over (the slots are reused), and a second submit on a busy slot is refused.  The pipelined form's tail is ONE kernel (L/R check,
+    int16 map, mono8 map and scan: k_scan<false, true>), the synchronous route's is k_sw_lr, k_sgm_to_u8 and k_scan one after the other:
+    with and without the sub-pixel step, with the L/R check off, widths that are no multiple of anything."""
     from jackal_navigation_amd.device import DeviceArray
     from jackal_navigation_amd import node, _lib
-    W, H, D, n, S = 320, 180, 64, 2, 4
+    D, n, S = 64, 2, 4
     sp = node.scan_params(W, H)
     lut = node.build_valid_disp_lut(sp, W, H)
     frames = [[oracle.synth_pair(W, H, 48, 300 + 10 * k + t) for t in range(n)] for k in range(2 * S)]
     dL = [DeviceArray.from_numpy(np.stack([f[0] for f in fs])) for fs in frames]
     dR = [DeviceArray.from_numpy(np.stack([f[1] for f in fs])) for fs in frames]
-    with jn.Sgm(jn.Sgm.parameters(num_disparities=D, subpixel=1), W, H, max_batch=n) as m:
+    kw = dict(num_disparities=D, subpixel=sub)
+    if lr is not None:
+        kw["lr_max_diff"] = lr
+    with jn.Sgm(jn.Sgm.parameters(**kw), W, H, max_batch=n) as m:
         want = []
         for k in range(2 * S):                                 # the synchronous route: three calls per batch
             dd = DeviceArray((n, H, W), np.int16); du = DeviceArray((n, H, W), np.uint8)
