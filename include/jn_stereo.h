@@ -75,7 +75,8 @@ typedef struct jn_elas jn_elas;   /* opaque; replaces an `Elas` object (elas.h:1
  *   host_threads  worker threads for the host stage (the hull recursion of the Delaunay triangulations; the support
  *                 filters only where no kernel takes the lattice); 0 = one per CPU the process may use (affinity
  *                 mask, cut down to the container's cgroup CPU quota); 16 feed one MI355X at 22 k 720p pairs/s.
- *                 A batch handle (max_batch > 1) of a process pinned to 16 cores or fewer (or with a CPU quota below 14) has NO host
+ *                 A batch handle (max_batch > 1) of a process pinned to 16 cores or fewer (or with a CPU quota below 14, or created
+ *                 with 0 < host_threads < 14: the caller's share of cores that several ranks divide) has NO host
  *                 stage: the hull recursion runs on the GPU as well (19.6 k pairs/s with 0.3 busy cores; JN_GPU_DELAUNAY=0/1 decides
  *                 otherwise) and the pool idles; a batch the GPU cannot triangulate (coinciding right-image vertices, more than ~3 700
  *                 support points a side) goes through the host stage after all.

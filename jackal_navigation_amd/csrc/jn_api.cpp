@@ -791,7 +791,9 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   {
     cpu_set_t set;
     const int pinned = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
-    h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14);
+    // (an explicit host_threads below 14 says the same thing — the caller's share of a quota that several ranks divide, which no rank can
+    // see from its own affinity mask or cpu.max: bench.py passes quota / world)
+    h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14 || (host_threads > 0 && host_threads < 14));
   }
   if (const char* e = getenv("JN_GPU_DELAUNAY")) h->gpu_delaunay = gpu_dt_possible && atoi(e) != 0;
   h->stage_events = max_batch > 1;
