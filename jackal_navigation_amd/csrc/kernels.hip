@@ -1997,6 +1997,40 @@ struct RunLists {
   __device__ uint16_t* ends(int frame) const { return starts(frame) + (size_t)H * pitch; }
   __device__ int32_t* count(int frame) const { return reinterpret_cast<int32_t*>(ends(frame) + (size_t)H * pitch); }
 };
+// One 64-pixel chunk of a row's run labelling, on one wave: d = this lane's pixel (u = u0 + lane), nxt = the pixel 64 further.
+// Neighbours come by DPP wave shifts (lane 0 / 63 take the carried `left` / the next chunk's first pixel as the shift's `old` operand),
+// the latest run start by the DPP prefix maximum (row_shr 1, 2, 4, 8, then row_bcast 15 / 31), the run's ordinal by v_mbcnt: ~45 vector
+// instructions a chunk where the ds_bpermute forms of round 4 took ~90 (the post chain is bound by vector issue like the rest of the path).
+struct RunCarry { int carry = -1, cnt = 0; float left = -10.0f; };          // latest run start / runs so far / pixel just before the chunk
+#define JN_DPP(old, v, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(v), ctrl, rmask, 0xf, false)
+DEV void ccl_chunk(float d, float nxt, int u, int W, int v, float sim, RunCarry& c, int32_t* __restrict__ lab_row, int32_t* __restrict__ sz_row,
+                   uint16_t* __restrict__ rs, uint16_t* __restrict__ re) {
+  const float nxt0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nxt)));
+  const float prev = __int_as_float(JN_DPP(__float_as_int(c.left), __float_as_int(d), 0x138, 0xf));      // wave_shr:1
+  const float foll = __int_as_float(JN_DPP(__float_as_int(nxt0), __float_as_int(d), 0x130, 0xf));        // wave_shl:1
+  const bool valid = d >= 0;
+  const bool conn = valid && prev >= 0 && fabsf(d - prev) <= sim;
+  const bool conn_next = valid && foll >= 0 && fabsf(foll - d) <= sim;
+  const bool start = valid && !conn, last = valid && !conn_next;
+  // (run starts biased by one, unsigned: 0 = none is then the maximum's identity AND what a DPP read beyond the row returns, so each step
+  // is ONE v_max_u32 with a DPP operand)
+  uint32_t sb = start ? (uint32_t)u + 1u : 0u;
+#define JN_DPP0(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xf, true)
+  sb = max(sb, JN_DPP0(sb, 0x111, 0xf)); sb = max(sb, JN_DPP0(sb, 0x112, 0xf));                         // row_shr:1, :2
+  sb = max(sb, JN_DPP0(sb, 0x114, 0xf)); sb = max(sb, JN_DPP0(sb, 0x118, 0xf));                         // row_shr:4, :8
+  sb = max(sb, JN_DPP0(sb, 0x142, 0xa));                                                                // row_bcast:15 into rows 1 and 3
+  sb = max(sb, JN_DPP0(sb, 0x143, 0xc));                                                                // row_bcast:31 into rows 2 and 3
+#undef JN_DPP0
+  const int s = max((int)sb - 1, c.carry);
+  const unsigned long long starts = __ballot(start);
+  const int k = c.cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(starts >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)starts, 0u)) + (start ? 0 : -1);   // ordinal of the run this pixel belongs to
+  if (u < W) lab_row[u] = valid ? v * W + s : -1;
+  if (start) { sz_row[u] = 0; rs[k] = (uint16_t)u; }         // sizes live at roots, and roots are run starts
+  if (last) re[k] = (uint16_t)u;
+  c.carry = __builtin_amdgcn_readlane(s, 63);
+  c.cnt += __popcll(starts);
+  c.left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), 63));
+}
 // One wave per image row, walking it in 64-pixel chunks: the carries (latest run start, runs so far) are wave-uniform,
 // so there is no LDS and no barrier, and the next chunk's pixels are loaded before the current one is processed.
 __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
@@ -2009,36 +2043,15 @@ __global__ void __launch_bounds__(256) k_ccl_rows(DevParams dp, const FrameInfo*
   uint16_t* r_starts = runs.starts(frame); uint16_t* r_ends = runs.ends(frame);
   const float* row = D + base;
   const float sim = dp.speckle_sim;
-  int carry = -1;                                           // last run start seen in earlier chunks
-  int carry_cnt = 0;                                        // runs started in earlier chunks
-  float left = -10.0f;                                      // pixel just before the chunk
+  RunCarry c;
   float d = lane < W ? row[lane] : -10.0f;
   for (int u0 = 0; u0 < W; u0 += 64) {
     const int u = u0 + lane;
     const float nxt = u + 64 < W ? row[u + 64] : -10.0f;    // next chunk, in flight while this one is processed
-    const float nxt0 = __shfl(nxt, 0);                      // read with all lanes active: a shuffle inside `if (lane == 63)` would
-    float prev = __shfl_up(d, 1), foll = __shfl_down(d, 1); // pull from an inactive lane
-    if (lane == 0) prev = left;
-    if (lane == 63) foll = nxt0;
-    const bool valid = d >= 0;
-    const bool conn = valid && prev >= 0 && fabsf(d - prev) <= sim;
-    const bool conn_next = valid && foll >= 0 && fabsf(foll - d) <= sim;
-    const bool start = valid && !conn, last = valid && !conn_next;
-    int s = start ? u : -1;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(s, off); if (lane >= off) s = max(s, o); }
-    s = max(s, carry);
-    const unsigned long long starts = __ballot(start);
-    const int k = carry_cnt + __popcll(starts & (~0ull >> (63 - lane))) - 1;   // ordinal of the run this pixel belongs to
-    if (u < W) lab[base + u] = valid ? v * W + s : -1;
-    if (start) { sz[base + u] = 0; r_starts[rbase + k] = (uint16_t)u; }    // sizes live at roots, and roots are run starts
-    if (last) r_ends[rbase + k] = (uint16_t)u;
-    carry = __shfl(s, 63);
-    carry_cnt += __popcll(starts);
-    left = __shfl(d, 63);
+    ccl_chunk(d, nxt, u, W, v, sim, c, lab + base, sz + base, r_starts + rbase, r_ends + rbase);
     d = nxt;
   }
-  if (lane == 0) runs.count(frame)[v] = carry_cnt;
+  if (lane == 0) runs.count(frame)[v] = c.cnt;
 }
 // k_lr and k_ccl_rows in one pass over the row (the route where the left map travels raw -> tmp -> D1): the workgroup that has just formed the
 // row's L/R-checked values keeps the left ones in LDS, and its first wave labels their runs from there — the row is not read back from
@@ -2077,35 +2090,15 @@ __global__ void __launch_bounds__(256) k_lr_ccl_rows(DevParams dp, const FrameIn
   const size_t rbase = (size_t)v * runs.pitch;
   uint16_t* r_starts = runs.starts(frame); uint16_t* r_ends = runs.ends(frame);
   const float sim = dp.speckle_sim;
-  int carry = -1, carry_cnt = 0;
-  float left = -10.0f;
+  RunCarry c;
   float d = lane < W ? s_o1[lane] : -10.0f;
   for (int u0 = 0; u0 < W; u0 += 64) {
     const int u = u0 + lane;
     const float nxt = u + 64 < W ? s_o1[u + 64] : -10.0f;
-    const float nxt0 = __shfl(nxt, 0);
-    float prev = __shfl_up(d, 1), foll = __shfl_down(d, 1);
-    if (lane == 0) prev = left;
-    if (lane == 63) foll = nxt0;
-    const bool valid = d >= 0;
-    const bool conn = valid && prev >= 0 && fabsf(d - prev) <= sim;
-    const bool conn_next = valid && foll >= 0 && fabsf(foll - d) <= sim;
-    const bool start = valid && !conn, last = valid && !conn_next;
-    int s = start ? u : -1;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(s, off); if (lane >= off) s = max(s, o); }
-    s = max(s, carry);
-    const unsigned long long starts = __ballot(start);
-    const int k = carry_cnt + __popcll(starts & (~0ull >> (63 - lane))) - 1;
-    if (u < W) lab[base + u] = valid ? v * W + s : -1;
-    if (start) { sz[base + u] = 0; r_starts[rbase + k] = (uint16_t)u; }
-    if (last) r_ends[rbase + k] = (uint16_t)u;
-    carry = __shfl(s, 63);
-    carry_cnt += __popcll(starts);
-    left = __shfl(d, 63);
+    ccl_chunk(d, nxt, u, W, v, sim, c, lab + base, sz + base, r_starts + rbase, r_ends + rbase);
     d = nxt;
   }
-  if (lane == 0) runs.count(frame)[v] = carry_cnt;
+  if (lane == 0) runs.count(frame)[v] = c.cnt;
 }
 // Column pass: unite vertically adjacent runs.  A pixel issues the union only if it is the first
 // column of the contact between its run and the run below (the pixel to its left belongs to the
