@@ -139,8 +139,8 @@ def parse_args():
     ap.add_argument("--subpixel", type=int, default=0, help="sgm / bm mode: 1/16-pixel refinement")
     ap.add_argument("--block-radius", type=int, default=4, help="bm mode: block radius r (2, 3, 4)")
     ap.add_argument("--bm-slots", type=int, default=4, help="bm mode: batches in flight (jn_bm_submit_scan / jn_bm_wait), as --sgm-slots for the SGM mode")
-    ap.add_argument("--sgm-slots", type=int, default=4,
-                    help="sgm mode: batches in flight (jn_sgm_submit_scan / jn_sgm_wait; 1 = one synchronous batch at a time as in rounds 2-3; each further "
+    ap.add_argument("--sgm-slots", type=int, default=6,
+                    help="sgm mode: batches in flight (six measured best: 4.70 / 4.76 / 4.95 / 4.95 / 4.83 k pairs/s with 4 / 5 / 6 / 7 / 8) (jn_sgm_submit_scan / jn_sgm_wait; 1 = one synchronous batch at a time as in rounds 2-3; each further "
                          "slot holds its own three W*H*D byte volumes per pair of the batch)")
     ap.add_argument("--bm-cost", default="sad", choices=["sad", "ssd"],
                     help="bm mode: sad = absolute differences (v_qsad kernel, default); ssd = squared differences as a banded int8 contraction on the matrix "
@@ -937,20 +937,25 @@ def run_rank(a):
                 else:
                     m = jn.Bm(jn.Bm.parameters(num_disparities=a.disp, block_radius=4, cost_function=1 if kind == "bm_ssd" else 0), W, H, max_batch=B, device=local_rank)
                 reps_m = 120 if kind == "sgm" else 160   # the pipelined legs need enough batches (0.8 / 0.25 s) for their fill and drain not to weigh
-                if kind == "sgm":                            # four batches in flight (jn_sgm_submit_scan / jn_sgm_wait), as `--mode sgm` runs it
-                    nsl = 4
+                if kind == "sgm":                            # six batches in flight (jn_sgm_submit_scan / jn_sgm_wait), as `--mode sgm --sgm-slots 6` runs it
+                    nsl = 6
                     outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
+                    rot_m = [(s_ * max(1, B // nsl)) % B for s_ in range(nsl)]           # a distinct copy of the batch per slot: the same B pairs rotated by rot_m[slot] frames
+                    base_l = torch.roll(dLs[0], shifts=rot[0], dims=0); base_r = torch.roll(dRs[0], shifts=rot[0], dims=0)
+                    in_l = [torch.roll(base_l, shifts=-r_, dims=0) for r_ in rot_m]; in_r = [torch.roll(base_r, shifts=-r_, dims=0) for r_ in rot_m]
+                    seed_m = lambda s_, i: 12345 + (i + rot_m[s_]) % B + 1000 * rank
 
                     def run_m(k):
                         for i in range(k):
                             if i >= nsl:
                                 m.wait(i % nsl)
-                            m.submit_scan(i % nsl, B, dLs[(i % nsl) % len(dLs)].data_ptr(), dRs[(i % nsl) % len(dRs)].data_ptr(), W, H * W, outs_m[i % nsl].data_ptr())
+                            m.submit_scan(i % nsl, B, in_l[i % nsl].data_ptr(), in_r[i % nsl].data_ptr(), W, H * W, outs_m[i % nsl].data_ptr())
                         for sl in range(nsl):
                             m.wait(sl)
                 else:                                        # the block matcher the same way (jn_bm_submit_scan / jn_bm_wait)
                     nsl = 4
                     outs_m = [disp16] + [torch.zeros_like(disp16) for _ in range(nsl - 1)]
+                    seed_m = lambda s_, i: seed_of(s_ % S, i)
 
                     def run_m(k):
                         for i in range(k):
@@ -980,13 +985,13 @@ def run_rank(a):
                     for s_ in range(nsl):
                         hm = outs_m[s_].cpu().numpy()
                         for i in range(B):
-                            g = modes_gold.get(str(seed_of(s_ % S, i)))
+                            g = modes_gold.get(str(seed_m(s_, i)))
                             if g is None:
                                 continue
                             gh = "%016x" % jn.load().jn_fnv1a64_u32(hm[i].ctypes.data, hm[i].size // 2)
                             n_checked += 1
                             if gh != g[kind]:
-                                bad_m.append({"slot": s_, "frame": i, "seed": seed_of(s_ % S, i), "got": gh, "expected": g[kind]})
+                                bad_m.append({"slot": s_, "frame": i, "seed": seed_m(s_, i), "got": gh, "expected": g[kind]})
                     check_m = {"frames_checked": n_checked, "slots": nsl, "n_mismatches": len(bad_m), "mismatches": bad_m[:4], "ok": (len(bad_m) == 0) if n_checked else None,
                                "source": "tests/golden/bench_modes_golden.json (the mode's scalar definition on every pair of the batch; the reference has no such matcher)"}
                 else:
@@ -1004,12 +1009,12 @@ def run_rank(a):
                 if kind == "sgm":                            # SURVEY 8d's B_sgm = one read + one write of the W x H x D byte volume and the images, per batch, against the step time
                     b_sgm = float((4 * W * H * a.disp + 5 * W * H) * B)
                     roof_m = {"bound": "hbm", "achieved": round(b_sgm / el_m / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_sgm / el_m / 1e9 / HBM_PEAK_GBS, 4),
-                              "algorithmic_bytes_per_batch": int(b_sgm), "traffic": None, "is": "B_sgm per batch / step time with four batches in flight"}
+                              "algorithmic_bytes_per_batch": int(b_sgm), "traffic": None, "is": "B_sgm per batch / step time with six batches in flight"}
                     pm_ = sgm_pmc_traffic(W, H, a.disp, B)
                     if pm_:
                         roof_m["traffic"] = pm_["bytes"]; roof_m["traffic_is"] = pm_["note"]
                 other_modes[kind] = {"roofline": roof_m, "workload": "%dx%d D=%d %s batch=%d, disparity maps only (jn_%s_submit_scan / wait), a distinct input batch per slot, same pairs as the ELAS regions" %
-                                                 (W, H, a.disp, {"sgm": "SGM 8 paths (four batches in flight)", "bm": "9x9 block matching (SAD, v_qsad; four batches in flight)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8; four batches in flight)"}[kind], B,
+                                                 (W, H, a.disp, {"sgm": "SGM 8 paths (six batches in flight)", "bm": "9x9 block matching (SAD, v_qsad; four batches in flight)", "bm_ssd": "9x9 block matching (SSD as an int8 contraction, v_mfma_i32_32x32x32_i8; four batches in flight)"}[kind], B,
                                                   "bm" if kind == "bm_ssd" else kind),
                                      "pairs_per_sec": round(B / el_m, 1), "ms_per_batch": round(el_m * 1e3, 3), "gpu_ms_stages": {k: round(v, 3) for k, v in m.last_times().items()},
                                      "check": check_m}

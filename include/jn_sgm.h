@@ -54,9 +54,10 @@ void jn_sgm_destroy(jn_sgm* h);
 jn_status jn_sgm_process_batch(jn_sgm* h, int32_t n, const uint8_t* dI1, const uint8_t* dI2, int32_t pitch, int64_t image_stride,
                                int16_t* dDisp);
 
-/* Pipelined form: up to six batches in flight, one per slot (slot 0 shares jn_sgm_process_batch's buffers; slots 1-5 allocate their
+/* Pipelined form: up to eight batches in flight, one per slot (slot 0 shares jn_sgm_process_batch's buffers; slots 1-7 allocate their
  * own — three byte volumes of max_batch*W*H*D each — when first used).  jn_sgm_submit_scan queues the whole mode on the slot's stream and
- * returns; with sp != NULL also the node's tail on the same stream: the mono8 map (jn_sgm_disparity_to_u8) into dDispU8 and the LUT scan
+ * returns; with sp != NULL also the node's tail on the same stream, as ONE kernel that applies the L/R check, writes dDisp, the mono8 map
+ * (jn_sgm_disparity_to_u8's values) into dDispU8 and the LUT scan
  * of it (jn_obstacle_scan's outputs dBins [n][sp->bins], dMeta [n][4]; dLut from jn_build_valid_disp_lut).  jn_sgm_wait returns when the
  * slot's batch is complete (the caller's buffers must stay untouched until then).  Batches on different slots overlap on the GPU — the
  * row sweeps are pipelines whose ends leave part of the GPU idle, which the next batch's sweeps fill.  All device pointers. */
