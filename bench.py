@@ -341,7 +341,7 @@ def run_sgm(a):
     u8 = torch.zeros((B, H, W), dtype=torch.uint8, device=dev)
     bins = torch.zeros((B, 90), dtype=torch.float64, device=dev); meta = torch.zeros((B, 4), dtype=torch.float64, device=dev)
     # SGM: batches pipelined over --sgm-slots slots (jn_sgm_submit_scan / jn_sgm_wait), each with its own outputs and its own copy of the inputs
-    SS = 1 if os.environ.get("JN_SGM_IMPL") == "0" else max(1, min(6 if bm else 8, a.bm_slots if bm else a.sgm_slots))     # (round 2's kernels, JN_SGM_IMPL=0, have no pipelined form; the block matcher pipelines the same way: jn_bm_submit_scan / jn_bm_wait)
+    SS = max(1, min(6 if bm else 8, a.bm_slots if bm else a.sgm_slots))     # (the block matcher pipelines the same way: jn_bm_submit_scan / jn_bm_wait)
     slot_in = [(dL, dR)] + [(dL.clone(), dR.clone()) for _ in range(SS - 1)]
     slot_out = [(disp, u8, bins, meta)] + [(torch.zeros_like(disp), torch.zeros_like(u8), torch.zeros_like(bins), torch.zeros_like(meta)) for _ in range(SS - 1)]
     if bm:
@@ -438,8 +438,8 @@ def run_sgm(a):
                             % (("bm", "bm") if bm else ("sgm", "sgm"))) if want else None,
                  "ok": (got == want) if want else None}
     # roofline: SURVEY 8d's algorithmic bytes of the cost-volume mode, B_sgm = 4 W H D + 5 W H per pair, over the GPU time of
-    # one batch (the three kernels, HIP events on the library's stream); the path kernel dominates.  `traffic` = the bytes
-    # this decomposition really moves: eight u8 volumes written by the path kernel and read by the WTA kernel.
+    # one batch (HIP events on the library's stream).  `traffic` = the bytes this decomposition really moves (PMC file, or the
+    # three byte volumes written and read once).
     b_sgm = (4.0 * W * H * D + 5.0 * W * H) * B
     if bm:
         roofline = bm_ssd_roofline(W, H, D, B, a.block_radius, ms) if a.bm_cost == "ssd" else bm_roofline(W, H, D, B, a.block_radius, a.subpixel, ms)
@@ -448,15 +448,12 @@ def run_sgm(a):
         # batches' kernels too, so the time a batch COSTS is the step time
         batch_ms = ms["total"] if SS == 1 else elapsed / a.steps * 1e3
         achieved = b_sgm / (batch_ms * 1e-3) / 1e9
-        old = os.environ.get("JN_SGM_IMPL") == "0"
-        moved = ((16.0 if old else 6.0) * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
-        pmc = sgm_pmc_traffic(W, H, D, B) if not old else None
-        roofline = {"bound": "hbm", "kernel": ("k_sgm_path (+ k_sgm_prefilter, k_sgm_wta: one batch)" if old else
-                                                "k_sw_h + k_sw_w<down> + k_sw_w<up, winners> (+ k_sw_prefilter, k_sw_lr: one batch)"),
+        moved = (6.0 * W * H * D + 2.0 * W * H * 2 + 2.0 * W * H) * B
+        pmc = sgm_pmc_traffic(W, H, D, B)
+        roofline = {"bound": "hbm", "kernel": "k_sw_h + k_sw_w<down> + k_sw_w<up, winners> (+ k_sw_prefilter, the L/R check: one batch)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": pmc["bytes"] if pmc else int(moved),
-                    "traffic_note": (pmc["note"] if pmc else "computed, not PMC: %s; " % ("8 W H D written by the path kernel + 8 W H D read by the WTA kernel" if old else
-                                     "3 byte volumes of W H D written (two horizontal sweeps, the downward sweep) and read once by the upward sweep")) +
+                    "traffic_note": (pmc["note"] if pmc else "computed, not PMC: 3 byte volumes of W H D written (two horizontal sweeps, the downward sweep) and read once by the upward sweep; ") +
                                     " moved bytes / time = %.0f GB/s" % ((pmc["bytes"] if pmc else moved) / (batch_ms * 1e-3) / 1e9),
                     "ms_per_launch": round(ms["paths"], 4), "ms_per_batch_all_kernels": round(ms["total"], 4), "ms_per_batch_pipelined": round(batch_ms, 4), "slots": SS,
                     "algorithmic_bytes_per_launch": int(b_sgm),

@@ -66,7 +66,7 @@ jn_status jn_sgm_submit_scan(jn_sgm* h, int32_t slot, int32_t n, const uint8_t* 
 jn_status jn_sgm_wait(jn_sgm* h, int32_t slot);
 
 /* Milliseconds of the last batch: prefilter; paths = the two horizontal sweeps + the downward sweep; wta = the upward sweep with the
- * winners + the L/R check (with JN_SGM_IMPL=0: the eight path launches; sum + WTA + check). */
+ * winners + the L/R check. */
 typedef struct jn_sgm_times { float prefilter, paths, wta, total; } jn_sgm_times;
 jn_status jn_sgm_last_times(jn_sgm* h, jn_sgm_times* out);
 

@@ -10,11 +10,8 @@ struct SwDev {
   int W, H, D, P1, P2, lr, subpixel, cap;
   int Wp, padl;      // prefiltered rows, x-mirrored and padded: Wp bytes per row, image column x_k = W-1-x at byte padl + x_k
   int NB, xmin;      // sheared blocks of the row sweeps: x' = x_k - (row in sweep order) in [xmin, W-1], NB blocks
-  int dbg;           // JN_SGM_DBG profiling switches of k_sw_v (JN_SGM_FLOW=0) only, results are then WRONG: 4 = row sweeps without volume stores /
-                     // loads, 8 = without the per-row barrier.  (The switches of the horizontal sweep went with its rewrite; what they measured is in
-                     // profiles/r03_sgm_dbg_switches.txt.)
+  int dbg;           // JN_SGM_DBG profiling switches of k_sw_w (builds with -DJN_SGM_PROFILE only; results are then WRONG): see sgm_sweep.hip
   int wide;          // 3 P2 > 255: the three-path volume is u16, the horizontal volumes are unpacked one by one
-  int flow;          // row sweeps: 1 = k_sw_w (no workgroup barrier, no communication wave; 4 strips per block), 0 = k_sw_v (JN_SGM_FLOW=0)
   int epoch;         // k_sw_w: 16-bit tag of this launch's boundary columns (set per launch from SweepBuffers::epoch, never 0)
 };
 
@@ -28,7 +25,7 @@ struct SweepBuffers {
   uint32_t* gx;           // boundary columns handed from block to block [n][NB][H][3][4][D/8]; zeroed by the owner when allocated
   size_t gx_bytes;        // size of gx (all max_batch frames): what is zeroed when the tag wraps
   uint32_t epoch;         // launches of k_sw_w on gx so far, modulo 2^16 (sweep_run advances it and zeroes gx when it wraps)
-  uint32_t* flags;        // rows done per (frame, block), then the ticket counter
+  uint32_t* flags;        // the ticket counters of the two row sweeps ([0] downward, [1] upward)
   uint32_t* minr;         // right-image winners [n][H][W] (S << 16 | d)
   uint32_t* dl;           // left winners [n][H][W] (d | d16 << 16), mirrored columns
   // The horizontal sweep and the downward sweep are independent (both read the prefiltered rows, they write different volumes): they run

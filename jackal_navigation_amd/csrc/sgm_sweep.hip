@@ -3,7 +3,7 @@
 // No reference counterpart (the reference's only matcher is libelas); the definition is in jn_sgm.h, everything is integer
 // arithmetic and the bar is bit-exactness against its scalar restatement (the checker, outside the product).
 //
-// Why this decomposition (round 3; sgm.hip keeps the round-2 one-wave-per-line kernels for A/B).  With lanes = disparities
+// Why this decomposition (round 3; round 2's one-wave-per-line kernels are described in DESIGN_HISTORY.md).  With lanes = disparities
 // a path pixel costs ~27 wave-instructions (a 6-step DPP prefix-min and two wave shifts per pixel) and every direction
 // writes and re-reads its own W*H*D volume (16 W H D bytes of traffic).  Here a lane owns a PIXEL and DPL = D/4
 // consecutive disparities of it (four lanes per pixel), the path values live in registers as packed u16 pairs and all the
@@ -20,17 +20,17 @@
 //     registers, one byte volume out;  row sweep <FINAL=true>: the three upward paths in one bottom-to-top sweep which
 //     also reads the three stored volumes, forms S, takes the left winner (keys S << 16 | j), the right image's
 //     winners (LDS atomic minima, flushed per row with global atomic minima) and the sub-pixel offset;
-//     k_sw_lr applies the L/R check.  Two forms of the row sweep: k_sw_w (default) and k_sw_v (JN_SGM_FLOW=0, the first one).
+//     k_sw_lr applies the L/R check (or, with a scan behind the mode, k_scan<false, true> in kernels.hip while it scans).
 // HBM traffic: 3 volumes written + 3 read = 6 W H D (+ images), against 16 W H D before; SURVEY 8d's bound is 4 W H D.
 //
 // The row sweeps and their one-directional pipeline.  A pixel's three downward paths need the previous row at x, x-1 and
 // x+1, so 16-pixel strips of a row sweep cannot be independent.  In the SHEARED coordinate x' = x - y (a lane keeps x' and
 // so walks along the (1,1) diagonal) the three predecessors sit at x'+0, x'+1 and x'+2: all on ONE side.  A strip then
-// depends only on its right neighbour's first two columns of the previous row — a pipeline, not a lock-step.  k_sw_v: inside
-// a workgroup (NS strips, one barrier per row) the columns go through LDS; between workgroups through a global buffer with
-// a progress flag per block (write-through stores, drain, flag; polled and fetched by a COMMUNICATION wave that does no
-// arithmetic).  k_sw_w (see there): no barrier and no communication wave — an LDS ring with row counters between the strips
-// of a block, self-validating tagged columns between blocks.  Workgroups take a ticket when they start, and tickets
+// depends only on its right neighbour's first two columns of the previous row — a pipeline, not a lock-step.  k_sw_w (see
+// there): no workgroup barrier and no communication wave — an LDS ring with row counters between the strips of a block,
+// self-validating tagged columns between blocks.  (Round 3's first form, k_sw_v — one barrier per row, the columns between
+// blocks fetched by a wave that did no arithmetic, 14 % slower — left the library in round 5: DESIGN_HISTORY.md.)
+// Workgroups take a ticket when they start, and tickets
 // are numbered so that a block's producer always holds a smaller one: whatever the dispatch order, a waiting block's
 // producer is running or done (placement-independent, no co-residency assumption).
 // The kernels work in x-mirrored image space (x_k = W-1-x), where the right-image tap x - d becomes x_k + d and the bytes a
@@ -47,7 +47,6 @@ namespace jnav_sgm {
 
 #define DEV static __device__ __forceinline__
 
-constexpr int PX = 16;           // pixels per strip = lanes per disparity quarter (one DPP row)
 constexpr int NQ = 4;            // lanes per pixel
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
@@ -390,259 +389,10 @@ __global__ void __launch_bounds__(256, NR <= 16 ? 4 : 2) k_sw_h(SwDev s, int n, 
 }
 
 // ---- the three paths of one vertical direction, sheared strips ----
-DEV uint32_t ld_sc1(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV void st_sc1(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV uint64_t ld_sc1_64(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEV void st_sc1_64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int NR, int NS, bool FINAL, bool WIDE>
-__global__ void __launch_bounds__((NS + 1) * 64) k_sw_v(SwDev s, int n, int flip, const uint8_t* __restrict__ gm, uint8_t* __restrict__ volF,
-                                                        const uint8_t* __restrict__ volH0, const uint8_t* __restrict__ volH1,
-                                                        uint32_t* __restrict__ gx, uint32_t* __restrict__ gflag, uint32_t* __restrict__ ctr,
-                                                        uint32_t* __restrict__ gminR, uint32_t* __restrict__ dLp) {
-  constexpr int DPL = 2 * NR, SLOT = 3 * NQ * NR, BLK = NS * PX, MR = BLK + DPL + 8;
-  __shared__ uint32_t exch[2][NS + 1][SLOT];                   // boundary columns: [row parity][strip; NS = from the next block][V0 | M0 | M1][quarter][NR]
-  __shared__ uint32_t minR[FINAL ? 2 : 1][FINAL ? NQ : 1][FINAL ? MR : 1];   // right-image winners of one row of this block, per disparity quarter
-  __shared__ int s_ticket;
-  extern __shared__ uint16_t sS[];                             // FINAL + sub-pixel: S of the block's pixels [BLK][D]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int W = s.W, H = s.H, D = s.D, NB = s.NB;
-  const uint32_t P2pk = (uint32_t)s.P2 * 0x10001u;
-  if (tid == 0) s_ticket = (int)atomicAdd(ctr, 1u);
-  for (int k = tid; k < 2 * (NS + 1) * SLOT; k += (NS + 1) * 64) (&exch[0][0][0])[k] = P2pk;     // X = P2: a path that starts here
-  if (FINAL) for (int k = tid; k < 2 * NQ * MR; k += (NS + 1) * 64) (&minR[0][0][0])[k] = 0xFFFFFFFFu;
-  __syncthreads();
-  const int ticket = __builtin_amdgcn_readfirstlane(s_ticket);     // wave-uniform, and known to be: everything derived from it (frame, block, rows) stays scalar
-  const int j = NB - 1 - ticket / n, frame = ticket % n;       // producers (larger j) hold the smaller tickets
-  const int x0 = s.xmin + BLK * j;                             // sheared origin of this block: x' in [x0, x0 + BLK)
-  const int ybs = max(0, -(x0 + BLK - 1)), ybe = min(H - 1, W - 1 - x0);
-  if (ybs > ybe) return;
-  const size_t slot_stride = (size_t)SLOT;
-  uint32_t* my_gx = gx + ((size_t)frame * NB + j) * H * slot_stride;
-  uint32_t* my_flag = gflag + (size_t)frame * NB + j;
-
-  if (wave == NS) {
-    // ---- communication wave: fetches the producer's boundary columns one row ahead, publishes this block's, flushes the
-    // right-image minima.  It has a whole row's time for each of these, so their latencies never reach a computing wave.
-    const bool has_prod = j + 1 < NB;
-    const int x0p = x0 + BLK;
-    const int ybsp = max(0, -(x0p + BLK - 1)), ybep = min(H - 1, W - 1 - x0p);
-    const uint32_t* p_gx = gx + ((size_t)frame * NB + j + 1) * H * slot_stride;
-    const uint32_t* p_flag = gflag + (size_t)frame * NB + j + 1;
-    int known = 0;
-    auto fetch = [&](int yb) __attribute__((always_inline)) {                                 // producer's columns after ITS row yb -> exch[yb & 1][NS]
-      uint32_t* dst = &exch[yb & 1][NS][0];
-      if (has_prod && yb >= ybsp && yb <= ybep) {
-        if (known < yb + 1) {
-          int v = (int)ld_sc1(p_flag);
-          while (v < yb + 1) { __builtin_amdgcn_s_sleep(8); v = (int)ld_sc1(p_flag); }
-          known = v;
-        }
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(p_gx + (size_t)yb * slot_stride);
-        for (int o = lane; o < SLOT / 2; o += 64) { const uint64_t v = ld_sc1_64(src + o); dst[2 * o] = (uint32_t)v; dst[2 * o + 1] = (uint32_t)(v >> 32); }
-      } else {
-        for (int o = lane; o < SLOT; o += 64) dst[o] = P2pk;
-      }
-    };
-    fetch(ybs - 1);
-    __syncthreads();
-    for (int yb = ybs; yb <= ybe; yb++) {
-      if (yb < ybe) fetch(yb);
-      if (!(s.dbg & 8)) __syncthreads();                       // the computing waves have finished row yb (dbg 8: profiling without the row barrier, results WRONG)
-      if (j > 0) {
-        const uint32_t* src = &exch[yb & 1][0][0];
-        uint64_t* dst = reinterpret_cast<uint64_t*>(my_gx + (size_t)yb * slot_stride);
-        for (int o = lane; o < SLOT / 2; o += 64) st_sc1_64(dst + o, (uint64_t)src[2 * o] | ((uint64_t)src[2 * o + 1] << 32));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every write-through store of this wave has left before the flag does
-        if (lane == 0) st_sc1(my_flag, (uint32_t)(yb + 1));
-      }
-      if (FINAL) {
-        const int y = flip ? H - 1 - yb : yb;
-        uint32_t* grow = gminR + ((size_t)frame * H + y) * W;
-        for (int e = lane; e < BLK + DPL; e += 64) {
-#pragma unroll
-          for (int qq = 0; qq < NQ; qq++) {
-            const uint32_t k = minR[yb & 1][qq][e];
-            if (k != 0xFFFFFFFFu) {
-              minR[yb & 1][qq][e] = 0xFFFFFFFFu;
-              const int xr = x0 + yb + e + DPL * qq;
-              if (xr >= 0 && xr < W) atomicMin(grow + xr, k + (uint32_t)(DPL * qq));
-            }
-          }
-        }
-      }
-    }
-    return;
-  }
-
-  // ---- computing waves: strip `wave` of the block ----
-  const int q = lane >> 4, p = lane & 15;
-  const int xl = x0 + PX * wave + p;                           // this lane's sheared column
-  const uint32_t P1pk = (uint32_t)s.P1 * 0x10001u;
-  uint32_t V[NR], G[NR], M[NR];                                // X of the pixel this lane computed last, per path: vertical, own diagonal, other diagonal
-#pragma unroll
-  for (int r = 0; r < NR; r++) V[r] = G[r] = M[r] = P2pk;
-  const size_t img_rows = (size_t)H * s.Wp;
-  // a row's inputs: the prefiltered bytes for the costs and, in the final sweep, this pixel's bytes of the three stored volumes.
-  // They are fetched one row ahead (the next row's loads are in flight while this row's arithmetic runs).  From one row to
-  // the next a lane moves one column to the right and one image row down (up, in the flipped sweep): plain pointer steps —
-  // the rows are padded by a block's width on both sides, so columns outside the image need no clamping.
-  struct RowIn { uint32_t w[NR / 2 + 1], ref; };
-  const int y0 = flip ? H - 1 - ybs : ybs;
-  const long long row_step = (flip ? -(long long)s.Wp : (long long)s.Wp) + 1;
-  const uint8_t* rowL = gm + (size_t)frame * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs);
-  const uint8_t* rowR = gm + (size_t)(n + frame) * img_rows + (size_t)y0 * s.Wp + s.padl - 1 + (xl + ybs) + DPL * q;
-  auto fetch_row = [&](RowIn& in_) __attribute__((always_inline)) {
-#pragma unroll
-    for (int k = 0; k < NR / 2 + 1; k++) in_.w[k] = load_u32_unaligned(rowR + 4 * k);
-    in_.ref = load_u32_unaligned(rowL);
-    rowL += row_step; rowR += row_step;
-  };
-  RowIn cur;
-  fetch_row(cur);
-  __syncthreads();
-  for (int yb = ybs; yb <= ybe; yb++) {
-    const int y = flip ? H - 1 - yb : yb;
-    const int xk = xl + yb;
-    const bool in = xk >= 0 && xk < W;
-    const size_t pix = ((size_t)frame * H + y) * W + (size_t)min(max(xk, 0), W - 1);
-    // NR <= 16 runs three or four waves per SIMD, which hide this row's loads; holding the next row's bytes as well would
-    // cost the registers that occupancy needs.  NR = 32 (one wave per SIMD) fetches a row ahead instead.
-    constexpr bool AHEAD = true;
-    RowIn nxt;
-    if constexpr (AHEAD) { if (yb < ybe) fetch_row(nxt); else nxt = cur; }
-    else { if (yb > ybs) fetch_row(cur); }
-    // the final sweep's three stored volumes for this pixel: loaded now, used after the three paths (the arithmetic hides them)
-    uint32_t fF[FINAL ? (WIDE ? NR : NR / 2) : 1], fH0[FINAL ? NR / 2 : 1], fH1[FINAL ? NR / 2 : 1];
-    if constexpr (FINAL) {
-      if (in && !(s.dbg & 4)) {
-        if constexpr (WIDE) load_words<NR>(volF + pix * D * 2, q, fF); else load_bytes<NR>(volF + pix * D, q, fF);
-        load_bytes<NR>(volH0 + pix * D, q, fH0);
-        load_bytes<NR>(volH1 + pix * D, q, fH1);
-      }
-    }
-    // predecessors: vertical from x'+1, other diagonal from x'+2 (one / two shifts along the strip; the last lane takes the
-    // right neighbour's columns, which DPP leaves in place as the `old` operand), own diagonal in place
-    {
-      const uint32_t* e = &exch[(yb + 1) & 1][wave + 1][0];
-#pragma unroll
-      for (int r4 = 0; r4 < NR; r4 += 4) {                     // four registers at a time: the scheduler would otherwise hoist all 3 NR LDS reads and hold them
-        const uint4 v0 = *reinterpret_cast<const uint4*>(e + (0 * NQ + q) * NR + r4);
-        const uint4 m0 = *reinterpret_cast<const uint4*>(e + (1 * NQ + q) * NR + r4);
-        const uint4 m1 = *reinterpret_cast<const uint4*>(e + (2 * NQ + q) * NR + r4);
-        const uint32_t a0[4] = {v0.x, v0.y, v0.z, v0.w}, b0[4] = {m0.x, m0.y, m0.z, m0.w}, b1[4] = {m1.x, m1.y, m1.z, m1.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int r = r4 + k;
-          V[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)a0[k], (int)V[r], 0x101, 0xf, 0xf, false);           // row_shl:1
-          const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)b0[k], (int)M[r], 0x101, 0xf, 0xf, false);
-          M[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)b1[k], (int)t, 0x101, 0xf, 0xf, false);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    uint32_t Cp[NR], acc[NR];
-    costs<NR>(cur.w, cur.ref & 0x00FFFFFFu, P2pk, Cp);
-#pragma unroll
-    for (int r = 0; r < NR; r++) acc[r] = 0u;
-    {
-      // all quarter-boundary permutes first (their LDS round trip overlaps the first path's cells), then one path at a time:
-      // side by side the three paths would keep 3 NR unnormalised registers alive and cost a wave per SIMD in occupancy
-      uint32_t upV, dnV, upG, dnG, upM, dnM, mn, Ln[NR];
-      path_neighbours<NR>(V, lane, q, P1pk, upV, dnV);
-      path_neighbours<NR>(G, lane, q, P1pk, upG, dnG);
-      path_neighbours<NR>(M, lane, q, P1pk, upM, dnM);
-      path_cells<NR>(V, upV, dnV, Cp, acc, Ln, mn, P1pk);
-      path_normalise<NR>(V, Ln, pixel_min(mn), (uint32_t)s.P2);
-      path_cells<NR>(G, upG, dnG, Cp, acc, Ln, mn, P1pk);
-      path_normalise<NR>(G, Ln, pixel_min(mn), (uint32_t)s.P2);
-      path_cells<NR>(M, upM, dnM, Cp, acc, Ln, mn, P1pk);
-      path_normalise<NR>(M, Ln, pixel_min(mn), (uint32_t)s.P2);
-    }
-    if (__builtin_amdgcn_ballot_w64(!in)) {                    // a strip crossing the image border: pixels outside carry Lq = 0 (a path entering the image starts with L = C)
-#pragma unroll
-      for (int r = 0; r < NR; r++) { V[r] = in ? V[r] : P2pk; G[r] = in ? G[r] : P2pk; M[r] = in ? M[r] : P2pk; }
-    }
-    {
-      uint32_t* o = &exch[yb & 1][wave][0];
-      if (p == 0) {
-#pragma unroll
-        for (int r = 0; r < NR; r++) { o[(0 * NQ + q) * NR + r] = V[r]; o[(1 * NQ + q) * NR + r] = M[r]; }
-      }
-      if (p == 1) {
-#pragma unroll
-        for (int r = 0; r < NR; r++) o[(2 * NQ + q) * NR + r] = M[r];
-      }
-    }
-    if constexpr (!FINAL) {
-      if (in && !(s.dbg & 4)) {
-        if constexpr (WIDE) store_words<NR>(volF + pix * D * 2, q, acc); else store_bytes<NR>(volF + pix * D, q, acc);
-      }
-    } else {
-      // S = 8 (C + P2) - (the three upward Y + the stored five)
-      uint32_t S[NR];
-#pragma unroll
-      for (int k = 0; k < NR / 2; k++) {
-        uint32_t a, b;
-        if constexpr (WIDE) { a = pk_add(pk_add(fF[2 * k], unpack_lo(fH0[k])), unpack_lo(fH1[k])); b = pk_add(pk_add(fF[2 * k + 1], unpack_hi(fH0[k])), unpack_hi(fH1[k])); }
-        else { const uint32_t hb = fH0[k] + fH1[k];    // bytes <= 2 P2 <= 170: no carry between bytes
-               a = pk_add(unpack_lo(fF[k]), unpack_lo(hb)); b = pk_add(unpack_hi(fF[k]), unpack_hi(hb)); }
-        S[2 * k] = pk_sub(pk_shl3(Cp[2 * k]), pk_add(acc[2 * k], a));
-        S[2 * k + 1] = pk_sub(pk_shl3(Cp[2 * k + 1]), pk_add(acc[2 * k + 1], b));
-      }
-      // winners.  Keys S << 16 | j (j = disparity within the quarter): the smallest key is the smallest S, ties to the smallest j.
-      // Left image: minimum over this lane's cells, then over the pixel's four lanes (+ DPL q: larger quarters lose ties).
-      // Right image: cell (x_k, d) belongs to right pixel x_k + d: LDS atomic minima per quarter, merged when the row is flushed.
-      uint32_t key = 0xFFFFFFFFu;
-      uint32_t* mr = &minR[yb & 1][q][PX * wave + p];
-#pragma unroll
-      for (int r = 0; r < NR; r++) {
-        const uint32_t klo = (S[r] << 16) | (uint32_t)r, khi = (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR);
-        key = min(key, min(klo, khi));
-      }
-      if (in) {
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-          atomicMin(mr + r, (S[r] << 16) | (uint32_t)r);
-          atomicMin(mr + r + NR, (S[r] & 0xFFFF0000u) | (uint32_t)(r + NR));
-        }
-      }
-      key = in ? key + (uint32_t)(DPL * q) : 0xFFFFFFFFu;
-      {
-        const auto a = __builtin_amdgcn_permlane16_swap(key, key, false, false);
-        key = min(a[0], a[1]);
-        const auto b = __builtin_amdgcn_permlane32_swap(key, key, false, false);
-        key = min(b[0], b[1]);
-      }
-      const int d = (int)(key & 0xFFFFu);
-      int d16 = 16 * d;
-      if (s.subpixel) {
-        uint32_t* my = reinterpret_cast<uint32_t*>(sS + ((size_t)(PX * wave + p) * D + DPL * q));
-#pragma unroll
-        for (int r = 0; r < NR; r += 2) {                      // S in disparity order: low halves are j = r, high halves j = r + NR
-          my[r / 2] = __builtin_amdgcn_perm(S[r + 1], S[r], 0x05040100u);
-          my[(r + NR) / 2] = __builtin_amdgcn_perm(S[r + 1], S[r], 0x07060302u);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (in && q == 0 && d > 0 && d < D - 1) {
-          const uint16_t* ps = sS + (size_t)(PX * wave + p) * D;
-          const int sm = ps[d - 1], sc = ps[d], sp = ps[d + 1];
-          const int den = max(sm + sp - 2 * sc, 1);
-          d16 = 16 * d + (16 * (sm - sp) + den) / (2 * den);
-        }
-      }
-      if (in && q == 0) dLp[pix] = (uint32_t)d | ((uint32_t)(uint16_t)d16 << 16);
-    }
-    if constexpr (AHEAD) cur = nxt;
-    if (!(s.dbg & 8)) __syncthreads();
-  }
-}
-
-// ---- the same sweep without a workgroup barrier and without a communication wave (SwDev::flow = 1) ----
-// k_sw_v keeps a block's strips in lock-step (one s_barrier per row: every row takes as long as the slowest strip) and spends a
-// quarter of the wave slots — and of the register file — on communication waves.  Here every wave computes, and a strip runs as
+// ---- the row sweeps: no workgroup barrier, no communication wave ----
+// (The first form kept a block's strips in lock-step — one s_barrier per row: every row took as long as the slowest strip — and spent a
+// quarter of the wave slots and of the register file on communication waves.)  Every wave computes, and a strip runs as
 // far ahead of its left neighbour as a ring of RING rows in LDS allows:
 //   * inside a block: strip w publishes its boundary columns of row y in ring[y mod RING][w] and then prog[w] = y + 1; strip w-1
 //     polls prog[w] only when its cached copy is too old, reads the columns and acknowledges with cons[w] = y + 1 (back pressure:
@@ -1183,35 +933,26 @@ __global__ void __launch_bounds__(256) k_sw_lr(SwDev s, int n, const uint32_t* _
 // ---------------------------------------------------------------- host side ----------------------------------------------------------------
 namespace jnav_sgm {
 
-// JN_SGM_FLOW=0 selects the round sweeps with one barrier per row and a communication wave (k_sw_v); default is k_sw_w
-static int flow_mode() { const char* e = getenv("JN_SGM_FLOW"); return e ? (atoi(e) != 0) : 1; }
-// computing waves per workgroup.  k_sw_v (+ 1 communication wave): D = 256 runs four waves, one per SIMD, so that 96 pairs of path state plus a row of
-// inputs fit the registers.  k_sw_w: four strips
+// strips (= computing waves) per workgroup of the row sweeps: 4 (JN_SGM_NS=2 or 8 for A/B; D = 256 always 4)
 static int strips_for(int D) {
-  if (flow_mode()) {                                           // k_sw_w: 4 strips per block (JN_SGM_NS=2 or 8 for A/B; D = 256 always 4)
-    const char* e = getenv("JN_SGM_NS");
-    const int v = e ? atoi(e) : 4;
-    return (D != 256 && (v == 2 || v == 8)) ? v : 4;
-  }
-  if (D == 256) return 3;
-  const char* e = getenv("JN_SGM_NS");                         // A/B switch: 3 (default), 5 or 7 strips per workgroup
-  const int v = e ? atoi(e) : 3;                               // measured at 1280x720 D=128 batch 32: 11.3 / 13.8 / 12.6 ms per batch (profiles/r03_sgm_strips_ab.txt)
-  return v == 5 || v == 7 ? v : 3;
+  const char* e = getenv("JN_SGM_NS");
+  const int v = e ? atoi(e) : 4;
+  return (D != 256 && (v == 2 || v == 8)) ? v : 4;
 }
 
 // Lanes per pixel.  D = 256 with four lanes per pixel means 32 disparity pairs per lane and path: 96 registers of path state, ~320 with the
 // temporaries — one wave per SIMD, and one wave issues a vector instruction every ~8 cycles at best (scripts/probes/dep_chain_probe.hip): half
 // the SIMD's rate.  With EIGHT lanes per pixel (strips of 8 pixels) a lane holds 16 pairs as at D = 128: the same code, three waves per SIMD.
-// JN_SGM_LQ=4 keeps the four-lane layout for A/B.  (k_sw_v, JN_SGM_FLOW=0, always uses four.)
+// JN_SGM_LQ=4 keeps the four-lane layout for A/B.
 static int lanes_per_pixel(int D) {
-  if (!flow_mode() || D != 256) return 4;
+  if (D != 256) return 4;
   const char* e = getenv("JN_SGM_LQ");
   return e && atoi(e) == 4 ? 4 : 8;
 }
 
 void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int subpixel, SwDev* s, SweepSizes* z, int max_batch) {
   s->W = W; s->H = H; s->D = D; s->P1 = P1; s->P2 = P2; s->cap = cap; s->lr = lr; s->subpixel = subpixel ? 1 : 0;
-  s->flow = flow_mode(); s->epoch = 0;
+  s->epoch = 0;
   const int BLK = strips_for(D) * (64 / lanes_per_pixel(D));
   s->padl = BLK + 32; s->Wp = ((s->padl + W + D + BLK + 64) + 15) / 16 * 16;   // a block's width of padding: lanes outside the image read plain bytes
   s->xmin = -(H - 1);
@@ -1222,28 +963,9 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
   z->gm = (size_t)2 * max_batch * H * s->Wp + 256;
   z->vol = (size_t)max_batch * px * D + 4096;                   // one byte volume (+ slack: where k_sw_w's lanes outside the image store); the F volume is twice that when wide
   z->gx = (size_t)max_batch * s->NB * H * (3 * NQ * (D / 8)) * sizeof(uint32_t);
-  z->flags = ((size_t)max_batch * s->NB + 16) * sizeof(uint32_t);
+  z->flags = 16 * sizeof(uint32_t);                             // the two sweeps' ticket counters
   z->minr = (size_t)max_batch * px * sizeof(uint32_t);
   z->dl = ((size_t)max_batch * px + 64) * sizeof(uint32_t);     // + a slack row: where k_sw_w's lanes without a pixel store
-}
-
-template <int NR, int NS>
-static hipError_t launch_v(const SwDev& s, int n, bool final, hipStream_t st, const SweepBuffers& b) {
-  const dim3 grid((unsigned)(n * s.NB)), block((NS + 1) * 64);
-  const size_t dyn = final && s.subpixel ? (size_t)NS * PX * s.D * sizeof(uint16_t) : 0;
-  uint32_t* ctr = b.flags + (size_t)n * s.NB;                   // the ticket counter sits behind the flags (one memset clears both)
-#define JN_SW_V(FINAL, WIDE)                                                                                                            \
-  do {                                                                                                                                  \
-    if (dyn > 48 * 1024) {                                                                                                              \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sw_v<NR, NS, FINAL, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); \
-      if (e != hipSuccess) return e;                                                                                                    \
-    }                                                                                                                                   \
-    hipLaunchKernelGGL((k_sw_v<NR, NS, FINAL, WIDE>), grid, block, dyn, st, s, n, FINAL ? 1 : 0, b.gm, b.volF, b.volH0, b.volH1, b.gx, b.flags, ctr, b.minr, b.dl); \
-  } while (0)
-  if (final) { if (s.wide) JN_SW_V(true, true); else JN_SW_V(true, false); }
-  else { if (s.wide) JN_SW_V(false, true); else JN_SW_V(false, false); }
-#undef JN_SW_V
-  return hipGetLastError();
 }
 
 // k_sw_w: every launch on the buffer gets the next 16-bit tag; when the tag wraps the buffer is zeroed (tag 0 is never used), so
@@ -1253,7 +975,7 @@ static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuff
   constexpr int RING = (NR <= 16 && LQ == 4) ? 8 : 4, PX = 64 / LQ;     // rows of boundary columns a strip may run ahead of its left neighbour (LDS: 3 x 4 NR x lanes-per-pixel dwords per strip and row)
   const dim3 grid((unsigned)(n * s.NB)), block(NS * 64);
   const size_t dyn = final && s.subpixel ? (size_t)NS * PX * s.D * sizeof(uint16_t) : 0;
-  uint32_t* ctr = b.flags + (size_t)n * s.NB;
+  uint32_t* ctr = b.flags + (final ? 1 : 0);                    // the sweep's ticket counter (both zeroed by run_all's one memset)
   if (++b.epoch > 0xFFFFu) {
     hipError_t e = hipMemsetAsync(b.gx, 0, b.gx_bytes, st);     // the WHOLE buffer: frames a smaller batch does not touch keep older tags
     if (e != hipSuccess) return e;
@@ -1274,7 +996,7 @@ static hipError_t launch_w(SwDev s, int n, bool final, hipStream_t st, SweepBuff
   return hipGetLastError();
 }
 
-template <int NR, int NS, bool FLOW, int LQ = 4>
+template <int NR, int NS, int LQ = 4>
 static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int pitch, long long stride, int16_t* dDisp, hipStream_t st,
                           SweepBuffers& b, hipEvent_t* ev, bool side_overlap, bool lr_kernel) {
   hipError_t e;
@@ -1307,16 +1029,11 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   }
   hipLaunchKernelGGL((k_sw_h<NR, LQ>), dim3((s.H + 4 * PXL - 1) / (4 * PXL), n, 2), dim3(256), 0, hs, s, n, b.gm, b.volH0, b.volH1);
   if (overlap && (e = hipEventRecord(b.ev_join, b.side)) != hipSuccess) return e;
-  const size_t flag_bytes = ((size_t)n * s.NB + 1) * sizeof(uint32_t);
-  auto sweep = [&](bool final) -> hipError_t {
-    if constexpr (FLOW) return launch_w<NR, NS, LQ>(s, n, final, st, b);
-    else return launch_v<NR, NS>(s, n, final, st, b);
-  };
-  if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
+  auto sweep = [&](bool final) -> hipError_t { return launch_w<NR, NS, LQ>(s, n, final, st, b); };
+  if ((e = hipMemsetAsync(b.flags, 0, 2 * sizeof(uint32_t), st)) != hipSuccess) return e;
   if ((e = sweep(false)) != hipSuccess) return e;
   if (overlap && (e = hipStreamWaitEvent(st, b.ev_join, 0)) != hipSuccess) return e;   // the final sweep reads the horizontal volumes
   if ((e = hipEventRecord(ev[2], st)) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(b.flags, 0, flag_bytes, st)) != hipSuccess) return e;
   if ((e = sweep(true)) != hipSuccess) return e;
 #ifdef JN_SGM_PROFILE
   if (!(exp_ & 2))
@@ -1336,16 +1053,11 @@ hipError_t sweep_run(const SwDev& s, int n, const uint8_t* dI1, const uint8_t* d
                      SweepBuffers& b, hipEvent_t* ev, bool side_overlap, bool lr_kernel) {
   const int lq = lanes_per_pixel(s.D);
   const int ns = (s.padl - 32) / (64 / lq);                    // strips per block, as sweep_geometry() chose them (padl = BLK + 32)
-#define JN_RUN(NR, NS, FLOW) run_all<NR, NS, FLOW>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap, lr_kernel)
-  if (s.flow) {
-    if (s.D == 64) return ns == 2 ? JN_RUN(8, 2, true) : ns == 8 ? JN_RUN(8, 8, true) : JN_RUN(8, 4, true);
-    if (s.D == 128) return ns == 2 ? JN_RUN(16, 2, true) : ns == 8 ? JN_RUN(16, 8, true) : JN_RUN(16, 4, true);
-    if (lq == 8) return run_all<16, 4, true, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap, lr_kernel);     // D = 256: eight lanes per pixel, 16 pairs per lane
-    return JN_RUN(32, 4, true);
-  }
-  if (s.D == 64) return ns == 3 ? JN_RUN(8, 3, false) : ns == 5 ? JN_RUN(8, 5, false) : JN_RUN(8, 7, false);
-  if (s.D == 128) return ns == 3 ? JN_RUN(16, 3, false) : ns == 5 ? JN_RUN(16, 5, false) : JN_RUN(16, 7, false);
-  return JN_RUN(32, 3, false);
+#define JN_RUN(NR, NS) run_all<NR, NS>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap, lr_kernel)
+  if (s.D == 64) return ns == 2 ? JN_RUN(8, 2) : ns == 8 ? JN_RUN(8, 8) : JN_RUN(8, 4);
+  if (s.D == 128) return ns == 2 ? JN_RUN(16, 2) : ns == 8 ? JN_RUN(16, 8) : JN_RUN(16, 4);
+  if (lq == 8) return run_all<16, 4, 8>(s, n, dI1, dI2, pitch, stride, dDisp, st, b, ev, side_overlap, lr_kernel);     // D = 256: eight lanes per pixel, 16 pairs per lane
+  return JN_RUN(32, 4);
 #undef JN_RUN
 }
 

@@ -55,7 +55,7 @@ put(newest("%s_bm/*/*kernel_stats.csv" % tag), "%s_bm_kernel_stats.csv" % tag)
 put(newest("%s_bm_ssd/*/*kernel_stats.csv" % tag), "%s_bm_ssd_kernel_stats.csv" % tag)
 for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.json"), ("default_occupancy.txt", "default_bench_occupancy.txt"),
                   ("pmc_FETCH_SIZE.txt", None), ("pmc_WRITE_SIZE.txt", None), ("bench_line.json", None), ("sgm_bench_line.json", None),
-                  ("sgm_round2_kernels_bench_line.json", None), ("sgm_pmc_FETCH_SIZE.txt", None), ("sgm_pmc_WRITE_SIZE.txt", None), ("sgm_pmc_SQ.txt", None),
+                  ("sgm_pmc_FETCH_SIZE.txt", None), ("sgm_pmc_WRITE_SIZE.txt", None), ("sgm_pmc_SQ.txt", None),
                   ("sgm_strips_ab.txt", None), ("sgm_slots_ab.txt", None), ("bm_slots_ab.txt", None), ("bm_bench_line.json", None), ("bm_config2_bench_line.json", None), ("other_configs.jsonl", None),
                   ("merge_in_worker.txt", None), ("node_rate.txt", None), ("latency_check.txt", None), ("host_pointer_rate.txt", None),
                   ("valu_rate_probe.txt", None), ("stage_a_priority_ab.txt", None), ("pace_ab.txt", None), ("parity_sweep.txt", None), ("sgm_stress.txt", None),

@@ -113,48 +113,6 @@ def test_sgm_config5_share_1080p_d256_subpixel(jn, sgm, oracle):
     assert np.array_equal(out, again)
 
 
-def test_sgm_round2_kernels_still_agree(jn, sgm, oracle):
-    """JN_SGM_IMPL=0 keeps the one-wave-per-line kernels of round 2 for A/B runs; both implementations give the definition."""
-    import os
-    W, H, D = 320, 180, 128
-    L, R = oracle.synth_pair(W, H, 60, 77)
-    exp = sgm.process(sgm.params(D), L, R)
-    old = os.environ.get("JN_SGM_IMPL")
-    try:
-        for impl in ("0", "1"):
-            os.environ["JN_SGM_IMPL"] = impl
-            out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D), L[None], R[None])
-            assert np.array_equal(out[0], exp), impl
-    finally:
-        if old is None:
-            del os.environ["JN_SGM_IMPL"]
-        else:
-            os.environ["JN_SGM_IMPL"] = old
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("D,sub", [(64, 0), (128, 1), (256, 0)])
-def test_sgm_row_sweeps_with_and_without_the_workgroup_barrier(jn, sgm, oracle, D, sub):
-    """JN_SGM_FLOW=0 keeps round 3's first row sweeps (one barrier per row, a communication wave) next to the default ones (no barrier,
-    tagged columns between blocks); both give the definition, also on a frame wide enough for several blocks and with sub-pixel output."""
-    import os
-    W, H = 700, 130
-    L, R = oracle.synth_pair(W, H, min(D - 1, 100), 5)
-    exp = sgm.process(sgm.params(D, subpixel=sub), L, R)
-    old = os.environ.get("JN_SGM_FLOW")
-    try:
-        for flow in ("0", "1"):
-            os.environ["JN_SGM_FLOW"] = flow
-            out, _, _ = run(jn, jn.Sgm.parameters(num_disparities=D, subpixel=sub), np.stack([L, L]), np.stack([R, R]))
-            assert np.array_equal(out[0], exp), flow
-            assert np.array_equal(out[1], exp), flow
-    finally:
-        if old is None:
-            del os.environ["JN_SGM_FLOW"]
-        else:
-            os.environ["JN_SGM_FLOW"] = old
-
-
 @pytest.mark.gpu
 def test_sgm_launch_tag_wraps_around(jn, sgm, oracle, monkeypatch):
     """The columns handed from block to block carry a 16-bit launch tag (sgm_sweep.hip); when it wraps the buffer is zeroed.  Start a
