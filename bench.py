@@ -382,6 +382,8 @@ def run_sgm(a):
     def drain():
         for slot in sorted(step.inflight):
             sgm.wait(slot)
+            for k, v in sgm.last_times().items():          # (a region shorter than the slots never comes back to a slot: its batches' times are read here)
+                acc.setdefault(k, []).append(v)
         step.inflight.clear()
 
     def sync():

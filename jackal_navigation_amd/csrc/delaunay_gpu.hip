@@ -172,9 +172,19 @@ struct DT {
     if (il_dest == org(farleft)) farleft = ccw_edge(base);
     if (ir_org == dest(farright)) farright = cw_edge(base);
 
-    // the seam walk, with the four vertices' coordinates carried in registers (lo_l, lo_r change once a step; only a flip candidate w is fetched)
+    // The seam walk.  Carried in registers from step to step: the four vertices' coordinates, and — round 5 — each side's FLIP CANDIDATE
+    // (the edge across the candidate's far side, its apex w and w's coordinates).  A step changes one side only: the other side's candidate is
+    // still what it was (its in-circle test is recomputed, lo_l / lo_r have moved, but nothing is fetched), and the side that advanced
+    // fetches its new candidate and that candidate's flip candidate TOGETHER (both hang off the new handle).  A step was nine dependent
+    // LDS round trips (three per side and three for the advance), one thread walking alone; now four.
     P lo_l = pt(il_dest), lo_r = pt(ir_org);
-    P up_l = pt(apex(lcand)), up_r = pt(apex(rcand));
+    H fe_l, fe_r; int fw_l, fw_r; P fp_l = lo_l, fp_r = lo_r;
+    int al = apex(lcand), ar = apex(rcand);
+    fe_l = across(cw_edge(lcand)); fe_r = across(ccw_edge(rcand));
+    fw_l = apex(fe_l); fw_r = apex(fe_r);
+    P up_l = pt(al), up_r = pt(ar);
+    if (fw_l >= 0) fp_l = pt(fw_l);
+    if (fw_r >= 0) fp_r = pt(fw_r);
 
     for (;;) {
       if (--budget <= 0) return;
@@ -203,49 +213,41 @@ struct DT {
         return;
       }
       if (!l_done) {   // flip away left-hull edges that the new cross edge invalidates
-        H e = across(cw_edge(lcand));
-        int w = apex(e);
-        if (w >= 0) {
-          P pw = pt(w);
-          bool bad = in_circle(lo_l, lo_r, up_l, pw) > 0;
-          while (bad && --budget > 0) {
-            e = ccw_edge(e); const H top = across(e);
-            e = ccw_edge(e); const H side = across(e);
-            glue(e, top);
-            glue(lcand, side);
-            lcand = ccw_edge(lcand); const H outer = across(lcand);
-            e = cw_edge(e);
-            glue(e, outer);
-            set_org(lcand, lo_l.v); set_dest(lcand, -1); set_apex(lcand, w);
-            set_org(e, -1); set_dest(e, up_l.v); set_apex(e, w);
-            up_l = pw;
-            e = side; w = apex(e);
-            bad = false;
-            if (w >= 0) { pw = pt(w); bad = in_circle(lo_l, lo_r, up_l, pw) > 0; }
-          }
+        bool bad = fw_l >= 0 && in_circle(lo_l, lo_r, up_l, fp_l) > 0;
+        while (bad && --budget > 0) {
+          H e = fe_l;
+          e = ccw_edge(e); const H top = across(e);
+          e = ccw_edge(e); const H side = across(e);
+          glue(e, top);
+          glue(lcand, side);
+          lcand = ccw_edge(lcand); const H outer = across(lcand);
+          e = cw_edge(e);
+          glue(e, outer);
+          set_org(lcand, lo_l.v); set_dest(lcand, -1); set_apex(lcand, fw_l);
+          set_org(e, -1); set_dest(e, up_l.v); set_apex(e, fw_l);
+          up_l = fp_l;
+          fe_l = side; fw_l = apex(side);
+          bad = false;
+          if (fw_l >= 0) { fp_l = pt(fw_l); bad = in_circle(lo_l, lo_r, up_l, fp_l) > 0; }
         }
       }
       if (!r_done) {   // same on the right hull, mirrored
-        H e = across(ccw_edge(rcand));
-        int w = apex(e);
-        if (w >= 0) {
-          P pw = pt(w);
-          bool bad = in_circle(lo_l, lo_r, up_r, pw) > 0;
-          while (bad && --budget > 0) {
-            e = cw_edge(e); const H top = across(e);
-            e = cw_edge(e); const H side = across(e);
-            glue(e, top);
-            glue(rcand, side);
-            rcand = cw_edge(rcand); const H outer = across(rcand);
-            e = ccw_edge(e);
-            glue(e, outer);
-            set_org(rcand, -1); set_dest(rcand, lo_r.v); set_apex(rcand, w);
-            set_org(e, up_r.v); set_dest(e, -1); set_apex(e, w);
-            up_r = pw;
-            e = side; w = apex(e);
-            bad = false;
-            if (w >= 0) { pw = pt(w); bad = in_circle(lo_l, lo_r, up_r, pw) > 0; }
-          }
+        bool bad = fw_r >= 0 && in_circle(lo_l, lo_r, up_r, fp_r) > 0;
+        while (bad && --budget > 0) {
+          H e = fe_r;
+          e = cw_edge(e); const H top = across(e);
+          e = cw_edge(e); const H side = across(e);
+          glue(e, top);
+          glue(rcand, side);
+          rcand = cw_edge(rcand); const H outer = across(rcand);
+          e = ccw_edge(e);
+          glue(e, outer);
+          set_org(rcand, -1); set_dest(rcand, lo_r.v); set_apex(rcand, fw_r);
+          set_org(e, up_r.v); set_dest(e, -1); set_apex(e, fw_r);
+          up_r = fp_r;
+          fe_r = side; fw_r = apex(side);
+          bad = false;
+          if (fw_r >= 0) { fp_r = pt(fw_r); bad = in_circle(lo_l, lo_r, up_r, fp_r) > 0; }
         }
       }
       if (l_done || (!r_done && in_circle(up_l, lo_l, lo_r, up_r) > 0)) {
@@ -254,14 +256,20 @@ struct DT {
         set_dest(base, lo_l.v);
         lo_r = up_r;
         rcand = across(base);
-        up_r = pt(apex(rcand));
+        ar = apex(rcand); fe_r = across(ccw_edge(rcand));       // the new candidate's apex and its flip candidate's edge: independent reads
+        fw_r = apex(fe_r);
+        up_r = pt(ar);
+        if (fw_r >= 0) fp_r = pt(fw_r);
       } else {
         glue(base, lcand);
         base = ccw_edge(lcand);
         set_org(base, lo_r.v);
         lo_l = up_l;
         lcand = across(base);
-        up_l = pt(apex(lcand));
+        al = apex(lcand); fe_l = across(cw_edge(lcand));
+        fw_l = apex(fe_l);
+        up_l = pt(al);
+        if (fw_l >= 0) fp_l = pt(fw_l);
       }
     }
   }

@@ -536,27 +536,54 @@ __global__ void __launch_bounds__(1024) k_support_lds(DevParams dp, int n, const
 // so "before" sees this pass's deletions and "after" does not.  An 11-cell register window slides along
 // the line: one LDS read per step, issued a step ahead, and branch-free compares.
 __device__ __forceinline__ void redundant_line(int16_t* line, int stride, int n) {
+  // The window of 11 values is a RING in registers: element e of the line sits in slot (e + 5) mod 11, the loop is unrolled by 11 so that every
+  // slot index is a constant, and the element that enters (i + 6) takes the slot of the one that leaves (i - 5).  (Rounds 1-4 shifted the
+  // window by ten register moves a cell — a third of the pass, which one thread a line walks alone: instruction issue is all it costs.)
   int w[11];
 #pragma unroll
   for (int k = 0; k < 11; k++) w[k] = line[(k - 5) * stride];
-  for (int i = 0; i < n; i++) {
-    const int nxt = line[min(i + 6, n + 4) * stride];
-    const int d = w[5];
-    const int lo = max(d - 1, 0);
-    const unsigned span = (unsigned)(d + 1 - lo);
-    bool before = false, after = false;
+  for (int i0 = 0; i0 < n; i0 += 11) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) before |= (unsigned)(w[k] - lo) <= span;
+    for (int s = 0; s < 11; s++) {
+      const int i = i0 + s;
+      if (i >= n) break;
+      const int nxt = line[min(i + 6, n + 4) * stride];
+      const int d = w[(s + 5) % 11];
+      const int lo = max(d - 1, 0);
+      const unsigned span = (unsigned)(d + 1 - lo);
+      bool before = false, after = false;
 #pragma unroll
-    for (int k = 6; k < 11; k++) after |= (unsigned)(w[k] - lo) <= span;
-    if (d >= 0 && before && after) { line[i * stride] = -1; w[5] = -1; }
+      for (int k = 0; k < 5; k++) before |= (unsigned)(w[(s + k) % 11] - lo) <= span;
 #pragma unroll
-    for (int k = 0; k < 10; k++) w[k] = w[k + 1];
-    w[10] = nxt;
+      for (int k = 6; k < 11; k++) after |= (unsigned)(w[(s + k) % 11] - lo) <= span;
+      if (d >= 0 && before && after) { line[i * stride] = -1; w[(s + 5) % 11] = -1; }
+      w[s] = nxt;                                          // slot of element i - 5 = (i0 + s) mod 11 = s
+    }
   }
 }
 
 constexpr int kFilterThreads = 512;
+// Exclusive prefix sum of `mine` over the workgroup's kFilterThreads threads (thread order), and the total: a DPP scan inside each wave
+// (row_shr 1, 2, 4, 8, row_bcast 15 / 31), the waves' totals through LDS — two barriers where the log-step scan through LDS of rounds 1-4
+// took eighteen (k_filter_resolve runs three of these on a lone pair's critical path).
+__device__ __forceinline__ int block_scan_excl(int mine, int& total) {
+  __shared__ int s_wtot[kFilterThreads / 64];
+  int v = mine;
+#define JN_DPP_ADD(ctrl, rmask) v += __builtin_amdgcn_update_dpp(0, v, ctrl, rmask, 0xf, true)
+  JN_DPP_ADD(0x111, 0xf); JN_DPP_ADD(0x112, 0xf); JN_DPP_ADD(0x114, 0xf); JN_DPP_ADD(0x118, 0xf);
+  JN_DPP_ADD(0x142, 0xa); JN_DPP_ADD(0x143, 0xc);
+#undef JN_DPP_ADD
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 63) s_wtot[wv] = v;
+  __syncthreads();
+  int before = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < kFilterThreads / 64; w++) { const int t = s_wtot[w]; before += w < wv ? t : 0; all += t; }
+  __syncthreads();                                        // s_wtot may be written again by the next scan
+  total = all;
+  return before + v - mine;
+}
+
 // Copy lattice columns [c0,c1) x rows [r0,r1) (cells outside the lattice read as invalid) into an LDS block of
 // pitch pw, and the interior back.
 __device__ __forceinline__ void lattice_load(int16_t* s, const int16_t* g, int cw, int ch, int c0, int c1, int r0, int r1, int pw) {
@@ -724,7 +751,6 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
   // List the undecided points in sweep order: every thread owns a contiguous stretch of the (column-major) codes,
   // counts its undecided points, an exclusive scan over the threads gives its place in the list.  Points that are
   // dead for sure leave the lattice on the way (the resolution below never looks at the value of a dead point).
-  __shared__ int s_off[kFilterThreads + 1];
   __shared__ uint16_t s_todo[kFilterTodo];
   const int per = (N + kFilterThreads - 1) / kFilterThreads, i_lo = min(tid * per, N), i_hi = min(i_lo + per, N);
   int mine = 0;
@@ -737,18 +763,11 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
       if (++v == ch) { v = 0; u++; }
     }
   }
-  s_off[tid + 1] = mine;
-  if (tid == 0) s_off[0] = 0;
-  __syncthreads();
-  for (int step = 1; step < kFilterThreads; step <<= 1) {    // inclusive scan of s_off[1..]
-    const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
-    __syncthreads();
-    s_off[tid + 1] += add;
-    __syncthreads();
-  }
-  const int total = s_off[kFilterThreads];
+  int scan_total1;
+  const int scan_at1 = block_scan_excl(mine, scan_total1);
+  const int total = scan_total1;
   if (total <= kFilterTodo) {
-    int at = s_off[tid];
+    int at = scan_at1;
     for (int i = i_lo; i < i_hi; i++) { const int c = s_code[i]; if (c != 0 && c != 255) s_todo[at++] = (uint16_t)i; }
   }
   __syncthreads();
@@ -833,18 +852,10 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
         if (++v == ch) { v = 0; u++; }
       }
     }
-    __syncthreads();                                         // s_off is reused
-    s_off[tid + 1] = mine2;
-    if (tid == 0) s_off[0] = 0;
-    __syncthreads();
-    for (int step = 1; step < kFilterThreads; step <<= 1) {
-      const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
-      __syncthreads();
-      s_off[tid + 1] += add;
-      __syncthreads();
-    }
+    int scan_total2;
+    const int scan_at2 = block_scan_excl(mine2, scan_total2);
     int16_t* out = list + (size_t)blockIdx.x * list_cap * 3;
-    int at = s_off[tid];
+    int at = scan_at2;
     int u = i_lo / ch, v = i_lo - u * ch;
     for (int i = i_lo; i < i_hi; i++) {
       const int d = base[v * pw + u];
@@ -854,7 +865,7 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve(DevParams dp,
       }
       if (++v == ch) { v = 0; u++; }
     }
-    if (tid == 0) count[blockIdx.x] = s_off[kFilterThreads];
+    if (tid == 0) count[blockIdx.x] = scan_total2;
   }
 }
 
@@ -866,7 +877,6 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve_big(DevParams
                                                                        const uint8_t* __restrict__ code) {
   extern __shared__ int16_t s_lat[];
   uint8_t* s_code = reinterpret_cast<uint8_t*>(s_lat);
-  __shared__ int s_off[kFilterThreads + 1];
   __shared__ uint32_t s_todo[kFilterTodo / 2];             // 32-bit indices: these lattices can exceed 65536 points
   const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x, N = cw * ch;
   int16_t* g = d_can + (size_t)blockIdx.x * N;
@@ -884,19 +894,12 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve_big(DevParams
       if (++v == ch) { v = 0; u++; }
     }
   }
-  s_off[tid + 1] = mine;
-  if (tid == 0) s_off[0] = 0;
-  __syncthreads();
-  for (int step = 1; step < kFilterThreads; step <<= 1) {
-    const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
-    __syncthreads();
-    s_off[tid + 1] += add;
-    __syncthreads();
-  }
-  const int total = s_off[kFilterThreads];
+  int scan_total3;
+  const int scan_at3 = block_scan_excl(mine, scan_total3);
+  const int total = scan_total3;
   const bool listed = total <= kFilterTodo / 2;
   if (listed) {
-    int at = s_off[tid];
+    int at = scan_at3;
     for (int i = i_lo; i < i_hi; i++) { const int c = s_code[i]; if (c != 0 && c != 255) s_todo[at++] = (uint32_t)i; }
   }
   __syncthreads();
@@ -938,7 +941,6 @@ __global__ void __launch_bounds__(kFilterThreads) k_filter_resolve_big(DevParams
 // One workgroup per frame; every thread owns a contiguous stretch of the column-major index range.
 __global__ void __launch_bounds__(kFilterThreads) k_support_list(DevParams dp, const int16_t* __restrict__ d_can, int16_t* __restrict__ list,
                                                                  int32_t* __restrict__ count, int cap) {
-  __shared__ int s_off[kFilterThreads + 1];
   const int cw = dp.cw, ch = dp.ch, tid = threadIdx.x, N = cw * ch;
   const int16_t* g = d_can + (size_t)blockIdx.x * N;
   int16_t* out = list + (size_t)blockIdx.x * cap * 3;
@@ -951,16 +953,9 @@ __global__ void __launch_bounds__(kFilterThreads) k_support_list(DevParams dp, c
       if (++v == ch) { v = 0; u++; }
     }
   }
-  s_off[tid + 1] = mine;
-  if (tid == 0) s_off[0] = 0;
-  __syncthreads();
-  for (int step = 1; step < kFilterThreads; step <<= 1) {
-    const int add = tid + 1 > step ? s_off[tid + 1 - step] : 0;
-    __syncthreads();
-    s_off[tid + 1] += add;
-    __syncthreads();
-  }
-  int at = s_off[tid];
+  int scan_total4;
+  const int scan_at4 = block_scan_excl(mine, scan_total4);
+  int at = scan_at4;
   int u = i_lo / ch, v = i_lo - u * ch;
   for (int i = i_lo; i < i_hi; i++) {
     const int d = g[v * cw + u];
@@ -970,7 +965,7 @@ __global__ void __launch_bounds__(kFilterThreads) k_support_list(DevParams dp, c
     }
     if (++v == ch) { v = 0; u++; }
   }
-  if (tid == 0) count[blockIdx.x] = s_off[kFilterThreads];
+  if (tid == 0) count[blockIdx.x] = scan_total4;
 }
 
 // seg_c == 0: the whole lattice (plus border) sits in LDS for all three passes.  Otherwise the lattice is larger
