@@ -405,7 +405,7 @@ def run_sgm(a):
             el = float(t.item())
         return el
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, SS)):                       # (every slot once before the timed regions: a slot allocates its volumes when it is first used)
         step()
     drain()
     acc.clear()

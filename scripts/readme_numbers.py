@@ -80,7 +80,7 @@ def block():
         ("ELAS 320x180, disp_max 255, batch 128 (the reference's native size)", "%.0f k pairs/s" % (find("320x180")["value"] / 1e3)),
         ("ELAS 1920x1080, D=256, batch 8", "%.1f k pairs/s" % (find("1920x1080 rectified pairs (scene disparities <= 256), ELAS")["value"] / 1e3)),
         ("lone 640x480 pair, ELAS (median of 200 calls)", "%.3f ms" % b["latency_config"]["ms_per_frame"]),
-        ("SGM 8 paths 1280x720, D=128, batch 32 (`--mode sgm`)", "%.2f k pairs/s, frac %.3f on SURVEY's B_sgm" % (s["value"] / 1e3, s["roofline"]["frac"])),
+        ("SGM 8 paths 1280x720, D=128, batch 32 (`--mode sgm`, six batches in flight)", "%.2f k pairs/s, frac %.3f on SURVEY's B_sgm" % (s["value"] / 1e3, s["roofline"]["frac"])),
         ("block matching 9x9 1280x720, D=128, batch 32 (`--mode bm`, SAD, `v_qsad`)", "%.1f k pairs/s" % (m["value"] / 1e3)),
         ("  the same with the squared-difference cost on the matrix cores (`--bm-cost ssd`, `v_mfma_i32_32x32x32_i8`)", "%.1f k pairs/s" % (line("%s_bm_ssd_bench_line.json" % tag)["value"] / 1e3)),
         ("  1920x1080, D=256, batch 8: SSD on the matrix cores / SAD", "%.2f k / %.2f k pairs/s" % (line("%s_bm_ssd_1080p_bench_line.json" % tag)["value"] / 1e3, line("%s_bm_sad_1080p_bench_line.json" % tag)["value"] / 1e3)),

@@ -124,6 +124,17 @@ def test_batches_through_both_triangulation_routes(jn, oracle, monkeypatch, gpu_
         assert e.last_times(0)["host_stage"] == 0 if gpu_dt == "1" else e.last_times(0)["host_stage"] > 0
 
 
+def test_an_explicit_small_host_share_selects_the_gpu_route(jn, monkeypatch):
+    """No rank of a multi-GPU job can see from its own affinity mask or cpu.max that it shares the container's CPU quota with seven others:
+    a batch handle created with 0 < host_threads < 14 (bench.py passes quota / world) triangulates on the GPU; a latency handle never does."""
+    monkeypatch.delenv("JN_GPU_DELAUNAY", raising=False)
+    p = jn.Elas.parameters(0, disp_max=63)
+    with jn.Elas(p, 320, 180, max_batch=2, host_threads=4) as e:
+        assert e.route_stats(0)[0] == 1
+    with jn.Elas(p, 320, 180, max_batch=1, host_threads=4) as e:
+        assert e.route_stats(0)[0] == 0
+
+
 def test_a_side_the_gpu_hands_back_sends_the_batch_through_the_host_stage(jn, oracle, monkeypatch):
     """With lr_threshold 6 two left-image support points 5 columns apart may map to ONE right-image vertex: k_arrange hands such a side back
     (which of the two survives depends on Triangle's randomised quicksort, replayed on the host), k_delaunay flags the frame, and the worker
