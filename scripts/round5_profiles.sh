@@ -21,7 +21,7 @@ cd $R
 python3 scripts/kstats.py $(ls $out/${tag}_sgm/*/*kernel_stats.csv | tail -1) 8 > $out/${tag}_sgm_summary.txt
 for c in FETCH_SIZE WRITE_SIZE; do python3 scripts/pmc.py $(ls $out/${tag}_sgm_pmc_$c/*/*counter_collection.csv | tail -1) "k_sw_" > $out/${tag}_sgm_pmc_$c.txt; done
 python3 scripts/pmc.py $(ls $out/${tag}_sgm_sq/*/*counter_collection.csv | tail -1) "k_sw_" > $out/${tag}_sgm_pmc_SQ.txt
-python3 bench.py --mode sgm --steps 20 --warmup 6 > $out/${tag}_sgm_bench_line.json 2> $out/${tag}_sgm_bench.err
+python3 bench.py --mode sgm --steps 60 --warmup 6 > $out/${tag}_sgm_bench_line.json 2> $out/${tag}_sgm_bench.err
 { for ss in 1 2 4 6 8 6 1; do echo "--sgm-slots $ss: $(python3 bench.py --mode sgm --sgm-slots $ss --steps 12 --warmup 6 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch, frac", j["roofline"]["frac"])')"; done
   echo "--sgm-slots 6, JN_SGM_TAIL=3 (L/R kernel, mono8 kernel, scan one after the other): $(JN_SGM_TAIL=3 python3 bench.py --mode sgm --sgm-slots 6 --steps 12 --warmup 6 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch")')"
   for ss in 1 4 6; do echo "1920x1080 D=256 + 1/16 px batch 8, --sgm-slots $ss: $(python3 bench.py --mode sgm --sgm-slots $ss --width 1920 --height 1080 --disp 256 --batch 8 --subpixel 1 --steps 8 --warmup 4 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch")')"; done
