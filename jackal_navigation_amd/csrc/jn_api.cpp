@@ -325,8 +325,7 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
     HIP_TRY(mark(EV_H2D));
     if (any_ok) {
       if (!grid_early) launch_grid(st, dp, n, s.info, payload, 0, max_sup, s.mark, s.gridbits, !cleared);      // offsets in FrameInfo are batch-absolute
-      launch_tri_setup(st, dp, n, s.info, payload, 0, max_tri, h->tri_cap, s.recs);
-      launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list, !cleared);
+      launch_bin(st, dp, n, s.info, s.recs, h->tri_cap, max_tri, s.bin_count, s.bin_list, !cleared, payload, 0);   // (forms the triangles' records on the way: k_tri_setup's work)
       HIP_TRY(mark(EV_RASTER));
       launch_dense(st, dp, n, s.info, s.recs, h->tri_cap, s.bin_count, s.bin_list, s.gridbits, dsrc, s.raw, false, (stage_events && h->plane_flow) ? s.ev_owner : nullptr);
       HIP_TRY(mark(EV_DENSE));
@@ -367,9 +366,8 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
         }
         HIP_TRY(mark(EV_GAP));
       } else {
-        launch_lr(st, dp, n, s.info, s.raw, j.dD1, j.dD2);
+        launch_lr_speckle(st, dp, n, s.info, s.raw, j.dD1, j.dD2, s.label, s.size, s.tmp);   // L/R check of both maps + the left map's speckle pass (its row labelling in the L/R kernel)
         HIP_TRY(mark(EV_LR));
-        launch_speckle(st, dp, n, s.info, j.dD1, s.label, s.size, s.tmp);
         if (!h->p.postprocess_only_left) launch_speckle(st, dp, n, s.info, j.dD2, s.label, s.size, s.tmp);
         HIP_TRY(mark(EV_SPECKLE));
         launch_gap(st, dp, n, s.info, j.dD1, s.tmp);

@@ -69,8 +69,9 @@ void launch_grid_from_list(hipStream_t st, const DevParams& dp, int n, const int
 void launch_tri_setup(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const uint8_t* payload,
                       int64_t payload_stride, int max_tri, int tri_cap, TriRec* recs);
 // Triangle candidates per 32x8 tile with their row masks: bin_count [n][2][tiles], bin_list [n][2][tiles][kBinCap].
-void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear = true);
+// payload != nullptr: the triangles' records are formed on the way (launch_tri_setup's work, same kernel) and written to recs.
+void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, TriRec* recs, int tri_cap,
+                int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear = true, const uint8_t* payload = nullptr, int64_t payload_stride = 0);
 void launch_bin_clear(hipStream_t st, const DevParams& dp, int n, int32_t* bin_count);
 // Dense MAP matching with in-kernel triangle lookup (elas.cpp:683-907): raw [n][2][H][W] float.
 // Planes: k_owner (which triangle owns a pixel, its plane's disparity: one 16-bit word per pixel, left in `raw`) + k_dense_row; materialised

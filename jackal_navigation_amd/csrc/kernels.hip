@@ -1147,12 +1147,8 @@ DEV bool gauss_jordan3(double A[3][3], double b[3]) {
   return true;
 }
 
-__global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
-                                                   long long payload_stride, int tri_cap, TriRec* __restrict__ recs) {
-  const int t = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y, side = blockIdx.z;
-  const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
-  if (!fi.ok || t >= fi.ntri[side]) return;
-  const uint8_t* fp = payload + (long long)frame * payload_stride;
+// the record of triangle t of a frame side (fp: the frame's payload): planes of both sides, edge lines, column and row ranges
+DEV TriRec tri_record(const FrameInfo& fi, const uint8_t* __restrict__ fp, int side, int t) {
   const int32_t* sup = reinterpret_cast<const int32_t*>(fp + fi.sup_offset);
   const int32_t* c = reinterpret_cast<const int32_t*>(fp + fi.corner_offset[side]) + 3 * t;
   int su[3], sv[3], sd[3];
@@ -1188,7 +1184,14 @@ __global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo
   o.Au = (int16_t)tu[0]; o.Bu = (int16_t)tu[1]; o.Cu = (int16_t)tu[2];
   o.vmin = (int16_t)(min(sv[0], min(sv[1], sv[2])) - 1);      // truncated line values can land one row above the top corner
   o.vmax = (int16_t)max(sv[0], max(sv[1], sv[2]));
-  recs[(size_t)(frame * 2 + side) * tri_cap + t] = o;
+  return o;
+}
+__global__ void __launch_bounds__(256) k_tri_setup(DevParams dp, const FrameInfo* __restrict__ info, const uint8_t* __restrict__ payload,
+                                                   long long payload_stride, int tri_cap, TriRec* __restrict__ recs) {
+  const int t = blockIdx.x * 256 + threadIdx.x, frame = blockIdx.y, side = blockIdx.z;
+  const FrameInfo& fi = info[frame];      // by reference: a by-value copy of the 48-byte struct lands in scratch memory
+  if (!fi.ok || t >= fi.ntri[side]) return;
+  recs[(size_t)(frame * 2 + side) * tri_cap + t] = tri_record(fi, payload + (long long)frame * payload_stride, side, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1231,8 +1234,12 @@ DEV bool bin_entry(const DevParams& dp, const TriRec& q, int t, int u0, int v0, 
 // So the (triangle, tile) pairs of the workgroup's triangles are numbered consecutively (prefix sum of the box
 // sizes in LDS) and the 256 threads stride over that flat list.
 enum { kBinTris = 64 };
-__global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs,
-                                             int tri_cap, int32_t* __restrict__ bin_count, BinEntry* __restrict__ bin_list) {
+// kSetup: the workgroup forms its 64 triangles' records itself (k_tri_setup's work, one thread a triangle) and writes them out for the
+// kernels behind it, instead of reading them back from memory: one launch less on a batch's — and a lone pair's — critical path.
+template <bool kSetup>
+__global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __restrict__ info, TriRec* __restrict__ recs,
+                                             int tri_cap, int32_t* __restrict__ bin_count, BinEntry* __restrict__ bin_list,
+                                             const uint8_t* __restrict__ payload, long long payload_stride) {
   __shared__ int s_first[kBinTris + 1];                    // first flat index of each triangle's tiles
   __shared__ int s_box[kBinTris][3];                       // tx0, ty0, ntx of the bounding box in tiles
   __shared__ int s_cols[kBinTris][2];                      // c0, c1
@@ -1241,12 +1248,18 @@ __global__ void __launch_bounds__(256) k_bin(DevParams dp, const FrameInfo* __re
   if (!fi.ok) return;
   const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
   const size_t base = (size_t)(frame * 2 + side) * tiles_x * tiles_y;
-  const TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
+  TriRec* R = recs + (size_t)(frame * 2 + side) * tri_cap;
   const int t0 = blockIdx.x * kBinTris;
   // the workgroup's triangle records go to LDS in one coalesced sweep: read field by field from memory, every
   // item would wait out a dozen dependent global loads
   __shared__ TriRec s_rec[kBinTris];
-  {
+  if constexpr (kSetup) {
+    if (tid < kBinTris && t0 + tid < fi.ntri[side]) {
+      const TriRec o = tri_record(fi, payload + (long long)frame * payload_stride, side, t0 + tid);
+      s_rec[tid] = o;
+      R[t0 + tid] = o;
+    }
+  } else {
     const int ntri_here = min(kBinTris, fi.ntri[side] - t0);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(R + t0);
     uint32_t* dst = reinterpret_cast<uint32_t*>(s_rec);
@@ -3325,11 +3338,19 @@ void launch_bin_clear(hipStream_t st, const DevParams& dp, int n, int32_t* bin_c
   const int tiles = ((dp.W + kTileW - 1) / kTileW) * ((dp.H + kTileH - 1) / kTileH);
   hipMemsetAsync(bin_count, 0, (size_t)n * 2 * tiles * sizeof(int32_t), st);
 }
-void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
-                int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear) {
+void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, TriRec* recs, int tri_cap,
+                int max_tri, int32_t* bin_count, BinEntry* bin_list, bool clear, const uint8_t* payload, int64_t payload_stride) {
   if (clear) launch_bin_clear(st, dp, n, bin_count);
   if (max_tri <= 0) return;
-  hipLaunchKernelGGL(k_bin, dim3((max_tri + kBinTris - 1) / kBinTris, n, 2), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list);
+  const dim3 grid((max_tri + kBinTris - 1) / kBinTris, n, 2);
+  // One launch less matters on a lone pair's critical path (0.283-0.296 against 0.301-0.302 ms per 640x480 pair, same box); in a batch the
+  // records' FP64 plane fits on one of a workgroup's four waves make the binning workgroups longer and the pipelined rate 2 % lower
+  // (22.3 against 22.8 k pairs/s): small batches only.  JN_BIN_SETUP=0 / 1 forces one form (A/B).
+  static const int fuse_env = getenv("JN_BIN_SETUP") ? atoi(getenv("JN_BIN_SETUP")) : -1;
+  const bool fuse = fuse_env >= 0 ? fuse_env != 0 : n <= 2;
+  if (payload && fuse) { hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list, payload, (long long)payload_stride); return; }
+  if (payload) launch_tri_setup(st, dp, n, info, payload, payload_stride, max_tri, tri_cap, recs);
+  hipLaunchKernelGGL(k_bin<false>, grid, dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list, nullptr, 0ll);
 }
 bool dense_row_applies(const DevParams& dp) {
   if (dp.grid_size < 8) return false;                 // tiny grids: a wave would touch many cells
