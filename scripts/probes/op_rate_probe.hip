@@ -34,11 +34,16 @@
 #define S_CNDMASK(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
 #define S_CMP(i) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a[i]), "v"(b) : "vcc");
 #define S_MIN3(i) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+#define S_MQSAD(i) asm volatile("v_mqsad_pk_u16_u8 %0, %0, %1, %0" : "+v"(q[i]) : "v"(b));
+#define S_QSAD(i) asm volatile("v_qsad_pk_u16_u8 %0, %0, %1, %0" : "+v"(q[i]) : "v"(b));
+#define S_PKADD(i) asm volatile("v_pk_add_u16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+#define S_PKMAX3(i) asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
 #define S_CVTPK(i) asm volatile("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(a[i]) : "v"(c));
 KERNEL(k_lshl32, REP8(S_LSHL32)) KERNEL(k_lshl64, REP8(S_LSHL64)) KERNEL(k_sadhi, REP8(S_SADHI)) KERNEL(k_sad, REP8(S_SAD))
 KERNEL(k_mullo, REP8(S_MULLO)) KERNEL(k_mulhi, REP8(S_MULHI)) KERNEL(k_med3, REP8(S_MED3)) KERNEL(k_bfe, REP8(S_BFE))
 KERNEL(k_andor, REP8(S_ANDOR)) KERNEL(k_perm, REP8(S_PERM)) KERNEL(k_bfm, REP8(S_BFM)) KERNEL(k_align, REP8(S_ALIGN))
 KERNEL(k_ffbl, REP8(S_FFBL)) KERNEL(k_lshladd, REP8(S_LSHLADD)) KERNEL(k_add64, REP8(S_ADD64)) KERNEL(k_bitop3, REP8(S_BITOP3))
+KERNEL(k_mqsad, REP8(S_MQSAD)) KERNEL(k_qsad, REP8(S_QSAD)) KERNEL(k_pkadd, REP8(S_PKADD)) KERNEL(k_pkmax3, REP8(S_PKMAX3))
 KERNEL(k_readlane, REP8(S_READLANE)) KERNEL(k_cndmask, REP8(S_CNDMASK)) KERNEL(k_cmp, REP8(S_CMP)) KERNEL(k_min3, REP8(S_MIN3))
 template <typename K> static void run(const char* name, K kern, uint32_t* o) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -52,6 +57,6 @@ int main() {
   uint32_t* o; (void)hipMalloc(&o, 4 * 256 * 4096 * 4);
 #define R(k) run(#k, k, o);
   R(k_lshl32) R(k_lshl64) R(k_sadhi) R(k_sad) R(k_mullo) R(k_mulhi) R(k_med3) R(k_bfe) R(k_andor) R(k_perm) R(k_bfm) R(k_align) R(k_ffbl) R(k_lshladd)
-  R(k_add64) R(k_bitop3) R(k_readlane) R(k_cndmask) R(k_cmp) R(k_min3)
+  R(k_add64) R(k_bitop3) R(k_mqsad) R(k_qsad) R(k_pkadd) R(k_pkmax3) R(k_readlane) R(k_cndmask) R(k_cmp) R(k_min3)
   return 0;
 }
