@@ -6,6 +6,19 @@ for T in 2 4 8 12 16; do
   echo "cores $T  host route: $(JN_GPU_DELAUNAY=0 taskset -c 0-$((T-1)) bash -c "$(declare -f line); line --host-threads $T")"
   echo "cores $T  GPU route:  $(JN_GPU_DELAUNAY=1 taskset -c 0-$((T-1)) bash -c "$(declare -f line); line --host-threads $T")"
 done
+# what parallel.pin_rank gives a rank on a 2 x 64-core node with 8 GPUs: 16 physical cores with their SMT siblings (the library's rule counts logical CPUs: host route)
+SIB=$(python3 - <<'PY'
+import os
+sib=set()
+for c in range(16):
+    try: sib.update(int(x) for x in open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list"%c).read().replace("-",",").split(","))
+    except OSError: sib.add(c)
+print(",".join(str(c) for c in sorted(sib)))
+PY
+)
+echo "16 physical cores + siblings (16 + 16 logical CPUs) host route: $(JN_GPU_DELAUNAY=0 taskset -c $SIB bash -c "$(declare -f line); line --host-threads 16")"
+echo "16 physical cores + siblings (16 + 16 logical CPUs) GPU route:  $(JN_GPU_DELAUNAY=1 taskset -c $SIB bash -c "$(declare -f line); line --host-threads 16")"
+echo "16 physical cores + siblings (16 + 16 logical CPUs) library's choice: $(taskset -c $SIB bash -c "$(declare -f line); line --host-threads 16")"
 echo "all cores, library's choice: $(line)"
 echo "all cores, JN_GPU_DELAUNAY=1: $(JN_GPU_DELAUNAY=1 line)"
 echo "all cores, JN_GPU_DELAUNAY=0: $(JN_GPU_DELAUNAY=0 line)"
