@@ -2108,124 +2108,14 @@ __global__ void __launch_bounds__(256) k_lr_ccl_rows(DevParams dp, const FrameIn
   }
   if (lane == 0) runs.count(frame)[v] = c.cnt;
 }
-// ---- small batches (a lone pair): bands of kBandRows rows labelled AND united in LDS ----
-// k_ccl_merge unites the runs of all row pairs at once: a component that spans the image (the background) becomes a chain of one hop per
-// row pair before anybody compresses it, and the finds of the kernels behind walk it — on a lone pair's critical path that is 30-40 us of
-// dependent global loads.  Here a workgroup takes kBandRows rows: L/R check, row labelling (one wave per row, as k_lr_ccl_rows), then the
-// unions of its own row pairs on LOCAL labels in LDS (a hop is an LDS access), and writes global labels whose run starts already point at
-// their band's root.  k_ccl_merge is left with one row pair per band (step = kBandRows).  Same components as the row-by-row route (the
-// unions are the same set, a root is the smallest label either way), so everything behind is unchanged.  Batches keep k_lr_ccl_rows: with
-// thousands of rows in flight the chains are walked by waves that have nothing else to wait for, and four rows a workgroup was measured
-// slower there (DESIGN_HISTORY.md R5-b).
-constexpr int kBandRows = 8;
-DEV int uf_find_lds(int32_t* lab, int x) {
-  int p = lab[x];
-  while (p != x) { const int g = lab[p]; if (g != p) lab[x] = g; x = p; p = g; }
-  return x;
-}
-DEV void uf_union_lds(int32_t* lab, int a, int b) {
-  for (;;) {
-    a = uf_find_lds(lab, a); b = uf_find_lds(lab, b);
-    if (a == b) return;
-    if (a < b) { const int t = a; a = b; b = t; }
-    const int old = atomicMin(&lab[a], b);
-    if (old == a) return;
-    a = old;
-  }
-}
-__global__ void __launch_bounds__(256) k_lr_ccl_band(DevParams dp, const FrameInfo* __restrict__ info, const int16_t* __restrict__ raw,
-                                                     float* __restrict__ D1, float* __restrict__ D2, int32_t* __restrict__ lab, int32_t* __restrict__ sz, RunLists runs) {
-  extern __shared__ int16_t s_raw[];                     // [2][W] raw rows (one image row at a time) | [kBandRows][W] float: the checked left rows | [kBandRows][W] local labels
-  const int v0 = blockIdx.x * kBandRows, frame = blockIdx.y;
-  if (!info[frame].ok) return;
-  const int W = dp.W, nrows = min(kBandRows, dp.H - v0), W2 = (W + 1) & ~1;
-  const size_t plane = (size_t)dp.H * W;
-  int16_t* s1 = s_raw; int16_t* s2 = s_raw + W2;
-  float* s_o = reinterpret_cast<float*>(s_raw + 2 * W2);
-  int32_t* s_lab = reinterpret_cast<int32_t*>(s_o + (size_t)kBandRows * W);
-  const float thr = (float)dp.lr_threshold;
-  for (int r = 0; r < nrows; r++) {
-    const int v = v0 + r;
-    const int16_t* r1 = raw + (size_t)(frame * 2) * plane + (size_t)v * W;
-    const int16_t* r2 = r1 + plane;
-    if (r) __syncthreads();                              // the previous row's raw values have been read
-    for (int u = threadIdx.x; u < W; u += 256) { s1[u] = r1[u]; s2[u] = r2[u]; }
-    __syncthreads();
-    float* o1row = D1 + (size_t)frame * plane + (size_t)v * W;
-    float* o2row = D2 + (size_t)frame * plane + (size_t)v * W;
-    float* so = s_o + (size_t)r * W;
-    for (int u = threadIdx.x; u < W; u += 256) {         // elas.cpp:909-979, as k_lr
-      const float d1 = (float)s1[u], d2 = (float)s2[u];
-      float o1 = d1, o2 = d2;
-      const float w1 = (float)u - d1, w2 = (float)u + d2;
-      if (d1 >= 0 && w1 >= 0 && w1 < (float)W) { if (fabsf((float)s2[(int)w1] - d1) > thr) o1 = -10.0f; } else o1 = -10.0f;
-      if (d2 >= 0 && w2 >= 0 && w2 < (float)W) { if (fabsf((float)s1[(int)w2] - d2) > thr) o2 = -10.0f; } else o2 = -10.0f;
-      o1row[u] = o1; so[u] = o1;
-      o2row[u] = o2;
-    }
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float sim = dp.speckle_sim;
-  // the rows' runs (a wave takes rows wv, wv + 4, ...): LOCAL labels r * W + run start into LDS, sizes and run lists to memory as k_ccl_rows
-  for (int r = wv; r < nrows; r += 4) {
-    const int v = v0 + r;
-    const float* so = s_o + (size_t)r * W;
-    const size_t base = (size_t)frame * plane + (size_t)v * W;
-    const size_t rbase = (size_t)v * runs.pitch;
-    RunCarry c;
-    float d = lane < W ? so[lane] : -10.0f;
-    for (int u0 = 0; u0 < W; u0 += 64) {
-      const int u = u0 + lane;
-      const float nxt = u + 64 < W ? so[u + 64] : -10.0f;
-      ccl_chunk(d, nxt, u, W, r, sim, c, s_lab + (size_t)r * W, sz + base, runs.starts(frame) + rbase, runs.ends(frame) + rbase);
-      d = nxt;
-    }
-    if (lane == 0) runs.count(frame)[v] = c.cnt;
-  }
-  __syncthreads();
-  // unions of the band's own row pairs (r, r + 1), on the local labels
-  for (int r = wv; r + 1 < nrows; r += 4) {
-    const float* ra = s_o + (size_t)r * W; const float* rb = ra + W;
-    float a_left = -10.0f, b_left = -10.0f;
-    for (int u0 = 0; u0 < W; u0 += 64) {
-      const int u = u0 + lane;
-      const float a = u < W ? ra[u] : -10.0f, b = u < W ? rb[u] : -10.0f;
-      const float a0 = __int_as_float(JN_DPP(__float_as_int(a_left), __float_as_int(a), 0x138, 0xf));      // wave_shr:1, lane 0 takes the carried column
-      const float b0 = __int_as_float(JN_DPP(__float_as_int(b_left), __float_as_int(b), 0x138, 0xf));
-      const bool contact = a >= 0 && b >= 0 && fabsf(a - b) <= sim;
-      const bool same_pair = a0 >= 0 && b0 >= 0 && fabsf(a0 - b0) <= sim && fabsf(a - a0) <= sim && fabsf(b - b0) <= sim;
-      if (contact && !same_pair) uf_union_lds(s_lab, s_lab[r * W + u], s_lab[(r + 1) * W + u]);
-      a_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
-      b_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
-    }
-  }
-  __syncthreads();
-  // global labels: a pixel points at its run start (as ever), a run start at its band's root
-  for (int r = 0; r < nrows; r++) {
-    const float* so = s_o + (size_t)r * W;
-    int32_t* grow = lab + (size_t)frame * plane + (size_t)(v0 + r) * W;
-    for (int u = threadIdx.x; u < W; u += 256) {
-      const float d = so[u];
-      int g = -1;
-      if (d >= 0) {
-        const bool conn = u > 0 && so[u - 1] >= 0 && fabsf(d - so[u - 1]) <= sim;       // not a run start: the label is the run start's index
-        g = v0 * W + (conn ? s_lab[r * W + u] : uf_find_lds(s_lab, r * W + u));
-      }
-      grow[u] = g;
-    }
-  }
-}
 // Column pass: unite vertically adjacent runs.  A pixel issues the union only if it is the first
 // column of the contact between its run and the run below (the pixel to its left belongs to the
 // same two runs otherwise), which removes almost all redundant atomics.
 __global__ void __launch_bounds__(256) k_ccl_merge(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ D,
-                                                   int32_t* __restrict__ lab, int segs, int step) {
+                                                   int32_t* __restrict__ lab, int segs) {
   // one wave per pair of rows (v, v+1) — per column segment of it when a small batch has few rows to offer —
-  // 64 columns at a time; left neighbours come from the lane below.  step > 1: only the pairs between bands of `step` rows
-  // (v = step - 1, 2 step - 1, ...): k_lr_ccl_band has united the rows inside a band.
-  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), pr = wave / segs, seg = wave - pr * segs, frame = blockIdx.y;
-  const int v = pr * step + step - 1;
+  // 64 columns at a time; left neighbours come from the lane below
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), v = wave / segs, seg = wave - v * segs, frame = blockIdx.y;
   if (v + 1 >= dp.H || !info[frame].ok) return;
   const int W = dp.W, lane = threadIdx.x & 63;
   const int seg_len = ((W + segs - 1) / segs + 63) & ~63, c0 = seg * seg_len, c1 = min(c0 + seg_len, W);
@@ -3519,7 +3409,7 @@ void launch_speckle(hipStream_t st, const DevParams& dp, int n, const FrameInfo*
   // enough waves to fill the GPU even for a lone small pair: split the rows of the merge pass into column segments
   const int row_waves = dp.H * n, chunks = (dp.W + 63) / 64;
   const int segs = row_waves >= 4096 ? 1 : max(1, min(chunks, 4096 / max(row_waves, 1)));
-  hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs, 1);
+  hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs);
   hipLaunchKernelGGL(k_ccl_count, gr, dim3(256), 0, st, dp, info, label, size, runs);
   hipLaunchKernelGGL(k_ccl_apply, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
 }
@@ -3534,24 +3424,11 @@ void launch_lr_speckle(hipStream_t st, const DevParams& dp, int n, const FrameIn
   runs.base = reinterpret_cast<uint8_t*>(scratch);
   runs.frame_bytes = (size_t)dp.H * dp.W * sizeof(float);
   const size_t lds = (size_t)2 * ((dp.W + 1) & ~1) * sizeof(int16_t) + (size_t)dp.W * sizeof(float);
-  const dim3 gr((dp.H + 3) / 4, n);
-  const int chunks = (dp.W + 63) / 64;
-  // a lone pair (batches of one or two): bands of rows labelled and united in LDS (k_lr_ccl_band), one row pair per band left for k_ccl_merge
-  const size_t lds_band = (size_t)2 * ((dp.W + 1) & ~1) * sizeof(int16_t) + (size_t)2 * kBandRows * dp.W * sizeof(float);
-  static const int band_env = getenv("JN_CCL_BAND") ? atoi(getenv("JN_CCL_BAND")) : -1;
-  const bool band = (band_env >= 0 ? band_env != 0 : n <= 2) && lds_band <= 64 * 1024 && dp.H > kBandRows;
-  if (band) {
-    hipLaunchKernelGGL(k_lr_ccl_band, dim3((dp.H + kBandRows - 1) / kBandRows, n), dim3(256), lds_band, st, dp, info, raw, D, D2, label, size, runs);
-    const int pairs = (dp.H - 1) / kBandRows;                // v = kBandRows - 1, 2 kBandRows - 1, ... with v + 1 < H
-    const int row_waves = pairs * n;
-    const int segs = row_waves >= 4096 ? 1 : max(1, min(chunks, 4096 / max(row_waves, 1)));
-    if (pairs > 0) hipLaunchKernelGGL(k_ccl_merge, dim3((pairs * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs, kBandRows);
-  } else {
   hipLaunchKernelGGL(k_lr_ccl_rows, dim3(dp.H, n), dim3(256), lds, st, dp, info, raw, D, D2, label, size, runs);
-  const int row_waves = dp.H * n;
+  const dim3 gr((dp.H + 3) / 4, n);
+  const int row_waves = dp.H * n, chunks = (dp.W + 63) / 64;
   const int segs = row_waves >= 4096 ? 1 : max(1, min(chunks, 4096 / max(row_waves, 1)));
-  hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs, 1);
-  }
+  hipLaunchKernelGGL(k_ccl_merge, dim3((dp.H * segs + 3) / 4, n), dim3(256), 0, st, dp, info, D, label, segs);
   hipLaunchKernelGGL(k_ccl_count, gr, dim3(256), 0, st, dp, info, label, size, runs);
   hipLaunchKernelGGL(k_ccl_apply, gr, dim3(256), 0, st, dp, info, D, label, size, runs);
 }
