@@ -13,7 +13,7 @@ import os as _os
 # in the environment before the HIP runtime initialises; an explicit setting by the user wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-from ._lib import load, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH  # noqa: F401
+from ._lib import load, hooks_library, JnError, ElasParams, ScanParams, EXPORTS, LIB_PATH, HOOKS_LIB_PATH  # noqa: F401
 from .elas import Elas  # noqa: F401
 from . import node, device, parallel, navigate  # noqa: F401
 from .sgm import Sgm, SGM_EXPORTS  # noqa: F401

@@ -10,6 +10,9 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # JN_STEREO_LIB: another build of the same library (A/B runs of kernel variants); there is still no fallback if it does not load
 LIB_PATH = os.environ.get("JN_STEREO_LIB") or os.path.join(HERE, "libjn_stereo.so")
+# The hooks build (csrc/hooks.h, `make -C csrc hooks`): the same sources with the test hooks, the profiling switches and the A/B knobs
+# compiled in.  Only tests and measurement scripts load it (hooks_library() below, or JN_STEREO_LIB for a child process).
+HOOKS_LIB_PATH = os.path.join(HERE, "libjn_stereo_hooks.so")
 
 JN_OK, JN_ERR_FEW_SUPPORT, JN_ERR_UNSUPPORTED, JN_ERR_INVALID, JN_ERR_NO_DEVICE, JN_ERR_INTERNAL, JN_ERR_COMM = range(7)
 STATUS_NAMES = ["JN_OK", "JN_ERR_FEW_SUPPORT", "JN_ERR_UNSUPPORTED", "JN_ERR_INVALID", "JN_ERR_NO_DEVICE", "JN_ERR_INTERNAL", "JN_ERR_COMM"]
@@ -93,21 +96,45 @@ EXPORTS = [
 ]
 
 _lib = None
+_bound = {}
 
 
 def load():
     """Return the ctypes handle of libjn_stereo.so; raises if it is not built."""
     global _lib
-    if _lib is not None:
+    if _lib is None:
+        _lib = _bind(LIB_PATH)
+    return _lib
+
+
+class hooks_library:
+    """Tests and measurement scripts only: inside the `with` block every call of this package goes to the hooks build
+    (libjn_stereo_hooks.so: csrc/hooks.h), where the JN_TEST_* hooks, the *_DBG profiling switches and the A/B knobs exist.  Handles made
+    inside the block must be closed inside it.  The release library carries none of those switches."""
+
+    def __enter__(self):
+        global _lib
+        self._prev = _lib
+        _lib = _bind(HOOKS_LIB_PATH)
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("libjn_stereo.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "or `make -C jackal_navigation_amd/csrc`); there is no CPU fallback")
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
+
+
+def _bind(path):
+    if path in _bound:
+        return _bound[path]
+    if not os.path.exists(path):
+        raise ImportError("%s is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C jackal_navigation_amd/csrc [hooks]`); there is no CPU fallback" % os.path.basename(path))
     try:  # share torch's HIP runtime when torch is present
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the C-ABI itself
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.jn_version.restype = C.c_char_p
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.jn_elas_create.argtypes = [C.POINTER(ElasParams), i32, i32, i32, i32, i32, i32, C.POINTER(vp)]
@@ -171,7 +198,7 @@ def load():
     L.jn_comm_destroy.restype = None
     L.jn_fnv1a64_u32.argtypes = [vp, i64]
     L.jn_fnv1a64_u32.restype = C.c_uint64
-    _lib = L
+    _bound[path] = L
     return L
 
 

@@ -22,6 +22,7 @@
 // check; with the sub-pixel option it stages the band again and evaluates the two costs next to each winner directly.
 // HBM traffic is ~13 bytes per pixel; the kernel is bound by vector issue.
 #include <hip/hip_runtime.h>
+#include "hooks.h"
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
@@ -435,7 +436,7 @@ static jn_status bm_submit(jn_bm* h, int k, int32_t n, const uint8_t* dI1, const
     int turns = (kBmMaxBand + 2 * s.r) / ring;
     while (turns > 2 && (long long)((s.W + 63) / 64) * ((s.H + turns * ring - 2 * s.r - 1) / (turns * ring - 2 * s.r)) * n < 1024) turns--;
     int band = turns * ring - 2 * s.r;
-    if (const char* e = getenv("JN_BM_BAND")) band = std::min(std::max(atoi(e), 1), kBmMaxBand);
+    if (const char* e = JN_HOOK_ENV("JN_BM_BAND")) band = std::min(std::max(atoi(e), 1), kBmMaxBand);
     BM_TRY(launch_bm<0>(st, s, n, band, x.g, keysL));
     if (s.lr >= 0) BM_TRY(launch_bm<1>(st, s, n, band, x.g, keysR));
     BM_TRY(hipEventRecord(x.ev[2], st));

@@ -24,6 +24,7 @@
 // Arithmetic per row and 32 columns (D = 128): 5 MFMAs (5 x 32 cycles), ~150 vector instructions; the pass is bound by vector issue, not by
 // the matrix cores — DESIGN.md has the measured numbers next to the v_qsad (SAD) kernel's.
 #include <hip/hip_runtime.h>
+#include "hooks.h"
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
@@ -360,7 +361,7 @@ hipError_t run(const QDev& s, int n, const uint8_t* dI1, const uint8_t* dI2, int
   int band = 96;
   const long long tiles = (long long)((s.W + 31) / 32) * n;
   while (band > 12 && tiles * ((s.H + band - 1) / band) < 8192) band = (band + 1) / 2;
-  if (const char* env = getenv("JN_BMQ_BAND")) band = std::min(std::max(atoi(env), 1), 1024);
+  if (const char* env = JN_HOOK_ENV("JN_BMQ_BAND")) band = std::min(std::max(atoi(env), 1), 1024);
   if ((e = launch_match_any<0>(st, s, n, band, g, Q, keysL)) != hipSuccess) return e;
   if (s.lr >= 0 && (e = launch_match_any<1>(st, s, n, band, g, Q, keysR)) != hipSuccess) return e;
   if ((e = hipEventRecord(ev[2], st)) != hipSuccess) return e;

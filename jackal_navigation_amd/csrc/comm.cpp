@@ -98,6 +98,11 @@ struct jn_comm {
   hipStream_t stream = nullptr;
   double* flat = nullptr;          // packed [n*bins | n*4] doubles, grow-only
   size_t cap = 0;
+  double* h_inf = nullptr;         // pinned, every element +inf: what a failed batch feeds the reduction (comm_merge_identity), grow-only
+  size_t inf_cap = 0;
+  // Buffers a growth replaced.  They are NOT freed while the communicator lives: hipFree waits for the device, and the stream may be
+  // inside a collective whose peer is gone — the one wait that must never happen under `m` (comm_abort needs it).  jn_comm_destroy frees them.
+  std::vector<void*> retired_dev, retired_host;
   std::mutex m;
   std::atomic<bool> dead{false};   // aborted after a merge that did not complete (comm_abort): every later collective returns JN_ERR_COMM
 };
@@ -159,6 +164,17 @@ jn_status jn_comm_info(jn_comm* c, int32_t* rank, int32_t* world, int32_t* devic
   return JN_OK;
 }
 
+// Room for `count` doubles in c->flat.  Called under c->m; never waits: the old buffer may still be read by a merge queued earlier (it is
+// retired, not freed), and nothing here synchronises with a stream that may be stuck in a collective.
+static jn_status grow_flat(jn_comm* c, size_t count) {
+  if (count <= c->cap) return JN_OK;
+  double* fresh = nullptr;
+  HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&fresh), count * sizeof(double)));
+  if (c->flat) c->retired_dev.push_back(c->flat);
+  c->flat = fresh; c->cap = count;
+  return JN_OK;
+}
+
 // pack -> all-reduce -> unpack queued on the communicator's stream.  `ready` (may be null) is an event the inputs are
 // complete behind; `done` (may be null) is recorded behind the unpack.  Every collective of a communicator goes through
 // here under its mutex and onto its ONE stream, so all ranks execute them in the order they were queued.
@@ -174,13 +190,7 @@ static jn_status queue_merge(jn_comm* c, Rccl* R, int n, int bins, double* dBins
     if (done) HIP_TRY_C(hipEventRecord(done, c->stream));
     return JN_OK;
   }
-  if (count > c->cap) {
-    HIP_TRY_C(hipStreamSynchronize(c->stream));            // a merge queued earlier may still use the old buffer
-    if (c->flat) hipFree(c->flat);
-    c->flat = nullptr; c->cap = 0;
-    HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
-    c->cap = count;
-  }
+  if (const jn_status gs = grow_flat(c, count); gs != JN_OK) return gs;
   if (ready) HIP_TRY_C(hipStreamWaitEvent(c->stream, ready, 0));
   launch_scan_pack(c->stream, n, bins, dBins, dMeta, c->flat, true);
   RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
@@ -240,19 +250,21 @@ jn_status comm_merge_identity(jn_comm* c, int n, int bins) {
   Rccl* R = rccl();
   if (!R) return JN_ERR_COMM;
   const size_t count = (size_t)n * (bins + 4);
-  const std::vector<double> ident(count, INFINITY);
   {
     std::lock_guard<std::mutex> guard(c->m);
     if (c->dead.load()) return JN_ERR_COMM;
     HIP_TRY_C(hipSetDevice(c->device));
-    if (count > c->cap) {
-      HIP_TRY_C(hipStreamSynchronize(c->stream));
-      if (c->flat) hipFree(c->flat);
-      c->flat = nullptr; c->cap = 0;
-      HIP_TRY_C(hipMalloc(reinterpret_cast<void**>(&c->flat), count * sizeof(double)));
-      c->cap = count;
+    if (const jn_status gs = grow_flat(c, count); gs != JN_OK) return gs;
+    if (count > c->inf_cap) {                                // the +inf source: pinned and persistent, so the fill below can be asynchronous
+      double* fresh = nullptr;
+      HIP_TRY_C(hipHostMalloc(reinterpret_cast<void**>(&fresh), count * sizeof(double), hipHostMallocDefault));
+      for (size_t i = 0; i < count; i++) fresh[i] = INFINITY;
+      if (c->h_inf) c->retired_host.push_back(c->h_inf);
+      c->h_inf = fresh; c->inf_cap = count;
     }
-    HIP_TRY_C(hipMemcpy(c->flat, ident.data(), count * sizeof(double), hipMemcpyHostToDevice));   // synchronous: `ident` is pageable and dies with this call
+    // ON the communicator's stream: ordered behind any in-place all-reduce on c->flat that is still running there (a null-stream copy
+    // is not ordered against a non-blocking stream and could overwrite partially reduced chunks)
+    HIP_TRY_C(hipMemcpyAsync(c->flat, c->h_inf, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     RCCL_TRY(R, R->AllReduce(c->flat, c->flat, count, ncclDouble, ncclMin, c->comm, c->stream));
   }
   // bounded like every other wait on the communicator (the peer this rank is feeding may itself be gone), and outside c->m so that an
@@ -282,6 +294,9 @@ void jn_comm_destroy(jn_comm* c) {
   if (Rccl* R = rccl()) if (c->comm) R->CommDestroy(c->comm);
   if (c->stream) hipStreamDestroy(c->stream);
   if (c->flat) hipFree(c->flat);
+  for (void* q : c->retired_dev) hipFree(q);
+  if (c->h_inf) hipHostFree(c->h_inf);
+  for (void* q : c->retired_host) hipHostFree(q);
   delete c;
 }
 

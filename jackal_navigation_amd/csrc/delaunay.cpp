@@ -9,6 +9,7 @@
 // Predicates are evaluated exactly in int64 (coordinates are pixel integers), which equals the
 // sign the reference's adaptive float predicates return (:2706-2745, :3334-3379).
 #include "delaunay.h"
+#include "hooks.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -357,7 +358,7 @@ int Delaunay::prepare(const int32_t* x, const int32_t* y, int n, int want_parts)
   // cutting pays once a part is worth more than the two extra pool rounds it costs (measured on the GPU box: 819 points
   // of a 640x480 pair 0.09 -> 0.135 ms when cut in four, 3232 points of a 1280x720 pair 0.63 -> 0.27 ms); the test hook
   // JN_DELAUNAY_MIN_POINTS lowers the bar so that small inputs exercise the cuts too
-  static const int min_pts = getenv("JN_DELAUNAY_MIN_POINTS") ? atoi(getenv("JN_DELAUNAY_MIN_POINTS")) : 1024;
+  static const int min_pts = JN_HOOK_ENV("JN_DELAUNAY_MIN_POINTS") ? atoi(JN_HOOK_ENV("JN_DELAUNAY_MIN_POINTS")) : 1024;
   int parts = (want_parts >= 4 && k >= 2 * min_pts) ? 4 : ((want_parts >= 2 && k >= min_pts) ? 2 : 1);
   if (parts == 1) part_[0] = Part{0, k, 0, 0, 0, 0, 0};
   else {

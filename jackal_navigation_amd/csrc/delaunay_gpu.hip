@@ -22,6 +22,7 @@
 // Time: the top merges are one thread each walking a seam of ~sqrt(n) steps through LDS; ~0.3 ms per 720p side, all sides of a batch
 // side by side on 64 CUs, no host round trip, no host cores.
 #include "kernels.h"
+#include "hooks.h"
 #include <algorithm>
 #include <mutex>
 
@@ -397,12 +398,23 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   if (tid == 0) fi->ntri[side] = s_scan[kDtThreads];
 }
 
+#ifdef JN_HOOKS
+__global__ void __launch_bounds__(kDtThreads) k_dt_dummy(int ticks) {
+  extern __shared__ uint8_t s_dummy[];
+  if (threadIdx.x == 0) { const long long t0 = wall_clock64(); while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32); }
+  __syncthreads();
+}
+#endif
+
 }  // namespace
 
 int delaunay_gpu_capacity(size_t lds_bytes) { return (int)((lds_bytes > 64 ? lds_bytes - 64 : 0) / kDtBytesPerVertex); }
 size_t delaunay_gpu_lds_bytes(int points) { return (size_t)((points + 3) & ~3) * kDtBytesPerVertex + 64; }
 
 hipError_t configure_delaunay_kernel() {
+#ifdef JN_HOOKS
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_dt_dummy), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+#endif
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
 
@@ -410,6 +422,16 @@ void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* 
                      int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock) {
   cap_pts = std::min(cap_pts, delaunay_gpu_capacity(152 * 1024));
   hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st);
+#ifdef JN_HOOKS
+  // experiment (what k_delaunay costs the pipeline, and why): a kernel that does nothing for JN_DT_DUMMY_US microseconds behind the real one,
+  // JN_DT_DUMMY=1: one wave and no LDS per workgroup (the wait alone), 2: 1024 threads and 152 KB (the wait on a CU nothing else fits on)
+  static const int dummy = JN_HOOK_ENV("JN_DT_DUMMY") ? atoi(JN_HOOK_ENV("JN_DT_DUMMY")) : 0;
+  static const int dummy_us = JN_HOOK_ENV("JN_DT_DUMMY_US") ? atoi(JN_HOOK_ENV("JN_DT_DUMMY_US")) : 870;
+  if (dummy == 1) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(64), 0, st, dummy_us * 100);
+  if (dummy == 2) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(kDtThreads), 152 * 1024, st, dummy_us * 100);
+  if (dummy == 3) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(64), 152 * 1024, st, dummy_us * 100);
+  if (dummy == 4) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(kDtThreads), 0, st, dummy_us * 100);
+#endif
   hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
                      payload, payload_stride, info, need_host, dbg_clock);
 }

@@ -12,6 +12,7 @@
 // Batch handles of processes with few cores of their own have NO host stage: the hull recursion runs on the GPU too (delaunay_gpu.hip),
 // FrameInfo and the payload are written on the device and stage B is queued right behind it (run_batch_route).
 #include "../../include/jn_stereo.h"
+#include "hooks.h"
 #include "kernels.h"
 #include "host_stage.h"
 #include "pool.h"
@@ -773,7 +774,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   // Sides with more vertices than the LDS can order (8192; a 1920x1080 frame has 11 k) could run k_arrange in global scratch
   // (up to 16384, JN_ARRANGE_GLOBAL=1), but through L2 the kernel takes milliseconds, which a batch of 8 such frames on 4
   // slots cannot hide: 4.6 k against 5.4 k pairs/s with the host doing it — off by default, those sides stay on the host.
-  h->arr_stride = (getenv("JN_ARRANGE_GLOBAL") && atoi(getenv("JN_ARRANGE_GLOBAL"))) ? std::min(dp.cw * dp.ch, 16384) : h->arr_cap;
+  h->arr_stride = (JN_HOOK_ENV("JN_ARRANGE_GLOBAL") && atoi(JN_HOOK_ENV("JN_ARRANGE_GLOBAL"))) ? std::min(dp.cw * dp.ch, 16384) : h->arr_cap;
   h->gpu_arrange = !h->hp.add_corners;                     // the six corner points join the list on the host
   if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
   // Batch handles triangulate on the GPU as well (a latency-mode handle keeps the host stage: two pool threads finish a 640x480 pair's
@@ -798,8 +799,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   h->wait_spin_us = max_batch > 1 ? 60 : 1000;
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
   if (const char* e = getenv("JN_COMM_TIMEOUT_MS")) h->comm_timeout_ms = atoi(e);
-  if (const char* e = getenv("JN_TEST_FAIL_SEQ")) h->test_fail_seq = atoll(e);
-  if (const char* e = getenv("JN_TEST_SLOT_DELAY_US")) {
+  if (const char* e = JN_HOOK_ENV("JN_TEST_FAIL_SEQ")) h->test_fail_seq = atoll(e);
+  if (const char* e = JN_HOOK_ENV("JN_TEST_SLOT_DELAY_US")) {
     for (const char* q = e; *q;) { h->test_slot_delay_us.push_back(atoi(q)); while (*q && *q != ',') q++; if (*q == ',') q++; }
   }
   h->pace = max_batch > 1 && slots > 1;
@@ -1265,7 +1266,7 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
   if (e == hipSuccess) {
     launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, arr_cap, d_arr, d_ok, nullptr, 0);
     long long* d_clk = nullptr;
-    const bool want_clk = getenv("JN_DT_CLOCKS") != nullptr;
+    const bool want_clk = JN_HOOK_ENV("JN_DT_CLOCKS") != nullptr;
     if (want_clk && hipMalloc(reinterpret_cast<void**>(&d_clk), 64 * sizeof(long long)) == hipSuccess) hipMemset(d_clk, 0, 64 * sizeof(long long));
     launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, arr_cap, delaunay_gpu_capacity(152 * 1024), d_pay, (long long)pay, d_info, d_need, d_clk);
     e = hipStreamSynchronize(nullptr);

@@ -5,6 +5,7 @@
 // in the same order (built with -ffp-contract=off; products/sums that must not fuse use
 // __fmul_rn/__fadd_rn explicitly).
 #include "kernels.h"
+#include "hooks.h"
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -1634,8 +1635,25 @@ DEV int match_pixel(const DevParams& dp, const uint4& a, bool elig, int d_plane,
 // plane prior is valid (elas.cpp:872), bits 0..13 = d_plane + 32 (elas.cpp:722), clamped to [-32, 8000] — every use of d_plane is a
 // comparison against a range inside [-radius - 1, disp_max + radius + 1], so the clamp changes nothing.
 enum { kOwnerBias = 32, kOwnerMax = 8000 };
+// The profiling switches (JN_OWNER_DBG, JN_DENSE_DBG: results WRONG) and the test hooks that send ordinary lists through the long-list routes
+// (JN_OWNER_FAST_MAX, JN_OWNER_SCAN_FROM: results unchanged) exist in the hooks build only (hooks.h); the release kernels have neither the
+// arguments nor the branches.
+#ifdef JN_HOOKS
+#define JN_OWNER_HOOK_PARAMS , int dbg, int fast_max, int scan_from
+#define JN_OWNER_HOOK_LOCALS
+#define JN_DENSE_HOOK_PARAMS , int dbg
+#define JN_DENSE_HOOK_LOCALS
+#define JN_DENSE_HOOK_PULL , "s"(dbg)
+#else
+#define JN_OWNER_HOOK_PARAMS
+#define JN_OWNER_HOOK_LOCALS constexpr int dbg = 0, fast_max = kBinLds, scan_from = kBinCap;
+#define JN_DENSE_HOOK_PARAMS
+#define JN_DENSE_HOOK_LOCALS constexpr int dbg = 0;
+#define JN_DENSE_HOOK_PULL
+#endif
 __global__ void __launch_bounds__(256) k_owner(DevParams dp, const FrameInfo* __restrict__ info, const TriRec* __restrict__ recs, int tri_cap,
-                                               const int32_t* __restrict__ bin_count, const BinEntry* __restrict__ bin_list, uint16_t* __restrict__ owner, int dbg, int fast_max, int scan_from) {
+                                               const int32_t* __restrict__ bin_count, const BinEntry* __restrict__ bin_list, uint16_t* __restrict__ owner JN_OWNER_HOOK_PARAMS) {
+  JN_OWNER_HOOK_LOCALS
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
   const int tx = blockIdx.x * 4 + wave, ty = blockIdx.y, fs = blockIdx.z, frame = fs >> 1, side = fs & 1;
@@ -1775,13 +1793,14 @@ __global__ void __launch_bounds__(256) k_owner(DevParams dp, const FrameInfo* __
 template <int NW>
 __global__ void __launch_bounds__(kDenseThreads) k_dense_row(DevParams dp, int n, const FrameInfo* __restrict__ info, const uint32_t* __restrict__ gridbits,
                                                              const uint8_t* __restrict__ planes, int Wp, int16_t* __restrict__ raw, int nbx, int nby,
-                                                             int xcd_order, int dbg, uint32_t nbx_magic, uint32_t nby_magic) {
+                                                             int xcd_order, uint32_t nbx_magic, uint32_t nby_magic JN_DENSE_HOOK_PARAMS) {
+  JN_DENSE_HOOK_LOCALS
   extern __shared__ uint4 s_Bx[];                            // kDense2Slack + [kTileH][kStripW + disp_max] + kDense2Slack
   // Every kernel argument the wave will need is pulled into scalar registers HERE, behind one wait: left alone the compiler fetches
   // them one basic block at a time, each fetch a scalar-cache round trip in series with the loads below.
   asm volatile("" :: "s"(info), "s"(gridbits), "s"(planes), "s"(Wp), "s"(raw),
                "s"(dp.W), "s"(dp.H), "s"(dp.disp_max), "s"(dp.gw), "s"(dp.gh), "s"(dp.grid_magic), "s"(dp.radius), "s"(dp.match_texture),
-               "s"(dp.P[0]), "s"(dp.P[1]), "s"(dp.P[2]), "s"(n), "s"(nbx), "s"(nby), "s"(dbg), "s"(nbx_magic), "s"(nby_magic));
+               "s"(dp.P[0]), "s"(dp.P[1]), "s"(dp.P[2]), "s"(n), "s"(nbx), "s"(nby), "s"(nbx_magic), "s"(nby_magic) JN_DENSE_HOOK_PULL);
   const int total = nbx * nby * 2 * n;
   int item = blockIdx.x;
   if (xcd_order) { const int per_xcd = (total + 7) / 8; item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3); }   // see k_dense
@@ -3081,10 +3100,10 @@ bool launch_support(hipStream_t st, const DevParams& dp, int n, const DescSrc& d
   // the segment itself, else of 128.  Alone, one workgroup per row is a little quicker (it stages every descriptor once);
   // among the other slots' kernels the small workgroups find room at once instead of queueing for 80 KB of LDS, and the
   // pipelined rate gains 1.5 % (profiles/r02_d_support_split_ab.txt).  JN_SUPPORT_SPLIT=k forces k segments (1 = one per row).
-  const int split = getenv("JN_SUPPORT_SPLIT") ? atoi(getenv("JN_SUPPORT_SPLIT")) : 0;
+  const int split = JN_HOOK_ENV("JN_SUPPORT_SPLIT") ? atoi(JN_HOOK_ENV("JN_SUPPORT_SPLIT")) : 0;
   if (split >= 1 && launch_support_bucket(st, dp, n, desc, d_can, split, dry)) return true;
   const int per = 2 * dp.disp_max + 8 <= 64 * dp.step ? 64 : 128;
-  static const int max_seg = getenv("JN_SUPPORT_SEGMENTS") ? atoi(getenv("JN_SUPPORT_SEGMENTS")) : 8;
+  static const int max_seg = JN_HOOK_ENV("JN_SUPPORT_SEGMENTS") ? atoi(JN_HOOK_ENV("JN_SUPPORT_SEGMENTS")) : 8;
   for (int nseg = std::min(std::max(1, (dp.cw + per - 1) / per), std::max(1, max_seg)); nseg <= std::max(1, max_seg); nseg++)
     if (launch_support_bucket(st, dp, n, desc, d_can, nseg, dry)) return true;       // more segments until the window fits a bucket
   if (launch_support_bucket(st, dp, n, desc, d_can, 1, dry)) return true;
@@ -3096,7 +3115,7 @@ bool launch_support(hipStream_t st, const DevParams& dp, int n, const DescSrc& d
 // 2: lattice and codes fit the LDS together (k_filter_resolve), 1: only the codes do (k_filter_resolve_big), 0: neither
 static int support_filters_form(const DevParams& dp, int win, int min_support) {
   static const bool wavefront_only = getenv("JN_FILTER_WAVEFRONT") != nullptr && atoi(getenv("JN_FILTER_WAVEFRONT")) != 0;
-  const char* kb = getenv("JN_FILTER_LDS_KB");
+  const char* kb = JN_HOOK_ENV("JN_FILTER_LDS_KB");
   const size_t budget_bytes = (size_t)(kb ? atoi(kb) : 150) * 1024;
   const size_t codes = (size_t)dp.cw * dp.ch, both = (size_t)(dp.cw + 10) * (dp.ch + 10) * sizeof(int16_t) + codes;
   if (win != 5 || wavefront_only || min_support < 1 || min_support > 254) return 0;
@@ -3114,9 +3133,9 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
     if (form == 2) {
       uint8_t* code = reinterpret_cast<uint8_t*>(scratch);          // [n][cw*ch], column-major
       hipLaunchKernelGGL(k_filter_classify<WIN>, dim3((dp.cw + 15) / 16, (dp.ch + 15) / 16, n), dim3(256), 0, st, dp, tol, min_support, d_can, code);
-      static const bool fuse_list = !(getenv("JN_FUSE_LIST") && atoi(getenv("JN_FUSE_LIST")) == 0);
+      static const bool fuse_list = !(JN_HOOK_ENV("JN_FUSE_LIST") && atoi(JN_HOOK_ENV("JN_FUSE_LIST")) == 0);
       const bool with_list = fuse_list && list && count && listed;
-      const int rounds = getenv("JN_FILTER_ROUNDS") ? atoi(getenv("JN_FILTER_ROUNDS")) : 1;      // read per launch (A/B, tests)
+      const int rounds = JN_HOOK_ENV("JN_FILTER_ROUNDS") ? atoi(JN_HOOK_ENV("JN_FILTER_ROUNDS")) : 1;      // read per launch (A/B, tests)
       hipLaunchKernelGGL(k_filter_resolve<WIN>, dim3(n), dim3(kFilterThreads), need, st, dp, tol, min_support, d_can, code,
                          with_list ? list : static_cast<int16_t*>(nullptr), count, list_cap, rounds);
       if (with_list) *listed = true;
@@ -3124,7 +3143,7 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
     }
   }
   // LDS budget in int16 cells (JN_FILTER_LDS_KB shrinks it: a test hook that forces the streamed variant)
-  const char* env = getenv("JN_FILTER_LDS_KB");
+  const char* env = JN_HOOK_ENV("JN_FILTER_LDS_KB");
   const int budget = (env ? atoi(env) : 150) * 1024 / (int)sizeof(int16_t);
   const int cw = dp.cw, ch = dp.ch, ph = ch + 2 * WIN, pwr = cw + 2 * WIN;
   int seg_c = 0, seg_r = 0, cells = pwr * ph;
@@ -3346,7 +3365,7 @@ void launch_bin(hipStream_t st, const DevParams& dp, int n, const FrameInfo* inf
   // One launch less matters on a lone pair's critical path (0.283-0.296 against 0.301-0.302 ms per 640x480 pair, same box); in a batch the
   // records' FP64 plane fits on one of a workgroup's four waves make the binning workgroups longer and the pipelined rate 2 % lower
   // (22.3 against 22.8 k pairs/s): small batches only.  JN_BIN_SETUP=0 / 1 forces one form (A/B).
-  static const int fuse_env = getenv("JN_BIN_SETUP") ? atoi(getenv("JN_BIN_SETUP")) : -1;
+  static const int fuse_env = JN_HOOK_ENV("JN_BIN_SETUP") ? atoi(JN_HOOK_ENV("JN_BIN_SETUP")) : -1;
   const bool fuse = fuse_env >= 0 ? fuse_env != 0 : n <= 2;
   if (payload && fuse) { hipLaunchKernelGGL(k_bin<true>, grid, dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list, payload, (long long)payload_stride); return; }
   if (payload) launch_tri_setup(st, dp, n, info, payload, payload_stride, max_tri, tri_cap, recs);
@@ -3361,7 +3380,7 @@ bool dense_row_applies(const DevParams& dp) {
 // dry: nothing is launched; the return value says whether the plane form takes these parameters.
 bool launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const TriRec* recs, int tri_cap,
                   const int32_t* bin_count, const BinEntry* bin_list, const uint32_t* gridbits, const DescSrc& desc, int16_t* raw, bool dry, hipEvent_t ev_owner) {
-  static const int xcd_order = getenv("JN_DENSE_XCD_ORDER") ? atoi(getenv("JN_DENSE_XCD_ORDER")) : 1;
+  static const int xcd_order = JN_HOOK_ENV("JN_DENSE_XCD_ORDER") ? atoi(JN_HOOK_ENV("JN_DENSE_XCD_ORDER")) : 1;
   const int nbx = (dp.W + kStripW - 1) / kStripW, nby = (dp.H + kTileH - 1) / kTileH;
   const int total = nbx * nby * 2 * n;
   const int blocks = xcd_order ? (total + 7) / 8 * 8 : total;
@@ -3372,20 +3391,27 @@ bool launch_dense(hipStream_t st, const DevParams& dp, int n, const FrameInfo* i
     if (!(dense_row_applies(dp) && magic_ok)) return false;
     if (dry) return true;
     const uint32_t nbx_magic = (uint32_t)(((1ull << 32) + nbx - 1) / nbx), nby_magic = (uint32_t)(((1ull << 32) + nby - 1) / nby);
-    static const int dbg = getenv("JN_DENSE_DBG") ? atoi(getenv("JN_DENSE_DBG")) : 0;
     const size_t lds2 = lds + 2 * kDense2Slack * sizeof(uint4);
     const int tiles_x = (dp.W + kTileW - 1) / kTileW, tiles_y = (dp.H + kTileH - 1) / kTileH;
-    static const int odbg = getenv("JN_OWNER_DBG") ? atoi(getenv("JN_OWNER_DBG")) : 0;          // profiling switches (results wrong): 1 no list loads, 2 no stores, 4 empty
+#ifdef JN_HOOKS
+    static const int dbg = JN_HOOK_ENV("JN_DENSE_DBG") ? atoi(JN_HOOK_ENV("JN_DENSE_DBG")) : 0;
+    static const int odbg = JN_HOOK_ENV("JN_OWNER_DBG") ? atoi(JN_HOOK_ENV("JN_OWNER_DBG")) : 0;          // profiling switches (results wrong): 1 no list loads, 2 no stores, 4 empty
     // test hooks (read per launch; results stay right): lists longer than JN_OWNER_FAST_MAX take the general loop, longer than JN_OWNER_SCAN_FROM the all-triangles scan
-    const char* e1 = getenv("JN_OWNER_FAST_MAX"); const char* e2 = getenv("JN_OWNER_SCAN_FROM");
+    const char* e1 = JN_HOOK_ENV("JN_OWNER_FAST_MAX"); const char* e2 = JN_HOOK_ENV("JN_OWNER_SCAN_FROM");
     const int fast_max = e1 ? std::min(atoi(e1), (int)kBinLds) : (int)kBinLds, scan_from = e2 ? std::min(atoi(e2), (int)kBinCap) : (int)kBinCap;
-    hipLaunchKernelGGL(k_owner, dim3((tiles_x + 3) / 4, tiles_y, 2 * n), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list, reinterpret_cast<uint16_t*>(raw), odbg, fast_max, scan_from);
+#define JN_OWNER_HOOK_ARGS , odbg, fast_max, scan_from
+#define JN_DENSE_HOOK_ARGS , dbg
+#else
+#define JN_OWNER_HOOK_ARGS
+#define JN_DENSE_HOOK_ARGS
+#endif
+    hipLaunchKernelGGL(k_owner, dim3((tiles_x + 3) / 4, tiles_y, 2 * n), dim3(256), 0, st, dp, info, recs, tri_cap, bin_count, bin_list, reinterpret_cast<uint16_t*>(raw) JN_OWNER_HOOK_ARGS);
     if (ev_owner) hipEventRecord(ev_owner, st);                // (timing of the matcher proper, jn_elas_kernel_time)
     const uint8_t* pl = static_cast<const uint8_t*>(desc.ptr);
     if (dp.disp_max < 128)
-      hipLaunchKernelGGL(k_dense_row<4>, dim3(blocks), dim3(kDenseThreads), lds2, st, dp, n, info, gridbits, pl, desc.Wp, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
+      hipLaunchKernelGGL(k_dense_row<4>, dim3(blocks), dim3(kDenseThreads), lds2, st, dp, n, info, gridbits, pl, desc.Wp, raw, nbx, nby, xcd_order, nbx_magic, nby_magic JN_DENSE_HOOK_ARGS);
     else
-      hipLaunchKernelGGL(k_dense_row<8>, dim3(blocks), dim3(kDenseThreads), lds2, st, dp, n, info, gridbits, pl, desc.Wp, raw, nbx, nby, xcd_order, dbg, nbx_magic, nby_magic);
+      hipLaunchKernelGGL(k_dense_row<8>, dim3(blocks), dim3(kDenseThreads), lds2, st, dp, n, info, gridbits, pl, desc.Wp, raw, nbx, nby, xcd_order, nbx_magic, nby_magic JN_DENSE_HOOK_ARGS);
     return true;
   }
   if (!dry && !desc.planes)
@@ -3479,7 +3505,7 @@ bool gap_mean_fusable(const DevParams& dp, int n) {
 void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const float* in, float* out, bool mean) {
   // rows per band: flat between 40 and 120 (0.209 / 0.206 / 0.205 / 0.202 / 0.197 / 0.205 / 0.214 ms at 40 / 48 / 60 / 72 / 80 / 90 / 120 rows, 720p batch 32,
   // scripts/post_band_sweep.sh): fewer halo rows against fewer workgroups
-  static const int band_rows = getenv("JN_POST_BAND") ? atoi(getenv("JN_POST_BAND")) : 80;
+  static const int band_rows = JN_HOOK_ENV("JN_POST_BAND") ? atoi(JN_HOOK_ENV("JN_POST_BAND")) : 80;
   const int bands = (dp.H + band_rows - 1) / band_rows, rows = (dp.H + bands - 1) / bands;
   hipLaunchKernelGGL(k_gap_mean_fused, dim3((dp.W + kPostCols - 1) / kPostCols, bands, n), dim3(256), 0, st, dp, info, in, out, rows, mean ? 1 : 0);
 }

@@ -5,6 +5,7 @@
 // The kernels are sgm_sweep.hip's four sweeps (lanes = pixels).  Round 2's one-wave-per-line kernels (lanes = disparities, eight u8 volumes,
 // 16 W H D bytes of traffic, 1.3 k pairs/s) lived here behind JN_SGM_IMPL=0 until round 5; their description and numbers: DESIGN_HISTORY.md.
 #include <hip/hip_runtime.h>
+#include "hooks.h"
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
@@ -106,7 +107,7 @@ jn_status jn_sgm_create(const jn_sgm_params* p, int32_t W, int32_t H, int32_t ma
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.gx), z.gx));
     SGM_CREATE_TRY(hipMemset(h->sb.gx, 0, z.gx));               // tag 0 = "never written" (sgm_sweep.hip, k_sw_w)
     h->sb.gx_bytes = z.gx;
-    if (const char* e = getenv("JN_SGM_EPOCH_START")) h->sb.epoch = (uint32_t)atoi(e) & 0xFFFFu;   // test hook: start next to the tag's wrap-around
+    if (const char* e = JN_HOOK_ENV("JN_SGM_EPOCH_START")) h->sb.epoch = (uint32_t)atoi(e) & 0xFFFFu;   // test hook: start next to the tag's wrap-around
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.flags), z.flags));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.minr), z.minr));
     SGM_CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->sb.dl), z.dl));

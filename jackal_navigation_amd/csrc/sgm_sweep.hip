@@ -36,6 +36,7 @@
 // The kernels work in x-mirrored image space (x_k = W-1-x), where the right-image tap x - d becomes x_k + d and the bytes a
 // lane needs ascend with d; the upward sweep is the downward one on the row-flipped image.
 #include <hip/hip_runtime.h>
+#include "hooks.h"
 #include <stdint.h>
 #include <algorithm>
 #include <cstdio>
@@ -935,7 +936,7 @@ namespace jnav_sgm {
 
 // strips (= computing waves) per workgroup of the row sweeps: 4 (JN_SGM_NS=2 or 8 for A/B; D = 256 always 4)
 static int strips_for(int D) {
-  const char* e = getenv("JN_SGM_NS");
+  const char* e = JN_HOOK_ENV("JN_SGM_NS");
   const int v = e ? atoi(e) : 4;
   return (D != 256 && (v == 2 || v == 8)) ? v : 4;
 }
@@ -946,7 +947,7 @@ static int strips_for(int D) {
 // JN_SGM_LQ=4 keeps the four-lane layout for A/B.
 static int lanes_per_pixel(int D) {
   if (D != 256) return 4;
-  const char* e = getenv("JN_SGM_LQ");
+  const char* e = JN_HOOK_ENV("JN_SGM_LQ");
   return e && atoi(e) == 4 ? 4 : 8;
 }
 
@@ -958,7 +959,7 @@ void sweep_geometry(int W, int H, int D, int P1, int P2, int cap, int lr, int su
   s->xmin = -(H - 1);
   s->NB = (W + H - 1 + BLK - 1) / BLK;
   s->wide = 3 * P2 > 255 ? 1 : 0;
-  s->dbg = getenv("JN_SGM_DBG") ? atoi(getenv("JN_SGM_DBG")) : 0;
+  s->dbg = JN_HOOK_ENV("JN_SGM_DBG") ? atoi(JN_HOOK_ENV("JN_SGM_DBG")) : 0;
   const size_t px = (size_t)W * H;
   z->gm = (size_t)2 * max_batch * H * s->Wp + 256;
   z->vol = (size_t)max_batch * px * D + 4096;                   // one byte volume (+ slack: where k_sw_w's lanes outside the image store); the F volume is twice that when wide
@@ -1003,7 +1004,7 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   const size_t px = (size_t)s.W * s.H;
   if ((e = hipEventRecord(ev[0], st)) != hipSuccess) return e;
 #ifdef JN_SGM_PROFILE
-  static const int exp_ = getenv("JN_SGM_EXP") ? atoi(getenv("JN_SGM_EXP")) : 0;   // attribution only (results WRONG): 1 no prefilter, 2 no L/R kernel, 8 no minima memset
+  static const int exp_ = JN_HOOK_ENV("JN_SGM_EXP") ? atoi(JN_HOOK_ENV("JN_SGM_EXP")) : 0;   // attribution only (results WRONG): 1 no prefilter, 2 no L/R kernel, 8 no minima memset
   if (!(exp_ & 1))
 #endif
   hipLaunchKernelGGL(k_sw_prefilter, dim3((s.Wp + 255) / 256, (s.H + 4 * kPreRows - 1) / (4 * kPreRows), 2 * n), dim3(256), 0, st, s, dI1, dI2, pitch, stride, n, b.gm);
@@ -1014,7 +1015,7 @@ static hipError_t run_all(const SwDev& s, int n, const uint8_t* dI1, const uint8
   if ((e = hipEventRecord(ev[1], st)) != hipSuccess) return e;
   constexpr int PXL = 64 / LQ;                                  // image rows per wave of the horizontal sweep = pixels per strip of the row sweeps
   // the horizontal sweep on the side stream, next to the downward sweep (JN_SGM_OVERLAP=0: one after the other on `st`, for A/B)
-  static const int overlap_env = getenv("JN_SGM_OVERLAP") ? atoi(getenv("JN_SGM_OVERLAP")) : -1;
+  static const int overlap_env = JN_HOOK_ENV("JN_SGM_OVERLAP") ? atoi(JN_HOOK_ENV("JN_SGM_OVERLAP")) : -1;
   const bool overlap = overlap_env >= 0 ? overlap_env != 0 : side_overlap;      // default: on for a lone synchronous batch, off when batches are pipelined over slots (the other slots fill the GPU; measured neutral to -3 % there)
   hipStream_t hs = st;
   if (overlap) {

@@ -3,6 +3,7 @@ import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["JN_DT_CLOCKS"] = "1"
+os.environ.setdefault("JN_STEREO_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jackal_navigation_amd", "libjn_stereo_hooks.so"))   # JN_DT_CLOCKS: hooks build only
 import jackal_navigation_amd as jn
 from oracle.binding import Oracle
 o = Oracle(); L = jn.load()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Attribution of the SGM mode's batch time (pipelined): what each part is worth when it is switched off (results are then WRONG).
-# Needs libjn_stereo_prof.so (make EXTRA=-DJN_SGM_PROFILE, copied aside).  Usage: gpurun -- bash scripts/sgm_attrib.sh
+# Needs libjn_stereo_prof.so: the hooks build with the sweeps' profiling branches (make -C jackal_navigation_amd/csrc hooks EXTRA=-DJN_SGM_PROFILE, then copy ../libjn_stereo_hooks.so aside under that name).  Usage: gpurun -- bash scripts/sgm_attrib.sh
 R=$(pwd); out=gpurun_out
 run() { python3 bench.py --mode sgm --sgm-slots ${SS:-6} --steps 18 --warmup 6 --no-cpu-baseline 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms per batch")'; }
 {

@@ -1,4 +1,5 @@
 #!/bin/bash
+export JN_STEREO_LIB=${JN_STEREO_LIB:-${GRAFT_REPO_ROOT:-$(pwd)}/jackal_navigation_amd/libjn_stereo_hooks.so}   # the switches used below exist in the hooks build only (csrc/hooks.h)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 timeout 300 python scripts/sgm_debug.py > gpurun_out/sgm_ns_debug.txt 2>&1; echo "debug rc=$?"; grep -E "differ|ALL OK|FAIL|rror" gpurun_out/sgm_ns_debug.txt | head
 for ns in 7 5 3; do

@@ -43,6 +43,15 @@ def jn():
     return jn
 
 
+@pytest.fixture
+def hooks(jn):
+    """For the duration of the test every call of the package goes to the HOOKS build (libjn_stereo_hooks.so, csrc/hooks.h): the
+    JN_TEST_* hooks, the route-forcing knobs (JN_OWNER_FAST_MAX, JN_FILTER_LDS_KB, JN_BM_BAND ...) exist only there.  A test that takes this
+    fixture says by that that it does NOT exercise the release library; everything else does."""
+    with jn.hooks_library() as L:
+        yield L
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

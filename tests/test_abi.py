@@ -79,6 +79,33 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in src.replace("# oracle", ""), os.path.join(dirpath, f)
 
 
+def _jn_strings(path):
+    import re
+    data = open(path, "rb").read()
+    return sorted(set(m.decode() for m in re.findall(rb"JN_[A-Z][A-Z0-9_]{2,}", data)))
+
+
+def test_release_library_carries_no_test_or_debug_switches(jn):
+    """a product .so must not compute wrong disparities (or fail batches, or stall slots) because an environment variable
+    leaked in.  The *_DBG profiling switches, the JN_TEST_* hooks and the A/B knobs exist only in the hooks build (csrc/hooks.h); what the
+    release library reads is exactly what INTEGRATION.md section 9's first table lists."""
+    import re
+    rel = _jn_strings(jn.LIB_PATH)
+    assert len(rel) <= 25, rel
+    assert not [v for v in rel if v.endswith("_DBG") or v.startswith("JN_TEST_") or v in ("JN_SGM_EXP", "JN_DT_CLOCKS")], rel
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 9. Environment switches"):]
+    first, second = sec.split("### 9b.")[0], sec.split("### 9b.")[1]
+    listed = set(re.findall(r"`(JN_[A-Z0-9_]+)`", "\n".join(l.split("|")[1] for l in first.split("\n") if l.startswith("| `"))))
+    assert set(rel) <= listed, sorted(set(rel) - listed)          # every switch that ships is documented
+    hooks = _jn_strings(jn.HOOKS_LIB_PATH)
+    assert set(rel) < set(hooks)                                   # the hooks build = the release switches + the hooks
+    listed_hooks = set(re.findall(r"`(JN_[A-Z0-9_]+)`", "\n".join(l.split("|")[1] for l in second.split("\n") if l.startswith("| `"))))
+    assert set(hooks) - set(rel) <= listed_hooks | {"JN_DT_DUMMY", "JN_DT_DUMMY_US", "JN_HOOKS"}, sorted(set(hooks) - set(rel) - listed_hooks)
+    for v in ("JN_TEST_FAIL_SEQ", "JN_DENSE_DBG", "JN_OWNER_FAST_MAX"):
+        assert v in hooks, v
+
+
 def test_synth_generator_matches_appendix_a(jn, oracle):
     import numpy as np
     a = jn.node.synth_pair(320, 180, 48, 12345)

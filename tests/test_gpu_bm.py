@@ -61,7 +61,7 @@ def test_bm_bit_exact_vs_its_definition(jn, bm, sgm, oracle, W, H, D, scene, n, 
 
 
 @pytest.mark.parametrize("band", ["8", "16", "37", "5", "64"])
-def test_bm_band_heights_give_the_same_map(jn, bm, oracle, monkeypatch, band):
+def test_bm_band_heights_give_the_same_map(jn, hooks, bm, oracle, monkeypatch, band):
     """The launch picks the rows per workgroup band from the batch size (JN_BM_BAND overrides): any height, the same bits."""
     monkeypatch.setenv("JN_BM_BAND", band)
     L, R = oracle.synth_pair(320, 200, 40, 9)
@@ -178,7 +178,7 @@ def test_bm_ssd_on_the_matrix_cores_bit_exact_vs_its_definition(jn, bm, sgm, ora
 
 
 @pytest.mark.parametrize("band", ["1", "7", "16", "37", "200"])
-def test_bm_ssd_band_heights_give_the_same_map(jn, bm, oracle, monkeypatch, band):
+def test_bm_ssd_band_heights_give_the_same_map(jn, hooks, bm, oracle, monkeypatch, band):
     """rows per wave (JN_BMQ_BAND overrides the launch's choice): the running sums restart per band, the bits must not change"""
     monkeypatch.setenv("JN_BMQ_BAND", band)
     L, R = oracle.synth_pair(320, 200, 40, 9)

@@ -40,7 +40,8 @@ def fake_rccl(tmp_path_factory):
 def run_ranks(fake, out_dir, scenario, env_per_rank, timeout=240):
     procs = []
     for r in range(2):
-        env = dict(os.environ, JN_RCCL_LIB=fake, JN_COMM_INIT_TIMEOUT_S="60")
+        # the ranks load the HOOKS build: JN_TEST_SLOT_DELAY_US / JN_TEST_FAIL_SEQ_MERGED (the skews and the failing batch) exist only there
+        env = dict(os.environ, JN_RCCL_LIB=fake, JN_COMM_INIT_TIMEOUT_S="60", JN_STEREO_LIB=os.path.join(ROOT, "jackal_navigation_amd", "libjn_stereo_hooks.so"))
         env.update(env_per_rank[r])
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mocks", "comm_rank_worker.py"), str(r), "2", str(out_dir), scenario],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))

@@ -122,7 +122,7 @@ def test_parameter_variations(jn, oracle, same, kw):
     assert st == (1 if kw.get("disp_min", 0) == 70 else 0)                      # JN_ERR_FEW_SUPPORT: outputs untouched, as elas.cpp:66-71
 
 
-def test_support_filters_on_device_and_on_host_agree(jn, oracle, same, monkeypatch):
+def test_support_filters_on_device_and_on_host_agree(jn, hooks, oracle, same, monkeypatch):
     """The support-point filters run in k_support_filters when the lattice fits its LDS wavefront and on the host
     workers otherwise; by default lone pairs also go to the host, which is faster for latency (JN_HOST_FILTERS=0/1 forces a route
     at create time).  Both routes must give the oracle's maps,
@@ -483,7 +483,7 @@ def test_subsampling_gives_the_reference_half_size_maps(jn, oracle, same, W, H, 
 
 
 @pytest.mark.parametrize("fast_max,scan_from", [(16, 64), (3, 64), (0, 64), (3, 6), (0, 0)])
-def test_every_ownership_route_gives_the_same_maps(jn, oracle, same, monkeypatch, fast_max, scan_from):
+def test_every_ownership_route_gives_the_same_maps(jn, hooks, oracle, same, monkeypatch, fast_max, scan_from):
     """k_owner resolves which triangle owns a pixel three ways: ranked cover words for lists of up to 16 triangles per 32x8 tile (every
     list at 720p so far), the largest covering triangle number entry by entry for longer lists, and a scan over all of a side's triangles
     for tiles whose list overflowed its 64 entries.  The two test hooks lower the thresholds so that ORDINARY lists take the other routes:

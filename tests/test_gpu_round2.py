@@ -730,7 +730,7 @@ def _scan_rounds(jn, W, H, B, S, rounds, comm_env, monkeypatch, fail_seq=None):
     return got, order
 
 
-def test_merges_are_queued_in_submission_order_when_slots_finish_out_of_order(jn, monkeypatch):
+def test_merges_are_queued_in_submission_order_when_slots_finish_out_of_order(jn, hooks, monkeypatch):
     """the only cross-rank ordering logic (merge_seq / submit_seq) under skew.  Slots 1 and 3 are held up before their
     merge turn (JN_TEST_SLOT_DELAY_US: what a longer host stage does), so batches reach the merge out of submission order; RCCL
     needs every rank to queue a communicator's collectives in ONE order: the queue order must still be 0, 1, 2, ... and the bins
@@ -743,7 +743,7 @@ def test_merges_are_queued_in_submission_order_when_slots_finish_out_of_order(jn
         assert isinstance(a, np.ndarray) and isinstance(b, np.ndarray) and np.array_equal(a, b)
 
 
-def test_a_failing_batch_keeps_its_turn_and_feeds_the_collective_the_identity(jn, monkeypatch):
+def test_a_failing_batch_keeps_its_turn_and_feeds_the_collective_the_identity(jn, hooks, monkeypatch):
     """A batch that dies on this rank before its merge (JN_TEST_FAIL_SEQ) must not strand anybody: it still takes its turn in the
     merge order and contributes the identity of MIN to the all-reduce its peers are waiting in, its jn_elas_wait reports the error,
     and every later batch completes with the right bins."""
@@ -790,6 +790,7 @@ import ctypes as C, os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 rank = int(os.environ["RANK"])
+os.environ["JN_STEREO_LIB"] = os.path.join(%r, "jackal_navigation_amd", "libjn_stereo_hooks.so")   # JN_TEST_FAIL_SEQ exists in the hooks build only
 if rank == 1:
     os.environ["JN_TEST_FAIL_SEQ"] = "2"
 os.environ["JN_COMM_TIMEOUT_MS"] = "20000"
@@ -822,7 +823,7 @@ with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, device=rank, slots=2, hos
     e.set_comm(None)
 comm.close()
 print("RANK", rank, res, flush=True)
-''' % ROOT)
+''' % (ROOT, ROOT))
     port = 29000 + os.getpid() % 900
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]

@@ -114,7 +114,7 @@ def test_sgm_config5_share_1080p_d256_subpixel(jn, sgm, oracle):
 
 
 @pytest.mark.gpu
-def test_sgm_launch_tag_wraps_around(jn, sgm, oracle, monkeypatch):
+def test_sgm_launch_tag_wraps_around(jn, hooks, sgm, oracle, monkeypatch):
     """The columns handed from block to block carry a 16-bit launch tag (sgm_sweep.hip); when it wraps the buffer is zeroed.  Start a
     handle three launches before the wrap, run a larger batch, then smaller ones across the wrap, then the larger one again."""
     from jackal_navigation_amd.device import DeviceArray

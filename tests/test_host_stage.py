@@ -112,7 +112,7 @@ def test_delaunay_degenerate_inputs(jn, oracle, same):
     assert triangulate(jn, same_pt)[0] == -1
 
 
-def test_delaunay_cut_into_parts_equals_the_sequential_run(jn, oracle, same, monkeypatch):
+def test_delaunay_cut_into_parts_equals_the_sequential_run(jn, hooks, oracle, same, monkeypatch):
     """The phased triangulation (2 or 4 parts on their own threads, merged afterwards; what jn_elas does when its pool has
     idle threads) must reproduce the sequential output exactly, triangle ORDER included — the order decides doubly
     covered pixels downstream.  Lattice points with and without duplicates, random points, sizes around the split
