@@ -19,8 +19,9 @@
 //     vertices per side in 152 KB (a 720p frame has 3 100 - 3 400).  Sides that do not fit, or whose vertices coincide (k_arrange hands
 //     those back: which duplicate survives depends on Triangle's randomised quicksort), set the frame's need_host flag and the slot's
 //     worker sends the batch through the host stage instead (jn_api.cpp).
-// Time: the top merges are one thread each walking a seam of ~sqrt(n) steps through LDS; ~0.3 ms per 720p side, all sides of a batch
-// side by side on 64 CUs, no host round trip, no host cores.
+// Time: the top merges are one thread each walking a seam of ~sqrt(n) steps through LDS (a lone wave issues one instruction every ~4.5
+// cycles whatever its kind: profiles/r06_lone_wave_probe.txt — the walk costs its instruction count); see DESIGN.md section 8 for the
+// measured per-level times.  All sides of a batch side by side on 64 CUs, no host round trip, no host cores.
 #include "kernels.h"
 #include "hooks.h"
 #include <algorithm>
@@ -35,13 +36,24 @@ namespace {
 // LDS pointers carry their address space: a plain (generic) pointer that is also volatile makes every access a FLAT instruction — through the
 // vector-memory path, several hundred nanoseconds each, which is what the first version of this kernel spent its 1.5 ms on.
 typedef __attribute__((address_space(3))) const int16_t lds_ci16;
-typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
-typedef __attribute__((address_space(3))) volatile int16_t lds_vi16;
+#ifdef JN_DT_NO_VOLATILE      // (probe build: scripts/probes/dt_no_volatile.sh)
+#define JN_DT_VOL
+#else
+#define JN_DT_VOL volatile
+#endif
+typedef __attribute__((address_space(3))) JN_DT_VOL uint16_t lds_vu16;
+typedef __attribute__((address_space(3))) JN_DT_VOL int16_t lds_vi16;
 struct DT {
   lds_ci16* X; lds_ci16* Y;                 // vertex coordinates
-  // volatile: every access is the 16-bit LDS operation it says.  Left to itself the compiler merges neighbouring halfword stores (the three
-  // of fresh(), org / dest pairs) into 4-, 8- and 16-byte ones at 2-byte alignment, and the triangles of the two-vertex leaves came out wrong
-  // on the device (a record is 6 bytes: odd slots start in the middle of a dword); nothing here would gain from wider accesses anyway.
+  // volatile: every access is the 16-bit LDS operation it says, in program order.  Round 5 added it after an intermediate version with 6-byte
+  // records gave wrong two-vertex leaves once the compiler had merged neighbouring halfword stores.  Looked into in round 6:
+  //  * NOT the hardware: ds_write_b16 / b32 / b64 / b96 / b128 land correctly at every byte offset 0..15 on gfx950, and the exact pattern
+  //    (two fresh() records of three halfwords through a plain pointer, which the compiler turns into ds_write_b16 + ds_write_b96 at 2-byte
+  //    alignment) comes out right (scripts/probes/lds_misaligned_store_probe.hip, profiles/r06_lds_misaligned_store_probe.txt);
+  //  * not this tree: with the 8-byte records below a build WITHOUT volatile (-DJN_DT_NO_VOLATILE: 97 ds_write_b16 + 26 ds_write_b32 instead
+  //    of 142 + 8) passes tests/test_gpu_delaunay.py and runs in the same time (757 against 760 us a batch, profiles/r06_dt_no_volatile.txt).
+  // So the fault was in that intermediate version, not in a misaligned-store rule; volatile stays because it costs nothing here and keeps the
+  // access widths what the source says (scripts/probes/dt_no_volatile.sh repeats the comparison after a compiler update).
   lds_vu16* LINK;                           // [3 T]: handle across that edge
   lds_vi16* VERT;                           // [3 T]: vertex or -1 (ghost corner)
   int budget;                               // loop iterations left before the node gives up (a corrupt structure must not spin for ever on the GPU; the frame then goes to the host)
@@ -74,13 +86,17 @@ struct DT {
   struct P { int v; double x, y; };
   __device__ __forceinline__ P pt(int v) const { return P{v, (double)X[v], (double)Y[v]}; }
   __device__ __forceinline__ static int sgn(double d) { return d > 0 ? 1 : (d < 0 ? -1 : 0); }
+  // (explicit fused multiply-adds: every product and sum below is an integer smaller than 2^53, so the fused and the unfused forms give the same
+  // exact value; the library is built with -ffp-contract=off, which would otherwise keep them apart — 7 and 22 instructions instead of 11 and 31)
   __device__ __forceinline__ static int orient(const P& a, const P& b, const P& c) {
-    return sgn((a.x - c.x) * (b.y - c.y) - (a.y - c.y) * (b.x - c.x));
+    return sgn(__builtin_fma(a.x - c.x, b.y - c.y, -((a.y - c.y) * (b.x - c.x))));
   }
   __device__ __forceinline__ int orient(int a, int b, int c) const { return orient(pt(a), pt(b), pt(c)); }
   __device__ __forceinline__ static int in_circle(const P& a, const P& b, const P& c, const P& d) {
     const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
-    return sgn((ax * ax + ay * ay) * (bx * cy - by * cx) + (bx * bx + by * by) * (cx * ay - cy * ax) + (cx * cx + cy * cy) * (ax * by - ay * bx));
+    const double al = __builtin_fma(ax, ax, ay * ay), bl = __builtin_fma(bx, bx, by * by), cl = __builtin_fma(cx, cx, cy * cy);
+    const double dbc = __builtin_fma(bx, cy, -(by * cx)), dca = __builtin_fma(cx, ay, -(cy * ax)), dab = __builtin_fma(ax, by, -(ay * bx));
+    return sgn(__builtin_fma(al, dbc, __builtin_fma(bl, dca, cl * dab)));
   }
 
   // the 2- and 3-vertex base cases (delaunay.cpp conquer(), triangle.cpp:5964-6060)
@@ -288,7 +304,7 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
                                                          int32_t* __restrict__ need_host, long long* __restrict__ dbg_clock) {
   extern __shared__ uint8_t s_dt[];
   __shared__ int s_f[kDtMaxDepth + 2], s_c[kDtMaxDepth + 2][2], s_K;
-  __shared__ int s_scan[kDtThreads + 1];
+  __shared__ int s_scan[132];
   const int frame = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
   const int n = count[frame];
   const int nlist = min(n, list_cap);
@@ -298,21 +314,25 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   const long long sup_bytes = (long long)nlist * 12, side_bytes = (2ll * nlist + 8) * 12;
   if (side == 0 && tid == 0) {
     fi->nsup = nlist; fi->ok = nlist >= 3 ? 1 : 0;                         // elas.cpp:66-71
-    fi->sup_offset = base; fi->corner_offset[0] = base + sup_bytes; fi->corner_offset[1] = base + sup_bytes + side_bytes; fi->reserved = 0;
+    fi->sup_offset = base; fi->corner_offset[0] = base + sup_bytes; fi->corner_offset[1] = base + sup_bytes + side_bytes;
+    fi->reserved = n;                                                      // what the list held, clipped or not: the host sizes the next launches by it
   }
   if (nlist < 3) { if (tid == 0) fi->ntri[side] = 0; return; }
+  const int16_t* t = list + (size_t)frame * list_cap * 3;
+  int32_t* sup_out = reinterpret_cast<int32_t*>(payload + base);
   if (n > list_cap || n > cap_pts || !arr_ok[frame * 2 + side]) {          // not for this kernel: the host stage takes the batch
+    // The frame is still marked ok and stage B is queued behind this kernel: the OTHER side's triangles index the support points, so they
+    // are written here too (they were left stale, and the batch's first, discarded pass ran on whatever the payload held).
+    if (side == 0) for (int i = tid; i < nlist; i += kDtThreads) { sup_out[3 * i] = t[3 * i] * step; sup_out[3 * i + 1] = t[3 * i + 1] * step; sup_out[3 * i + 2] = t[3 * i + 2]; }
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;
   }
-  const int16_t* t = list + (size_t)frame * list_cap * 3;
   // LDS: X, Y, A, HL, HR [n] 16-bit each | LINK, VERT [4 T], T = 2 n (count(n) <= 2 n - 2)
   const int np = (n + 3) & ~3, T = 2 * n;
   int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
   uint16_t* A = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HL = A + np; uint16_t* HR = HL + np;
   uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
   const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
-  int32_t* sup_out = reinterpret_cast<int32_t*>(payload + base);
   for (int i = tid; i < n; i += kDtThreads) {
     const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
     X[i] = (int16_t)(side ? u - d : u); Y[i] = (int16_t)v;                  // right image: (u - d, v), elas.cpp:466-467
@@ -382,20 +402,29 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   const int per = (total + kDtThreads - 1) / kDtThreads, t0 = tid * per, t1 = min(t0 + per, total);
   int mine = 0;
   for (int s = t0; s < t1; s++) mine += (VERT[4 * s] | VERT[4 * s + 1] | VERT[4 * s + 2]) >= 0 ? 1 : 0;
-  s_scan[tid + 1] = mine;
-  if (tid == 0) s_scan[0] = 0;
+  // exclusive scan of the 1024 counts: within the wave by DPP row shifts + two cross-row steps, across the sixteen waves through LDS
+  // (one thread used to add up 1024 entries while 1023 waited)
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += up; }
+  if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
   __syncthreads();
-  if (tid == 0) for (int i = 1; i <= kDtThreads; i++) s_scan[i] += s_scan[i - 1];
+  if (tid < 64) {
+    const int v = tid < kDtThreads / 64 ? s_scan[tid] : 0;
+    int w = v;
+    for (int d = 1; d < kDtThreads / 64; d <<= 1) { const int up = __shfl_up(w, d, 64); if (tid >= d) w += up; }
+    if (tid < kDtThreads / 64) s_scan[64 + tid] = w - v;                  // exclusive wave offsets
+    if (tid == kDtThreads / 64 - 1) s_scan[128] = w;                      // the side's triangle count
+  }
   __syncthreads();
   int32_t* tri = reinterpret_cast<int32_t*>(payload + base + sup_bytes + (side ? side_bytes : 0));
-  int out = s_scan[tid];
+  int out = s_scan[64 + (tid >> 6)] + incl - mine;
   for (int s = t0; s < t1; s++) {
     const int c0 = VERT[4 * s], c1 = VERT[4 * s + 1], c2 = VERT[4 * s + 2];
     if ((c0 | c1 | c2) < 0) continue;
     tri[3 * out] = c1; tri[3 * out + 1] = c2; tri[3 * out + 2] = c0;
     out++;
   }
-  if (tid == 0) fi->ntri[side] = s_scan[kDtThreads];
+  if (tid == 0) fi->ntri[side] = s_scan[128];
 }
 
 #ifdef JN_HOOKS
@@ -418,10 +447,10 @@ hipError_t configure_delaunay_kernel() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
 
-void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
+hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                      int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock) {
   cap_pts = std::min(cap_pts, delaunay_gpu_capacity(152 * 1024));
-  hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st);
+  if (const hipError_t e = hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st); e != hipSuccess) return e;
 #ifdef JN_HOOKS
   // experiment (what k_delaunay costs the pipeline, and why): a kernel that does nothing for JN_DT_DUMMY_US microseconds behind the real one,
   // JN_DT_DUMMY=1: one wave and no LDS per workgroup (the wait alone), 2: 1024 threads and 152 KB (the wait on a CU nothing else fits on)
@@ -434,6 +463,7 @@ void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* 
 #endif
   hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
                      payload, payload_stride, info, need_host, dbg_clock);
+  return hipGetLastError();
 }
 
 }  // namespace jnav

@@ -83,6 +83,9 @@ struct Slot {
   int16_t* h_can = nullptr; FrameInfo* h_info = nullptr; uint8_t* h_payload = nullptr;
   int16_t* h_list = nullptr; int32_t* h_cnt = nullptr;       // support lists the GPU writes straight into pinned memory
   uint16_t* h_arr = nullptr; int32_t* h_arr_ok = nullptr;    // alternating-cut arrangements per frame side (k_arrange), same route
+  // the same four buffers in DEVICE memory, for handles that triangulate on the GPU: k_arrange and k_delaunay then read the list and the
+  // arrangement from HBM instead of pulling ~26 KB per frame side over PCIe at the start of two latency-bound kernels
+  int16_t* d_list = nullptr; int32_t* d_cnt = nullptr; uint16_t* d_arr = nullptr; int32_t* d_arr_ok = nullptr;
   int arr_hint = 0;                                           // most support points a frame of this slot's last kArrHist batches had
   static constexpr int kArrHist = 4;
   int arr_hist[kArrHist] = {0, 0, 0, 0}; int arr_pos = 0;
@@ -280,10 +283,19 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
   }
   const int list_cap = dp.cw * dp.ch;
   bool listed = false;                                   // k_filter_resolve wrote the support list too
+  // Where the list and the arrangement live: in device memory when this batch is going to triangulate on the GPU (everything that decides
+  // it is known here except whether the filter kernel lists the points itself: if it does not, the list goes to pinned memory and the host
+  // route is taken), in pinned host memory for the host stage.
+  const bool want_gpu_dt = h->gpu_delaunay && !force_host && sa == st && s.d_list && s.arr_hint <= delaunay_gpu_capacity(152 * 1024) &&
+                           h->gpu_arrange && s.arr_hint <= h->arr_stride;
+  int16_t* const list_buf = want_gpu_dt ? s.d_list : s.h_list; int32_t* const cnt_buf = want_gpu_dt ? s.d_cnt : s.h_cnt;
+  uint16_t* const arr_buf = want_gpu_dt ? s.d_arr : s.h_arr; int32_t* const arr_ok_buf = want_gpu_dt ? s.d_arr_ok : s.h_arr_ok;
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
-      launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp, s.h_list, s.h_cnt, list_cap, &listed);
+      launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp, list_buf, cnt_buf, list_cap, &listed);
   HIP_TRY(mark_a(EV_SUPPORT));
   bool arranged = false, gpu_dt = false;
+  if (filtered && want_gpu_dt && !listed)                // (a filter route that does not list: this batch through the host stage, lists and all)
+    return run_batch_route(h, s, j, turn, true);
   if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
     if (!listed) launch_support_list(sa, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
     // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
@@ -293,17 +305,16 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
     // The triangulation itself on the GPU (delaunay_gpu.hip) wherever it applies: batch handles, no corner points, lattices the LDS holds.
     // Then there is NO host stage: k_delaunay writes FrameInfo and the payload on the device, stage B is queued right behind it with
     // capacity-sized launches, and the worker only waits for the batch's end.
-    gpu_dt = h->gpu_delaunay && !force_host && listed && sa == st && s.arr_hint <= delaunay_gpu_capacity(152 * 1024);
+    gpu_dt = want_gpu_dt && listed;
     arranged = h->gpu_arrange && (gpu_dt || delaunay_parts(h, n) == 1) && s.arr_hint <= h->arr_stride;
-    gpu_dt = gpu_dt && arranged;
     if (arranged) {
       const int want = s.arr_hint ? s.arr_hint + s.arr_hint / 4 + 64 : h->arr_cap;
       // more points than the LDS can order (1920x1080: 11 k): every side works in its slice of the global scratch, the launch asks for the minimum of LDS
       const int cap = s.arr_hint > h->arr_cap ? 1024 : std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
-      launch_arrange(sa, n, s.h_list, s.h_cnt, list_cap, dp.step, cap, h->arr_stride, s.h_arr, s.h_arr_ok, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
+      launch_arrange(sa, n, list_buf, cnt_buf, list_cap, dp.step, cap, h->arr_stride, arr_buf, arr_ok_buf, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
       if (gpu_dt)                                        // LDS for what the slot's last batches held (+25 %), as the arrangement; a side beyond it goes to the host
-        launch_delaunay(sa, n, s.h_list, s.h_cnt, list_cap, dp.step, s.h_arr, s.h_arr_ok, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
-                        (long long)h->payload_cap, s.info, s.need_host);
+        HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
+                                (long long)h->payload_cap, s.info, s.need_host));
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -318,7 +329,7 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
   // GPU has just written, so the grid is queued HERE, behind stage A, and is built while the host triangulates (JN_GRID_EARLY=0: in stage B).
   static const bool grid_early_env = !(getenv("JN_GRID_EARLY") && atoi(getenv("JN_GRID_EARLY")) == 0);
   const bool grid_early = grid_early_env && filtered && !dp.add_corners && sa == st;
-  if (grid_early) launch_grid_from_list(st, dp, n, s.h_list, s.h_cnt, list_cap, s.mark, s.gridbits);
+  if (grid_early) launch_grid_from_list(st, dp, n, list_buf, cnt_buf, list_cap, s.mark, s.gridbits);
   auto queue_stage_b = [&](int max_sup, int max_tri, bool any_ok, const uint8_t* payload, size_t payload_bytes, bool cleared, bool device_info = false) -> jn_status {
     HIP_TRY(mark(EV_H2D0));
     if (!device_info) HIP_TRY(hipMemcpyAsync(s.info, s.h_info, sizeof(FrameInfo) * n, hipMemcpyHostToDevice, st));
@@ -407,7 +418,7 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
     HIP_TRY(wait_event(s.ev[EV_END], h->wait_spin_us));
     HIP_TRY(hipGetLastError());
     int batch_most = 0, handed_back = 0;
-    for (int i = 0; i < n; i++) { batch_most = std::max(batch_most, (int)s.h_cnt[i]); handed_back |= s.h_need[i]; }
+    for (int i = 0; i < n; i++) { batch_most = std::max(batch_most, (int)s.h_info[i].reserved); handed_back |= s.h_need[i]; }   // (k_delaunay leaves the frame's support count, clipped or not, in `reserved`)
     s.arr_hist[s.arr_pos] = batch_most; s.arr_pos = (s.arr_pos + 1) % Slot::kArrHist;
     s.arr_hint = *std::max_element(s.arr_hist, s.arr_hist + Slot::kArrHist);
     if (handed_back) {                                   // coinciding vertices or more of them than the launch's LDS held: the whole batch again, host stage and all
@@ -863,6 +874,11 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr), B * 2 * (size_t)h->arr_stride * sizeof(uint16_t), hipHostMallocDefault));
     if (h->arr_stride > h->arr_cap) CREATE_TRY(hipMalloc(&s->arr_scratch, arrange_scratch_bytes((int)B, h->arr_stride)));
     CREATE_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_arr_ok), B * 2 * sizeof(int32_t), hipHostMallocDefault));
+    if (h->gpu_delaunay) {
+      CREATE_TRY(dmalloc(&s->d_list, B * dp.cw * dp.ch * 3)); CREATE_TRY(dmalloc(&s->d_cnt, B));
+      CREATE_TRY(dmalloc(&s->d_arr, B * 2 * (size_t)h->arr_stride)); CREATE_TRY(dmalloc(&s->d_arr_ok, B * 2));
+      CREATE_TRY(hipMemset(s->payload, 0, B * h->payload_cap));      // (a side k_delaunay hands back leaves its part unwritten: never uninitialised memory)
+    }
   }
   h->s_pitch = dp.pitch;
   CREATE_TRY(dmalloc(&h->s_img, 2 * (size_t)H * dp.pitch));
@@ -893,6 +909,7 @@ void jn_elas_destroy(jn_elas* h) {
     if (s->ev_head) hipEventDestroy(s->ev_head);
     if (s->ev_owner) hipEventDestroy(s->ev_owner);
     hipFree(s->need_host); if (s->h_need) hipHostFree(s->h_need);
+    hipFree(s->d_list); hipFree(s->d_cnt); hipFree(s->d_arr); hipFree(s->d_arr_ok);
     if (s->gate) hipFree(s->gate);
     if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);

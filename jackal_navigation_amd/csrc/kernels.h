@@ -48,7 +48,7 @@ void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* c
 int delaunay_gpu_capacity(size_t lds_bytes);          // vertices per side that fit
 size_t delaunay_gpu_lds_bytes(int points);
 hipError_t configure_delaunay_kernel();
-void launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
+hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                      int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host,
                      long long* dbg_clock = nullptr);   // dbg_clock (optional, 64 entries): 100 MHz time stamps per tree level of frame 0's sides
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
