@@ -611,9 +611,11 @@ def run_rank(a):
     # the cross-rig merge: the library's own RCCL communicator (C-ABI), torch.distributed as the alternative
     comm, merge_kind, comm_info = None, None, None
     if dist is not None:
-        if on_gpu and a.merge == "cabi":
+        # the C-ABI communicator needs device buffers, not an NCCL process group: with --dist-backend gloo it is still used when JN_RCCL_LIB
+        # names the library to bind (the dry run of an N-rank job on one GPU: tests/mocks/fake_rccl.cpp, --share-gpu)
+        if (on_gpu or os.environ.get("JN_RCCL_LIB")) and a.merge == "cabi":
             def exchange(raw):
-                t = torch.zeros(128, dtype=torch.uint8, device=dev)
+                t = torch.zeros(128, dtype=torch.uint8, device=dev if on_gpu else "cpu")
                 if raw is not None:
                     t.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
                 dist.broadcast(t, src=0)
@@ -625,7 +627,7 @@ def run_rank(a):
             except _lib.JnError as e:
                 print("bench.py rank %d: %s; falling back to torch.distributed for the merge" % (rank, e), file=sys.stderr)
                 comm = None
-            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            ok = torch.tensor([1 if comm is not None else 0], device=dev if on_gpu else "cpu")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)                      # all ranks take the same route
             if int(ok.item()) == 0 and comm is not None:
                 comm.close(); comm = None

@@ -14,7 +14,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 rank, world, out_dir, scenario = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-W, H, B, S, ROUNDS = 320, 180, 2, 4, 3
+W, H, B, S = 320, 180, 2, 4
+ROUNDS = int(os.environ.get("JN_WORKER_ROUNDS", "3"))             # batches per slot
+HOST_THREADS = int(os.environ.get("JN_WORKER_HOST_THREADS", "4"))  # what bench.py passes a rank of an N-rank job: its share of the CPU quota
 N = S * ROUNDS
 
 
@@ -42,12 +44,12 @@ def main():
             return raw
         t0 = time.time()
         while not os.path.exists(path):
-            if time.time() - t0 > 60:
+            if time.time() - t0 > float(os.environ.get("JN_WORKER_ID_WAIT_S", "60")):
                 raise RuntimeError("rank 0 never wrote the communicator id")
             time.sleep(0.01)
         return open(path, "rb").read()
 
-    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=4) as e:
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=HOST_THREADS) as e:
         bufs = [dict(d1=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)), d2=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)),
                      u8=DeviceArray((B, H, W), np.uint8), bins=DeviceArray((B, sp.bins), np.float64), meta=DeviceArray((B, 4), np.float64),
                      st=(C.c_int32 * B)()) for _ in range(S)]
@@ -77,7 +79,7 @@ def main():
     fail_seq = os.environ.get("JN_TEST_FAIL_SEQ_MERGED")
     if fail_seq is not None:
         os.environ["JN_TEST_FAIL_SEQ"] = fail_seq
-    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=4) as e:
+    with jn.Elas(jn.Elas.parameters(0), W, H, max_batch=B, slots=S, host_threads=HOST_THREADS) as e:
         bufs = [dict(d1=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)), d2=DeviceArray.from_numpy(np.zeros((B, H, W), np.float32)),
                      u8=DeviceArray((B, H, W), np.uint8), bins=DeviceArray((B, sp.bins), np.float64), meta=DeviceArray((B, 4), np.float64),
                      st=(C.c_int32 * B)()) for _ in range(S)]
@@ -111,6 +113,7 @@ def main():
             finish(s0, k0)
         elapsed = time.time() - t0
         order = e.merge_order()
+        route = [list(e.route_stats(sl)) for sl in range(S)]      # per slot: [GPU triangulation route chosen, batches handed back to the host, plane flow]
         # the one-call form on both ranks (plain scenario): min over ranks of a buffer that differs per rank
         direct = None
         if scenario == "plain":
@@ -124,7 +127,7 @@ def main():
     ok_meta = [g[1] if isinstance(g, tuple) else np.full((B, 4), np.nan) for g in got]
     np.save(os.path.join(out_dir, "merged_bins%d.npy" % rank), np.stack(ok_bins))
     np.save(os.path.join(out_dir, "merged_meta%d.npy" % rank), np.stack(ok_meta))
-    json.dump({"status": [0 if isinstance(g, tuple) else g for g in got], "order": order, "elapsed": elapsed, "info": list(info), "direct": direct},
+    json.dump({"status": [0 if isinstance(g, tuple) else g for g in got], "order": order, "elapsed": elapsed, "info": list(info), "direct": direct, "route": route},
               open(os.path.join(out_dir, "report%d.json" % rank), "w"))
 
 

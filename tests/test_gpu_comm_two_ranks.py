@@ -39,11 +39,12 @@ def fake_rccl(tmp_path_factory):
 
 def run_ranks(fake, out_dir, scenario, env_per_rank, timeout=240):
     procs = []
-    for r in range(2):
+    world = len(env_per_rank)
+    for r in range(world):
         # the ranks load the HOOKS build: JN_TEST_SLOT_DELAY_US / JN_TEST_FAIL_SEQ_MERGED (the skews and the failing batch) exist only there
         env = dict(os.environ, JN_RCCL_LIB=fake, JN_COMM_INIT_TIMEOUT_S="60", JN_STEREO_LIB=os.path.join(ROOT, "jackal_navigation_amd", "libjn_stereo_hooks.so"))
         env.update(env_per_rank[r])
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mocks", "comm_rank_worker.py"), str(r), "2", str(out_dir), scenario],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mocks", "comm_rank_worker.py"), str(r), str(world), str(out_dir), scenario],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     t0 = time.time()
     outs = []
@@ -143,3 +144,51 @@ def test_a_rank_that_dies_mid_run_makes_its_peer_fail_fast_not_hang(fake_rccl, t
     mb0 = np.load(os.path.join(tmp_path, "merged_bins0.npy"))
     lb0 = np.load(os.path.join(tmp_path, "local_bins0.npy"))
     assert (mb0[:6] <= lb0[:6]).all()                                                  # merged = min(own, peer's)
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_take_the_gpu_route_and_merge_in_order(fake_rccl, tmp_path):
+    """what an 8-GPU job will run, before the driver's node does.  EIGHT rank processes on device 0 through the product: every
+    rank a handle with its share of the CPU quota as `host_threads` (2: below the library's bar, so the triangulations run on the GPU and
+    there is no host stage), 4 slots x 6 scan batches, the slots held up differently on every rank, the cross-rig merge as every batch's tail
+    over an eight-rank communicator.  Every rank must have taken the GPU triangulation route with no batch handed back, issued its 24 merges
+    in submission order, and hold the same robot-level bins: the element-wise MIN over the eight ranks' own scans (extrema: MIN / MAX)."""
+    world, rounds = 8, 6
+    n = S * rounds
+    skews = ["0,6000,0,3000", "4000,0,0,1000", "0,0,5000,0", "2000,2000,0,0", "0,0,0,7000", "1000,3000,500,0", "0,0,0,0", "3000,0,3000,0"]
+    env = [{"JN_TEST_SLOT_DELAY_US": skews[r], "JN_WORKER_ROUNDS": str(rounds), "JN_WORKER_HOST_THREADS": "2", "JN_COMM_TIMEOUT_MS": "120000", "JN_WORKER_ID_WAIT_S": "300", "JN_COMM_INIT_TIMEOUT_S": "300"} for r in range(world)]
+    rc, outs, _ = run_ranks(fake_rccl, tmp_path, "many", env, timeout=600)
+    assert rc == [0] * world, outs
+    reps = [load(tmp_path, r) for r in range(world)]
+    for r, (rep, mb, mm, lb, lm) in enumerate(reps):
+        assert rep["info"] == [r, world, 0], rep["info"]
+        assert rep["status"] == [0] * n, (r, rep["status"])
+        assert rep["order"] == list(range(n)), (r, rep["order"])
+        assert all(rt[0] == 1 and rt[1] == 0 for rt in rep["route"]), (r, rep["route"])     # GPU triangulation, nothing handed back to the host
+    eb = np.minimum.reduce([x[3] for x in reps])
+    em = reps[0][4].copy()
+    em[..., 0::2] = np.minimum.reduce([x[4][..., 0::2] for x in reps]); em[..., 1::2] = np.maximum.reduce([x[4][..., 1::2] for x in reps])
+    for r, (rep, mb, mm, lb, lm) in enumerate(reps):
+        assert np.array_equal(mb, eb) and np.array_equal(mm, em), r
+    assert len({x[3].tobytes() for x in reps}) == world                                  # eight different sets of rigs
+
+
+@pytest.mark.timeout(1200)
+def test_bench_dry_run_with_eight_ranks_on_one_gpu(fake_rccl):
+    """`bench.py --gpus 8` as the driver will start it — eight rank processes, pinning plan, quota / 8 as `host_threads`, the merge as
+    every batch's tail through the C-ABI communicator — on ONE GPU: --share-gpu, gloo for torch.distributed's rendezvous and barriers,
+    the library's communicator bound to the stand-in RCCL.  The line must carry eight `ranks` entries that report an eight-rank
+    communicator, a merge time, and no failed pair."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--dist-backend", "gloo", "--steps", "6", "--warmup", "2",
+           "--width", "640", "--height", "480", "--disp", "64", "--batch", "2", "--slots", "2", "--min-time", "0", "--no-cpu-baseline", "--no-latency-config", "--no-alone-leg"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(JN_RCCL_LIB=fake_rccl, JN_COMM_INIT_TIMEOUT_S="300", JN_BENCH_STARTUP_TIMEOUT_S="600")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1100, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 8 and sorted(r["rank"] for r in j["ranks"]) == list(range(8))
+    assert all(r["rccl_comm"] and r["rccl_comm"][1] == 8 for r in j["ranks"]), j["ranks"]
+    assert j["merge"]["merge_ms_per_step"] is not None and j["merge"]["merge_ms_per_step"] > 0
+    assert "jn_elas_set_comm" in j["merge"]["kind"]
+    assert j["value"] > 0 and j["config"]["pairs_failed"] == 0
+    assert j["config"]["host_threads"] <= 4                                       # a rank's share of the quota: the GPU triangulation route
