@@ -192,12 +192,13 @@ def bench_golden(W, H, scene, disp_max):
     only for the other recorded configurations (reference_hashes.txt + scan_golden.json)."""
     out = {}
     g = os.path.join(ROOT, "tests", "golden")
-    try:
-        j = json.load(open(os.path.join(g, "bench_batch_golden.json")))
-        if j.get("config") == [W, H, scene, disp_max]:
-            out = {int(k): v for k, v in j.items() if k.isdigit()}
-    except (OSError, ValueError):
-        pass
+    for name in ("bench_batch_golden.json", "bench_vga_golden.json"):
+        try:
+            j = json.load(open(os.path.join(g, name)))
+            if j.get("config") == [W, H, scene, disp_max]:
+                out = {int(k): v for k, v in j.items() if k.isdigit()}
+        except (OSError, ValueError):
+            pass
     if 12345 not in out:
         h = golden_hash(W, H, scene, disp_max)
         if h:
@@ -873,7 +874,7 @@ def run_rank(a):
             extra["block_matching"] = {"error": repr(exc)}
 
     # north_star asks for the rate at 640x480 too: the same pipelined path (ELAS -> u8 map -> scan, inputs resident, four batches of 32 in
-    # flight) on 640x480 D=64 Appendix-A pairs, informational, outside `value`; frame 0 of every slot against the compiled reference's hash
+    # flight) on 640x480 D=64 Appendix-A pairs, informational, outside `value`; EVERY frame of every slot against the compiled reference (round 6)
     vga = None
     if rank == 0 and world == 1 and not a.no_latency_config and (W, H) != (640, 480):
         try:
@@ -881,7 +882,10 @@ def run_rank(a):
             L3 = np.empty((b3, h3, w3), np.uint8); R3 = np.empty((b3, h3, w3), np.uint8)
             for b in range(b3):
                 L3[b], R3[b] = node.synth_pair(w3, h3, d3, 12345 + b)
-            tL3, tR3 = torch.from_numpy(L3).to(dev), torch.from_numpy(R3).to(dev)
+            # one DISTINCT copy of the batch per slot (rotated by slot * B / S frames, as the headline's), every frame of every slot checked
+            rot3 = [(sl * b3) // S for sl in range(S)]
+            tL3 = [torch.from_numpy(np.roll(L3, -rot3[sl], axis=0)).to(dev) for sl in range(S)]
+            tR3 = [torch.from_numpy(np.roll(R3, -rot3[sl], axis=0)).to(dev) for sl in range(S)]
             e3 = jn.Elas(jn.Elas.parameters(jn.Elas.ROBOTICS, disp_max=d3 - 1), w3, h3, max_batch=b3, device=local_rank, host_threads=host_threads, slots=S)
             sp3 = node.scan_params(w3, h3); lut3 = node.build_valid_disp_lut(sp3, w3, h3, device=local_rank)
             o1 = [torch.zeros((b3, h3, w3), dtype=torch.float32, device=dev) for _ in range(S)]; o2 = [torch.zeros_like(x) for x in o1]
@@ -895,7 +899,7 @@ def run_rank(a):
                     sl = i % S
                     if len(fl) == S:
                         e3.wait(fl.pop(0))
-                    e3.submit_scan(sl, b3, tL3.data_ptr(), tR3.data_ptr(), w3, h3 * w3, o1[sl].data_ptr(), o2[sl].data_ptr(), sp3, lut3.ptr,
+                    e3.submit_scan(sl, b3, tL3[sl].data_ptr(), tR3[sl].data_ptr(), w3, h3 * w3, o1[sl].data_ptr(), o2[sl].data_ptr(), sp3, lut3.ptr,
                                    u3[sl].data_ptr(), sc3[sl].bins.data_ptr(), sc3[sl].meta.data_ptr(), st3[sl])
                     fl.append(sl)
                 while fl:
@@ -906,16 +910,36 @@ def run_rank(a):
             for _ in range(5):
                 t1 = time.perf_counter(); run3(80); torch.cuda.synchronize(); regs3.append(time.perf_counter() - t1)
             el3 = float(np.median(regs3)) / 80
-            want3 = golden_hash(w3, h3, d3, d3 - 1)
-            got3 = []
+            gold3 = bench_golden(w3, h3, d3, d3 - 1)          # tests/golden/bench_vga_golden.json: the compiled reference on all 32 seeds
+            L_ = jn.load()
+            n3 = {"D1": 0, "u8_map": 0, "scan": 0}; bad3 = []; worst3 = 0.0
             for sl in range(S):
-                h_ = o1[sl][0].cpu().numpy()                 # (kept alive while its pointer is used)
-                got3.append("%016x" % jn.load().jn_fnv1a64_u32(h_.ctypes.data, h3 * w3))
-            vga = {"workload": "640x480 D=64, ELAS -> u8 map -> 90-bin scan, batch=32, %d batches in flight, inputs resident in HBM" % S,
+                d_h, u_h = o1[sl].cpu().numpy(), u3[sl].cpu().numpy()
+                b_h, m_h = sc3[sl].bins.cpu().numpy(), sc3[sl].meta.cpu().numpy()
+                for i in range(b3):
+                    seed = 12345 + (i + rot3[sl]) % b3
+                    g3 = gold3.get(seed)
+                    if g3 is None:
+                        continue
+                    got = "%016x" % L_.jn_fnv1a64_u32(d_h[i].ctypes.data, d_h[i].size); n3["D1"] += 1
+                    if got != g3["d1_fnv"]:
+                        bad3.append({"slot": sl, "frame": i, "seed": seed, "what": "D1", "got": got, "expected": g3["d1_fnv"]})
+                    if "u8_fnv" in g3:
+                        got = "%016x" % L_.jn_fnv1a64_u32(u_h[i].ctypes.data, u_h[i].size // 4); n3["u8_map"] += 1
+                        if got != g3["u8_fnv"]:
+                            bad3.append({"slot": sl, "frame": i, "seed": seed, "what": "u8 map", "got": got, "expected": g3["u8_fnv"]})
+                    if "bins" in g3:
+                        diff = max(float(np.abs(b_h[i] - np.array(g3["bins"])).max()), float(np.abs(m_h[i] - np.array(g3["meta"])).max()))
+                        worst3 = max(worst3, diff); n3["scan"] += 1
+                        if not diff <= 1e-4:
+                            bad3.append({"slot": sl, "frame": i, "seed": seed, "what": "scan", "max_abs_diff": diff})
+            vga = {"workload": "640x480 D=64, ELAS -> u8 map -> 90-bin scan, batch=32, %d batches in flight (a distinct copy of the batch per slot), inputs resident in HBM" % S,
                    "pairs_per_sec": round(b3 / el3, 1), "ms_per_step": round(el3 * 1e3, 3), "steps_per_region": 80, "regions": 5,
                    "whole_path_frac": round(b3 / el3 * 97.0 * w3 * h3 / 1e9 / HBM_PEAK_GBS, 4),
-                   "check": {"what": "frame 0 (seed 12345) of every slot: FNV-1a-64 of D1 against the compiled reference's", "expected": want3, "got": got3,
-                             "ok": all(g == want3 for g in got3) if want3 else None}}
+                   "check": {"what": "every frame of every slot against the compiled reference (tests/golden/bench_vga_golden.json): FNV-1a-64 of D1 and of the u8 map "
+                                     "(bit-exact), 90 bins + 4 extrema within 1e-4",
+                             "frames_checked": n3, "scan_max_abs_diff": worst3 if n3["scan"] else None, "mismatches": bad3[:8], "n_mismatches": len(bad3),
+                             "ok": (len(bad3) == 0) if n3["D1"] else None}}
             e3.close()
             del o1, o2, u3, tL3, tR3
         except Exception as exc:                             # informational leg: never let it take the headline line down
@@ -1072,6 +1096,8 @@ def run_rank(a):
         dist.destroy_process_group()
     if rank == 0 and check and check["ok"] is False:
         raise SystemExit("bench.py: D1 of the timed path differs from the reference's golden hash: %s" % check)
+    if rank == 0 and vga and vga.get("check", {}).get("ok") is False:
+        raise SystemExit("bench.py: the 640x480 leg differs from the reference's recorded answers: %s" % vga["check"])
 
 
 def enough_gpus(a):

@@ -2604,6 +2604,10 @@ DEV float am_select(const float (&pw)[4], const float (&pf)[4], bool enabled, fl
   else d = fs / (ws > 0 ? ws : 1.0f);
   return (enabled && ws > 0 && d >= 0) ? d : keep;
 }
+// (Round 6, VERDICT r05 #3: a sum-only form for waves in which every tap lies within 2 of the centre — all weights are 4 there, the mean is
+// ((s_0 + s_1) + s_2) + s_3 over the pair sums, times 1/8, bit for bit — was built behind a wave-wide test on the window's extremes and
+// measured: k_gap_mean_fused 194.5 against 196.7 us, nothing in the pipeline (profiles/r06_adaptive_mean_smooth_ab.txt).  Too few waves are
+// smooth in all 64 lanes for the test to pay for itself; removed.)
 __global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const FrameInfo* __restrict__ info, const float* __restrict__ in,
                                                         float* __restrict__ out, int rows_per_band, int do_mean) {
   __shared__ float s_row[2][256 + 8], s_g2[2][256];            // s_row: 4 cells of "invalid" on either side, so the gap search reads without bounds tests

@@ -5,7 +5,9 @@ scene disparities <= 128, disp_max 127, Appendix-A generator, seeds 12345 .. 123
 the 4 extrema — as restated in oracle/node_oracle.cpp (OpenCV / ROS are not installed: those are definitions, point_cloud.cpp:422,
 :104-147, :213-296).  bench.py checks ALL frames of ALL slots against it after the timed region.  Run in the dev container only:
 
-    python tests/golden/make_bench_golden.py
+    python tests/golden/make_bench_golden.py            # the headline batch -> bench_batch_golden.json
+    python tests/golden/make_bench_golden.py vga        # the 640x480 D=64 batch of the line's vga_config (round 6: every frame of
+                                                        # every slot is checked there too) -> bench_vga_golden.json
 """
 import json
 import os
@@ -17,7 +19,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
-W, H, SD, DMAX, SEED0, COUNT = 1280, 720, 128, 127, 12345, 32
+VGA = len(sys.argv) > 1 and sys.argv[1] == "vga"
+W, H, SD, DMAX, SEED0, COUNT = (640, 480, 64, 63, 12345, 32) if VGA else (1280, 720, 128, 127, 12345, 32)
 
 
 def one(seed):
@@ -39,4 +42,4 @@ if __name__ == "__main__":
         for seed, rec in ex.map(one, range(SEED0, SEED0 + COUNT)):
             out[str(seed)] = rec
             print(seed, rec["d1_fnv"], rec["u8_fnv"])
-    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "bench_batch_golden.json"), "w"), indent=0)
+    json.dump(out, open(os.path.join(ROOT, "tests", "golden", "bench_vga_golden.json" if VGA else "bench_batch_golden.json"), "w"), indent=0)
