@@ -19,6 +19,14 @@
 //     vertices per side in 152 KB (a 720p frame has 3 100 - 3 400).  Sides that do not fit, or whose vertices coincide (k_arrange hands
 //     those back: which duplicate survives depends on Triangle's randomised quicksort), set the frame's need_host flag and the slot's
 //     worker sends the batch through the host stage instead (jn_api.cpp).
+//   * Round 6 — sides beyond one workgroup's LDS (1920x1080: ~11 200 support points a side): the tree is cut at depth C.
+//     k_delaunay_sub runs every subtree below the cut in its own workgroup (the structure of ITS vertices in LDS, 16-bit links relative to
+//     the subtree's first slot) and writes its records, with 32-bit links, and its hull handles to a global scratch; k_delaunay_top runs the
+//     C levels above the cut — 2^C - 1 merges — on that global structure (one thread a merge, a memory round trip where the LDS form has an
+//     LDS one: slow, but there are few of them) and compacts the output.  The same zip() / leaf(), instantiated for the two memories.
+//   * Vertices are numbered by their POSITION in k_arrange's arrangement (round 6; they were the list's indices): the recursion only ever
+//     compares vertex numbers and looks their coordinates up, a subtree's vertices are then a contiguous range, and the arrangement itself
+//     is needed again only when the triangles are written out (corner = arrangement[position]).
 // Time: the top merges are one thread each walking a seam of ~sqrt(n) steps through LDS (a lone wave issues one instruction every ~4.5
 // cycles whatever its kind: profiles/r06_lone_wave_probe.txt — the walk costs its instruction count); see DESIGN.md section 8 for the
 // measured per-level times.  All sides of a batch side by side on 64 CUs, no host round trip, no host cores.
@@ -41,10 +49,27 @@ typedef __attribute__((address_space(3))) const int16_t lds_ci16;
 #else
 #define JN_DT_VOL volatile
 #endif
-typedef __attribute__((address_space(3))) JN_DT_VOL uint16_t lds_vu16;
-typedef __attribute__((address_space(3))) JN_DT_VOL int16_t lds_vi16;
+// Where the triangle records live.  LDS: 16-bit links, stored RELATIVE to the first record the workgroup holds (`off`: a subtree's handles
+// then fit sixteen bits whatever its place in the whole numbering); global: 32-bit links, absolute.
+struct LdsMem {
+  typedef __attribute__((address_space(3))) JN_DT_VOL uint16_t* LinkP;
+  typedef __attribute__((address_space(3))) JN_DT_VOL int16_t* VertP;
+  typedef __attribute__((address_space(3))) JN_DT_VOL uint16_t* HullP;
+  typedef uint16_t link_t;
+  static constexpr bool kGlobal = false;
+};
+// (plain pointers in global memory: a thread reads back what it wrote itself — one wave's accesses to an address keep their order — and what
+// other threads wrote reaches it across the fence + barrier between tree levels; volatile would make every access a system-scope round trip)
+struct GlobalMem {
+  typedef __attribute__((address_space(1))) uint32_t* LinkP;
+  typedef __attribute__((address_space(1))) int16_t* VertP;
+  typedef __attribute__((address_space(1))) uint32_t* HullP;
+  typedef uint32_t link_t;
+  static constexpr bool kGlobal = true;
+};
+template <class M>
 struct DT {
-  lds_ci16* X; lds_ci16* Y;                 // vertex coordinates
+  lds_ci16* X; lds_ci16* Y;                 // vertex coordinates (always in LDS), indexed by vertex number - voff
   // volatile: every access is the 16-bit LDS operation it says, in program order.  Round 5 added it after an intermediate version with 6-byte
   // records gave wrong two-vertex leaves once the compiler had merged neighbouring halfword stores.  Looked into in round 6:
   //  * NOT the hardware: ds_write_b16 / b32 / b64 / b96 / b128 land correctly at every byte offset 0..15 on gfx950, and the exact pattern
@@ -54,29 +79,33 @@ struct DT {
   //    of 142 + 8) passes tests/test_gpu_delaunay.py and runs in the same time (757 against 760 us a batch, profiles/r06_dt_no_volatile.txt).
   // So the fault was in that intermediate version, not in a misaligned-store rule; volatile stays because it costs nothing here and keeps the
   // access widths what the source says (scripts/probes/dt_no_volatile.sh repeats the comparison after a compiler update).
-  lds_vu16* LINK;                           // [3 T]: handle across that edge
-  lds_vi16* VERT;                           // [3 T]: vertex or -1 (ghost corner)
+  typename M::LinkP LINK;                   // [4 T] (the fourth of a record unused): handle across that edge
+  typename M::VertP VERT;                   // [4 T]: vertex or -1 (ghost corner)
+  uint32_t off;                             // handle of the first record held here (4 x its triangle number); 0 for a whole side and in global memory
+  int voff;                                 // number of the first vertex whose coordinates are held here
   int budget;                               // loop iterations left before the node gives up (a corrupt structure must not spin for ever on the GPU; the frame then goes to the host)
-  typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge
+  typedef uint32_t H;                       // oriented triangle handle: (triangle << 2) | edge, triangle = its number in the whole side's creation order
+  typedef typename M::link_t link_t;
   struct Ctx { int next; };
 
-  __device__ __forceinline__ static uint32_t at(H h) { return h; }                          // records are [triangle][4] halfwords (the fourth unused): the handle IS the index — one address instruction per access (3 t + e cost three, in front of ~20 accesses per seam step)
+  __device__ __forceinline__ uint32_t at(H h) const { return h - off; }                      // records are [triangle][4]: the handle IS the index — one address instruction per access
   __device__ __forceinline__ static unsigned up(unsigned e) { return e == 2 ? 0u : e + 1u; }
   __device__ __forceinline__ static unsigned down(unsigned e) { return e == 0 ? 2u : e - 1u; }
   __device__ __forceinline__ static H ccw_edge(H h) { return (h & ~3u) | up(h & 3); }
   __device__ __forceinline__ static H cw_edge(H h) { return (h & ~3u) | down(h & 3); }
-  __device__ __forceinline__ H across(H h) const { return (H)LINK[at(h)]; }
+  __device__ __forceinline__ H across(H h) const { return (H)LINK[at(h)] + off; }
   __device__ __forceinline__ int org(H h) const { return VERT[at(ccw_edge(h))]; }
   __device__ __forceinline__ int dest(H h) const { return VERT[at(cw_edge(h))]; }
   __device__ __forceinline__ int apex(H h) const { return VERT[at(h)]; }
   __device__ __forceinline__ void set_org(H h, int v) { VERT[at(ccw_edge(h))] = (int16_t)v; }
   __device__ __forceinline__ void set_dest(H h, int v) { VERT[at(cw_edge(h))] = (int16_t)v; }
   __device__ __forceinline__ void set_apex(H h, int v) { VERT[at(h)] = (int16_t)v; }
-  __device__ __forceinline__ void glue(H a, H b) { LINK[at(a)] = (uint16_t)b; LINK[at(b)] = (uint16_t)a; }
+  __device__ __forceinline__ void glue(H a, H b) { LINK[at(a)] = (link_t)(b - off); LINK[at(b)] = (link_t)(a - off); }
   __device__ __forceinline__ H fresh(Ctx& c) {
     const int t = c.next++;
-    LINK[4 * t] = 0xFFFFu; LINK[4 * t + 1] = 0xFFFFu; LINK[4 * t + 2] = 0xFFFFu;
-    VERT[4 * t] = -1; VERT[4 * t + 1] = -1; VERT[4 * t + 2] = -1;
+    const uint32_t i = 4u * (uint32_t)t - off;
+    LINK[i] = (link_t)~0u; LINK[i + 1] = (link_t)~0u; LINK[i + 2] = (link_t)~0u;
+    VERT[i] = -1; VERT[i + 1] = -1; VERT[i + 2] = -1;
     return (H)t << 2;
   }
   // Predicates in FP64.  Coordinates lie in (-2048, 2048) (launch_delaunay's caller guarantees it: image widths below 2048), so differences
@@ -84,7 +113,9 @@ struct DT {
   // every intermediate is an integer a double holds exactly, i.e. the sign is delaunay.cpp's int64 sign — at a tenth of the instructions
   // (a 64-bit integer multiply is a dozen 32-bit operations here; the top merges are ONE thread, which issues an instruction every ~8 cycles).
   struct P { int v; double x, y; };
-  __device__ __forceinline__ P pt(int v) const { return P{v, (double)X[v], (double)Y[v]}; }
+  __device__ __forceinline__ int xx(int v) const { return X[v - voff]; }
+  __device__ __forceinline__ int yy(int v) const { return Y[v - voff]; }
+  __device__ __forceinline__ P pt(int v) const { return P{v, (double)X[v - voff], (double)Y[v - voff]}; }
   __device__ __forceinline__ static int sgn(double d) { return d > 0 ? 1 : (d < 0 ? -1 : 0); }
   // (explicit fused multiply-adds: every product and sum below is an integer smaller than 2^53, so the fused and the unfused forms give the same
   // exact value; the library is built with -ffp-contract=off, which would otherwise keep them apart — 7 and 22 instructions instead of 11 and 31)
@@ -100,7 +131,9 @@ struct DT {
   }
 
   // the 2- and 3-vertex base cases (delaunay.cpp conquer(), triangle.cpp:5964-6060)
-  __device__ void leaf(__attribute__((address_space(3))) const uint16_t* a, int n, H& farleft, H& farright, Ctx& c) {
+  // (the node's vertices are the positions first, first + 1[, first + 2] of the arrangement)
+  __device__ void leaf(int first, int n, H& farleft, H& farright, Ctx& c) {
+    const int a[3] = {first, first + 1, first + 2};
     if (n == 2) {   // a lone edge: two ghosts glued on all three sides
       farleft = fresh(c);  set_org(farleft, a[0]);  set_dest(farleft, a[1]);
       farright = fresh(c); set_org(farright, a[1]); set_dest(farright, a[0]);
@@ -147,22 +180,22 @@ struct DT {
     if (axis == 1) {   // horizontal cut: hull handles must point at the extreme-y vertices
       int fl_pt = org(farleft), fl_apex = apex(farleft);
       int fr_pt = dest(farright);
-      while (Y[fl_apex] < Y[fl_pt] && --budget > 0) {
+      while (yy(fl_apex) < yy(fl_pt) && --budget > 0) {
         farleft = across(ccw_edge(farleft));
         fl_pt = fl_apex; fl_apex = apex(farleft);
       }
       H probe = across(innerleft); int pv = apex(probe);
-      while (Y[pv] > Y[il_dest] && --budget > 0) {
+      while (yy(pv) > yy(il_dest) && --budget > 0) {
         innerleft = ccw_edge(probe);
         il_apex = il_dest; il_dest = pv;
         probe = across(innerleft); pv = apex(probe);
       }
-      while (Y[ir_apex] < Y[ir_org] && --budget > 0) {
+      while (yy(ir_apex) < yy(ir_org) && --budget > 0) {
         innerright = across(ccw_edge(innerright));
         ir_org = ir_apex; ir_apex = apex(innerright);
       }
       probe = across(farright); pv = apex(probe);
-      while (Y[pv] > Y[fr_pt] && --budget > 0) {
+      while (yy(pv) > yy(fr_pt) && --budget > 0) {
         farright = ccw_edge(probe);
         fr_pt = pv;
         probe = across(farright); pv = apex(probe);
@@ -217,12 +250,12 @@ struct DT {
           int fl_pt = org(farleft);
           int fr_pt = dest(farright), fr_apex = apex(farright);
           H probe = across(farleft); int pv = apex(probe);
-          while (X[pv] < X[fl_pt] && --budget > 0) {
+          while (xx(pv) < xx(fl_pt) && --budget > 0) {
             farleft = cw_edge(probe);
             fl_pt = pv;
             probe = across(farleft); pv = apex(probe);
           }
-          while (X[fr_apex] > X[fr_pt] && --budget > 0) {
+          while (xx(fr_apex) > xx(fr_pt) && --budget > 0) {
             farright = across(cw_edge(farright));
             fr_pt = fr_apex; fr_apex = apex(farright);
           }
@@ -292,7 +325,106 @@ struct DT {
   }
 };
 
-enum { kDtThreads = 1024, kDtMaxDepth = 16, kDtBytesPerVertex = 42 };   // 5 x 2 (X, Y, A, HL, HR) + 2 triangles x (4 + 4) x 2
+enum { kDtThreads = 1024, kDtTopThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 40,   // 4 x 2 (X, Y, HL, HR) + 2 triangles x (4 + 4) x 2
+       kDtMaxPoints = 16384 };                                                                  // arrangement positions are 16-bit, vertex numbers int16 with room to spare
+
+// Sizes and triangle counts per depth: at depth k a node holds f_k = n >> k or f_k + 1 vertices; c[k][b] = count(f_k + b), the triangles a
+// subtree of that size creates (a leaf of two vertices 2, of three 4, a merge 2 more than its halves).  K = the depth at which every node
+// is a leaf.  Thread 0 fills the tables; the caller synchronises.
+DEV void dt_tables(int n, int* s_f, int (*s_c)[2], int* s_K) {
+  int K = 0;
+  while ((n >> K) > 2) K++;
+  for (int k = 0; k <= K + 1; k++) s_f[k] = n >> k;
+  for (int k = K + 1; k >= 0; k--)
+    for (int b = 0; b < 2; b++) {
+      const int m = s_f[k] + b;
+      int cnt = 0;
+      if (m == 2) cnt = 2; else if (m == 3) cnt = 4;
+      else if (m >= 4 && k <= K) { const int h = m >> 1; cnt = s_c[k + 1][h - s_f[k + 1]] + s_c[k + 1][(m - h) - s_f[k + 1]] + 2; }
+      s_c[k][b] = cnt;
+    }
+  *s_K = K;
+}
+// node (k, j): walk down from the root -> its first position, size and first triangle slot; false when an ancestor is already a leaf
+DEV bool dt_node(int n, int k, int j, const int* s_f, const int (*s_c)[2], int& lo, int& size, int& slot) {
+  lo = 0; size = n; slot = 0;
+  for (int d = 0; d < k; d++) {
+    if (size <= 3) return false;
+    const int half = size >> 1;
+    if ((j >> (k - 1 - d)) & 1) { slot += s_c[d + 1][half - s_f[d + 1]]; lo += half; size -= half; } else size = half;
+  }
+  return true;
+}
+// Levels k_deep .. k_top of the tree below node (root_k, root_j), the nodes of a level each on its own thread, a barrier between levels.
+// HL / HR: the hull handles a node leaves for its parent, indexed by the node's first position minus hoff (relative handles in LDS).
+// Which thread takes which node: neighbouring nodes go to DIFFERENT waves (node i of a round -> wave i % (NT / 64), lane i / (NT / 64)).  The
+// merges are data-dependent loops: lanes of one wave that sit in different merges are executed one after the other, so the levels with
+// 2 .. 16 nodes — the long merges — took longer in one wave than the root's single merge (measured: 153 us for the two merges below the
+// root against 135).
+template <class M, int NT>
+DEV bool dt_levels(DT<M>& dt, int n, int k_deep, int k_top, int root_k, int root_j, typename M::HullP HL, typename M::HullP HR, int hoff,
+                   const int* s_f, const int (*s_c)[2], int tid, long long* dbg_clock, int dbg_side) {
+  typedef typename DT<M>::H H;
+  bool gave_up = false;
+  for (int k = k_deep; k >= k_top; k--) {
+    const int count = 1 << (k - root_k);
+    for (int i0 = 0; i0 < count; i0 += NT) {
+      const int i = i0 + (tid & 63) * (NT / 64) + (tid >> 6);
+      if (i >= count) continue;
+      int lo, size, slot;
+      if (!dt_node(n, k, (root_j << (k - root_k)) + i, s_f, s_c, lo, size, slot)) continue;
+      H fl, fr;
+      if (size <= 3) {
+        typename DT<M>::Ctx c{slot};
+        dt.leaf(lo, size, fl, fr, c);
+      } else {
+        const int half = size >> 1;
+        typename DT<M>::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
+        fl = (H)HL[lo - hoff] + dt.off; fr = (H)HR[lo + half - hoff] + dt.off;
+        H il = (H)HR[lo - hoff] + dt.off, ir = (H)HL[lo + half - hoff] + dt.off;
+        dt.budget = 16 * size + 256;                                       // (a merge of `size` vertices takes a few steps per seam vertex)
+        dt.zip(fl, il, ir, fr, k & 1, c);                                  // the root is cut on axis 0, its children on axis 1, ...
+        gave_up |= dt.budget <= 0;
+      }
+      HL[lo - hoff] = (typename M::link_t)(fl - dt.off); HR[lo - hoff] = (typename M::link_t)(fr - dt.off);
+    }
+    if (M::kGlobal) __threadfence();                                       // the next level's threads read what this level's wrote, through memory
+    __syncthreads();
+    if (dbg_clock && tid == 0) dbg_clock[dbg_side * 32 + k] = wall_clock64();      // (profiling aid: when each level of the tree was done)
+  }
+  return gave_up;
+}
+// exclusive scan of one count per thread over the workgroup (NT a multiple of 64, at most 1024): within the wave by shuffles, across the
+// waves through LDS (one thread used to add up 1024 entries while 1023 waited).  Returns the thread's offset; *total = the sum.
+template <int NT>
+DEV int dt_scan(int mine, int tid, int* s_scan, int* total) {
+  int incl = mine;
+  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += up; }
+  if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
+  __syncthreads();
+  if (tid < 64) {
+    const int v = tid < NT / 64 ? s_scan[tid] : 0;
+    int w = v;
+    for (int d = 1; d < NT / 64; d <<= 1) { const int up = __shfl_up(w, d, 64); if (tid >= d) w += up; }
+    if (tid < NT / 64) s_scan[64 + tid] = w - v;                           // exclusive wave offsets
+    if (tid == NT / 64 - 1) s_scan[128] = w;
+  }
+  __syncthreads();
+  *total = s_scan[128];
+  return s_scan[64 + (tid >> 6)] + incl - mine;
+}
+// FrameInfo and the frame's place in the payload (HostWorker::place): [nsup x (u, v, d)][<= 2 nsup + 8 triangles of the left side][... of the right side]
+struct DtPlace { long long base, sup_bytes, side_bytes; };
+DEV DtPlace dt_place(FrameInfo* fi, int frame, int side, int n, int nlist, long long payload_stride, int tid) {
+  DtPlace p;
+  p.base = (long long)frame * payload_stride; p.sup_bytes = (long long)nlist * 12; p.side_bytes = (2ll * nlist + 8) * 12;
+  if (side == 0 && tid == 0) {
+    fi->nsup = nlist; fi->ok = nlist >= 3 ? 1 : 0;                         // elas.cpp:66-71
+    fi->sup_offset = p.base; fi->corner_offset[0] = p.base + p.sup_bytes; fi->corner_offset[1] = p.base + p.sup_bytes + p.side_bytes;
+    fi->reserved = n;                                                      // what the list held, clipped or not: the host sizes the next launches by it
+  }
+  return p;
+}
 
 // One workgroup per frame side.  list: (uc, vc, d) int16 triples of the frame's support points in the reference's order; count: how many;
 // arr / arr_ok: k_arrange's alternating-cut arrangement of this side's vertices.  Writes FrameInfo (side 0: ok, nsup, the payload
@@ -309,122 +441,160 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   const int n = count[frame];
   const int nlist = min(n, list_cap);
   FrameInfo* fi = info + frame;
-  // the frame's place in the payload (HostWorker::place): [nsup x (u, v, d)][<= 2 nsup + 8 triangles of the left side][... of the right side]
-  const long long base = (long long)frame * payload_stride;
-  const long long sup_bytes = (long long)nlist * 12, side_bytes = (2ll * nlist + 8) * 12;
-  if (side == 0 && tid == 0) {
-    fi->nsup = nlist; fi->ok = nlist >= 3 ? 1 : 0;                         // elas.cpp:66-71
-    fi->sup_offset = base; fi->corner_offset[0] = base + sup_bytes; fi->corner_offset[1] = base + sup_bytes + side_bytes;
-    fi->reserved = n;                                                      // what the list held, clipped or not: the host sizes the next launches by it
-  }
+  const DtPlace pl = dt_place(fi, frame, side, n, nlist, payload_stride, tid);
   if (nlist < 3) { if (tid == 0) fi->ntri[side] = 0; return; }
   const int16_t* t = list + (size_t)frame * list_cap * 3;
-  int32_t* sup_out = reinterpret_cast<int32_t*>(payload + base);
+  int32_t* sup_out = reinterpret_cast<int32_t*>(payload + pl.base);
+  if (side == 0) for (int i = tid; i < nlist; i += kDtThreads) { sup_out[3 * i] = t[3 * i] * step; sup_out[3 * i + 1] = t[3 * i + 1] * step; sup_out[3 * i + 2] = t[3 * i + 2]; }
   if (n > list_cap || n > cap_pts || !arr_ok[frame * 2 + side]) {          // not for this kernel: the host stage takes the batch
-    // The frame is still marked ok and stage B is queued behind this kernel: the OTHER side's triangles index the support points, so they
-    // are written here too (they were left stale, and the batch's first, discarded pass ran on whatever the payload held).
-    if (side == 0) for (int i = tid; i < nlist; i += kDtThreads) { sup_out[3 * i] = t[3 * i] * step; sup_out[3 * i + 1] = t[3 * i + 1] * step; sup_out[3 * i + 2] = t[3 * i + 2]; }
+    // (the frame is still marked ok and stage B is queued behind this kernel: the OTHER side's triangles index the support points, which is
+    // why they were written above whatever happens here — ADVICE r05)
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;
   }
-  // LDS: X, Y, A, HL, HR [n] 16-bit each | LINK, VERT [4 T], T = 2 n (count(n) <= 2 n - 2)
+  // LDS: X, Y, HL, HR [n] 16-bit each | LINK, VERT [4 T], T = 2 n (count(n) <= 2 n - 2)
   const int np = (n + 3) & ~3, T = 2 * n;
   int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
-  uint16_t* A = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HL = A + np; uint16_t* HR = HL + np;
+  uint16_t* HL = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HR = HL + np;
   uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
   const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
-  for (int i = tid; i < n; i += kDtThreads) {
+  for (int p = tid; p < n; p += kDtThreads) {                               // vertex p = the p-th of the arrangement
+    const int i = a_in[p];
     const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
-    X[i] = (int16_t)(side ? u - d : u); Y[i] = (int16_t)v;                  // right image: (u - d, v), elas.cpp:466-467
-    A[i] = a_in[i];
-    if (side == 0) { sup_out[3 * i] = u; sup_out[3 * i + 1] = v; sup_out[3 * i + 2] = d; }
+    X[p] = (int16_t)(side ? u - d : u); Y[p] = (int16_t)v;                  // right image: (u - d, v), elas.cpp:466-467
   }
-  // sizes at depth k are f_k = n >> k or f_k + 1; c[k][b] = count(f_k + b) triangles a subtree of that size creates
-  if (tid == 0) {
-    int K = 0;
-    while ((n >> K) > 2) K++;                                              // at depth K every node has at most 3 vertices
-    for (int k = 0; k <= K + 1; k++) s_f[k] = n >> k;
-    for (int k = K + 1; k >= 0; k--)
-      for (int b = 0; b < 2; b++) {
-        const int m = s_f[k] + b;
-        int cnt = 0;
-        if (m == 2) cnt = 2; else if (m == 3) cnt = 4;
-        else if (m >= 4 && k <= K) { const int h = m >> 1; cnt = s_c[k + 1][h - s_f[k + 1]] + s_c[k + 1][(m - h) - s_f[k + 1]] + 2; }
-        s_c[k][b] = cnt;
-      }
-    s_K = K;
-  }
+  if (tid == 0) dt_tables(n, s_f, s_c, &s_K);
   __syncthreads();
-  DT dt{(lds_ci16*)X, (lds_ci16*)Y, (lds_vu16*)LINK, (lds_vi16*)VERT, 0};
-  bool gave_up = false;
+  DT<LdsMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 0u, 0, 0};
   const int K = s_K;
-  if (dbg_clock && tid == 0 && frame == 0) dbg_clock[side * 32 + 31] = wall_clock64();
-  for (int k = K; k >= 0; k--) {
-    // Which thread takes which node: neighbouring nodes go to DIFFERENT waves (node j of a round -> wave j % 16, lane j / 16).  The merges are
-    // data-dependent loops: lanes of one wave that sit in different merges are executed one after the other, so the levels with 2 .. 16 nodes
-    // — the long merges — took longer in one wave than the root's single merge (measured: 153 us for the two merges below the root against 135).
-    for (int j0 = 0; j0 < (1 << k); j0 += kDtThreads) {
-      const int j = j0 + (tid & 63) * (kDtThreads / 64) + (tid >> 6);
-      if (j >= (1 << k)) continue;
-      // node (k, j): walk down from the root
-      int lo = 0, size = n, slot = 0;
-      bool exists = true;
-      for (int d = 0; d < k; d++) {
-        if (size <= 3) { exists = false; break; }
-        const int half = size >> 1;
-        if ((j >> (k - 1 - d)) & 1) { slot += s_c[d + 1][half - s_f[d + 1]]; lo += half; size -= half; } else size = half;
-      }
-      if (!exists) continue;
-      DT::H fl, fr;
-      if (size <= 3) {
-        DT::Ctx c{slot};
-        dt.leaf((__attribute__((address_space(3))) const uint16_t*)(A + lo), size, fl, fr, c);
-      } else {
-        const int half = size >> 1;
-        DT::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
-        fl = HL[lo]; fr = HR[lo + half];
-        DT::H il = HR[lo], ir = HL[lo + half];
-        dt.budget = 16 * size + 256;                                       // (a merge of `size` vertices takes a few steps per seam vertex)
-        dt.zip(fl, il, ir, fr, k & 1, c);                                  // the root is cut on axis 0, its children on axis 1, ...
-        gave_up |= dt.budget <= 0;
-      }
-      HL[lo] = (uint16_t)fl; HR[lo] = (uint16_t)fr;
-    }
-    __syncthreads();
-    if (dbg_clock && tid == 0 && frame == 0) dbg_clock[side * 32 + k] = wall_clock64();      // (profiling aid: when each level of the tree was done)
-  }
+  long long* clk = frame == 0 ? dbg_clock : nullptr;
+  if (clk && tid == 0) clk[side * 32 + 31] = wall_clock64();
+  const bool gave_up = dt_levels<LdsMem, kDtThreads>(dt, n, K, 0, 0, 0, (LdsMem::HullP)HL, (LdsMem::HullP)HR, 0, s_f, s_c, tid, clk, side);
   if (__syncthreads_or(gave_up)) {                                        // never seen; a structure that does not close must not hang the GPU
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;
   }
-  // output: non-ghost triangles in slot (= creation) order, (org, dest, apex) of edge 0 (delaunay.cpp finish())
+  // output: non-ghost triangles in slot (= creation) order, (org, dest, apex) of edge 0 (delaunay.cpp finish()), positions back to list indices
   const int total = s_c[0][0];
   const int per = (total + kDtThreads - 1) / kDtThreads, t0 = tid * per, t1 = min(t0 + per, total);
   int mine = 0;
-  for (int s = t0; s < t1; s++) mine += (VERT[4 * s] | VERT[4 * s + 1] | VERT[4 * s + 2]) >= 0 ? 1 : 0;
-  // exclusive scan of the 1024 counts: within the wave by DPP row shifts + two cross-row steps, across the sixteen waves through LDS
-  // (one thread used to add up 1024 entries while 1023 waited)
-  int incl = mine;
-  for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if ((tid & 63) >= d) incl += up; }
-  if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
-  __syncthreads();
-  if (tid < 64) {
-    const int v = tid < kDtThreads / 64 ? s_scan[tid] : 0;
-    int w = v;
-    for (int d = 1; d < kDtThreads / 64; d <<= 1) { const int up = __shfl_up(w, d, 64); if (tid >= d) w += up; }
-    if (tid < kDtThreads / 64) s_scan[64 + tid] = w - v;                  // exclusive wave offsets
-    if (tid == kDtThreads / 64 - 1) s_scan[128] = w;                      // the side's triangle count
-  }
-  __syncthreads();
-  int32_t* tri = reinterpret_cast<int32_t*>(payload + base + sup_bytes + (side ? side_bytes : 0));
-  int out = s_scan[64 + (tid >> 6)] + incl - mine;
-  for (int s = t0; s < t1; s++) {
-    const int c0 = VERT[4 * s], c1 = VERT[4 * s + 1], c2 = VERT[4 * s + 2];
+  for (int sl = t0; sl < t1; sl++) mine += (VERT[4 * sl] | VERT[4 * sl + 1] | VERT[4 * sl + 2]) >= 0 ? 1 : 0;
+  int ntri;
+  int out = dt_scan<kDtThreads>(mine, tid, s_scan, &ntri);
+  int32_t* tri = reinterpret_cast<int32_t*>(payload + pl.base + pl.sup_bytes + (side ? pl.side_bytes : 0));
+  for (int sl = t0; sl < t1; sl++) {
+    const int c0 = VERT[4 * sl], c1 = VERT[4 * sl + 1], c2 = VERT[4 * sl + 2];
     if ((c0 | c1 | c2) < 0) continue;
-    tri[3 * out] = c1; tri[3 * out + 1] = c2; tri[3 * out + 2] = c0;
+    tri[3 * out] = a_in[c1]; tri[3 * out + 1] = a_in[c2]; tri[3 * out + 2] = a_in[c0];
     out++;
   }
-  if (tid == 0) fi->ntri[side] = s_scan[128];
+  if (tid == 0) fi->ntri[side] = ntri;
+}
+
+// ---- sides beyond one workgroup's LDS: the subtrees below depth C in LDS, the C levels above them in global memory ----
+// Global scratch of one frame side, for at most `gcap` vertices: LINK uint32 [8 gcap] | HL, HR uint32 [gcap] each | VERT int16 [8 gcap].
+DEV uint32_t* dt_g_link(uint8_t* g, int gcap) { return reinterpret_cast<uint32_t*>(g); }
+DEV uint32_t* dt_g_hl(uint8_t* g, int gcap) { return reinterpret_cast<uint32_t*>(g) + 8 * (size_t)gcap; }
+DEV uint32_t* dt_g_hr(uint8_t* g, int gcap) { return reinterpret_cast<uint32_t*>(g) + 9 * (size_t)gcap; }
+DEV int16_t* dt_g_vert(uint8_t* g, int gcap) { return reinterpret_cast<int16_t*>(reinterpret_cast<uint32_t*>(g) + 10 * (size_t)gcap); }
+__host__ __device__ static inline size_t dt_g_bytes(int gcap) { return (size_t)gcap * (10 * 4 + 8 * 2); }
+
+// Subtree (C, blockIdx.z) of a side: its vertices are positions [lo, lo + size) of the arrangement, its triangles slots [slot, slot + count).
+__global__ void __launch_bounds__(kDtThreads) k_delaunay_sub(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
+                                                             const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int C, int cap_sub,
+                                                             uint8_t* __restrict__ gscratch, int gcap, int32_t* __restrict__ need_host) {
+  extern __shared__ uint8_t s_dt[];
+  __shared__ int s_f[kDtMaxDepth + 2], s_c[kDtMaxDepth + 2][2], s_K;
+  const int frame = blockIdx.x, side = blockIdx.y, jr = blockIdx.z, tid = threadIdx.x;
+  const int n = count[frame];
+  if (n < 3 || n > list_cap || n > gcap || !arr_ok[frame * 2 + side]) return;       // (k_delaunay_top reports it)
+  if (tid == 0) dt_tables(n, s_f, s_c, &s_K);
+  __syncthreads();
+  int lo, size, slot;
+  if (!dt_node(n, C, jr, s_f, s_c, lo, size, slot) || size > cap_sub || (n >> C) <= 3) return;   // (launch_delaunay chose C so that it fits; top checks again)
+  const int16_t* t = list + (size_t)frame * list_cap * 3;
+  const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
+  const int np = (size + 3) & ~3, T = 2 * size;
+  int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
+  uint16_t* HL = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HR = HL + np;
+  uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
+  for (int p = tid; p < size; p += kDtThreads) {
+    const int i = a_in[lo + p];
+    const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
+    X[p] = (int16_t)(side ? u - d : u); Y[p] = (int16_t)v;
+  }
+  __syncthreads();
+  DT<LdsMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 4u * (uint32_t)slot, lo, 0};
+  const bool gave_up = dt_levels<LdsMem, kDtThreads>(dt, n, s_K, C, C, jr, (LdsMem::HullP)HL, (LdsMem::HullP)HR, lo, s_f, s_c, tid, nullptr, 0);
+  if (__syncthreads_or(gave_up)) { if (tid == 0) atomicOr(&need_host[frame], 1 << side); return; }
+  // hand the subtree over: records with absolute 32-bit links, the root's hull handles
+  uint8_t* g = gscratch + (size_t)(frame * 2 + side) * dt_g_bytes(gcap);
+  uint32_t* gl = dt_g_link(g, gcap); int16_t* gv = dt_g_vert(g, gcap);
+  const int cnt = s_c[C][size - s_f[C]];
+  for (int k = tid; k < 4 * cnt; k += kDtThreads) {
+    gl[4 * (size_t)slot + k] = (uint32_t)LINK[k] + 4u * (uint32_t)slot;
+    gv[4 * (size_t)slot + k] = VERT[k];
+  }
+  if (tid == 0) { dt_g_hl(g, gcap)[lo] = (uint32_t)HL[0] + 4u * (uint32_t)slot; dt_g_hr(g, gcap)[lo] = (uint32_t)HR[0] + 4u * (uint32_t)slot; }
+}
+
+// The C levels above the subtrees on the global structure, FrameInfo, support points, output.  LDS: the coordinates of ALL the side's vertices.
+__global__ void __launch_bounds__(kDtTopThreads) k_delaunay_top(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
+                                                                const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int C, int cap_sub,
+                                                                int cap_all, uint8_t* __restrict__ gscratch, int gcap, uint8_t* __restrict__ payload, long long payload_stride,
+                                                                FrameInfo* __restrict__ info, int32_t* __restrict__ need_host) {
+  extern __shared__ uint8_t s_dt[];
+  __shared__ int s_f[kDtMaxDepth + 2], s_c[kDtMaxDepth + 2][2], s_K;
+  __shared__ int s_scan[132];
+  const int frame = blockIdx.x, side = blockIdx.y, tid = threadIdx.x;
+  const int n = count[frame];
+  const int nlist = min(n, list_cap);
+  FrameInfo* fi = info + frame;
+  const DtPlace pl = dt_place(fi, frame, side, n, nlist, payload_stride, tid);
+  if (nlist < 3) { if (tid == 0) fi->ntri[side] = 0; return; }
+  const int16_t* t = list + (size_t)frame * list_cap * 3;
+  int32_t* sup_out = reinterpret_cast<int32_t*>(payload + pl.base);
+  if (side == 0) for (int i = tid; i < nlist; i += kDtTopThreads) { sup_out[3 * i] = t[3 * i] * step; sup_out[3 * i + 1] = t[3 * i + 1] * step; sup_out[3 * i + 2] = t[3 * i + 2]; }
+  if (tid == 0) dt_tables(max(n, 3), s_f, s_c, &s_K);
+  __syncthreads();
+  // what the subtrees did not take (they returned without a word), and what they gave up on (need_host is set already)
+  bool mine_to_do = !(n > list_cap || n > gcap || n > cap_all || !arr_ok[frame * 2 + side] || (n >> C) <= 3 || s_f[C] + 1 > cap_sub);
+  if (mine_to_do && (need_host[frame] >> side) & 1) mine_to_do = false;
+  if (!mine_to_do) {
+    if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
+    return;
+  }
+  const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
+  const int np = (n + 3) & ~3;
+  int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
+  for (int p = tid; p < n; p += kDtTopThreads) {
+    const int i = a_in[p];
+    const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
+    X[p] = (int16_t)(side ? u - d : u); Y[p] = (int16_t)v;
+  }
+  __syncthreads();
+  uint8_t* g = gscratch + (size_t)(frame * 2 + side) * dt_g_bytes(gcap);
+  DT<GlobalMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (GlobalMem::LinkP)dt_g_link(g, gcap), (GlobalMem::VertP)dt_g_vert(g, gcap), 0u, 0, 0};
+  const bool gave_up = dt_levels<GlobalMem, kDtTopThreads>(dt, n, C - 1, 0, 0, 0, (GlobalMem::HullP)dt_g_hl(g, gcap), (GlobalMem::HullP)dt_g_hr(g, gcap), 0, s_f, s_c, tid, nullptr, 0);
+  if (__syncthreads_or(gave_up)) {
+    if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
+    return;
+  }
+  const int16_t* gv = dt_g_vert(g, gcap);
+  const int total = s_c[0][0];
+  const int per = (total + kDtTopThreads - 1) / kDtTopThreads, t0 = tid * per, t1 = min(t0 + per, total);
+  int mine = 0;
+  for (int sl = t0; sl < t1; sl++) mine += (gv[4 * sl] | gv[4 * sl + 1] | gv[4 * sl + 2]) >= 0 ? 1 : 0;
+  int ntri;
+  int out = dt_scan<kDtTopThreads>(mine, tid, s_scan, &ntri);
+  int32_t* tri = reinterpret_cast<int32_t*>(payload + pl.base + pl.sup_bytes + (side ? pl.side_bytes : 0));
+  for (int sl = t0; sl < t1; sl++) {
+    const int c0 = gv[4 * sl], c1 = gv[4 * sl + 1], c2 = gv[4 * sl + 2];
+    if ((c0 | c1 | c2) < 0) continue;
+    tri[3 * out] = a_in[c1]; tri[3 * out + 1] = a_in[c2]; tri[3 * out + 2] = a_in[c0];
+    out++;
+  }
+  if (tid == 0) fi->ntri[side] = ntri;
 }
 
 #ifdef JN_HOOKS
@@ -439,17 +609,25 @@ __global__ void __launch_bounds__(kDtThreads) k_dt_dummy(int ticks) {
 
 int delaunay_gpu_capacity(size_t lds_bytes) { return (int)((lds_bytes > 64 ? lds_bytes - 64 : 0) / kDtBytesPerVertex); }
 size_t delaunay_gpu_lds_bytes(int points) { return (size_t)((points + 3) & ~3) * kDtBytesPerVertex + 64; }
+int delaunay_gpu_max_points() { return kDtMaxPoints; }
+size_t delaunay_gpu_scratch_bytes(int frames, int gcap) { return (size_t)frames * 2 * dt_g_bytes(gcap); }
 
 hipError_t configure_delaunay_kernel() {
 #ifdef JN_HOOKS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_dt_dummy), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 #endif
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay_sub), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay_top), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
 
+// cap_pts: the most vertices a side of this batch is expected to hold (sizes the LDS).  gscratch / gcap (may be null / 0): the global scratch
+// of delaunay_gpu_scratch_bytes(n, gcap) bytes that lets sides of up to gcap vertices through, beyond what one workgroup's LDS holds.
 hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
-                     int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock) {
-  cap_pts = std::min(cap_pts, delaunay_gpu_capacity(152 * 1024));
+                           int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock,
+                           uint8_t* gscratch, int gcap) {
+  const int whole = delaunay_gpu_capacity(152 * 1024);
   if (const hipError_t e = hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st); e != hipSuccess) return e;
 #ifdef JN_HOOKS
   // experiment (what k_delaunay costs the pipeline, and why): a kernel that does nothing for JN_DT_DUMMY_US microseconds behind the real one,
@@ -461,8 +639,21 @@ hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int
   if (dummy == 3) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(64), 152 * 1024, st, dummy_us * 100);
   if (dummy == 4) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(kDtThreads), 0, st, dummy_us * 100);
 #endif
-  hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
-                     payload, payload_stride, info, need_host, dbg_clock);
+  if (cap_pts <= whole || !gscratch || gcap <= whole) {
+    cap_pts = std::min(cap_pts, whole);
+    hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
+                       payload, payload_stride, info, need_host, dbg_clock);
+    return hipGetLastError();
+  }
+  // the cut: the smallest depth C whose subtrees (at most (cap_pts >> C) + 1 vertices) fit one workgroup's LDS
+  cap_pts = std::min(cap_pts, gcap);
+  int C = 1;
+  while ((cap_pts >> C) + 1 > whole) C++;
+  const int cap_sub = std::min(whole, (cap_pts >> C) + 1);
+  hipLaunchKernelGGL(k_delaunay_sub, dim3(n, 2, 1 << C), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_sub), st, list, count, list_cap, step, arr, arr_ok, arr_stride, C, cap_sub,
+                     gscratch, gcap, need_host);
+  hipLaunchKernelGGL(k_delaunay_top, dim3(n, 2), dim3(kDtTopThreads), (size_t)((cap_pts + 3) & ~3) * 4 + 64, st, list, count, list_cap, step, arr, arr_ok, arr_stride, C, cap_sub,
+                     cap_pts, gscratch, gcap, payload, payload_stride, info, need_host);
   return hipGetLastError();
 }
 

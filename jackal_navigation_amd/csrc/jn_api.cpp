@@ -86,6 +86,7 @@ struct Slot {
   // the same four buffers in DEVICE memory, for handles that triangulate on the GPU: k_arrange and k_delaunay then read the list and the
   // arrangement from HBM instead of pulling ~26 KB per frame side over PCIe at the start of two latency-bound kernels
   int16_t* d_list = nullptr; int32_t* d_cnt = nullptr; uint16_t* d_arr = nullptr; int32_t* d_arr_ok = nullptr;
+  uint8_t* dt_scratch = nullptr;                              // frames whose sides exceed one workgroup's LDS (1920x1080): the global structure of k_delaunay_sub / _top
   int arr_hint = 0;                                           // most support points a frame of this slot's last kArrHist batches had
   static constexpr int kArrHist = 4;
   int arr_hist[kArrHist] = {0, 0, 0, 0}; int arr_pos = 0;
@@ -123,6 +124,7 @@ struct jn_elas {
   bool stage_events = true;         // JN_STAGE_EVENTS: default on, off for max_batch == 1 (see run_batch)
   bool gpu_arrange = true;          // JN_GPU_ARRANGE=0: the host computes the alternating-cut arrangement itself (A/B, tests)
   int arr_cap = 0, arr_stride = 0;  // vertices per frame side k_arrange orders in LDS / at all (more: in global scratch / on the host)
+  int dt_gcap = 0;                  // GPU triangulation: vertices per side beyond one workgroup's LDS that the global scratch lets through (0: none)
   bool split_delaunay = true;       // JN_SPLIT_DELAUNAY=0 keeps one task per frame side whatever the pool size (A/B, tests)
   bool filters_fast = false;        // the classify + resolve kernels apply (short, no serial sweep): device route for any batch size
   // cross-rig merge as the tail of a scan batch (jn_elas_set_comm): merges are queued in submission order on every rank
@@ -286,18 +288,16 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
   // Where the list and the arrangement live: in device memory when this batch is going to triangulate on the GPU (everything that decides
   // it is known here except whether the filter kernel lists the points itself: if it does not, the list goes to pinned memory and the host
   // route is taken), in pinned host memory for the host stage.
-  const bool want_gpu_dt = h->gpu_delaunay && !force_host && sa == st && s.d_list && s.arr_hint <= delaunay_gpu_capacity(152 * 1024) &&
-                           h->gpu_arrange && s.arr_hint <= h->arr_stride;
+  const bool want_gpu_dt = h->gpu_delaunay && !force_host && sa == st && s.d_list &&
+                           s.arr_hint <= (s.dt_scratch ? h->dt_gcap : delaunay_gpu_capacity(152 * 1024)) && h->gpu_arrange && s.arr_hint <= h->arr_stride;
   int16_t* const list_buf = want_gpu_dt ? s.d_list : s.h_list; int32_t* const cnt_buf = want_gpu_dt ? s.d_cnt : s.h_cnt;
   uint16_t* const arr_buf = want_gpu_dt ? s.d_arr : s.h_arr; int32_t* const arr_ok_buf = want_gpu_dt ? s.d_arr_ok : s.h_arr_ok;
   const bool filtered = (n >= h->filter_min_batch || (h->filter_min_batch < (1 << 30) && h->filters_fast)) &&
       launch_support_filters(sa, dp, n, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s.d_can, s.tmp, list_buf, cnt_buf, list_cap, &listed);
   HIP_TRY(mark_a(EV_SUPPORT));
   bool arranged = false, gpu_dt = false;
-  if (filtered && want_gpu_dt && !listed)                // (a filter route that does not list: this batch through the host stage, lists and all)
-    return run_batch_route(h, s, j, turn, true);
-  if (filtered) {                                        // the GPU lists the support points itself, into pinned host memory
-    if (!listed) launch_support_list(sa, dp, n, s.d_can, s.h_list, s.h_cnt, list_cap);
+  if (filtered) {                                        // the GPU lists the support points itself (into pinned host memory for the host stage)
+    if (!listed) { launch_support_list(sa, dp, n, s.d_can, list_buf, cnt_buf, list_cap); listed = true; }
     // the arrangement the triangulations start from, unless the pool has idle threads and will cut them into parts itself
     // Sized by what this slot's previous batch held (+25 %): a 720p frame has 3.2 k support points and needs 52 KB of LDS, not
     // the 104 KB of the 8192-vertex maximum — a workgroup that asks for less finds room among the other slots' kernels sooner.
@@ -314,7 +314,7 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
       launch_arrange(sa, n, list_buf, cnt_buf, list_cap, dp.step, cap, h->arr_stride, arr_buf, arr_ok_buf, s.arr_scratch, s.arr_scratch ? h->arr_stride : 0);
       if (gpu_dt)                                        // LDS for what the slot's last batches held (+25 %), as the arrangement; a side beyond it goes to the host
         HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
-                                (long long)h->payload_cap, s.info, s.need_host));
+                                (long long)h->payload_cap, s.info, s.need_host, nullptr, s.dt_scratch, h->dt_gcap));
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -806,6 +806,12 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14 || (host_threads > 0 && host_threads < 14));
   }
   if (const char* e = getenv("JN_GPU_DELAUNAY")) h->gpu_delaunay = gpu_dt_possible && atoi(e) != 0;
+  // Sides with more support points than one workgroup's LDS holds (a 1920x1080 side has ~11 k) go through k_delaunay_sub / k_delaunay_top and
+  // a global scratch (round 6); their arrangement then comes from k_arrange's global-scratch form (up to 16384 vertices a side).
+  if (h->gpu_delaunay && dp.cw * dp.ch > delaunay_gpu_capacity(152 * 1024)) {
+    h->dt_gcap = std::min(dp.cw * dp.ch, delaunay_gpu_max_points());
+    h->arr_stride = std::max(h->arr_stride, std::min(dp.cw * dp.ch, 16384));
+  }
   h->stage_events = max_batch > 1;
   h->wait_spin_us = max_batch > 1 ? 60 : 1000;
   if (const char* e = getenv("JN_WAIT_SPIN_US")) h->wait_spin_us = atoi(e);
@@ -877,7 +883,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     if (h->gpu_delaunay) {
       CREATE_TRY(dmalloc(&s->d_list, B * dp.cw * dp.ch * 3)); CREATE_TRY(dmalloc(&s->d_cnt, B));
       CREATE_TRY(dmalloc(&s->d_arr, B * 2 * (size_t)h->arr_stride)); CREATE_TRY(dmalloc(&s->d_arr_ok, B * 2));
-      CREATE_TRY(hipMemset(s->payload, 0, B * h->payload_cap));      // (a side k_delaunay hands back leaves its part unwritten: never uninitialised memory)
+      CREATE_TRY(hipMemset(s->payload, 0, B * h->payload_cap));
+      if (h->dt_gcap) CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&s->dt_scratch), delaunay_gpu_scratch_bytes((int)B, h->dt_gcap)));      // (a side k_delaunay hands back leaves its part unwritten: never uninitialised memory)
     }
   }
   h->s_pitch = dp.pitch;
@@ -909,7 +916,7 @@ void jn_elas_destroy(jn_elas* h) {
     if (s->ev_head) hipEventDestroy(s->ev_head);
     if (s->ev_owner) hipEventDestroy(s->ev_owner);
     hipFree(s->need_host); if (s->h_need) hipHostFree(s->h_need);
-    hipFree(s->d_list); hipFree(s->d_cnt); hipFree(s->d_arr); hipFree(s->d_arr_ok);
+    hipFree(s->d_list); hipFree(s->d_cnt); hipFree(s->d_arr); hipFree(s->d_arr_ok); hipFree(s->dt_scratch);
     if (s->gate) hipFree(s->gate);
     if (s->stream_a) hipStreamDestroy(s->stream_a);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -1266,12 +1273,16 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return JN_ERR_NO_DEVICE;
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(configure_device_kernels());
-  const int cap = std::max(n, 1), arr_cap = std::min(cap, 8192);
+  const int cap = std::max(n, 1), arr_cap = std::min(cap, 8192), g_cap = std::min(cap, 16384);
+  const int whole = delaunay_gpu_capacity(152 * 1024);
   const size_t pay = (size_t)cap * 12 + 2 * (2 * (size_t)cap + 8) * 12 + 256;
   int16_t* d_list = nullptr; int32_t* d_cnt = nullptr; uint16_t* d_arr = nullptr; int32_t* d_ok = nullptr; uint8_t* d_pay = nullptr; FrameInfo* d_info = nullptr; int32_t* d_need = nullptr;
+  void* d_ascr = nullptr; uint8_t* d_dscr = nullptr;            // more vertices than the LDS forms take: the arrangement's and the triangulation's global scratch
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_list), (size_t)cap * 3 * sizeof(int16_t));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cnt), sizeof(int32_t));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_arr), (size_t)2 * arr_cap * sizeof(uint16_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_arr), (size_t)2 * g_cap * sizeof(uint16_t));
+  if (e == hipSuccess && g_cap > arr_cap) e = hipMalloc(&d_ascr, arrange_scratch_bytes(1, g_cap));
+  if (e == hipSuccess && n > whole) e = hipMalloc(reinterpret_cast<void**>(&d_dscr), delaunay_gpu_scratch_bytes(1, g_cap));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), 2 * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_pay), pay);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_info), sizeof(FrameInfo));
@@ -1281,11 +1292,11 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
   FrameInfo fi;
   memset(&fi, 0, sizeof(fi));
   if (e == hipSuccess) {
-    launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, arr_cap, d_arr, d_ok, nullptr, 0);
+    launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, g_cap, d_arr, d_ok, d_ascr, d_ascr ? g_cap : 0);
     long long* d_clk = nullptr;
     const bool want_clk = JN_HOOK_ENV("JN_DT_CLOCKS") != nullptr;
     if (want_clk && hipMalloc(reinterpret_cast<void**>(&d_clk), 64 * sizeof(long long)) == hipSuccess) hipMemset(d_clk, 0, 64 * sizeof(long long));
-    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, arr_cap, delaunay_gpu_capacity(152 * 1024), d_pay, (long long)pay, d_info, d_need, d_clk);
+    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, g_cap, d_dscr ? n : whole, d_pay, (long long)pay, d_info, d_need, d_clk, d_dscr, d_dscr ? g_cap : 0);
     e = hipStreamSynchronize(nullptr);
     if (d_clk) {                                             // JN_DT_CLOCKS: microseconds per tree level (leaves first) of both sides, to stderr
       long long clk[64];
@@ -1307,7 +1318,7 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
     if (fi.ntri[0] > 0) e = hipMemcpy(tri_left, d_pay + fi.corner_offset[0], (size_t)fi.ntri[0] * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess && fi.ntri[1] > 0) e = hipMemcpy(tri_right, d_pay + fi.corner_offset[1], (size_t)fi.ntri[1] * 12, hipMemcpyDeviceToHost);
   }
-  hipFree(d_list); hipFree(d_cnt); hipFree(d_arr); hipFree(d_ok); hipFree(d_pay); hipFree(d_info); hipFree(d_need);
+  hipFree(d_list); hipFree(d_cnt); hipFree(d_arr); hipFree(d_ok); hipFree(d_pay); hipFree(d_info); hipFree(d_need); hipFree(d_ascr); hipFree(d_dscr);
   HIP_TRY(e);
   return JN_OK;
 }

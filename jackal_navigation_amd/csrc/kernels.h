@@ -48,9 +48,12 @@ void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* c
 int delaunay_gpu_capacity(size_t lds_bytes);          // vertices per side that fit
 size_t delaunay_gpu_lds_bytes(int points);
 hipError_t configure_delaunay_kernel();
+int delaunay_gpu_max_points();                         // most vertices a side may have at all (with the global scratch)
+size_t delaunay_gpu_scratch_bytes(int frames, int gcap);   // the scratch that lets sides of up to gcap vertices through (subtrees in LDS, the top levels in global memory)
 hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                      int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host,
-                     long long* dbg_clock = nullptr);   // dbg_clock (optional, 64 entries): 100 MHz time stamps per tree level of frame 0's sides
+                     long long* dbg_clock = nullptr,    // dbg_clock (optional, 64 entries): 100 MHz time stamps per tree level of frame 0's sides
+                     uint8_t* gscratch = nullptr, int gcap = 0);
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 // list / count / list_cap / listed (optional): where the classification + resolution route takes the lattice, k_filter_resolve also writes

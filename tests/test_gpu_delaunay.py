@@ -55,6 +55,49 @@ def test_gpu_triangulation_equals_the_hosts_on_lattices(jn):
     assert sides_checked >= 60
 
 
+def test_gpu_triangulation_beyond_one_workgroups_lds(jn):
+    """sides with more vertices than one workgroup's LDS holds (~3 890; a 1920x1080 side has ~11 200) are cut at depth C —
+    the subtrees below the cut in LDS (k_delaunay_sub), the C levels above them on a global structure (k_delaunay_top).  The same triangles
+    in the same order as the host's replay of Triangle: just over the LDS capacity (C = 1), a 1080p side's count (C = 2), the most a side may
+    hold (C = 3), both sides (the right side's x = u - d scatters the columns)."""
+    L = jn.load()
+    rng = np.random.default_rng(11)
+    for n, cw, ch in ((3900, 256, 144), (4200, 384, 216), (7777, 384, 216), (11200, 384, 216), (16384, 384, 216)):
+        t = lattice_case(rng, n, cw, ch, 255, row_d=(n % 2 == 0))
+        (kl, tl), (kr, tr), need = device_tri(L, t, 5)
+        for side, (k, tri) in ((0, (kl, tl)), (1, (kr, tr))):
+            x = t[:, 0].astype(np.int32) * 5 - (t[:, 2].astype(np.int32) if side else 0); y = t[:, 1].astype(np.int32) * 5
+            if need & (1 << side):
+                assert len(set(zip(x.tolist(), y.tolist()))) < n, (n, side)       # handed back only because vertices coincide
+                continue
+            ke, te = host_tri(L, x, y)
+            assert k == ke, (n, side, k, ke)
+            assert np.array_equal(tri, te), (n, side, int((tri != te).any(axis=1).sum()))
+        assert need != 3 or n == 0, n
+
+
+def test_full_hd_batch_triangulates_on_the_gpu_without_a_hand_back(jn, oracle, monkeypatch):
+    """BASELINE config 5's frame through a batch handle on the GPU route (JN_GPU_DELAUNAY=1): ~11 k support points a side, more than the LDS
+    form takes — no batch may be handed back to the host stage, and D1 is the reference's (SURVEY 8c's known answer for seed 12345)."""
+    from jackal_navigation_amd.device import DeviceArray
+    monkeypatch.setenv("JN_GPU_DELAUNAY", "1")
+    W, H, n = 1920, 1080, 2
+    pairs = [jn.node.synth_pair(W, H, 256, 12345 + b) for b in range(n)]
+    dL = DeviceArray.from_numpy(np.stack([q[0] for q in pairs])); dR = DeviceArray.from_numpy(np.stack([q[1] for q in pairs]))
+    d1 = DeviceArray((n, H, W), np.float32); d2 = DeviceArray((n, H, W), np.float32)
+    with jn.Elas(jn.Elas.parameters(0, disp_max=255), W, H, max_batch=n, host_threads=4, slots=2) as e:
+        assert e.route_stats(0)[0] == 1
+        for slot in (0, 1, 0):
+            e.submit(slot, n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
+            e.wait(slot)
+        assert e.route_stats(0)[1] == 0 and e.route_stats(1)[1] == 0, (e.route_stats(0), e.route_stats(1))    # zero hand-backs
+        assert e.last_times(0)["host_stage"] == 0
+    D1 = d1.numpy()
+    assert oracle.fnv(D1[0]) == 0xcd2740a7ac6afdf7
+    _, D1o, _ = oracle.process(oracle.params(0, disp_max=255), pairs[1][0], pairs[1][1])
+    assert np.array_equal(D1[1].view(np.uint32), D1o.view(np.uint32))
+
+
 def test_gpu_triangulation_on_support_points_of_real_frames(jn, oracle):
     """The support points the matcher really produces (Appendix-A pairs and two scene kinds, 720p included): the GPU's triangles equal the host's."""
     from scenes import make_scene
@@ -76,7 +119,7 @@ def test_gpu_triangulation_on_support_points_of_real_frames(jn, oracle):
 def test_sides_the_gpu_cannot_take_are_handed_back(jn):
     L = jn.load()
     rng = np.random.default_rng(3)
-    t = lattice_case(rng, 4200, 384, 216, 255, row_d=True)                 # more vertices than the LDS holds
+    t = lattice_case(rng, 17000, 384, 216, 255, row_d=True)                # more vertices than the kernels take at all (16384 a side)
     _, _, need = device_tri(L, t, 5)
     assert need == 3
     t = lattice_case(rng, 300, 256, 144, 127)
