@@ -627,7 +627,8 @@ hipError_t configure_delaunay_kernel() {
 hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                            int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock,
                            uint8_t* gscratch, int gcap) {
-  const int whole = delaunay_gpu_capacity(152 * 1024);
+  static const int whole_env = JN_HOOK_ENV("JN_DT_WHOLE") ? atoi(JN_HOOK_ENV("JN_DT_WHOLE")) : 0;   // (experiment: cut sides the LDS would hold, too)
+  const int whole = whole_env ? std::min(whole_env, delaunay_gpu_capacity(152 * 1024)) : delaunay_gpu_capacity(152 * 1024);
   if (const hipError_t e = hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st); e != hipSuccess) return e;
 #ifdef JN_HOOKS
   // experiment (what k_delaunay costs the pipeline, and why): a kernel that does nothing for JN_DT_DUMMY_US microseconds behind the real one,

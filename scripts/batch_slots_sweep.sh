@@ -1,3 +1,5 @@
+#!/bin/bash
+# Pairs per batch x batches in flight (inside gpurun): more kernels in flight than four lower the rate, whatever the batch size.
 line() { python3 bench.py --gpus 1 --steps 40 --warmup 8 --no-cpu-baseline --no-latency-config --no-alone-leg "$@" 2>/dev/null | grep '^{"metric"' | python3 -c 'import sys,json; j=json.loads(sys.stdin.read()); print(j["value"], "pairs/s,", j["ms_per_step"], "ms/step, host cores busy", j["host_cpu"].get("cores_total"), ", check", j["check"].get("ok"))'; }
 echo "batch 32 slots 4: $(line)"
 echo "batch 32 slots 5: $(line --slots 5)"

@@ -40,7 +40,8 @@ doc = {
     "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two passes, scripts/collect_profiles.sh) and SQ passes (scripts/pmc_sq.sh) -- "
                "python3 bench.py --steps 3 --warmup 1 --slots 1 --no-cpu-baseline --no-latency-config",
     "workload": "32 pairs 1280x720 disp_max=127 per launch",
-    "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane coalesced loads -> x2 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as is; KB = 1024 B",
+    "correction": "gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM section) — settled by a probe for the loads these kernels issue: a buffer streamed once with raw_buffer_load of 4, 8 and 16 bytes per lane "
+                  "shows HALF the bytes read in FETCH_SIZE in all three cases (scripts/probes/fetch_size_probe.hip, profiles/%s_fetch_size_probe.txt); WRITE_SIZE as is; KB = 1024 B" % tag,
     "kernels_hip_sha256": hashlib.sha256(open(os.path.join(root, "jackal_navigation_amd", "csrc", "kernels.hip"), "rb").read()).hexdigest(),
     "commit": subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip(),
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copy the evidence set scripts/round5_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
+"""Copy the evidence set scripts/round6_profiles.sh <tag> left under gpurun_out/ into profiles/ (tracked) and write
 profiles/<tag>_manifest.json: every published file, the sha256 of the kernel sources it was measured on, the commit.
     python3 scripts/publish_round.py <tag>
 Files are taken NEWEST FIRST (gpurun_out/ accumulates merged results of several calls; round 2 published stale ones)."""
@@ -62,7 +62,8 @@ for src, name in (("default_bench_line.json", "default_bench_line_under_rocprof.
                   ("bm_ssd_bench_line.json", None), ("bm_ssd_1080p_bench_line.json", None), ("bm_sad_1080p_bench_line.json", None), ("bm_ssd_pmc_mfma.txt", None),
                   ("host_threads.txt", None), ("pk3_probe.txt", None), ("dep_chain_probe.txt", None), ("lds_unaligned_probe.txt", None), ("op_rate_probe.txt", None),
                   ("dense_dbg_switches.txt", None), ("hw_queues_ab.txt", None), ("gate_ab.txt", None), ("lone_timeline.txt", None), ("gpu_tests.txt", None),
-                  ("gpu_delaunay_ab.txt", None), ("lone_env_ab.txt", None)):
+                  ("gpu_delaunay_ab.txt", None), ("lone_env_ab.txt", None), ("fetch_size_probe.txt", None), ("dt_no_volatile.txt", None),
+                  ("slot_timeline.txt", None), ("full_hd_routes.txt", None), ("lone_wave_probe.txt", None), ("lds_misaligned_store_probe.txt", None)):
     put(os.path.join(g, "%s_%s" % (tag, src)), "%s_%s" % (tag, name or src))
 sq = "".join(open(f).read() for f in (os.path.join(g, "%s_sq1.txt" % tag), os.path.join(g, "%s_sq2.txt" % tag)) if os.path.exists(f))
 if sq:
@@ -97,7 +98,7 @@ if os.path.exists(fs) and os.path.exists(ws):     # SGM traffic from its own PMC
             ker[k]["traffic_bytes"] = int(2 * ker[k]["FETCH_SIZE_KB"] * 1024 + ker[k]["WRITE_SIZE_KB"] * 1024)
     total = sum(v.get("traffic_bytes", 0) for v in ker.values())
     json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --mode sgm --steps 2 --warmup 1 --no-cpu-baseline",
-               "workload": [1280, 720, 128, 32], "correction": "gfx950: FETCH_SIZE x 2 for 16-byte-per-lane streaming loads (MI355X_MICROARCH.md, HBM); WRITE_SIZE as is; KB = 1024 B",
+               "workload": [1280, 720, 128, 32], "correction": "gfx950: FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM; measured: the counter shows half the bytes read for 4-, 8- and 16-byte-per-lane loads alike, profiles/%s_fetch_size_probe.txt); WRITE_SIZE as is; KB = 1024 B" % tag,
                "sgm_sweep_sha256": sha("jackal_navigation_amd/csrc/sgm_sweep.hip"), "kernels": ker, "bytes_per_batch": total,
                "algorithmic_bytes_per_batch": int((4 * 1280 * 720 * 128 + 5 * 1280 * 720) * 32)}, open(os.path.join(p, "%s_sgm_pmc_traffic.json" % rnd), "w"), indent=1)
     published["%s_sgm_pmc_traffic.json" % rnd] = "from %s_sgm_pmc_*.txt" % tag

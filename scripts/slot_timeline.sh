@@ -1,3 +1,5 @@
+#!/bin/bash
+# A slot's life in the pipelined path: rocprofv3 kernel trace of short bench runs (GPU route, host route, six slots) through scripts/slot_timeline.py.
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 for cfg in "1 4" "0 4" "1 6"; do

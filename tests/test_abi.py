@@ -101,7 +101,7 @@ def test_release_library_carries_no_test_or_debug_switches(jn):
     hooks = _jn_strings(jn.HOOKS_LIB_PATH)
     assert set(rel) < set(hooks)                                   # the hooks build = the release switches + the hooks
     listed_hooks = set(re.findall(r"`(JN_[A-Z0-9_]+)`", "\n".join(l.split("|")[1] for l in second.split("\n") if l.startswith("| `"))))
-    assert set(hooks) - set(rel) <= listed_hooks | {"JN_DT_DUMMY", "JN_DT_DUMMY_US", "JN_HOOKS"}, sorted(set(hooks) - set(rel) - listed_hooks)
+    assert set(hooks) - set(rel) <= listed_hooks | {"JN_HOOKS"}, sorted(set(hooks) - set(rel) - listed_hooks)
     for v in ("JN_TEST_FAIL_SEQ", "JN_DENSE_DBG", "JN_OWNER_FAST_MAX"):
         assert v in hooks, v
 

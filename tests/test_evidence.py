@@ -22,7 +22,7 @@ def test_manifest_lists_existing_files_and_was_taken_on_this_source():
     assert man["tag"] == tag and len(man["files"]) >= 20
     for name in man["files"]:
         assert os.path.getsize(os.path.join(P, name)) > 0, name
-    # kernel sources: the profiles describe THIS tree's kernels (re-publish after touching them: scripts/round5_profiles.sh + publish_round.py)
+    # kernel sources: the profiles describe THIS tree's kernels (re-publish after touching them: scripts/round6_profiles.sh + publish_round.py)
     for src in ("jackal_navigation_amd/csrc/kernels.hip", "jackal_navigation_amd/csrc/sgm_sweep.hip", "jackal_navigation_amd/csrc/bm.hip", "jackal_navigation_amd/csrc/bm_mfma.hip", "jackal_navigation_amd/csrc/prefilter.h", "jackal_navigation_amd/csrc/delaunay_gpu.hip"):
         sha = hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest()
         assert man["sources_sha256"][src] == sha, "%s changed after profiles/%s_* were taken" % (src, tag)
