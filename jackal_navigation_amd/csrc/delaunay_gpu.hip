@@ -622,11 +622,13 @@ hipError_t configure_delaunay_kernel() {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 }
 
-// cap_pts: the most vertices a side of this batch is expected to hold (sizes the LDS).  gscratch / gcap (may be null / 0): the global scratch
-// of delaunay_gpu_scratch_bytes(n, gcap) bytes that lets sides of up to gcap vertices through, beyond what one workgroup's LDS holds.
+// cap_pts: the most vertices a side of this batch is expected to hold, with a margin (sizes the LDS).  gscratch / gcap (may be null / 0): the
+// global scratch of delaunay_gpu_scratch_bytes(n, gcap) bytes that lets sides of up to gcap vertices through, beyond what one workgroup's
+// LDS holds; expect_pts: the most vertices a side of the caller's recent batches held (0: unknown) — the whole-side kernel is the faster
+// form wherever the sides fit it (profiles/r06_dt_cut_720p_ab.txt), so it is chosen by what the sides ARE, not by the margin on top.
 hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                            int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock,
-                           uint8_t* gscratch, int gcap) {
+                           uint8_t* gscratch, int gcap, int expect_pts) {
   static const int whole_env = JN_HOOK_ENV("JN_DT_WHOLE") ? atoi(JN_HOOK_ENV("JN_DT_WHOLE")) : 0;   // (experiment: cut sides the LDS would hold, too)
   const int whole = whole_env ? std::min(whole_env, delaunay_gpu_capacity(152 * 1024)) : delaunay_gpu_capacity(152 * 1024);
   if (const hipError_t e = hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st); e != hipSuccess) return e;
@@ -640,7 +642,7 @@ hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int
   if (dummy == 3) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(64), 152 * 1024, st, dummy_us * 100);
   if (dummy == 4) hipLaunchKernelGGL(k_dt_dummy, dim3(n, 2), dim3(kDtThreads), 0, st, dummy_us * 100);
 #endif
-  if (cap_pts <= whole || !gscratch || gcap <= whole) {
+  if (cap_pts <= whole || !gscratch || gcap <= whole || (expect_pts > 0 && expect_pts + expect_pts / 16 <= whole)) {
     cap_pts = std::min(cap_pts, whole);
     hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
                        payload, payload_stride, info, need_host, dbg_clock);

@@ -313,12 +313,12 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
       const int cap = s.arr_hint > h->arr_cap ? 1024 : std::min(h->arr_cap, std::max(1024, (want + 1023) / 1024 * 1024));
       {
         // (the global-scratch form only when the slot's recent batches held a side beyond the LDS form: at 1280x720 it would be an empty launch per batch)
-        const bool big = s.arr_scratch && s.arr_hint > h->arr_cap;
+        const bool big = s.arr_scratch && (s.arr_hint == 0 || s.arr_hint > h->arr_cap);   // (0: the slot's first batch — nothing known yet)
         launch_arrange(sa, n, list_buf, cnt_buf, list_cap, dp.step, cap, h->arr_stride, arr_buf, arr_ok_buf, big ? s.arr_scratch : nullptr, big ? h->arr_stride : 0);
       }
       if (gpu_dt)                                        // LDS for what the slot's last batches held (+25 %), as the arrangement; a side beyond it goes to the host
         HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
-                                (long long)h->payload_cap, s.info, s.need_host, nullptr, s.dt_scratch, h->dt_gcap));
+                                (long long)h->payload_cap, s.info, s.need_host, nullptr, s.dt_scratch, h->dt_gcap, s.arr_hint));
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
