@@ -792,6 +792,10 @@ def run_rank(a):
     # records around the kernel on the stream it runs on.
     alg_bytes = STAGE_BYTES_PER_PX["gpu_matching"] * W * H * B
     k_ms = k_ms_alone if k_ms_alone else k_ms_pipelined
+    if not k_ms or k_ms <= 0:                # JN_STAGE_EVENTS=0: the library recorded no events around the kernel — nothing to price
+        raise SystemExit("bench.py: the library recorded no kernel times (JN_STAGE_EVENTS=0?): the roofline object needs them; unset the switch")
+    if not k_ms_pipelined or k_ms_pipelined <= 0:
+        k_ms_pipelined = k_ms
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic, traffic_note, extra_roof = None, None, {}
     try:   # HBM bytes per launch from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 runs) of the same workload
