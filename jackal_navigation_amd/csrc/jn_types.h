@@ -43,7 +43,7 @@ struct FrameInfo {
   int32_t ntri[2];           // left, right
   int64_t sup_offset;        // byte offset of the support points inside the frame payload
   int64_t corner_offset[2];  // byte offset of each side's triangle corner indices
-  int64_t reserved;
+  int64_t reserved;          // GPU triangulation route: what the frame's support list held, clipped or not (k_delaunay writes it; the host sizes the next launches by it)
 };
 
 // Kernel-side view of the tunables (Elas::parameters subset + derived constants).
