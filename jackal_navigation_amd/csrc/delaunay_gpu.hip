@@ -558,7 +558,8 @@ __global__ void __launch_bounds__(kDtTopThreads) k_delaunay_top(const int16_t* _
   if (tid == 0) dt_tables(max(n, 3), s_f, s_c, &s_K);
   __syncthreads();
   // what the subtrees did not take (they returned without a word), and what they gave up on (need_host is set already)
-  bool mine_to_do = !(n > list_cap || n > gcap || n > cap_all || !arr_ok[frame * 2 + side] || (n >> C) <= 3 || s_f[C] + 1 > cap_sub);
+  const bool tiny = (n >> C) <= 3;                             // a side with next to no vertices under a deep cut: no subtree ran, the whole tree is done here
+  bool mine_to_do = !(n > list_cap || n > gcap || n > cap_all || !arr_ok[frame * 2 + side] || (!tiny && s_f[C] + 1 > cap_sub));
   if (mine_to_do && (need_host[frame] >> side) & 1) mine_to_do = false;
   if (!mine_to_do) {
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
@@ -575,7 +576,7 @@ __global__ void __launch_bounds__(kDtTopThreads) k_delaunay_top(const int16_t* _
   __syncthreads();
   uint8_t* g = gscratch + (size_t)(frame * 2 + side) * dt_g_bytes(gcap);
   DT<GlobalMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (GlobalMem::LinkP)dt_g_link(g, gcap), (GlobalMem::VertP)dt_g_vert(g, gcap), 0u, 0, 0};
-  const bool gave_up = dt_levels<GlobalMem, kDtTopThreads>(dt, n, C - 1, 0, 0, 0, (GlobalMem::HullP)dt_g_hl(g, gcap), (GlobalMem::HullP)dt_g_hr(g, gcap), 0, s_f, s_c, tid, nullptr, 0);
+  const bool gave_up = dt_levels<GlobalMem, kDtTopThreads>(dt, n, tiny ? s_K : C - 1, 0, 0, 0, (GlobalMem::HullP)dt_g_hl(g, gcap), (GlobalMem::HullP)dt_g_hr(g, gcap), 0, s_f, s_c, tid, nullptr, 0);
   if (__syncthreads_or(gave_up)) {
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;

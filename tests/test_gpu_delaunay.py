@@ -167,6 +167,34 @@ def test_batches_through_both_triangulation_routes(jn, oracle, monkeypatch, gpu_
         assert e.last_times(0)["host_stage"] == 0 if gpu_dt == "1" else e.last_times(0)["host_stage"] > 0
 
 
+def test_a_slots_first_batch_with_nearly_empty_sides_is_not_handed_back(jn, oracle, monkeypatch):
+    """A slot's first batch knows nothing about its frames yet and takes the cut form sized for the whole lattice; a side with a handful of
+    vertices then sits under a cut deeper than its tree.  No subtree runs for it, k_delaunay_top does its whole tree — the batch must not
+    go to the host stage, and the maps are the oracle's."""
+    from jackal_navigation_amd.device import DeviceArray
+    monkeypatch.setenv("JN_GPU_DELAUNAY", "1")
+    W, H, n = 640, 360, 3
+    rng = np.random.default_rng(5)
+    Ls = np.full((n, H, W), 128, np.uint8); Rs = np.full((n, H, W), 128, np.uint8)
+    for b, size in enumerate((25, 44)):                                      # flat images with one textured patch: 4 and 9 support points
+        patch = rng.integers(0, 255, (size, size)).astype(np.uint8)
+        Ls[b, 150:150 + size, 300:300 + size] = patch; Rs[b, 150:150 + size, 288:288 + size] = patch
+    Ls[2], Rs[2] = jn.node.synth_pair(W, H, 60, 77)                          # and an ordinary frame beside them
+    p = dict(disp_max=63)
+    counts = [len(np.asarray(oracle.support(oracle.params(0, **p), oracle.descriptor(Ls[b]), oracle.descriptor(Rs[b])))) for b in range(n)]
+    assert 3 <= counts[0] <= 15 and 3 <= counts[1] <= 15 and counts[2] > 500, counts
+    dL, dR = DeviceArray.from_numpy(Ls), DeviceArray.from_numpy(Rs)
+    d1 = DeviceArray((n, H, W), np.float32); d2 = DeviceArray((n, H, W), np.float32)
+    with jn.Elas(jn.Elas.parameters(0, **p), W, H, max_batch=n, host_threads=4) as e:
+        st = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)      # the handle's FIRST batch
+        assert e.route_stats(0)[0] == 1 and e.route_stats(0)[1] == 0, e.route_stats(0)
+    D1, D2 = d1.numpy(), d2.numpy()
+    for b in range(n):
+        st_o, D1o, D2o = oracle.process(oracle.params(0, **p), Ls[b], Rs[b])
+        assert st[b] == st_o == 0
+        assert np.array_equal(D1[b].view(np.uint32), D1o.view(np.uint32)) and np.array_equal(D2[b].view(np.uint32), D2o.view(np.uint32)), b
+
+
 def test_an_explicit_small_host_share_selects_the_gpu_route(jn, monkeypatch):
     """No rank of a multi-GPU job can see from its own affinity mask or cpu.max that it shares the container's CPU quota with seven others:
     a batch handle created with 0 < host_threads < 14 (bench.py passes quota / world) triangulates on the GPU; a latency handle never does."""
