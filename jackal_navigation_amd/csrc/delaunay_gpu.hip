@@ -34,6 +34,7 @@
 #include "hooks.h"
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 
 namespace jnav {
 
@@ -67,7 +68,7 @@ struct GlobalMem {
   typedef uint32_t link_t;
   static constexpr bool kGlobal = true;
 };
-template <class M>
+template <class M, bool WIDE = false>
 struct DT {
   lds_ci16* X; lds_ci16* Y;                 // vertex coordinates (always in LDS), indexed by vertex number - voff
   // volatile: every access is the 16-bit LDS operation it says, in program order.  Round 5 added it after an intermediate version with 6-byte
@@ -108,26 +109,38 @@ struct DT {
     VERT[i] = -1; VERT[i + 1] = -1; VERT[i + 2] = -1;
     return (H)t << 2;
   }
-  // Predicates in FP64.  Coordinates lie in (-2048, 2048) (launch_delaunay's caller guarantees it: image widths below 2048), so differences
+  // Predicates in FP64 (WIDE = false).  Coordinates lie in (-2048, 2048) (launch_delaunay's caller says so: `wide` otherwise), so differences
   // are below 2^12, the 2x2 determinants and the squared lengths below 2^25, their products below 2^50 and the sum of three below 2^52:
   // every intermediate is an integer a double holds exactly, i.e. the sign is delaunay.cpp's int64 sign — at a tenth of the instructions
   // (a 64-bit integer multiply is a dozen 32-bit operations here; the top merges are ONE thread, which issues an instruction every ~8 cycles).
-  struct P { int v; double x, y; };
+  // WIDE (images of 2048 columns or rows and more, coordinates below 8192 — round 6, VERDICT r05 #7 "do not assume it"): differences reach
+  // 2^14, the determinants and squared lengths 2^29, their products 2^58 — past what a double holds exactly, so a rounded term could turn
+  // the sign of a near-zero sum.  Those handles take integer predicates: 32-bit for `orient` and for in_circle's six small terms, 64-bit
+  // products and sum (below 2^60) — delaunay.cpp's own arithmetic, at ~15 more instructions per in_circle than the FP64 form.
+  typedef typename std::conditional<WIDE, int32_t, double>::type coord_t;
+  struct P { int v; coord_t x, y; };
   __device__ __forceinline__ int xx(int v) const { return X[v - voff]; }
   __device__ __forceinline__ int yy(int v) const { return Y[v - voff]; }
-  __device__ __forceinline__ P pt(int v) const { return P{v, (double)X[v - voff], (double)Y[v - voff]}; }
-  __device__ __forceinline__ static int sgn(double d) { return d > 0 ? 1 : (d < 0 ? -1 : 0); }
+  __device__ __forceinline__ P pt(int v) const { return P{v, (coord_t)X[v - voff], (coord_t)Y[v - voff]}; }
+  template <class T> __device__ __forceinline__ static int sgn(T d) { return d > 0 ? 1 : (d < 0 ? -1 : 0); }
   // (explicit fused multiply-adds: every product and sum below is an integer smaller than 2^53, so the fused and the unfused forms give the same
   // exact value; the library is built with -ffp-contract=off, which would otherwise keep them apart — 7 and 22 instructions instead of 11 and 31)
   __device__ __forceinline__ static int orient(const P& a, const P& b, const P& c) {
-    return sgn(__builtin_fma(a.x - c.x, b.y - c.y, -((a.y - c.y) * (b.x - c.x))));
+    if constexpr (WIDE) return sgn((a.x - c.x) * (b.y - c.y) - (a.y - c.y) * (b.x - c.x));
+    else return sgn(__builtin_fma(a.x - c.x, b.y - c.y, -((a.y - c.y) * (b.x - c.x))));
   }
   __device__ __forceinline__ int orient(int a, int b, int c) const { return orient(pt(a), pt(b), pt(c)); }
   __device__ __forceinline__ static int in_circle(const P& a, const P& b, const P& c, const P& d) {
-    const double ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
-    const double al = __builtin_fma(ax, ax, ay * ay), bl = __builtin_fma(bx, bx, by * by), cl = __builtin_fma(cx, cx, cy * cy);
-    const double dbc = __builtin_fma(bx, cy, -(by * cx)), dca = __builtin_fma(cx, ay, -(cy * ax)), dab = __builtin_fma(ax, by, -(ay * bx));
-    return sgn(__builtin_fma(al, dbc, __builtin_fma(bl, dca, cl * dab)));
+    const coord_t ax = a.x - d.x, ay = a.y - d.y, bx = b.x - d.x, by = b.y - d.y, cx = c.x - d.x, cy = c.y - d.y;
+    if constexpr (WIDE) {
+      const int32_t al = ax * ax + ay * ay, bl = bx * bx + by * by, cl = cx * cx + cy * cy;
+      const int32_t dbc = bx * cy - by * cx, dca = cx * ay - cy * ax, dab = ax * by - ay * bx;
+      return sgn((int64_t)al * dbc + (int64_t)bl * dca + (int64_t)cl * dab);
+    } else {
+      const double al = __builtin_fma(ax, ax, ay * ay), bl = __builtin_fma(bx, bx, by * by), cl = __builtin_fma(cx, cx, cy * cy);
+      const double dbc = __builtin_fma(bx, cy, -(by * cx)), dca = __builtin_fma(cx, ay, -(cy * ax)), dab = __builtin_fma(ax, by, -(ay * bx));
+      return sgn(__builtin_fma(al, dbc, __builtin_fma(bl, dca, cl * dab)));
+    }
   }
 
   // the 2- and 3-vertex base cases (delaunay.cpp conquer(), triangle.cpp:5964-6060)
@@ -361,10 +374,10 @@ DEV bool dt_node(int n, int k, int j, const int* s_f, const int (*s_c)[2], int& 
 // merges are data-dependent loops: lanes of one wave that sit in different merges are executed one after the other, so the levels with
 // 2 .. 16 nodes — the long merges — took longer in one wave than the root's single merge (measured: 153 us for the two merges below the
 // root against 135).
-template <class M, int NT>
-DEV bool dt_levels(DT<M>& dt, int n, int k_deep, int k_top, int root_k, int root_j, typename M::HullP HL, typename M::HullP HR, int hoff,
+template <class M, int NT, bool WIDE>
+DEV bool dt_levels(DT<M, WIDE>& dt, int n, int k_deep, int k_top, int root_k, int root_j, typename M::HullP HL, typename M::HullP HR, int hoff,
                    const int* s_f, const int (*s_c)[2], int tid, long long* dbg_clock, int dbg_side) {
-  typedef typename DT<M>::H H;
+  typedef typename DT<M, WIDE>::H H;
   bool gave_up = false;
   for (int k = k_deep; k >= k_top; k--) {
     const int count = 1 << (k - root_k);
@@ -375,11 +388,11 @@ DEV bool dt_levels(DT<M>& dt, int n, int k_deep, int k_top, int root_k, int root
       if (!dt_node(n, k, (root_j << (k - root_k)) + i, s_f, s_c, lo, size, slot)) continue;
       H fl, fr;
       if (size <= 3) {
-        typename DT<M>::Ctx c{slot};
+        typename DT<M, WIDE>::Ctx c{slot};
         dt.leaf(lo, size, fl, fr, c);
       } else {
         const int half = size >> 1;
-        typename DT<M>::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
+        typename DT<M, WIDE>::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
         fl = (H)HL[lo - hoff] + dt.off; fr = (H)HR[lo + half - hoff] + dt.off;
         H il = (H)HR[lo - hoff] + dt.off, ir = (H)HL[lo + half - hoff] + dt.off;
         dt.budget = 16 * size + 256;                                       // (a merge of `size` vertices takes a few steps per seam vertex)
@@ -430,6 +443,7 @@ DEV DtPlace dt_place(FrameInfo* fi, int frame, int side, int n, int nlist, long 
 // arr / arr_ok: k_arrange's alternating-cut arrangement of this side's vertices.  Writes FrameInfo (side 0: ok, nsup, the payload
 // offsets HostWorker::place() would give the frame at payload_stride * frame; both sides: their ntri), the support points (side 0) and the
 // triangles' corner indices into the batch payload.  cap_pts: vertices this launch's LDS holds.
+template <bool WIDE>
 __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
                                                          const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int cap_pts,
                                                          uint8_t* __restrict__ payload, long long payload_stride, FrameInfo* __restrict__ info,
@@ -465,11 +479,11 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
   }
   if (tid == 0) dt_tables(n, s_f, s_c, &s_K);
   __syncthreads();
-  DT<LdsMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 0u, 0, 0};
+  DT<LdsMem, WIDE> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 0u, 0, 0};
   const int K = s_K;
   long long* clk = frame == 0 ? dbg_clock : nullptr;
   if (clk && tid == 0) clk[side * 32 + 31] = wall_clock64();
-  const bool gave_up = dt_levels<LdsMem, kDtThreads>(dt, n, K, 0, 0, 0, (LdsMem::HullP)HL, (LdsMem::HullP)HR, 0, s_f, s_c, tid, clk, side);
+  const bool gave_up = dt_levels<LdsMem, kDtThreads, WIDE>(dt, n, K, 0, 0, 0, (LdsMem::HullP)HL, (LdsMem::HullP)HR, 0, s_f, s_c, tid, clk, side);
   if (__syncthreads_or(gave_up)) {                                        // never seen; a structure that does not close must not hang the GPU
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;
@@ -500,6 +514,7 @@ DEV int16_t* dt_g_vert(uint8_t* g, int gcap) { return reinterpret_cast<int16_t*>
 __host__ __device__ static inline size_t dt_g_bytes(int gcap) { return (size_t)gcap * (10 * 4 + 8 * 2); }
 
 // Subtree (C, blockIdx.z) of a side: its vertices are positions [lo, lo + size) of the arrangement, its triangles slots [slot, slot + count).
+template <bool WIDE>
 __global__ void __launch_bounds__(kDtThreads) k_delaunay_sub(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
                                                              const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int C, int cap_sub,
                                                              uint8_t* __restrict__ gscratch, int gcap, int32_t* __restrict__ need_host) {
@@ -524,8 +539,8 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay_sub(const int16_t* __re
     X[p] = (int16_t)(side ? u - d : u); Y[p] = (int16_t)v;
   }
   __syncthreads();
-  DT<LdsMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 4u * (uint32_t)slot, lo, 0};
-  const bool gave_up = dt_levels<LdsMem, kDtThreads>(dt, n, s_K, C, C, jr, (LdsMem::HullP)HL, (LdsMem::HullP)HR, lo, s_f, s_c, tid, nullptr, 0);
+  DT<LdsMem, WIDE> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 4u * (uint32_t)slot, lo, 0};
+  const bool gave_up = dt_levels<LdsMem, kDtThreads, WIDE>(dt, n, s_K, C, C, jr, (LdsMem::HullP)HL, (LdsMem::HullP)HR, lo, s_f, s_c, tid, nullptr, 0);
   if (__syncthreads_or(gave_up)) { if (tid == 0) atomicOr(&need_host[frame], 1 << side); return; }
   // hand the subtree over: records with absolute 32-bit links, the root's hull handles
   uint8_t* g = gscratch + (size_t)(frame * 2 + side) * dt_g_bytes(gcap);
@@ -539,6 +554,7 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay_sub(const int16_t* __re
 }
 
 // The C levels above the subtrees on the global structure, FrameInfo, support points, output.  LDS: the coordinates of ALL the side's vertices.
+template <bool WIDE>
 __global__ void __launch_bounds__(kDtTopThreads) k_delaunay_top(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
                                                                 const uint16_t* __restrict__ arr, const int32_t* __restrict__ arr_ok, int arr_stride, int C, int cap_sub,
                                                                 int cap_all, uint8_t* __restrict__ gscratch, int gcap, uint8_t* __restrict__ payload, long long payload_stride,
@@ -575,8 +591,8 @@ __global__ void __launch_bounds__(kDtTopThreads) k_delaunay_top(const int16_t* _
   }
   __syncthreads();
   uint8_t* g = gscratch + (size_t)(frame * 2 + side) * dt_g_bytes(gcap);
-  DT<GlobalMem> dt{(lds_ci16*)X, (lds_ci16*)Y, (GlobalMem::LinkP)dt_g_link(g, gcap), (GlobalMem::VertP)dt_g_vert(g, gcap), 0u, 0, 0};
-  const bool gave_up = dt_levels<GlobalMem, kDtTopThreads>(dt, n, tiny ? s_K : C - 1, 0, 0, 0, (GlobalMem::HullP)dt_g_hl(g, gcap), (GlobalMem::HullP)dt_g_hr(g, gcap), 0, s_f, s_c, tid, nullptr, 0);
+  DT<GlobalMem, WIDE> dt{(lds_ci16*)X, (lds_ci16*)Y, (GlobalMem::LinkP)dt_g_link(g, gcap), (GlobalMem::VertP)dt_g_vert(g, gcap), 0u, 0, 0};
+  const bool gave_up = dt_levels<GlobalMem, kDtTopThreads, WIDE>(dt, n, tiny ? s_K : C - 1, 0, 0, 0, (GlobalMem::HullP)dt_g_hl(g, gcap), (GlobalMem::HullP)dt_g_hr(g, gcap), 0, s_f, s_c, tid, nullptr, 0);
   if (__syncthreads_or(gave_up)) {
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;
@@ -617,10 +633,12 @@ hipError_t configure_delaunay_kernel() {
 #ifdef JN_HOOKS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_dt_dummy), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
 #endif
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay_sub), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-  if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay_top), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(k_delaunay), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+  const void* ks[] = {reinterpret_cast<const void*>(k_delaunay<false>), reinterpret_cast<const void*>(k_delaunay<true>),
+                      reinterpret_cast<const void*>(k_delaunay_sub<false>), reinterpret_cast<const void*>(k_delaunay_sub<true>),
+                      reinterpret_cast<const void*>(k_delaunay_top<false>), reinterpret_cast<const void*>(k_delaunay_top<true>)};
+  for (const void* k : ks)
+    if (const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); e != hipSuccess) return e;
+  return hipSuccess;
 }
 
 // cap_pts: the most vertices a side of this batch is expected to hold, with a margin (sizes the LDS).  gscratch / gcap (may be null / 0): the
@@ -629,9 +647,10 @@ hipError_t configure_delaunay_kernel() {
 // form wherever the sides fit it (profiles/r06_dt_cut_720p_ab.txt), so it is chosen by what the sides ARE, not by the margin on top.
 hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                            int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host, long long* dbg_clock,
-                           uint8_t* gscratch, int gcap, int expect_pts) {
+                           uint8_t* gscratch, int gcap, int expect_pts, bool wide) {
   static const int whole_env = JN_HOOK_ENV("JN_DT_WHOLE") ? atoi(JN_HOOK_ENV("JN_DT_WHOLE")) : 0;   // (experiment: cut sides the LDS would hold, too)
   const int whole = whole_env ? std::min(whole_env, delaunay_gpu_capacity(152 * 1024)) : delaunay_gpu_capacity(152 * 1024);
+  if (JN_HOOK_ENV("JN_DT_FP64")) wide = false;               // (experiment: the FP64 predicates on coordinates they are not exact for)
   if (const hipError_t e = hipMemsetAsync(need_host, 0, sizeof(int32_t) * n, st); e != hipSuccess) return e;
 #ifdef JN_HOOKS
   // experiment (what k_delaunay costs the pipeline, and why): a kernel that does nothing for JN_DT_DUMMY_US microseconds behind the real one,
@@ -645,8 +664,8 @@ hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int
 #endif
   if (cap_pts <= whole || !gscratch || gcap <= whole || (expect_pts > 0 && expect_pts + expect_pts / 16 <= whole)) {
     cap_pts = std::min(cap_pts, whole);
-    hipLaunchKernelGGL(k_delaunay, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok, arr_stride, cap_pts,
-                       payload, payload_stride, info, need_host, dbg_clock);
+    hipLaunchKernelGGL(wide ? k_delaunay<true> : k_delaunay<false>, dim3(n, 2), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_pts), st, list, count, list_cap, step, arr, arr_ok,
+                       arr_stride, cap_pts, payload, payload_stride, info, need_host, dbg_clock);
     return hipGetLastError();
   }
   // the cut: the smallest depth C whose subtrees (at most (cap_pts >> C) + 1 vertices) fit one workgroup's LDS
@@ -654,9 +673,9 @@ hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int
   int C = 1;
   while ((cap_pts >> C) + 1 > whole) C++;
   const int cap_sub = std::min(whole, (cap_pts >> C) + 1);
-  hipLaunchKernelGGL(k_delaunay_sub, dim3(n, 2, 1 << C), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_sub), st, list, count, list_cap, step, arr, arr_ok, arr_stride, C, cap_sub,
+  hipLaunchKernelGGL(wide ? k_delaunay_sub<true> : k_delaunay_sub<false>, dim3(n, 2, 1 << C), dim3(kDtThreads), delaunay_gpu_lds_bytes(cap_sub), st, list, count, list_cap, step, arr, arr_ok, arr_stride, C, cap_sub,
                      gscratch, gcap, need_host);
-  hipLaunchKernelGGL(k_delaunay_top, dim3(n, 2), dim3(kDtTopThreads), (size_t)((cap_pts + 3) & ~3) * 4 + 64, st, list, count, list_cap, step, arr, arr_ok, arr_stride, C, cap_sub,
+  hipLaunchKernelGGL(wide ? k_delaunay_top<true> : k_delaunay_top<false>, dim3(n, 2), dim3(kDtTopThreads), (size_t)((cap_pts + 3) & ~3) * 4 + 64, st, list, count, list_cap, step, arr, arr_ok, arr_stride, C, cap_sub,
                      cap_pts, gscratch, gcap, payload, payload_stride, info, need_host);
   return hipGetLastError();
 }

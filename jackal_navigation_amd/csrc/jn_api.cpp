@@ -318,7 +318,7 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
       }
       if (gpu_dt)                                        // LDS for what the slot's last batches held (+25 %), as the arrangement; a side beyond it goes to the host
         HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
-                                (long long)h->payload_cap, s.info, s.need_host, nullptr, s.dt_scratch, h->dt_gcap, s.arr_hint));
+                                (long long)h->payload_cap, s.info, s.need_host, nullptr, s.dt_scratch, h->dt_gcap, s.arr_hint, dp.W >= 2048 || dp.H >= 2048));
     }
   } else {
     const size_t can_bytes = (size_t)dp.cw * dp.ch * sizeof(int16_t);
@@ -794,8 +794,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
   // Batch handles triangulate on the GPU as well (a latency-mode handle keeps the host stage: two pool threads finish a 640x480 pair's
   // two sides in 65 us, the kernel's serial top merges take longer than that); needs the device filters' list and the device arrangement.
-  // (the FP64 predicates of the kernel are exact for coordinates in (-2048, 2048))
-  const bool gpu_dt_possible = max_batch > 1 && h->gpu_arrange && h->filters_fast && W < 2048 && H < 2048;
+  // (the kernels' FP64 predicates are exact for coordinates in (-2048, 2048); wider or taller images take their integer form)
+  const bool gpu_dt_possible = max_batch > 1 && h->gpu_arrange && h->filters_fast;
   // Which of the two is faster depends on the host cores this process has (profiles/r05_gpu_delaunay_ab.txt, one MI355X): the kernel's top
   // merges are one thread each walking a seam through LDS (0.8-0.9 ms a batch, 42 bytes per vertex of every side held in LDS meanwhile):
   // 19.6 k pairs/s whatever the cores (0.3 busy); the host stage gives 22.0 k with ~10 busy cores where the scheduler may spread 16
@@ -1300,7 +1300,9 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
     long long* d_clk = nullptr;
     const bool want_clk = JN_HOOK_ENV("JN_DT_CLOCKS") != nullptr;
     if (want_clk && hipMalloc(reinterpret_cast<void**>(&d_clk), 64 * sizeof(long long)) == hipSuccess) hipMemset(d_clk, 0, 64 * sizeof(long long));
-    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, g_cap, d_dscr ? n : whole, d_pay, (long long)pay, d_info, d_need, d_clk, d_dscr, d_dscr ? g_cap : 0);
+    bool wide = false;                                       // coordinates beyond (-2048, 2048): the integer predicates
+    for (int i = 0; i < n; i++) wide |= triples[3 * i] * step >= 2048 || triples[3 * i + 1] * step >= 2048;
+    launch_delaunay(nullptr, 1, d_list, d_cnt, cap, step, d_arr, d_ok, g_cap, d_dscr ? n : whole, d_pay, (long long)pay, d_info, d_need, d_clk, d_dscr, d_dscr ? g_cap : 0, 0, wide);
     e = hipStreamSynchronize(nullptr);
     if (d_clk) {                                             // JN_DT_CLOCKS: microseconds per tree level (leaves first) of both sides, to stderr
       long long clk[64];

@@ -53,7 +53,8 @@ size_t delaunay_gpu_scratch_bytes(int frames, int gcap);   // the scratch that l
 hipError_t launch_delaunay(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, const uint16_t* arr, const int32_t* arr_ok,
                      int arr_stride, int cap_pts, uint8_t* payload, long long payload_stride, FrameInfo* info, int32_t* need_host,
                      long long* dbg_clock = nullptr,    // dbg_clock (optional, 64 entries): 100 MHz time stamps per tree level of frame 0's sides
-                     uint8_t* gscratch = nullptr, int gcap = 0, int expect_pts = 0);
+                     uint8_t* gscratch = nullptr, int gcap = 0, int expect_pts = 0,
+                     bool wide = false);   // wide: coordinates may leave (-2048, 2048) (images of 2048 columns or rows and more): integer predicates
 // true when the classify + resolve form of the support filters applies (lattice and codes fit the LDS)
 bool support_filters_fast(const DevParams& dp, int win, int min_support);
 // list / count / list_cap / listed (optional): where the classification + resolution route takes the lattice, k_filter_resolve also writes

@@ -76,6 +76,40 @@ def test_gpu_triangulation_beyond_one_workgroups_lds(jn):
         assert need != 3 or n == 0, n
 
 
+def test_gpu_triangulation_of_wide_coordinates_uses_exact_integer_predicates(jn, oracle, monkeypatch):
+    """Coordinates beyond (-2048, 2048) (images of 2048 columns and more): the FP64 predicates would no longer be exact — differences reach
+    2^14, in_circle's products 2^58 — so those sides take the kernels' integer form.  Lattices up to 8 000 columns wide against the host's
+    int64 replay (whole-side kernel and the cut form), and a 2600 x 200 image through a batch handle on the GPU route against the oracle."""
+    from jackal_navigation_amd.device import DeviceArray
+    L = jn.load()
+    rng = np.random.default_rng(13)
+    for n, cw, ch in ((900, 1600, 40), (3500, 1600, 60), (6000, 1200, 300)):
+        t = lattice_case(rng, n, cw, ch, 255, row_d=(n == 3500))
+        (kl, tl), (kr, tr), need = device_tri(L, t, 5)
+        for side, (k, tri) in ((0, (kl, tl)), (1, (kr, tr))):
+            x = t[:, 0].astype(np.int32) * 5 - (t[:, 2].astype(np.int32) if side else 0); y = t[:, 1].astype(np.int32) * 5
+            if need & (1 << side):
+                assert len(set(zip(x.tolist(), y.tolist()))) < n, (n, side)
+                continue
+            ke, te = host_tri(L, x, y)
+            assert k == ke and np.array_equal(tri, te), (n, side)
+    monkeypatch.setenv("JN_GPU_DELAUNAY", "1")
+    W, H, n = 2600, 200, 2
+    pairs = [jn.node.synth_pair(W, H, 40, 3 + b) for b in range(n)]
+    dL = DeviceArray.from_numpy(np.stack([q[0] for q in pairs])); dR = DeviceArray.from_numpy(np.stack([q[1] for q in pairs]))
+    d1 = DeviceArray((n, H, W), np.float32); d2 = DeviceArray((n, H, W), np.float32)
+    with jn.Elas(jn.Elas.parameters(0, disp_max=63), W, H, max_batch=n, host_threads=4) as e:
+        assert e.route_stats(0)[0] == 1                                       # images this wide used to be the host's
+        for _ in range(2):
+            st = e.process_batch(n, dL.ptr, dR.ptr, W, H * W, d1.ptr, d2.ptr)
+        assert e.route_stats(0)[1] == 0, e.route_stats(0)
+    D1, D2 = d1.numpy(), d2.numpy()
+    for b in range(n):
+        st_o, D1o, D2o = oracle.process(oracle.params(0, disp_max=63), pairs[b][0], pairs[b][1])
+        assert st[b] == st_o == 0
+        assert np.array_equal(D1[b].view(np.uint32), D1o.view(np.uint32)) and np.array_equal(D2[b].view(np.uint32), D2o.view(np.uint32)), b
+
+
 def test_full_hd_batch_triangulates_on_the_gpu_without_a_hand_back(jn, oracle, monkeypatch):
     """BASELINE config 5's frame through a batch handle on the GPU route (JN_GPU_DELAUNAY=1): ~11 k support points a side, more than the LDS
     form takes — no batch may be handed back to the host stage, and D1 is the reference's (SURVEY 8c's known answer for seed 12345)."""
