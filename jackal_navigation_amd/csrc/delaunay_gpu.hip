@@ -58,6 +58,11 @@ struct LdsMem {
   typedef __attribute__((address_space(3))) JN_DT_VOL uint16_t* HullP;
   typedef uint16_t link_t;
   static constexpr bool kGlobal = false;
+  // Round 6: the fourth halfword of every [4]-record is free (it exists so that a handle IS its index), two triangles a vertex: eight bytes a
+  // vertex, exactly what its coordinates and its node's two hull handles take.  They live THERE — X(v) in LINK[8 v + 3], Y(v) in LINK[8 v + 7],
+  // HL / HR of the node that starts at v in VERT[8 v + 3] / [8 v + 7] — so a side costs 32 bytes a vertex instead of 40 and a CU that holds a
+  // k_delaunay workgroup of a 720p side (3 400 vertices: 109 KB) still takes one k_dense_row workgroup (33 KB) beside it.
+  static constexpr int kAuxShift = 3;                      // index of vertex v's / position p's auxiliary halfword: (v << 3) [+ 4]
 };
 // (plain pointers in global memory: a thread reads back what it wrote itself — one wave's accesses to an address keep their order — and what
 // other threads wrote reaches it across the fence + barrier between tree levels; volatile would make every access a system-scope round trip)
@@ -67,6 +72,7 @@ struct GlobalMem {
   typedef __attribute__((address_space(1))) uint32_t* HullP;
   typedef uint32_t link_t;
   static constexpr bool kGlobal = true;
+  static constexpr int kAuxShift = 0;                      // coordinates in plain LDS arrays, hull handles in plain global ones
 };
 template <class M, bool WIDE = false>
 struct DT {
@@ -119,9 +125,9 @@ struct DT {
   // products and sum (below 2^60) — delaunay.cpp's own arithmetic, at ~15 more instructions per in_circle than the FP64 form.
   typedef typename std::conditional<WIDE, int32_t, double>::type coord_t;
   struct P { int v; coord_t x, y; };
-  __device__ __forceinline__ int xx(int v) const { return X[v - voff]; }
-  __device__ __forceinline__ int yy(int v) const { return Y[v - voff]; }
-  __device__ __forceinline__ P pt(int v) const { return P{v, (coord_t)X[v - voff], (coord_t)Y[v - voff]}; }
+  __device__ __forceinline__ int xx(int v) const { return X[(v - voff) << M::kAuxShift]; }
+  __device__ __forceinline__ int yy(int v) const { return Y[(v - voff) << M::kAuxShift]; }
+  __device__ __forceinline__ P pt(int v) const { return P{v, (coord_t)xx(v), (coord_t)yy(v)}; }
   template <class T> __device__ __forceinline__ static int sgn(T d) { return d > 0 ? 1 : (d < 0 ? -1 : 0); }
   // (explicit fused multiply-adds: every product and sum below is an integer smaller than 2^53, so the fused and the unfused forms give the same
   // exact value; the library is built with -ffp-contract=off, which would otherwise keep them apart — 7 and 22 instructions instead of 11 and 31)
@@ -338,7 +344,7 @@ struct DT {
   }
 };
 
-enum { kDtThreads = 1024, kDtTopThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 40,   // 4 x 2 (X, Y, HL, HR) + 2 triangles x (4 + 4) x 2
+enum { kDtThreads = 1024, kDtTopThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 32,   // 2 triangles x (4 + 4) halfwords; X, Y, HL, HR ride in the records' spare halfwords (LdsMem)
        kDtMaxPoints = 16384 };                                                                  // arrangement positions are 16-bit, vertex numbers int16 with room to spare
 
 // Sizes and triangle counts per depth: at depth k a node holds f_k = n >> k or f_k + 1 vertices; c[k][b] = count(f_k + b), the triangles a
@@ -393,13 +399,14 @@ DEV bool dt_levels(DT<M, WIDE>& dt, int n, int k_deep, int k_top, int root_k, in
       } else {
         const int half = size >> 1;
         typename DT<M, WIDE>::Ctx c{slot + s_c[k + 1][half - s_f[k + 1]] + s_c[k + 1][(size - half) - s_f[k + 1]]};
-        fl = (H)HL[lo - hoff] + dt.off; fr = (H)HR[lo + half - hoff] + dt.off;
-        H il = (H)HR[lo - hoff] + dt.off, ir = (H)HL[lo + half - hoff] + dt.off;
+        constexpr int AS = M::kAuxShift;
+        fl = (H)(typename M::link_t)HL[(lo - hoff) << AS] + dt.off; fr = (H)(typename M::link_t)HR[(lo + half - hoff) << AS] + dt.off;
+        H il = (H)(typename M::link_t)HR[(lo - hoff) << AS] + dt.off, ir = (H)(typename M::link_t)HL[(lo + half - hoff) << AS] + dt.off;
         dt.budget = 16 * size + 256;                                       // (a merge of `size` vertices takes a few steps per seam vertex)
         dt.zip(fl, il, ir, fr, k & 1, c);                                  // the root is cut on axis 0, its children on axis 1, ...
         gave_up |= dt.budget <= 0;
       }
-      HL[lo - hoff] = (typename M::link_t)(fl - dt.off); HR[lo - hoff] = (typename M::link_t)(fr - dt.off);
+      HL[(lo - hoff) << M::kAuxShift] = (typename M::link_t)(fl - dt.off); HR[(lo - hoff) << M::kAuxShift] = (typename M::link_t)(fr - dt.off);
     }
     if (M::kGlobal) __threadfence();                                       // the next level's threads read what this level's wrote, through memory
     __syncthreads();
@@ -466,16 +473,16 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay(const int16_t* __restri
     if (tid == 0) { fi->ntri[side] = 0; atomicOr(&need_host[frame], 1 << side); }
     return;
   }
-  // LDS: X, Y, HL, HR [n] 16-bit each | LINK, VERT [4 T], T = 2 n (count(n) <= 2 n - 2)
-  const int np = (n + 3) & ~3, T = 2 * n;
-  int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
-  uint16_t* HL = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HR = HL + np;
-  uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
+  // LDS: LINK, VERT [4 T], T = 2 n (count(n) <= 2 n - 2); X, Y, HL, HR in the records' spare halfwords (LdsMem)
+  const int np = (n + 3) & ~3, T = 2 * np;
+  uint16_t* LINK = reinterpret_cast<uint16_t*>(s_dt); int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
+  int16_t* X = reinterpret_cast<int16_t*>(LINK) + 3; int16_t* Y = X + 4;
+  uint16_t* HL = reinterpret_cast<uint16_t*>(VERT) + 3; uint16_t* HR = HL + 4;
   const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
   for (int p = tid; p < n; p += kDtThreads) {                               // vertex p = the p-th of the arrangement
     const int i = a_in[p];
     const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
-    X[p] = (int16_t)(side ? u - d : u); Y[p] = (int16_t)v;                  // right image: (u - d, v), elas.cpp:466-467
+    X[8 * p] = (int16_t)(side ? u - d : u); Y[8 * p] = (int16_t)v;          // right image: (u - d, v), elas.cpp:466-467
   }
   if (tid == 0) dt_tables(n, s_f, s_c, &s_K);
   __syncthreads();
@@ -529,14 +536,14 @@ __global__ void __launch_bounds__(kDtThreads) k_delaunay_sub(const int16_t* __re
   if (!dt_node(n, C, jr, s_f, s_c, lo, size, slot) || size > cap_sub || (n >> C) <= 3) return;   // (launch_delaunay chose C so that it fits; top checks again)
   const int16_t* t = list + (size_t)frame * list_cap * 3;
   const uint16_t* a_in = arr + (size_t)(frame * 2 + side) * arr_stride;
-  const int np = (size + 3) & ~3, T = 2 * size;
-  int16_t* X = reinterpret_cast<int16_t*>(s_dt); int16_t* Y = X + np;
-  uint16_t* HL = reinterpret_cast<uint16_t*>(Y + np); uint16_t* HR = HL + np;
-  uint16_t* LINK = HR + np; int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
+  const int np = (size + 3) & ~3, T = 2 * np;
+  uint16_t* LINK = reinterpret_cast<uint16_t*>(s_dt); int16_t* VERT = reinterpret_cast<int16_t*>(LINK + 4 * T);
+  int16_t* X = reinterpret_cast<int16_t*>(LINK) + 3; int16_t* Y = X + 4;
+  uint16_t* HL = reinterpret_cast<uint16_t*>(VERT) + 3; uint16_t* HR = HL + 4;
   for (int p = tid; p < size; p += kDtThreads) {
     const int i = a_in[lo + p];
     const int u = t[3 * i] * step, v = t[3 * i + 1] * step, d = t[3 * i + 2];
-    X[p] = (int16_t)(side ? u - d : u); Y[p] = (int16_t)v;
+    X[8 * p] = (int16_t)(side ? u - d : u); Y[8 * p] = (int16_t)v;
   }
   __syncthreads();
   DT<LdsMem, WIDE> dt{(lds_ci16*)X, (lds_ci16*)Y, (LdsMem::LinkP)LINK, (LdsMem::VertP)VERT, 4u * (uint32_t)slot, lo, 0};

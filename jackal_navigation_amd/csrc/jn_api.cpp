@@ -316,8 +316,8 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
         const bool big = s.arr_scratch && (s.arr_hint == 0 || s.arr_hint > h->arr_cap);   // (0: the slot's first batch — nothing known yet)
         launch_arrange(sa, n, list_buf, cnt_buf, list_cap, dp.step, cap, h->arr_stride, arr_buf, arr_ok_buf, big ? s.arr_scratch : nullptr, big ? h->arr_stride : 0);
       }
-      if (gpu_dt)                                        // LDS for what the slot's last batches held (+25 %), as the arrangement; a side beyond it goes to the host
-        HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, want) : (1 << 30), s.payload,
+      if (gpu_dt)                                        // LDS for what the slot's last batches held + 6 % (a tight request: 32 bytes a vertex leave a k_dense_row workgroup room on the same CU); a side beyond it goes to the host
+        HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, s.arr_hint + s.arr_hint / 16 + 32) : (1 << 30), s.payload,
                                 (long long)h->payload_cap, s.info, s.need_host, nullptr, s.dt_scratch, h->dt_gcap, s.arr_hint, dp.W >= 2048 || dp.H >= 2048));
     }
   } else {

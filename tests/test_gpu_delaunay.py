@@ -56,13 +56,14 @@ def test_gpu_triangulation_equals_the_hosts_on_lattices(jn):
 
 
 def test_gpu_triangulation_beyond_one_workgroups_lds(jn):
-    """sides with more vertices than one workgroup's LDS holds (~3 890; a 1920x1080 side has ~11 200) are cut at depth C —
-    the subtrees below the cut in LDS (k_delaunay_sub), the C levels above them on a global structure (k_delaunay_top).  The same triangles
-    in the same order as the host's replay of Triangle: just over the LDS capacity (C = 1), a 1080p side's count (C = 2), the most a side may
-    hold (C = 3), both sides (the right side's x = u - d scatters the columns)."""
+    """sides with more vertices than one workgroup's LDS holds (4 860 at 32 bytes a vertex; a 1920x1080 side has ~11 200) are
+    cut at depth C — the subtrees below the cut in LDS (k_delaunay_sub), the C levels above them on a global structure (k_delaunay_top).
+    The same triangles in the same order as the host's replay of Triangle: the largest whole sides (3 900, 4 200, 4 860), just over the
+    capacity and up to twice it (C = 1), a 1080p side's count and the most a side may hold (C = 2); both sides (the right side's
+    x = u - d scatters the columns)."""
     L = jn.load()
     rng = np.random.default_rng(11)
-    for n, cw, ch in ((3900, 256, 144), (4200, 384, 216), (7777, 384, 216), (11200, 384, 216), (16384, 384, 216)):
+    for n, cw, ch in ((3900, 256, 144), (4200, 384, 216), (4860, 384, 216), (4900, 384, 216), (7777, 384, 216), (11200, 384, 216), (16384, 384, 216)):
         t = lattice_case(rng, n, cw, ch, 255, row_d=(n % 2 == 0))
         (kl, tl), (kr, tr), need = device_tri(L, t, 5)
         for side, (k, tri) in ((0, (kl, tl)), (1, (kr, tr))):
