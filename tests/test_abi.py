@@ -23,6 +23,11 @@ def test_header_symbols_are_exported(jn):
     missing = [n for n in declared if not hasattr(lib, n)]
     assert not missing, missing
     assert sorted(jn.EXPORTS) == declared, "python EXPORTS list out of sync with the header"
+    with jn.hooks_library() as hooks:                         # the hooks build is the same ABI (tests and scripts swap it in)
+        assert hooks is not lib and jn.load() is hooks
+        assert not [n for n in declared if not hasattr(hooks, n)]
+        assert hooks.jn_version() == lib.jn_version()
+    assert jn.load() is lib
 
 
 def test_params_default_mirror_reference_presets(jn, oracle):
