@@ -2,6 +2,7 @@
 # is `volatile` on k_delaunay's LDS accessors a workaround for something?  Builds the library with plain (non-volatile) LDS
 # pointers in delaunay_gpu.hip (-DJN_DT_NO_VOLATILE), shows what the compiler merges, and runs the triangulation tests against it.
 #   gpurun -- bash scripts/probes/dt_no_volatile.sh
+# (the same-box timing of the two builds that profiles/r06_dt_no_volatile.txt carries below the test results was taken once, on round 6's first tree)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 C=$R/jackal_navigation_amd/csrc
 T=/tmp/dt_novol; mkdir -p $T
