@@ -786,9 +786,9 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   if (const char* e = getenv("JN_HOST_FILTERS")) h->filter_min_batch = atoi(e) ? (1 << 30) : 1;
   if (const char* e = getenv("JN_SPLIT_DELAUNAY")) h->split_delaunay = atoi(e) != 0;
   h->arr_cap = std::min(dp.cw * dp.ch, 8192);
-  // Sides with more vertices than the LDS can order (8192; a 1920x1080 frame has 11 k) could run k_arrange in global scratch
-  // (up to 16384, JN_ARRANGE_GLOBAL=1), but through L2 the kernel takes milliseconds, which a batch of 8 such frames on 4
-  // slots cannot hide: 4.6 k against 5.4 k pairs/s with the host doing it — off by default, those sides stay on the host.
+  // Host route: sides with more vertices than k_arrange's 64-bit-key LDS form orders (8192; a 1920x1080 side has 11 k) are arranged on the
+  // host (JN_ARRANGE_GLOBAL=1 in the hooks build sends them through the kernel's larger forms instead).  The GPU route (below) always
+  // arranges on the device: 12288 vertices with compact keys in LDS (0.64 ms a 1080p batch), up to 16384 on global scratch (1.7 ms).
   h->arr_stride = (JN_HOOK_ENV("JN_ARRANGE_GLOBAL") && atoi(JN_HOOK_ENV("JN_ARRANGE_GLOBAL"))) ? std::min(dp.cw * dp.ch, 16384) : h->arr_cap;
   h->gpu_arrange = !h->hp.add_corners;                     // the six corner points join the list on the host
   if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
@@ -807,11 +807,14 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     const int pinned = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
     // (an explicit host_threads below 14 says the same thing — the caller's share of a quota that several ranks divide, which no rank can
     // see from its own affinity mask or cpu.max: bench.py passes quota / world)
-    h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14 || (host_threads > 0 && host_threads < 14));
+    // Frames of 1920x1080 and beyond take the GPU route whatever the cores: their 11 k-point sides keep 12.8 host cores busy for 4.9 k
+    // pairs/s, the kernels give 5.3 k with none (profiles/r06_full_hd_routes.txt).
+    h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14 || (host_threads > 0 && host_threads < 14) || (long long)W * H >= 1920LL * 1080);
   }
   if (const char* e = getenv("JN_GPU_DELAUNAY")) h->gpu_delaunay = gpu_dt_possible && atoi(e) != 0;
   // Sides with more support points than one workgroup's LDS holds (a 1920x1080 side has ~11 k) go through k_delaunay_sub / k_delaunay_top and
-  // a global scratch (round 6); their arrangement then comes from k_arrange's global-scratch form (up to 16384 vertices a side).
+  // a global scratch (round 6); their arrangement then comes from k_arrange's compact-key LDS form (up to 12288 vertices a side) or its
+  // global-scratch form (up to 16384).
   if (h->gpu_delaunay && dp.cw * dp.ch > delaunay_gpu_capacity(152 * 1024)) {
     h->dt_gcap = std::min(dp.cw * dp.ch, delaunay_gpu_max_points());
     h->arr_stride = std::max(h->arr_stride, std::min(dp.cw * dp.ch, 16384));

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 
 namespace jnav {
 
@@ -1538,19 +1539,27 @@ typedef unsigned int jn_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const jn_u32x4 jn_lds_u4;
 DEV uint32_t lds_addr(const uint4* p) { return (uint32_t)(uintptr_t)(jn_lds_u4*)p; }
 DEV uint4 lds_read16(uint32_t a) { const jn_u32x4 t = *(jn_lds_u4*)a; return make_uint4(t.x, t.y, t.z, t.w); }
+typedef __attribute__((address_space(3))) jn_u32x4 jn_lds_u4w;
+DEV void lds_write16(uint32_t a, const uint4& d) { jn_u32x4 t; t.x = d.x; t.y = d.y; t.z = d.z; t.w = d.w; *(jn_lds_u4w*)a = t; }
+// min(max(x, 0), 63) as ONE instruction (the compiler splits the clamp around the addition that feeds it: max, add, min)
+DEV int clamp_0_63(int x) { int r; asm("v_med3_i32 %0, %1, 0, 63" : "=v"(r) : "v"(x)); return r; }
 // One pixel of the dense matching behind the ownership lookup (elas.cpp:722-779), used by k_dense_row: `a` the pixel's own
 // descriptor, Bu[d] the descriptor of the column matched at disparity d in the LDS window (u + d in the right image's window, u - d in the
 // mirrored left one), cw the candidate set of the pixel's grid cell.  Every lane of the wave must call it (one ballot inside).
-template <int NW>
+// BORDER: the strip's disparity ranges can leave the image (the first strips of a left image, the last ones of a right image): only then do the
+// grid candidates need the range mask — a template argument because the compiler turns a uniform `if` around six instructions per word into
+// selects, which every strip then pays (48 vector instructions a wave row, 9 % of the kernel's).
+template <int NW, bool BORDER>
 DEV int match_pixel(const DevParams& dp, const uint4& a, bool elig, int d_plane, bool valid, int u, int side, const uint4* Bu,
-                    const uint32_t (&cw)[NW], bool border, int dbg) {
+                    const uint32_t (&cw)[NW], int dbg) {
   constexpr unsigned kNoKey = 0xFFFFFFFFu;
   const int radius = dp.radius, W = dp.W;
   const int lo = max(d_plane - radius, 0), hi = min(d_plane + radius, dp.disp_max);                      // :723-724
   // disparities whose warped column stays inside [2, W-2) (:746, :753, :764, :771)
-  const int dmax_ok = side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
+  // (a strip without BORDER holds no pixel whose range leaves the image: dmax_ok is disp_max there, phi is hi)
+  const int dmax_ok = !BORDER ? dp.disp_max : side ? min(dp.disp_max, W - 3 - u) : min(dp.disp_max, u - 2);
   const int dlow = d_plane - radius;
-  const int phi = min(hi, dmax_ok);
+  const int phi = BORDER ? min(hi, dmax_ok) : hi;
 
   // ---- grid candidates outside the plane range (:742-750): per-lane bit scan, one (different) disparity per lane and round ----
   // Keys here are (SAD << 16) + LDS byte address of the candidate's descriptor: the address is what the read needs anyway, it orders
@@ -1564,9 +1573,12 @@ DEV int match_pixel(const DevParams& dp, const uint4& a, bool elig, int d_plane,
     const unsigned long long T = (unsigned long long)(((1u << max(hi - lo + 1, 0)) - 1u) << 16);
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-      const uint32_t excl = (uint32_t)((T << min(max(lo + 16 - 32 * w, 0), 63)) >> 32);
+#ifndef JN_AB_NO_EMPTY_WORD_SKIP
+      if (__ballot(cw[w] != 0u) == 0ull) continue;          // no lane's cell holds a candidate in this word: six instructions saved for two spent
+#endif
+      const uint32_t excl = (uint32_t)((T << clamp_0_63(lo + 16 - 32 * w)) >> 32);
       uint32_t bits = cw[w] & ~excl;
-      if (border) bits &= range_mask(0, dmax_ok, w);
+      if (BORDER) bits &= range_mask(0, dmax_ok, w);
       while (bits) {
         const uint32_t ad = bu_a + (uint32_t)((w << 5) + __builtin_ctz(bits)) * 16u;
         bits &= bits - 1;
@@ -1913,24 +1925,38 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_row(DevParams dp, int n
   {
     const bool row_zero = vr < 3 || vr > H - 4;              // rows 2 and H-3 hold no descriptors: zeros
     const bool rim = row_zero || base < 3 || base + span - 1 > W - 4;      // only strips at the image's rim hold columns outside [3, W-4]
+    // the slot of column col + k is side ? c + k : span - 1 - (c + k); as a byte address: one xor-add for k = 0, a scalar step from there
+    const int mirror = side - 1, step = side ? 16 : -16;     // (scalars)
+    const uint32_t dst_a = lds_addr(dst);
+    // RIM as a template argument: left as a uniform `if` around the zeroing, the compiler turns it into four selects and two compares per
+    // descriptor, which every strip then pays (the same finding as match_pixel's BORDER)
+    PlaneRows pw[kPasses];                                    // (assembled once, in front of the two forms of the stores)
 #pragma unroll
     for (int i = 0; i < kPasses; i++) {
-      const int col = 4 * (g0 + lane + 64 * i), c = col - base;             // window slot of the group's first column
-      PlaneRows pw;
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         // the dword behind this lane's: the next lane's (wave_shl:1); the last lane keeps `old` = the next pass's first lane or the scalar load
         uint32_t lo = wL[i][k], behind = (i + 1 < kPasses) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)wL[kPasses - 1][k]) : wS[k];
-        if (dbg & 8) { lo = col + k; behind = col; }
+        if (dbg & 8) { lo = 4 * (g0 + lane + 64 * i) + k; behind = lo - k; }
         const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)behind, (int)lo, 0x130, 0xF, 0xF, false);
-        if (k < 5) { pw.al[k] = lo; pw.ah[k] = hi; } else { pw.bl[k - 5] = lo; pw.bh[k - 5] = hi; }
+        if (k < 5) { pw[i].al[k] = lo; pw[i].ah[k] = hi; } else { pw[i].bl[k - 5] = lo; pw[i].bh[k - 5] = hi; }
       }
-      auto put = [&](int k, uint4 d) {
-        if (rim && (row_zero || col + k < 3 || col + k > W - 4)) d = make_uint4(0, 0, 0, 0);
-        if ((unsigned)(c + k) < (unsigned)span) dst[side ? c + k : span - 1 - (c + k)] = d;
-      };
-      put(0, desc_from_rows<0>(pw)); put(1, desc_from_rows<1>(pw)); put(2, desc_from_rows<2>(pw)); put(3, desc_from_rows<3>(pw));
     }
+    auto window = [&](auto rim_tag) {
+      constexpr bool RIM = decltype(rim_tag)::value;
+#pragma unroll
+      for (int i = 0; i < kPasses; i++) {
+        const int col = 4 * (g0 + lane + 64 * i), c = col - base;           // window slot of the group's first column
+        uint32_t a = dst_a + ((uint32_t)((c ^ mirror) + (mirror & span)) << 4);
+        auto put = [&](int k, uint4 d) {
+          if (RIM && (row_zero || col + k < 3 || col + k > W - 4)) d = make_uint4(0, 0, 0, 0);
+          if ((unsigned)(c + k) < (unsigned)span) lds_write16(a, d);
+          a += (uint32_t)step;
+        };
+        put(0, desc_from_rows<0>(pw[i])); put(1, desc_from_rows<1>(pw[i])); put(2, desc_from_rows<2>(pw[i])); put(3, desc_from_rows<3>(pw[i]));
+      }
+    };
+    if (rim) window(std::true_type{}); else window(std::false_type{});
   }
   if (!ok) return;                                           // uniform over the wave (and the block)
   __builtin_amdgcn_wave_barrier();                           // LDS operations of one wave execute in order: the stores above precede the reads below
@@ -1940,19 +1966,22 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense_row(DevParams dp, int n
   // the strip needs the image-border mask only if some pixel's disparity range can leave [2, W-2)
   const bool border = side ? (u0 + kStripW - 1 + dp.disp_max > W - 3) : (u0 - dp.disp_max < 2);
   int res[2];
+  auto match = [&](auto border_tag) {
 #pragma unroll
-  for (int q = 0; q < 2; q++) {
-    const int u = up + q;
-    const bool inw = u < W;
-    const unsigned code = (ow >> (16 * q)) & 0xFFFFu;
-    const bool valid = (code >> 14) & 1u;
-    const int d_plane = (int)(code & 0x3FFFu) - kOwnerBias;
-    const uint4 a = a4[q];
-    const bool elig = inw && (code >> 15) && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture;   // :697, :715-719
-    const int uc = min(u, W - 1);
-    const uint4* Bu = dst + (side ? (uc - base) : (span - 1 + base - uc));
-    res[q] = match_pixel<NW>(dp, a, elig, d_plane, valid, u, side, Bu, cellw[q], border, dbg);
-  }
+    for (int q = 0; q < 2; q++) {
+      const int u = up + q;
+      const bool inw = u < W;
+      const unsigned code = (ow >> (16 * q)) & 0xFFFFu;
+      const bool valid = (code >> 14) & 1u;
+      const int d_plane = (int)(code & 0x3FFFu) - kOwnerBias;
+      const uint4 a = a4[q];
+      const bool elig = inw && (code >> 15) && u >= 2 && u < W - 2 && texture16(a) >= dp.match_texture;   // :697, :715-719
+      const int uc = min(u, W - 1);
+      const uint4* Bu = dst + (side ? (uc - base) : (span - 1 + base - uc));
+      res[q] = match_pixel<NW, decltype(border_tag)::value>(dp, a, elig, d_plane, valid, u, side, Bu, cellw[q], dbg);
+    }
+  };
+  if (border) match(std::true_type{}); else match(std::false_type{});
   int16_t* out = raw + ((size_t)fs * H + v) * W;             // integer disparity, -1 no match, -10 not visited (:797-798)
   if (pair_io) { if (up < W) *reinterpret_cast<uint32_t*>(out + up) = ((unsigned)res[0] & 0xFFFFu) | ((unsigned)res[1] << 16); }
   else { if (up < W) out[up] = (int16_t)res[0]; if (up + 1 < W) out[up + 1] = (int16_t)res[1]; }
@@ -3018,9 +3047,10 @@ template <int PITCH> static hipError_t configure_support_pitch() {
   if (e != hipSuccess) return e;
   return hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_lds<kSupportLanes, PITCH, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
-template <bool IN_LDS>
+template <int FORM>
 __global__ void k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step, int arr_cap,
                           int arr_stride, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok, unsigned long long* gbuf, int g_cap);
+static bool g_arrange_compact = false;       // the 160 KB form of k_arrange is available on this device (configure_device_kernels)
 hipError_t configure_device_kernels() {
   static std::mutex m;
   static uint64_t done = 0;
@@ -3041,7 +3071,10 @@ hipError_t configure_device_kernels() {
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_support_filters<WIN, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gap_rows_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess) return e;
+  // the compact form needs 159,760 B dynamic + 72 B static; without it, sides of 8193-12288 vertices take the global-scratch form
+  g_arrange_compact = hipFuncSetAttribute(reinterpret_cast<const void*>(k_arrange<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) == hipSuccess;
+  (void)hipGetLastError();
   if ((e = configure_delaunay_kernel()) != hipSuccess) return e;
   done |= bit;
   return hipSuccess;
@@ -3200,7 +3233,28 @@ DEV void arr_sort(unsigned long long* keys, int N, int tid) {      // bitonic, N
       __syncthreads();
     }
 }
-template <bool IN_LDS>
+DEV void arr_sort32(uint32_t* keys, uint16_t* vals, int N, int tid) {   // the same network over 32-bit keys; vals (may be null) move with them
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < N; i += kArrThreads) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint32_t a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b; keys[l] = a;
+            if (vals) { const uint16_t t = vals[i]; vals[i] = vals[l]; vals[l] = t; }
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+// FORM 1: working arrays in LDS, 64-bit sort keys (sides of <= 8192 vertices: every frame of the 1280x720 workload).
+// FORM 2: in LDS with 32-bit keys and a 16-bit payload array, 6 instead of 8 bytes per sorted element: 12288 vertices in 160 KB
+//         (a 1920x1080 side has 11 k).  FORM 0: in this side's slice of a global scratch buffer, up to g_cap vertices.
+constexpr int kArrCompactCap = 12288;
+template <int FORM>
 __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restrict__ list, const int32_t* __restrict__ count, int list_cap, int step,
                                                          int arr_cap, int arr_stride, uint16_t* __restrict__ arr, int32_t* __restrict__ arr_ok,
                                                          unsigned long long* gbuf, int g_cap) {
@@ -3208,23 +3262,26 @@ __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restri
   const int side = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
   const int n = count[frame];
   int32_t* ok = arr_ok + frame * 2 + side;
-  // Working arrays: in LDS (IN_LDS: sides whose vertices fit this launch's LDS, arr_cap; the others are marked for the host)
-  // or — second instantiation, launched only on request for frames with more support points than 160 KB of LDS can order
-  // (1920x1080: 11 k) — in this side's slice of a global scratch buffer: the same code, every pass then goes through L2.
-  // Two instantiations rather than a run-time choice: a pointer that may be either makes every access a flat one.
-  if (IN_LDS) {
+  // Working arrays: in LDS (FORM 1: sides whose vertices fit this launch's LDS, arr_cap; the others are marked for the host)
+  // or — further instantiations, launched only on request for frames with more support points than that (1920x1080: 11 k) —
+  // in LDS with compact sort keys (FORM 2) or in this side's slice of a global scratch buffer (FORM 0): the same code, every
+  // pass then goes through L2.  Instantiations rather than a run-time choice: a pointer that may be either makes every
+  // access a flat one.  FORM 0 / 2 take the sides with arr_cap < n <= g_cap: a smaller form has dealt with the others.
+  if (FORM == 1) {
     if (n < 3 || n > list_cap || n > arr_cap) { if (tid == 0) *ok = 0; return; }
   } else {
-    if (n <= arr_cap || n > list_cap || n > g_cap) return;             // the LDS launch has dealt with this side (or handed it back)
+    if (n <= arr_cap || n > list_cap || n > g_cap) return;
     arr_cap = g_cap;
   }
   int N = 1; while (N < n) N <<= 1;
-  // layout: [sort keys, N u64; afterwards tmp, rlo, rn, sx, arr_cap u16 each] | ord, byy [arr_cap] u16 | isleft [arr_cap] u8
+  // layout: [sort keys, N u64 (FORM 2: N u32 + N u16); afterwards tmp, rlo, rn, sx, arr_cap u16 each] | ord, byy [arr_cap] u16 | isleft [arr_cap] u8
   int Ncap = 1; while (Ncap < arr_cap) Ncap <<= 1;
-  unsigned long long* s_arr = IN_LDS ? s_lds : gbuf + ((size_t)frame * 2 + side) * (((size_t)Ncap * 8 + (size_t)arr_cap * 5 + 15) / 8);
+  const size_t head8 = FORM == 2 ? max((size_t)Ncap * 6, (size_t)arr_cap * 8) / 8 : (size_t)Ncap;
+  unsigned long long* s_arr = FORM ? s_lds : gbuf + ((size_t)frame * 2 + side) * (((size_t)Ncap * 8 + (size_t)arr_cap * 5 + 15) / 8);
   unsigned long long* keys = s_arr;
+  uint32_t* keys32 = reinterpret_cast<uint32_t*>(s_arr); uint16_t* vals = reinterpret_cast<uint16_t*>(keys32 + Ncap);
   uint16_t* tmp = reinterpret_cast<uint16_t*>(s_arr); uint16_t* rlo = tmp + arr_cap; uint16_t* rn = rlo + arr_cap; uint16_t* sx = rn + arr_cap;
-  uint16_t* ord = reinterpret_cast<uint16_t*>(s_arr + Ncap);
+  uint16_t* ord = reinterpret_cast<uint16_t*>(s_arr + head8);
   uint16_t* byy = ord + arr_cap;
   uint8_t* isleft = reinterpret_cast<uint8_t*>(byy + arr_cap);
   __shared__ int s_wave[kArrThreads / 64 + 1];
@@ -3235,6 +3292,20 @@ __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restri
   if (side == 0) {
     for (int i = tid; i < n; i += kArrThreads) ord[i] = (uint16_t)i;
     __syncthreads();
+  } else if (FORM == 2) {                                      // key (x, y), payload the list index; x + 32768 < 65535 always, so padding sorts last
+    for (int i = tid; i < N; i += kArrThreads) {
+      uint32_t k = ~0u;
+      if (i < n) { const int x = t[3 * i] * step - t[3 * i + 2], vc = t[3 * i + 1]; k = ((uint32_t)(x + 32768) << 16) | (uint32_t)vc; }
+      keys32[i] = k; vals[i] = (uint16_t)i;
+    }
+    __syncthreads();
+    arr_sort32(keys32, vals, N, tid);
+    for (int i = tid; i < n; i += kArrThreads) {
+      ord[i] = vals[i];
+      if (i > 0 && keys32[i] == keys32[i - 1]) s_flag = 1;
+    }
+    __syncthreads();
+    if (s_flag) { if (tid == 0) *ok = 0; return; }
   } else {
     for (int i = tid; i < N; i += kArrThreads) {
       unsigned long long k = ~0ull;
@@ -3251,14 +3322,25 @@ __global__ void __launch_bounds__(kArrThreads) k_arrange(const int16_t* __restri
     if (s_flag) { if (tid == 0) *ok = 0; return; }
   }
   // (y, x) order: stable sort of the x-sorted array by y
-  for (int i = tid; i < N; i += kArrThreads) {
-    unsigned long long k = ~0ull;
-    if (i < n) { const int v = ord[i]; k = ((unsigned long long)(unsigned)t[3 * v + 1] << 32) | ((unsigned)i << 16) | (unsigned)v; }
-    keys[i] = k;
+  if (FORM == 2) {                                             // key (y, position in the x order): no payload, the vertex is ord[position]
+    for (int i = tid; i < N; i += kArrThreads) {
+      uint32_t k = ~0u;
+      if (i < n) k = ((uint32_t)(unsigned)t[3 * ord[i] + 1] << 16) | (uint32_t)i;
+      keys32[i] = k;
+    }
+    __syncthreads();
+    arr_sort32(keys32, nullptr, N, tid);
+    for (int i = tid; i < n; i += kArrThreads) byy[i] = ord[keys32[i] & 0xFFFFu];
+  } else {
+    for (int i = tid; i < N; i += kArrThreads) {
+      unsigned long long k = ~0ull;
+      if (i < n) { const int v = ord[i]; k = ((unsigned long long)(unsigned)t[3 * v + 1] << 32) | ((unsigned)i << 16) | (unsigned)v; }
+      keys[i] = k;
+    }
+    __syncthreads();
+    arr_sort(keys, N, tid);
+    for (int i = tid; i < n; i += kArrThreads) byy[i] = (uint16_t)(keys[i] & 0xFFFFu);
   }
-  __syncthreads();
-  arr_sort(keys, N, tid);
-  for (int i = tid; i < n; i += kArrThreads) byy[i] = (uint16_t)(keys[i] & 0xFFFFu);
   __syncthreads();                                             // the key space is free now: it holds tmp, rlo, rn, sx from here on
   for (int i = tid; i < n; i += kArrThreads) { rlo[i] = 0; rn[i] = (uint16_t)n; }
   __syncthreads();
@@ -3325,13 +3407,23 @@ size_t arrange_lds_bytes(int arr_cap) {
   int N = 1; while (N < arr_cap) N <<= 1;
   return (size_t)N * 8 + (size_t)arr_cap * (2 * 2 + 1) + 16;
 }
+static size_t arrange_compact_lds_bytes() { return (size_t)16384 * 6 + (size_t)kArrCompactCap * 5 + 16; }
 size_t arrange_scratch_bytes(int n, int g_cap) { return (size_t)n * 2 * ((arrange_lds_bytes(g_cap) + 7) / 8 * 8); }
 void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
                     int32_t* arr_ok, void* gbuf, int g_cap) {
-  hipLaunchKernelGGL(k_arrange<true>, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr_stride, arr,
+  hipLaunchKernelGGL(k_arrange<1>, dim3(2, n), dim3(kArrThreads), arrange_lds_bytes(arr_cap), st, list, count, list_cap, step, arr_cap, arr_stride, arr,
                      arr_ok, static_cast<unsigned long long*>(nullptr), 0);
-  if (gbuf && g_cap > arr_cap)     // sides beyond the LDS capacity: same kernel on global scratch (it overwrites their "handed back" mark)
-    hipLaunchKernelGGL(k_arrange<false>, dim3(2, n), dim3(kArrThreads), 0, st, list, count, list_cap, step, arr_cap, arr_stride, arr, arr_ok,
+  if (!gbuf || g_cap <= arr_cap) return;
+  // sides beyond that capacity (requested by the caller: the launches overwrite their "handed back" mark): up to 12288 vertices
+  // with compact keys in LDS, the rest on global scratch
+  int done_to = arr_cap;
+  if (g_arrange_compact && arr_cap < kArrCompactCap) {
+    done_to = std::min(g_cap, kArrCompactCap);
+    hipLaunchKernelGGL(k_arrange<2>, dim3(2, n), dim3(kArrThreads), arrange_compact_lds_bytes(), st, list, count, list_cap, step, arr_cap, arr_stride, arr, arr_ok,
+                       static_cast<unsigned long long*>(nullptr), done_to);
+  }
+  if (g_cap > done_to)
+    hipLaunchKernelGGL(k_arrange<0>, dim3(2, n), dim3(kArrThreads), 0, st, list, count, list_cap, step, done_to, arr_stride, arr, arr_ok,
                        static_cast<unsigned long long*>(gbuf), g_cap);
 }
 void launch_support_list(hipStream_t st, const DevParams& dp, int n, const int16_t* d_can, int16_t* list, int32_t* count, int cap) {

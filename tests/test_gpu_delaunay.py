@@ -63,7 +63,8 @@ def test_gpu_triangulation_beyond_one_workgroups_lds(jn):
     x = u - d scatters the columns)."""
     L = jn.load()
     rng = np.random.default_rng(11)
-    for n, cw, ch in ((3900, 256, 144), (4200, 384, 216), (4860, 384, 216), (4900, 384, 216), (7777, 384, 216), (11200, 384, 216), (16384, 384, 216)):
+    for n, cw, ch in ((3900, 256, 144), (4200, 384, 216), (4860, 384, 216), (4900, 384, 216), (7777, 384, 216), (8193, 384, 216), (11200, 384, 216),
+                      (12288, 384, 216), (12289, 384, 216), (16384, 384, 216)):      # 8193-12288: k_arrange's compact LDS form; beyond: global scratch
         t = lattice_case(rng, n, cw, ch, 255, row_d=(n % 2 == 0))
         (kl, tl), (kr, tr), need = device_tri(L, t, 5)
         for side, (k, tri) in ((0, (kl, tl)), (1, (kr, tr))):
