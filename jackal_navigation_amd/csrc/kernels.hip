@@ -2659,27 +2659,38 @@ __global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const Fram
   float g1[8], g2[8], tw[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) { g1[k] = -10.0f; g2[k] = -10.0f; tw[k] = -10.0f; }
-  const int y_begin = (r0 - 7) & ~7, y_end = r1 + 7;          // first row multiple of 8 (also for negative rows), last row needed + 1
+  const int y_end = r1 + 7;                                    // last row needed + 1
   // (the column's values one row ahead of their use; eight rows ahead was measured in round 5: no change, 0.193 against 0.186 ms — the pass
   // is bound by its ~220 vector instructions per pixel, seven waves a SIMD, not by the loads)
-  float x_next = (col_in && y_begin >= 0 && y_begin < H) ? I[(size_t)y_begin * W + u] : -10.0f;
-  for (int yb = y_begin; yb < y_end; yb += 8) {
+  // What the band's output rows [r0, r1) need: T and G2 of rows >= r0 - 4, G1 of rows >= r0 - 7, nothing above those.  r0 is a multiple
+  // of 8 (launch_gap_mean_fused), so the band is walked in blocks of eight rows of three kinds, the phase of a row (its ring slot) a
+  // compile-time constant in each: STAGE 0, rows r0-8 .. r0-1: the row fill only (row r0-8 not at all, the column fill for row r0-4 in
+  // the last step); STAGE 1, rows r0 .. r0+7: no vertical mean before the last step (output row r0); STAGE 2: everything.  [Round 6:
+  // until then every step ran every part, a fifth of a band's steps a mean nobody read.  The same conditions as uniform branches inside
+  // one loop cost more than they saved: the rings' registers became conditional copies, 62 -> 76 VGPRs.]  Rows above the image are all
+  // "invalid", which is what the rings hold to begin with: the first band starts at row 0.
+  float x_next = -10.0f;
+  { const int yf = r0 > 0 ? r0 - 7 : 0; if (col_in && yf < H) x_next = I[(size_t)yf * W + u]; }
+  auto block = [&](int yb, auto stage_tag) {
+    constexpr int STAGE = decltype(stage_tag)::value;
 #pragma unroll
     for (int ph = 0; ph < 8; ph++) {
+      if (STAGE == 0 && ph == 0) continue;
       const int y = yb + ph;                                   // y & 7 == ph
       const float x = x_next;
       { const int yn = y + 1; x_next = (col_in && yn >= 0 && yn < H) ? I[(size_t)yn * W + u] : -10.0f; }
       float* sr = s_row[ph & 1] + 4; float* sg = s_g2[ph & 1];
       sr[t] = x;
-      sg[t] = g2[(ph + 4) & 7];                                // G2 of row y - 4 (computed in the previous step)
+      if (STAGE > 0) sg[t] = g2[(ph + 4) & 7];                 // G2 of row y - 4 (computed in the previous step)
       __syncthreads();
       // ---- G1(y): gap fill along the row (elas.cpp:1122-1166) ----
       // Branch-free (gw <= 3): nearest valid pixel within gw to the left, then within what is left of gw to the right.
       g1[ph] = gap_fill3(gw, x, sr[t - 1], sr[t - 2], sr[t - 3], sr[t + 1], sr[t + 2], sr[t + 3]);
       // ---- G2(y - 3): gap fill along the column (:1204-1247) on the ring of G1 ----
-      g2[(ph + 5) & 7] = gap_fill3(gw, g1[(ph + 5) & 7], g1[(ph + 4) & 7], g1[(ph + 3) & 7], g1[(ph + 2) & 7], g1[(ph + 6) & 7], g1[(ph + 7) & 7], g1[ph]);
+      if (STAGE > 0 || ph == 7)
+        g2[(ph + 5) & 7] = gap_fill3(gw, g1[(ph + 5) & 7], g1[(ph + 4) & 7], g1[(ph + 3) & 7], g1[(ph + 2) & 7], g1[(ph + 6) & 7], g1[(ph + 7) & 7], g1[ph]);
       // ---- T(y - 4): horizontal mean (:1394-1433) of the G2 row in LDS ----
-      {
+      if (STAGE > 0) {
         const int yt = y - 4;
         const float c = sg[t];
         float res = c;
@@ -2692,7 +2703,7 @@ __global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const Fram
         tw[(ph + 4) & 7] = res;
       }
       // ---- out(y - 7): vertical mean (:1436-1483) over the ring of T; where none forms the pixel keeps G2 ----
-      {
+      if (STAGE == 2 || (STAGE == 1 && ph == 7)) {
         const int yo = y - 7;
         float res = g2[(ph + 1) & 7];
         if (do_mean && yo >= 4 && yo <= H - 4) {              // wave-uniform
@@ -2702,10 +2713,13 @@ __global__ void __launch_bounds__(256) k_gap_mean_fused(DevParams dp, const Fram
           for (int l = 0; l < 4; l++) am_pair(tw[l], tw[l + 4], c, pw[l], pf[l]);
           res = am_select(pw, pf, mean_v_col, res);
         }
-        if (store_col && yo >= r0 && yo < r1) O[(size_t)yo * W + u] = res;
+        if (store_col && yo < r1) O[(size_t)yo * W + u] = res;
       }
     }
-  }
+  };
+  if (r0 > 0) block(r0 - 8, std::integral_constant<int, 0>{});
+  block(r0, std::integral_constant<int, 1>{});
+  for (int yb = r0 + 8; yb < y_end; yb += 8) block(yb, std::integral_constant<int, 2>{});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3602,7 +3616,8 @@ void launch_gap_mean_fused(hipStream_t st, const DevParams& dp, int n, const Fra
   // rows per band: flat between 40 and 120 (0.209 / 0.206 / 0.205 / 0.202 / 0.197 / 0.205 / 0.214 ms at 40 / 48 / 60 / 72 / 80 / 90 / 120 rows, 720p batch 32,
   // scripts/post_band_sweep.sh): fewer halo rows against fewer workgroups
   static const int band_rows = JN_HOOK_ENV("JN_POST_BAND") ? atoi(JN_HOOK_ENV("JN_POST_BAND")) : 80;
-  const int bands = (dp.H + band_rows - 1) / band_rows, rows = (dp.H + bands - 1) / bands;
+  // (a band's first row is a multiple of 8: the kernel's blocks of eight rows start there)
+  const int bands0 = (dp.H + band_rows - 1) / band_rows, rows = ((dp.H + bands0 - 1) / bands0 + 7) & ~7, bands = (dp.H + rows - 1) / rows;
   hipLaunchKernelGGL(k_gap_mean_fused, dim3((dp.W + kPostCols - 1) / kPostCols, bands, n), dim3(256), 0, st, dp, info, in, out, rows, mean ? 1 : 0);
 }
 void launch_lr_sub(hipStream_t st, const DevParams& dp, int n, const FrameInfo* info, const int16_t* raw, float* D1, float* D2) {
