@@ -807,8 +807,8 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
     const int pinned = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
     // (an explicit host_threads below 14 says the same thing — the caller's share of a quota that several ranks divide, which no rank can
     // see from its own affinity mask or cpu.max: bench.py passes quota / world)
-    // Frames of 1920x1080 and beyond take the GPU route whatever the cores: their 11 k-point sides keep 12.8 host cores busy for 4.9 k
-    // pairs/s, the kernels give 5.3 k with none (profiles/r06_full_hd_routes.txt).
+    // Frames of 1920x1080 and beyond take the GPU route whatever the cores: their 11 k-point sides keep 12.8-14.4 host cores busy for
+    // 4.9-5.7 k pairs/s, the kernels give 5.3-5.6 k with none (profiles/r06_full_hd_routes.txt, two boxes).
     h->gpu_delaunay = gpu_dt_possible && (pinned <= 16 || usable_cpus() < 14 || (host_threads > 0 && host_threads < 14) || (long long)W * H >= 1920LL * 1080);
   }
   if (const char* e = getenv("JN_GPU_DELAUNAY")) h->gpu_delaunay = gpu_dt_possible && atoi(e) != 0;
