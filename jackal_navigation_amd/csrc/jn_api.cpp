@@ -138,6 +138,7 @@ struct jn_elas {
   bool sub = false;                 // param.subsampling: half-size maps (elas.h:82, :160-162); dph = the post-processing's parameters at that size
   DevParams dph = {};
   bool zero_copy_payload = false;   // latency mode: stage B reads the host stage's output in pinned memory instead of a copy of it
+  bool arrange_sorts = false;       // hooks build, JN_ARRANGE_SORTS=1: k_arrange's sort forms where its rank form would run (A/B, tests)
   bool gpu_delaunay = false;        // batch handles: the triangulations' hull recursion on the GPU too (delaunay_gpu.hip; JN_GPU_DELAUNAY=0/1), no host stage
   bool plane_flow = true;           // descriptors assembled from the Sobel planes inside the matching kernels (JN_DESC_FLOW=desc: materialised, the old flow)
   std::atomic<bool> gate_stage_b{false};   // latency mode: stage B is queued behind a gate while the GPU runs stage A (JN_GATE_STAGE_B=0/1), see run_batch
@@ -314,7 +315,8 @@ jn_status run_batch_route(jn_elas* h, Slot& s, const Job& j, MergeTurn& turn, bo
       {
         // (the global-scratch form only when the slot's recent batches held a side beyond the LDS form: at 1280x720 it would be an empty launch per batch)
         const bool big = s.arr_scratch && (s.arr_hint == 0 || s.arr_hint > h->arr_cap);   // (0: the slot's first batch — nothing known yet)
-        launch_arrange(sa, n, list_buf, cnt_buf, list_cap, dp.step, cap, h->arr_stride, arr_buf, arr_ok_buf, big ? s.arr_scratch : nullptr, big ? h->arr_stride : 0);
+        launch_arrange(sa, n, list_buf, cnt_buf, list_cap, dp.step, cap, h->arr_stride, arr_buf, arr_ok_buf, big ? s.arr_scratch : nullptr, big ? h->arr_stride : 0,
+                       h->arrange_sorts ? ArrBounds{0, 0, 0, 0} : ArrBounds{dp.ch, dp.cw, -dp.disp_max, (dp.cw - 1) * dp.step + dp.disp_max + 1});
       }
       if (gpu_dt)                                        // LDS for what the slot's last batches held + 6 % (a tight request: 32 bytes a vertex leave a k_dense_row workgroup room on the same CU); a side beyond it goes to the host
         HIP_TRY(launch_delaunay(sa, n, list_buf, cnt_buf, list_cap, dp.step, arr_buf, arr_ok_buf, h->arr_stride, s.arr_hint ? std::max(1024, s.arr_hint + s.arr_hint / 16 + 32) : (1 << 30), s.payload,
@@ -790,6 +792,7 @@ jn_status jn_elas_create(const jn_elas_params* p, int32_t W, int32_t H, int32_t 
   // host (JN_ARRANGE_GLOBAL=1 in the hooks build sends them through the kernel's larger forms instead).  The GPU route (below) always
   // arranges on the device: 12288 vertices with compact keys in LDS (0.64 ms a 1080p batch), up to 16384 on global scratch (1.7 ms).
   h->arr_stride = (JN_HOOK_ENV("JN_ARRANGE_GLOBAL") && atoi(JN_HOOK_ENV("JN_ARRANGE_GLOBAL"))) ? std::min(dp.cw * dp.ch, 16384) : h->arr_cap;
+  if (const char* e = JN_HOOK_ENV("JN_ARRANGE_SORTS")) h->arrange_sorts = atoi(e) != 0;
   h->gpu_arrange = !h->hp.add_corners;                     // the six corner points join the list on the host
   if (const char* e = getenv("JN_GPU_ARRANGE")) h->gpu_arrange = h->gpu_arrange && atoi(e) != 0;
   // Batch handles triangulate on the GPU as well (a latency-mode handle keeps the host stage: two pool threads finish a 640x480 pair's
@@ -1246,6 +1249,18 @@ int32_t jn_host_arrangement(const int32_t* x, const int32_t* y, int32_t n, uint1
   return dt.arrangement(x, y, n, out) ? 1 : 0;
 }
 
+// bounds of a list of (uc, vc, d) triples for k_arrange's rank form (the product passes what the handle's lattice and disparity range give)
+static bool arrange_by_sorts() { const char* e = JN_HOOK_ENV("JN_ARRANGE_SORTS"); return e && atoi(e) != 0; }   // hooks build: the sort forms where the rank form would run
+static ArrBounds bounds_of(const int16_t* t, int n, int step) {
+  if (n <= 0 || arrange_by_sorts()) return ArrBounds{0, 0, 0, 0};
+  int ucm = 0, vcm = 0, xlo = 1 << 30, xhi = -(1 << 30);
+  for (int i = 0; i < n; i++) {
+    const int uc = t[3 * i], vc = t[3 * i + 1], x = uc * step - t[3 * i + 2];
+    if (uc < 0 || vc < 0) return ArrBounds{0, 0, 0, 0};
+    ucm = std::max(ucm, uc); vcm = std::max(vcm, vc); xlo = std::min(xlo, x); xhi = std::max(xhi, x);
+  }
+  return ArrBounds{vcm + 1, ucm + 1, xlo, xhi - xlo + 1};
+}
 jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t n, int32_t step, uint16_t* left, uint16_t* right,
                                 int32_t ok[2]) {
   if (!triples || !left || !right || !ok || n < 0 || step < 1) return JN_ERR_INVALID;
@@ -1263,7 +1278,7 @@ jn_status jn_device_arrangement(int32_t device, const int16_t* triples, int32_t 
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_ok), 2 * sizeof(int32_t));
   if (e == hipSuccess && n) e = hipMemcpy(d_list, triples, (size_t)n * 3 * sizeof(int16_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_cnt, &n, sizeof(int32_t), hipMemcpyHostToDevice);
-  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, g_cap, d_arr, d_ok, d_scratch, d_scratch ? g_cap : 0); e = hipStreamSynchronize(nullptr); }
+  if (e == hipSuccess) { launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, g_cap, d_arr, d_ok, d_scratch, d_scratch ? g_cap : 0, bounds_of(triples, n, step)); e = hipStreamSynchronize(nullptr); }
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpy(ok, d_ok, 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e == hipSuccess && ok[0]) e = hipMemcpy(left, d_arr, (size_t)n * sizeof(uint16_t), hipMemcpyDeviceToHost);
@@ -1299,7 +1314,7 @@ jn_status jn_device_triangulate(int32_t device, const int16_t* triples, int32_t 
   FrameInfo fi;
   memset(&fi, 0, sizeof(fi));
   if (e == hipSuccess) {
-    launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, g_cap, d_arr, d_ok, d_ascr, d_ascr ? g_cap : 0);
+    launch_arrange(nullptr, 1, d_list, d_cnt, cap, step, arr_cap, g_cap, d_arr, d_ok, d_ascr, d_ascr ? g_cap : 0, bounds_of(triples, n, step));
     long long* d_clk = nullptr;
     const bool want_clk = JN_HOOK_ENV("JN_DT_CLOCKS") != nullptr;
     if (want_clk && hipMalloc(reinterpret_cast<void**>(&d_clk), 64 * sizeof(long long)) == hipSuccess) hipMemset(d_clk, 0, 64 * sizeof(long long));

@@ -40,8 +40,11 @@ size_t arrange_lds_bytes(int arr_cap);
 // arr_cap: vertices per side this launch orders in LDS (sizes it); sides with more use their slice of gbuf (capacity g_cap per
 // side, arrange_scratch_bytes(n, g_cap) bytes in all; may be null) or are left to the host.  arr_stride: layout of arr.
 size_t arrange_scratch_bytes(int n, int g_cap);
+// What the support points' coordinates range over, for k_arrange's rank form (the orders from bitmaps and prefix counts instead of sorts):
+// lattice rows vc in [0, ny), lattice columns uc in [0, nxl), right-image abscissae uc * step - d in [xmin, xmin + nxr).  ny = 0: not known, sorts.
+struct ArrBounds { int ny, nxl, xmin, nxr; };
 void launch_arrange(hipStream_t st, int n, const int16_t* list, const int32_t* count, int list_cap, int step, int arr_cap, int arr_stride, uint16_t* arr,
-                    int32_t* arr_ok, void* gbuf, int g_cap);
+                    int32_t* arr_ok, void* gbuf, int g_cap, ArrBounds bnd = ArrBounds{0, 0, 0, 0});
 // The hull recursion of the Delaunay triangulation on the GPU (delaunay_gpu.hip): one workgroup per frame side, behind k_arrange.  Writes
 // FrameInfo (device), the support points and the triangles' corner indices into the batch payload (frame i at payload_stride * i, laid out
 // as HostWorker::place() does); sides it cannot take (too many vertices for cap_pts, coinciding vertices) set need_host[frame].

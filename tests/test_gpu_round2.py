@@ -501,11 +501,15 @@ def test_submit_host_streams_host_buffers_through_the_slots(jn, oracle, same):
     assert st1[0] == 0 and same(d1, D1o) and same(d2, D2o)
 
 
-def test_gpu_arrangement_equals_the_hosts(jn):
+@pytest.mark.parametrize("sorts", ["0", "1"])
+def test_gpu_arrangement_equals_the_hosts(jn, hooks, monkeypatch, sorts):
     """k_arrange (the alternating-cut arrangement of a frame side's support points, computed on the GPU so that the host only
     runs the hull recursion) against Delaunay::arrange + split on the host: lattice points as the support list holds them
-    (u-major, v ascending), right image x = u - d; sizes from 3 to the kernel's limit (8192 vertices in LDS, 16384 through global scratch); sides with coinciding vertices and
-    sides beyond the limit are handed back (ok = 0)."""
+    (u-major, v ascending), right image x = u - d; sizes from 3 to the kernel's limit (8192 vertices in LDS with 64-bit keys, 12288 with compact
+    keys, 16384 through global scratch); sides with coinciding vertices and sides beyond the limit are handed back (ok = 0).
+    Both ways of ordering the vertices: by ranks (bitmaps + prefix counts: what runs where the bitmaps fit the LDS) and by the bitonic
+    sorts (JN_ARRANGE_SORTS=1 in the hooks build; what runs for lattices too large for the bitmaps)."""
+    monkeypatch.setenv("JN_ARRANGE_SORTS", sorts)
     L = jn.load()
     rng = np.random.default_rng(12)
 
