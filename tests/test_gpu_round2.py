@@ -548,6 +548,7 @@ def test_gpu_arrangement_equals_the_hosts(jn, hooks, monkeypatch, sorts):
         assert case(n, 384, 216, 255, row_d=True) == (1, 1)     # beyond the LDS: the working arrays live in global scratch
         assert case(n, 384, 216, 255)[0] == 1                   # random disparities this dense: right-image vertices coincide
     assert case(16385, 384, 216, 255) == (0, 0)                 # beyond the kernel's limit: host
+    assert case(3000, 2000, 100, 127, row_d=True) == (1, 1)     # a lattice whose bitmaps do not fit the LDS (10 000 columns): the sorts, whatever JN_ARRANGE_SORTS says
     for n in (50, 700, 4000):
         case(n, 384, 216, 255)                                  # 1080p lattice, D = 256: negative right-image columns
     dup = 0
