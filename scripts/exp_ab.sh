@@ -1,5 +1,8 @@
 #!/bin/bash
-# (temporary) kernel-time effect of compile-time experiment flags on one box: bash scripts/exp_ab.sh <pattern> <flag> [<flag> ...]
+# Kernel-time effect of compile-time flags of kernels.hip (-DJN_AB_..., experiment macros) on one box, inside gpurun:
+#   bash scripts/exp_ab.sh <kernel name pattern> <flag> [<flag> ...]
+# One slot under rocprofv3 for every flag, this tree's library again after each (the box's clocks drift: read the RATIO of the kernel under
+# test to one that the flag does not touch, e.g. "k_dense_row|k_support_lds").
 PAT=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}; C=$R/jackal_navigation_amd/csrc; T=/tmp/exp_ab; mkdir -p $T
 HIP_RT_DIR=$(python3 -c "import os,torch;print(os.path.join(os.path.dirname(torch.__file__),'lib'))")
