@@ -344,7 +344,14 @@ struct DT {
   }
 };
 
-enum { kDtThreads = 1024, kDtTopThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 32,   // 2 triangles x (4 + 4) halfwords; X, Y, HL, HR ride in the records' spare halfwords (LdsMem)
+// Threads of k_delaunay / k_delaunay_sub.  512, not 1024 (round 6): alone the kernel is slower with fewer (0.75 / 0.79 / 0.89 ms at 1024 / 512 /
+// 256: the leaves and the low levels have more nodes than threads), in the pipeline faster — a sixteen-wave workgroup starts only on a CU with
+// sixteen free wave slots, which the other slots' eight-wave workgroups keep refilling: 23.25 / 23.75 / 23.87 k pairs/s on the GPU route,
+// 6.04 / 6.22 / 6.14 k at 1920x1080 (profiles/r06_dt_threads_ab.txt; k_arrange likewise, kernels.hip).
+#ifndef JN_AB_DT_THREADS
+#define JN_AB_DT_THREADS 512
+#endif
+enum { kDtThreads = JN_AB_DT_THREADS, kDtTopThreads = 256, kDtMaxDepth = 16, kDtBytesPerVertex = 32,   // 2 triangles x (4 + 4) halfwords; X, Y, HL, HR ride in the records' spare halfwords (LdsMem)
        kDtMaxPoints = 16384 };                                                                  // arrangement positions are 16-bit, vertex numbers int16 with room to spare
 
 // Sizes and triangle counts per depth: at depth k a node holds f_k = n >> k or f_k + 1 vertices; c[k][b] = count(f_k + b), the triangles a

@@ -3232,7 +3232,12 @@ bool launch_support_filters(hipStream_t st, const DevParams& dp, int n, int win,
 // other array to follow — one flag pass, one workgroup-wide prefix sum, one scatter per level.  Ranges of <= 3 vertices are
 // final (Delaunay::split).  Sides whose vertices are not all distinct (two support points can share (u - d, v) in the right
 // image) are left to the host, which must replay Triangle's randomised sort for them (delaunay.cpp): ok = 0.
-constexpr int kArrThreads = 1024;
+#ifndef JN_AB_ARR_THREADS
+#define JN_AB_ARR_THREADS 512
+#endif
+// 512 threads, not 1024 (round 6, with the orders as ranks): 75 against 85 us alone, and an eight-wave workgroup finds room among the other
+// slots' kernels where a sixteen-wave one waits for half a CU to drain: host route 24.7 -> 25.5 k pairs/s (profiles/r06_arr_threads_ab.txt).
+constexpr int kArrThreads = JN_AB_ARR_THREADS;
 DEV void arr_sort(unsigned long long* keys, int N, int tid) {      // bitonic, N a power of two, ascending
   for (int k = 2; k <= N; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
